@@ -1,0 +1,69 @@
+"""Test helpers (not product code): reference comparison rules and tiny KITTI text parsers."""
+import os
+
+import numpy as np
+
+
+def float_ulp_diff(a, b):
+    """ULP distance between a and b after casting both to IEEE float (gtest's ASSERT_FLOAT_EQ metric)."""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+
+    def biased(x):
+        i = x.view(np.int32).astype(np.int64)
+        return np.where(i < 0, -(i & 0x7FFFFFFF), i)
+
+    return np.abs(biased(a) - biased(b))
+
+
+def assert_float_eq(a, b, msg=""):
+    """gtest ASSERT_FLOAT_EQ: equal as float within 4 ULP."""
+    d = float_ulp_diff(a, b)
+    assert np.all(d <= 4), f"ASSERT_FLOAT_EQ failed {msg}: {a} vs {b} ({d} ulp)"
+
+
+def float_equal_eps(a, b, eps=1e-10):
+    """utilities_for_testing.hpp:4  FloatEqual(float a, float b, float eps)"""
+    return abs(np.float32(a) - np.float32(b)) <= np.float32(eps)
+
+
+def transformation_matrices_are_the_same(M1, M2):
+    """utilities_for_testing.hpp:6-11 criterion on 4x4 matrices."""
+    I = M1 @ np.linalg.inv(M2)
+    return float_equal_eps(np.trace(I), 4.0) and float_equal_eps(I.sum() - np.trace(I), 0.0)
+
+
+def hhmmss_to_seconds(tok):
+    """utils.cpp:31-38 restated: 'HH:MM:SS.nnnnnnnnn' -> seconds since midnight (double)."""
+    hours = int(tok[0:2])
+    minutes = int(tok[3:5])
+    seconds = float(tok[6:24])
+    return float(60 * hours * 60 + minutes * 60) + seconds
+
+
+def load_timestamp(path, frame_id):
+    """data_io.cpp:18-35 restated."""
+    with open(path) as f:
+        lines = f.read().splitlines()
+    return hhmmss_to_seconds(lines[frame_id].split(" ")[1])
+
+
+def load_oxts_fields(run_dir, frame_id):
+    """data_io.cpp:37-66 restated -> dict(stamp, lat, lon, alt, roll, pitch, yaw, vf, vl, vu)."""
+    stamp = load_timestamp(os.path.join(run_dir, "oxts", "timestamps.txt"), frame_id)
+    with open(os.path.join(run_dir, "oxts", "data", f"{frame_id:010d}.txt")) as f:
+        tok = f.readline().split(" ")
+    v = [float(t) for t in tok[:11]]
+    return dict(stamp=stamp, lat=v[0], lon=v[1], alt=v[2], roll=v[3], pitch=v[4], yaw=v[5], vf=v[8], vl=v[9], vu=v[10])
+
+
+def load_velodyne_bin(run_dir, frame_id):
+    """KITTI velodyne .bin: f32 AoS x,y,z,intensity (data_io.cpp:101-138)."""
+    return np.fromfile(os.path.join(run_dir, "velodyne_points", "data", f"{frame_id:010d}.bin"), dtype=np.float32).reshape(-1, 4)
+
+
+def rel_point_error(p, ref):
+    """SURVEY.md section 8(d) parity gate: ||p - ref||_2 / max(||ref||_2, 1e-3) per point."""
+    p = np.asarray(p, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.linalg.norm(p - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-3)
