@@ -1,0 +1,189 @@
+/*
+ * kmc_hip.h -- C-ABI of libkmc_hip.so: the MI355X (gfx950) per-point LiDAR deskew engine.
+ *
+ * This is the drop-in boundary for ONE hot path of fracgawd/kitti_motion_compensation:
+ *
+ *     kmc::MotionCompensateFrame(Frame const&, Time)          include/.../motion_compensation.hpp:13
+ *       -> per point kmc::MotionCompensatePoint(...)          src/.../motion_compensation.cpp:9-14, :22-25
+ *            -> TrajectoryInterpolator::RelativePoseBetweenTimes   trajectory_interpolation.cpp:43-45
+ *                 -> lie::Log / lie::Exp                       lie_algebra.cpp:83-103
+ *     with the per-point stamps of kmc::GetPseudoTimeStamps   timestamp_mocking.cpp:46-63
+ *
+ * The reference has no FFI of its own (it is a single C++ shared library, CMakeLists.txt:27-29); the
+ * entry points below are what a binding of that path needs.  The C++ shim that restores the reference's
+ * exact signatures on top of this ABI is include/kitti_motion_compensation/ (libkitti_motion_compensation_lib.so).
+ *
+ * Rules of the ABI
+ *   - plain C: pointers, sizes, PODs; no C++/torch/Eigen types; no exceptions cross it.
+ *   - every function returns an int status: KMC_OK (0) or a negative KMC_ERR_*; kmc_status_string()
+ *     names it and kmc_hip_last_error() gives the HIP error text for KMC_ERR_HIP.
+ *   - the caller owns every buffer it passes; `mem_kind` says where the point buffers live.
+ *   - a kmc_ctx is bound to one device and one HIP stream; calls on one ctx are not re-entrant, distinct
+ *     contexts are independent (one ctx per thread / per rank).
+ *   - there is NO CPU fallback: without a usable HIP device kmc_hip_create() fails with
+ *     KMC_ERR_NO_DEVICE and nothing else can be called.
+ *
+ * Data conventions
+ *   - pose      : double[12], row-major 3x4 [R | t]  (Eigen::Affine3d::matrix().topRows<3>(), row-major)
+ *   - twist     : double[6] = [rho(3); phi(3)]  -- same order as the reference, lie_algebra.cpp:84-85
+ *   - KITTI cloud (f32 path): float[4*n] AoS {x, y, z, intensity}, the on-disk .bin layout (data_io.cpp:101-138)
+ *   - Eigen cloud (f64 path): four double[n] columns x, y, z, w (= Eigen::MatrixX4d, column-major) + double stamps[n]
+ */
+#ifndef KMC_HIP_H
+#define KMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMC_ABI_VERSION 1
+
+/* ---- status codes ---- */
+#define KMC_OK 0
+#define KMC_ERR_INVALID_ARG (-1)
+#define KMC_ERR_HIP (-2)               /* a HIP runtime call failed; see kmc_hip_last_error() */
+#define KMC_ERR_NO_DEVICE (-3)         /* no usable gfx950 device: the product path has no CPU fallback */
+#define KMC_ERR_TIME_OUT_OF_RANGE (-4) /* a stamp or requested_time outside [stamp_start, stamp_end]:
+                                          the reference's release-mode assert, trajectory_interpolation.cpp:9,:32 */
+#define KMC_ERR_ALLOC (-5)
+#define KMC_ERR_DEGENERATE (-6)        /* stamp_start >= stamp_end, or a singular pose */
+
+typedef enum kmc_mem_kind {
+  KMC_MEM_HOST = 0,  /* pageable or pinned host memory: the library stages H2D / D2H (PCIe-bound) */
+  KMC_MEM_DEVICE = 1 /* device memory of the ctx's GPU: zero-copy, the roofline path */
+} kmc_mem_kind;
+
+typedef struct kmc_ctx kmc_ctx; /* opaque */
+
+/* Per-frame constants of the deskew: everything the device needs besides the points.
+ * Produced on the host in f64 by kmc_frame_params_from_poses() -- the loop-invariant half of
+ * GetPoseAtTime (trajectory_interpolation.cpp:35-36) hoisted out of the per-point loop. */
+typedef struct kmc_frame_params {
+  double twist[6]; /* f = Log(T_start^-1 * T_end) = [rho; phi] */
+  double x_req;    /* (requested_time - stamp_start) / (stamp_end - stamp_start), in [0,1] */
+} kmc_frame_params;
+
+/* include/kitti_motion_compensation/data_types.hpp:35-49 */
+typedef struct kmc_oxts {
+  double stamp, lat, lon, alt, roll, pitch, yaw, vf, vl, vu;
+} kmc_oxts;
+
+typedef struct kmc_stats {
+  uint64_t n_points;       /* points processed by the call */
+  uint64_t n_out_of_range; /* points whose stamp was outside [stamp_start, stamp_end] (f64 path only) */
+  uint32_t n_launches;     /* kernel launches issued */
+  uint32_t variant;        /* kernel tier used: 0 = series3 (theta<=0.25), 1 = series5 (theta<=1), 2 = trig */
+  float kernel_ms;         /* HIP-event time of the kernel launches (only if timing was enabled) */
+  float total_ms;          /* HIP-event time of the whole call incl. H2D/D2H staging (only if timing enabled) */
+} kmc_stats;
+
+typedef struct kmc_device_info {
+  char name[128];
+  char arch[64];
+  int device_id;
+  int compute_units;
+  int wavefront_size;
+  uint64_t hbm_bytes;
+  int clock_khz;
+} kmc_device_info;
+
+/* ------------------------------------------------------------------------------------------------
+ * library / context
+ * ---------------------------------------------------------------------------------------------- */
+int kmc_abi_version(void);
+const char* kmc_status_string(int status);
+
+/* Creates a context on HIP device `device_id`.  Fails with KMC_ERR_NO_DEVICE when there is none. */
+int kmc_hip_create(kmc_ctx** out, int device_id);
+void kmc_hip_destroy(kmc_ctx* ctx);
+/* Use the caller's hipStream_t (e.g. torch's current stream) for all launches; NULL = the ctx's own stream. */
+int kmc_hip_set_stream(kmc_ctx* ctx, void* hip_stream);
+int kmc_hip_synchronize(kmc_ctx* ctx);
+/* When enabled every call brackets its launches with hipEvents on the ctx stream, synchronizes, and fills
+ * kmc_stats.kernel_ms / total_ms.  Off by default (calls are then fully asynchronous for KMC_MEM_DEVICE). */
+int kmc_hip_enable_timing(kmc_ctx* ctx, int enabled);
+const char* kmc_hip_last_error(kmc_ctx* ctx);
+int kmc_hip_device_info(kmc_ctx* ctx, kmc_device_info* out);
+/* Launch-geometry override for tuning: blocks per CU (0 = default) and points per thread per tile
+ * (1, 2, 4 or 8; 0 = default). */
+int kmc_hip_set_launch_config(kmc_ctx* ctx, int blocks_per_cu, int points_per_thread);
+
+/* Testing hook: force the series/trig tier of the f32 kernels (-1 = automatic selection from |phi|). */
+int kmc_hip_force_tier(kmc_ctx* ctx, int tier);
+
+/* HIP-event stopwatch on the ctx stream: begin records an event, end records another, waits for it and
+ * returns the elapsed milliseconds between the two -- what bench.py uses around its timed region. */
+int kmc_hip_timer_begin(kmc_ctx* ctx);
+int kmc_hip_timer_end(kmc_ctx* ctx, float* elapsed_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * host pre-step (f64, pure host code, usable without a GPU)
+ * ---------------------------------------------------------------------------------------------- */
+/* twist = Log(T_start^-1 * T_end); x_req = FractionOfTrajectory(requested_time).
+ * Replaces the loop-invariant work of TrajectoryInterpolator::GetPoseAtTime
+ * (trajectory_interpolation.cpp:31-41 with lie_algebra.cpp:94-103) that the reference repeats twice per point.
+ * KMC_ERR_TIME_OUT_OF_RANGE if requested_time is outside [stamp_start, stamp_end] (the reference aborts). */
+int kmc_frame_params_from_poses(const double T_start[12], const double T_end[12], double stamp_start,
+                                double stamp_end, double requested_time, kmc_frame_params* out);
+
+/* data_io.cpp:68-88 OxtsToPose (Mercator + yaw/pitch/roll); scale = 1.0 is the reference's default. */
+int kmc_oxts_to_pose(const kmc_oxts* oxts, double scale, double T_out[12]);
+/* trajectory_interpolation.cpp:14-19 InterpolateTrajectory */
+int kmc_interpolate_trajectory(const kmc_oxts* o1, const kmc_oxts* o2, double time, double T_out[12]);
+/* data_io.cpp:253-269 MakeFrame (pose part): T_start from (o[n-1], o[n]) at stamp_start, T_end from
+ * (o[n], o[n+1]) at stamp_end. */
+int kmc_make_frame_poses(const kmc_oxts* o_nm1, const kmc_oxts* o_n, const kmc_oxts* o_np1, double stamp_start,
+                         double stamp_end, double T_start_out[12], double T_end_out[12]);
+
+/* ------------------------------------------------------------------------------------------------
+ * the hot path
+ * ---------------------------------------------------------------------------------------------- */
+/* Fused f32 deskew of ONE frame in the KITTI layout.  Per point (one HIP lane each):
+ *   frac = (pi - atan2(y, x)) / 2pi                    timestamp_mocking.cpp:46     (GetPseudoTimeStamps)
+ *   s    = frac - x_req                                trajectory_interpolation.cpp:49-51
+ *   p'   = Exp(s * twist) * p                          motion_compensation.cpp:9-14 (closed form)
+ * and intensity is passed through bit-identically.  32 algorithmic bytes per point (16 read + 16 written).
+ * xyzi_in and xyzi_out must be 16-byte aligned and must not partially overlap (in == out is allowed). */
+int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint64_t n,
+                       const kmc_frame_params* params, int mem_kind, kmc_stats* out_stats);
+
+/* Batched variant: n_frames frames concatenated in one buffer; frame f owns points
+ * [offsets[f], offsets[f+1]).  offsets (n_frames+1 entries) and params (n_frames entries) are HOST arrays.
+ * One launch covers the whole batch (a whole KITTI drive, or many 1M-point frames); per-frame constants
+ * are staged in LDS.  frame_idx_out (optional, may be NULL; same mem_kind as the points) receives the
+ * per-point frame index -- the integer "timestamp index" that is compared bit-exactly in the parity tests. */
+int kmc_hip_deskew_batch_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets,
+                             uint32_t n_frames, const kmc_frame_params* params, uint32_t* frame_idx_out,
+                             int mem_kind, kmc_stats* out_stats);
+
+/* f64 "Eigen-layout" deskew: honours caller-supplied per-point stamps exactly like
+ * MotionCompensateFrame(Frame const&, Time) does (motion_compensation.cpp:22-25 reads frame.scan.timestamps).
+ * Inputs: four columns x,y,z,w and stamps; outputs: four columns (w' = w, translation scaled by w like
+ * Affine3d * Vector4d).  All arithmetic in f64 on the device.  Out-of-range stamps are counted in
+ * out_stats->n_out_of_range and make the call return KMC_ERR_TIME_OUT_OF_RANGE (outputs for those points are NaN). */
+int kmc_hip_deskew_f64cols(kmc_ctx* ctx, const double* x, const double* y, const double* z, const double* w,
+                           const double* stamps, uint64_t n, double stamp_start, double stamp_end,
+                           const kmc_frame_params* params, double* ox, double* oy, double* oz, double* ow,
+                           int mem_kind, kmc_stats* out_stats);
+
+/* GetPseudoTimeStamps (timestamp_mocking.cpp:56-63) on the device, f64: stamps[i] = start + frac_i*(end-start). */
+int kmc_hip_pseudo_timestamps_f64(kmc_ctx* ctx, const double* x, const double* y, uint64_t n, double scan_start,
+                                  double scan_end, double* stamps_out, int mem_kind);
+
+/* ------------------------------------------------------------------------------------------------
+ * synthetic workload (measurement infrastructure; BASELINE.json configs 2-5 have no shippable data)
+ * ---------------------------------------------------------------------------------------------- */
+/* Fills xyzi_out (DEVICE memory) with n synthetic Velodyne-like points generated on the GPU from a
+ * counter-based PRNG keyed on (seed, point index): 64 rings, azimuth sweeping the full circle, range
+ * U[2,80) m, intensity on a 0.01 grid.  kmc_synth_points_host() produces the bit-identical points on the
+ * host (used by the tests to feed the oracle). */
+int kmc_hip_synth_points(kmc_ctx* ctx, float* xyzi_out_device, uint64_t n, uint64_t seed);
+int kmc_synth_points_host(float* xyzi_out_host, uint64_t n, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMC_HIP_H */

@@ -1,0 +1,325 @@
+"""ctypes binding of the C-ABI in include/kmc_hip.h (libkmc_hip.so).
+
+Plumbing only: the product is the HIP library; this module lets pytest and bench.py drive it with numpy
+arrays (KMC_MEM_HOST) or torch device tensors (KMC_MEM_DEVICE, zero-copy through data_ptr()).
+
+There is NO fallback: if the shared library has not been built, importing the symbols raises; if there is
+no HIP device, Context() raises KmcError(KMC_ERR_NO_DEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libkmc_hip.so")
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_HIP = -2
+ERR_NO_DEVICE = -3
+ERR_TIME_OUT_OF_RANGE = -4
+ERR_ALLOC = -5
+ERR_DEGENERATE = -6
+
+MEM_HOST = 0
+MEM_DEVICE = 1
+
+TIER_SERIES3, TIER_SERIES5, TIER_TRIG = 0, 1, 2
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("twist", C.c_double * 6), ("x_req", C.c_double)]
+
+    @staticmethod
+    def make(twist, x_req) -> "FrameParams":
+        p = FrameParams()
+        for i, v in enumerate(np.asarray(twist, dtype=np.float64).reshape(6)):
+            p.twist[i] = float(v)
+        p.x_req = float(x_req)
+        return p
+
+    def twist_np(self) -> np.ndarray:
+        return np.array(list(self.twist), dtype=np.float64)
+
+
+class Oxts(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("stamp", "lat", "lon", "alt", "roll", "pitch", "yaw", "vf", "vl", "vu")]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_points", C.c_uint64),
+        ("n_out_of_range", C.c_uint64),
+        ("n_launches", C.c_uint32),
+        ("variant", C.c_uint32),
+        ("kernel_ms", C.c_float),
+        ("total_ms", C.c_float),
+    ]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 128),
+        ("arch", C.c_char * 64),
+        ("device_id", C.c_int),
+        ("compute_units", C.c_int),
+        ("wavefront_size", C.c_int),
+        ("hbm_bytes", C.c_uint64),
+        ("clock_khz", C.c_int),
+    ]
+
+
+class KmcError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        msg = f"{where}: {status_string(status)}"
+        if detail:
+            msg += f" [{detail}]"
+        super().__init__(msg)
+
+
+_lib = None
+
+# every symbol include/kmc_hip.h declares: (restype, argtypes)
+_vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
+SIGNATURES = {
+    "kmc_abi_version": (C.c_int, []),
+    "kmc_status_string": (C.c_char_p, [C.c_int]),
+    "kmc_hip_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "kmc_hip_destroy": (None, [_vp]),
+    "kmc_hip_set_stream": (C.c_int, [_vp, _vp]),
+    "kmc_hip_synchronize": (C.c_int, [_vp]),
+    "kmc_hip_enable_timing": (C.c_int, [_vp, C.c_int]),
+    "kmc_hip_last_error": (C.c_char_p, [_vp]),
+    "kmc_hip_device_info": (C.c_int, [_vp, C.POINTER(DeviceInfo)]),
+    "kmc_hip_set_launch_config": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "kmc_hip_force_tier": (C.c_int, [_vp, C.c_int]),
+    "kmc_hip_timer_begin": (C.c_int, [_vp]),
+    "kmc_hip_timer_end": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "kmc_frame_params_from_poses": (C.c_int, [_dp, _dp, C.c_double, C.c_double, C.c_double, C.POINTER(FrameParams)]),
+    "kmc_oxts_to_pose": (C.c_int, [C.POINTER(Oxts), C.c_double, _dp]),
+    "kmc_interpolate_trajectory": (C.c_int, [C.POINTER(Oxts), C.POINTER(Oxts), C.c_double, _dp]),
+    "kmc_make_frame_poses": (C.c_int, [C.POINTER(Oxts), C.POINTER(Oxts), C.POINTER(Oxts), C.c_double, C.c_double, _dp, _dp]),
+    "kmc_hip_deskew_f32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(FrameParams), C.c_int, C.POINTER(Stats)]),
+    "kmc_hip_deskew_batch_f32": (
+        C.c_int,
+        [_vp, _vp, _vp, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(FrameParams), _vp, C.c_int, C.POINTER(Stats)],
+    ),
+    "kmc_hip_deskew_f64cols": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, C.POINTER(FrameParams), _vp, _vp, _vp, _vp,
+         C.c_int, C.POINTER(Stats)],
+    ),
+    "kmc_hip_pseudo_timestamps_f64": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, _vp, C.c_int]),
+    "kmc_hip_synth_points": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
+    "kmc_synth_points_host": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
+}
+
+
+def lib() -> C.CDLL:
+    """Loads libkmc_hip.so (built by `make -C kitti_motion_compensation_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the deskew path is HIP-only; there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # raises AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def status_string(status: int) -> str:
+    return lib().kmc_status_string(status).decode()
+
+
+def _ptr(a):
+    """numpy array / torch tensor / int / None -> void* value."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError(type(a))
+
+
+def _mem_kind(a) -> int:
+    if isinstance(a, np.ndarray):
+        return MEM_HOST
+    if hasattr(a, "is_cuda"):
+        return MEM_DEVICE if a.is_cuda else MEM_HOST
+    raise TypeError(type(a))
+
+
+def _pose12(T) -> np.ndarray:
+    T = np.asarray(T, dtype=np.float64)
+    if T.shape == (4, 4):
+        T = T[:3, :4]
+    return np.ascontiguousarray(T).reshape(12)
+
+
+# ---- host pre-step (no GPU needed) ------------------------------------------------------------------
+def frame_params_from_poses(T_start, T_end, stamp_start, stamp_end, requested_time) -> FrameParams:
+    a, b = _pose12(T_start), _pose12(T_end)
+    p = FrameParams()
+    rc = lib().kmc_frame_params_from_poses(a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), stamp_start, stamp_end,
+                                           requested_time, C.byref(p))
+    if rc != OK:
+        raise KmcError(rc, "kmc_frame_params_from_poses")
+    return p
+
+
+def oxts_to_pose(o: Oxts, scale: float = 1.0) -> np.ndarray:
+    T = np.zeros(12)
+    rc = lib().kmc_oxts_to_pose(C.byref(o), scale, T.ctypes.data_as(_dp))
+    if rc != OK:
+        raise KmcError(rc, "kmc_oxts_to_pose")
+    return T.reshape(3, 4)
+
+
+def interpolate_trajectory(o1: Oxts, o2: Oxts, time: float) -> np.ndarray:
+    T = np.zeros(12)
+    rc = lib().kmc_interpolate_trajectory(C.byref(o1), C.byref(o2), time, T.ctypes.data_as(_dp))
+    if rc != OK:
+        raise KmcError(rc, "kmc_interpolate_trajectory")
+    return T.reshape(3, 4)
+
+
+def make_frame_poses(o_nm1: Oxts, o_n: Oxts, o_np1: Oxts, stamp_start: float, stamp_end: float):
+    a, b = np.zeros(12), np.zeros(12)
+    rc = lib().kmc_make_frame_poses(C.byref(o_nm1), C.byref(o_n), C.byref(o_np1), stamp_start, stamp_end,
+                                    a.ctypes.data_as(_dp), b.ctypes.data_as(_dp))
+    if rc != OK:
+        raise KmcError(rc, "kmc_make_frame_poses")
+    return a.reshape(3, 4), b.reshape(3, 4)
+
+
+def synth_points_host(n: int, seed: int) -> np.ndarray:
+    out = np.empty((n, 4), dtype=np.float32)
+    rc = lib().kmc_synth_points_host(out.ctypes.data, n, seed)
+    if rc != OK:
+        raise KmcError(rc, "kmc_synth_points_host")
+    return out
+
+
+# ---- device context -----------------------------------------------------------------------------------
+class Context:
+    """One kmc_ctx: one GPU, one stream.  Raises KmcError(ERR_NO_DEVICE) when there is no HIP device."""
+
+    def __init__(self, device_id: int = 0, stream=None):
+        self._h = _vp()
+        rc = lib().kmc_hip_create(C.byref(self._h), device_id)
+        if rc != OK:
+            self._h = None
+            raise KmcError(rc, "kmc_hip_create")
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().kmc_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, where):
+        if rc != OK:
+            detail = lib().kmc_hip_last_error(self._h).decode() if rc == ERR_HIP else ""
+            raise KmcError(rc, where, detail)
+
+    def set_stream(self, stream):
+        """stream: an int hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None for the ctx's own."""
+        self._check(lib().kmc_hip_set_stream(self._h, stream if stream else None), "kmc_hip_set_stream")
+
+    def synchronize(self):
+        self._check(lib().kmc_hip_synchronize(self._h), "kmc_hip_synchronize")
+
+    def enable_timing(self, on=True):
+        self._check(lib().kmc_hip_enable_timing(self._h, 1 if on else 0), "kmc_hip_enable_timing")
+
+    def set_launch_config(self, blocks_per_cu=0, points_per_thread=0):
+        self._check(lib().kmc_hip_set_launch_config(self._h, blocks_per_cu, points_per_thread), "kmc_hip_set_launch_config")
+
+    def force_tier(self, tier=-1):
+        self._check(lib().kmc_hip_force_tier(self._h, tier), "kmc_hip_force_tier")
+
+    def device_info(self) -> dict:
+        d = DeviceInfo()
+        self._check(lib().kmc_hip_device_info(self._h, C.byref(d)), "kmc_hip_device_info")
+        return dict(name=d.name.decode(), arch=d.arch.decode(), device_id=d.device_id, compute_units=d.compute_units,
+                    wavefront_size=d.wavefront_size, hbm_bytes=d.hbm_bytes, clock_khz=d.clock_khz)
+
+    def timer_begin(self):
+        self._check(lib().kmc_hip_timer_begin(self._h), "kmc_hip_timer_begin")
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0)
+        self._check(lib().kmc_hip_timer_end(self._h, C.byref(ms)), "kmc_hip_timer_end")
+        return ms.value
+
+    # -- hot path ------------------------------------------------------------------------------------
+    def deskew_f32(self, xyzi_in, xyzi_out, params: FrameParams, n=None) -> Stats:
+        kind = _mem_kind(xyzi_in)
+        assert kind == _mem_kind(xyzi_out)
+        if n is None:
+            n = int(xyzi_in.shape[0])
+        st = Stats()
+        rc = lib().kmc_hip_deskew_f32(self._h, _ptr(xyzi_in), _ptr(xyzi_out), n, C.byref(params), kind, C.byref(st))
+        self._check(rc, "kmc_hip_deskew_f32")
+        return st
+
+    def deskew_batch_f32(self, xyzi_in, xyzi_out, offsets, params_list, frame_idx_out=None) -> Stats:
+        kind = _mem_kind(xyzi_in)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nf = len(offs) - 1
+        arr = (FrameParams * max(nf, 1))()
+        for i, p in enumerate(params_list):
+            arr[i] = p
+        st = Stats()
+        rc = lib().kmc_hip_deskew_batch_f32(self._h, _ptr(xyzi_in), _ptr(xyzi_out),
+                                            offs.ctypes.data_as(C.POINTER(C.c_uint64)), nf, arr, _ptr(frame_idx_out), kind,
+                                            C.byref(st))
+        self._check(rc, "kmc_hip_deskew_batch_f32")
+        return st
+
+    def deskew_f64cols(self, x, y, z, w, stamps, stamp_start, stamp_end, params: FrameParams, ox, oy, oz, ow=None,
+                       raise_on_range=True):
+        kind = _mem_kind(x)
+        n = int(x.shape[0])
+        st = Stats()
+        rc = lib().kmc_hip_deskew_f64cols(self._h, _ptr(x), _ptr(y), _ptr(z), _ptr(w), _ptr(stamps), n, stamp_start,
+                                          stamp_end, C.byref(params), _ptr(ox), _ptr(oy), _ptr(oz), _ptr(ow), kind,
+                                          C.byref(st))
+        if rc == ERR_TIME_OUT_OF_RANGE and not raise_on_range:
+            return rc, st
+        self._check(rc, "kmc_hip_deskew_f64cols")
+        return rc, st
+
+    def pseudo_timestamps_f64(self, x, y, scan_start, scan_end, out):
+        kind = _mem_kind(x)
+        rc = lib().kmc_hip_pseudo_timestamps_f64(self._h, _ptr(x), _ptr(y), int(x.shape[0]), scan_start, scan_end, _ptr(out), kind)
+        self._check(rc, "kmc_hip_pseudo_timestamps_f64")
+
+    def synth_points(self, out_device, n, seed):
+        self._check(lib().kmc_hip_synth_points(self._h, _ptr(out_device), n, seed), "kmc_hip_synth_points")

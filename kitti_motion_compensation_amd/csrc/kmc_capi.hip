@@ -1,0 +1,650 @@
+// kmc_capi.hip -- implementation of the C-ABI declared in include/kmc_hip.h (libkmc_hip.so).
+//
+// Thin on purpose: argument checks, f64 -> device-precision frame records, launch geometry, optional
+// host staging.  All per-point work is in kmc_kernels.hip.h.  There is no CPU fallback anywhere in this
+// file: every hot-path entry point needs a live kmc_ctx, and kmc_hip_create() fails without a HIP device.
+#include "../../include/kmc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kmc_host_math.hpp"
+#include "kmc_kernels.hip.h"
+
+using namespace kmc_dev;
+
+struct kmc_ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  bool timing = false;
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  std::string last_error;
+  hipDeviceProp_t prop;
+  int blocks_per_cu = 0;  // 0 = default
+  int ppt = 0;            // 0 = default
+  int force_tier = -1;
+  // out-of-range counter (f64 path)
+  unsigned long long* d_counter = nullptr;
+  // batch tables: device + pinned staging
+  BatchRec* d_recs = nullptr;
+  BatchRec* h_recs = nullptr;
+  size_t recs_cap = 0;
+  uint32_t* d_tiles = nullptr;
+  uint32_t* h_tiles = nullptr;
+  size_t tiles_cap = 0;
+  hipEvent_t ev_tables = nullptr;  // completion of the last table upload (guards the pinned staging)
+  bool tables_in_flight = false;
+  // host-staging buffers
+  hipStream_t pipe[2] = {nullptr, nullptr};
+  void* d_stage_in[2] = {nullptr, nullptr};
+  void* d_stage_out[2] = {nullptr, nullptr};
+  size_t stage_cap = 0;  // bytes per buffer
+  void* d_tmp = nullptr; // grow-only scratch for the f64 / batch host paths
+  size_t tmp_cap = 0;
+};
+
+namespace {
+
+constexpr int kDefaultBlocksPerCu = 8;
+constexpr int kDefaultPpt = 4;
+constexpr uint64_t kHostChunkPoints = 1ull << 22;  // 64 MiB per direction per pipeline slot
+
+int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
+  if (c) {
+    c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+  }
+  (void)hipGetLastError();
+  return KMC_ERR_HIP;
+}
+
+#define KMC_HIP_TRY(ctx, expr)                        \
+  do {                                                \
+    hipError_t _e = (expr);                           \
+    if (_e != hipSuccess) return fail_hip(ctx, _e, #expr); \
+  } while (0)
+
+int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n) {
+  if (c->force_tier >= 0 && c->force_tier <= 2) return c->force_tier;
+  double theta_max = 0.0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const double* f = p[i].twist;
+    const double phi = std::sqrt(f[3] * f[3] + f[4] * f[4] + f[5] * f[5]);
+    const double smax = std::fmax(std::fabs(p[i].x_req), std::fabs(1.0 - p[i].x_req));  // frac in [0,1]
+    theta_max = std::fmax(theta_max, phi * smax);
+  }
+  if (!(theta_max <= 1.0)) return kTrig;  // also catches NaN
+  return theta_max <= 0.25 ? kSeries3 : kSeries5;
+}
+
+template <typename REC>
+void fill_rec(const kmc_frame_params& p, REC* r) {
+  const kmc_host::Vec3 rho = {p.twist[0], p.twist[1], p.twist[2]};
+  const kmc_host::Vec3 phi = {p.twist[3], p.twist[4], p.twist[5]};
+  const kmc_host::Vec3 c1 = kmc_host::cross(phi, rho);
+  const kmc_host::Vec3 c2 = kmc_host::cross(phi, c1);
+  r->phi_x = (float)phi.x; r->phi_y = (float)phi.y; r->phi_z = (float)phi.z;
+  r->phi2 = (float)kmc_host::dot(phi, phi);
+  r->rho_x = (float)rho.x; r->rho_y = (float)rho.y; r->rho_z = (float)rho.z;
+  r->s0 = (float)(0.5 - p.x_req);
+  r->c1_x = (float)c1.x; r->c1_y = (float)c1.y; r->c1_z = (float)c1.z;
+  r->c2_x = (float)c2.x; r->c2_y = (float)c2.y; r->c2_z = (float)c2.z;
+}
+
+bool params_ok(const kmc_frame_params* p) {
+  for (int i = 0; i < 6; ++i)
+    if (!std::isfinite(p->twist[i])) return false;
+  return std::isfinite(p->x_req);
+}
+
+int grid_for(const kmc_ctx* c, uint64_t n_tiles) {
+  const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : kDefaultBlocksPerCu;
+  const uint64_t cap = (uint64_t)c->prop.multiProcessorCount * bpc;
+  return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, cap));
+}
+
+int ppt_of(const kmc_ctx* c) {
+  const int p = c->ppt > 0 ? c->ppt : kDefaultPpt;
+  return (p == 1 || p == 2 || p == 4 || p == 8) ? p : kDefaultPpt;
+}
+
+// ---- template dispatch ---------------------------------------------------------------------------
+template <int TIER, int PPT>
+void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
+  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, true, false>), dim3(grid), dim3(kBlock), 0, s, in, out, n, f);
+}
+template <int TIER>
+void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
+  switch (ppt) {
+    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f); break;
+    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f); break;
+    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f); break;
+    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f); break;
+  }
+}
+void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
+  const int ppt = ppt_of(c);
+  const uint64_t n_tiles = (n + (uint64_t)kBlock * ppt - 1) / ((uint64_t)kBlock * ppt);
+  const int grid = grid_for(c, n_tiles);
+  switch (tier) {
+    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f); break;
+    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f); break;
+    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f); break;
+  }
+}
+
+template <int TIER, int PPT>
+void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint32_t* tiles,
+                     uint32_t nf, uint64_t n, uint32_t* idx) {
+  if (idx)
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, true, true>), dim3(grid), dim3(kBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+  else
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, true, false>), dim3(grid), dim3(kBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+}
+template <int TIER>
+void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
+                    const uint32_t* tiles, uint32_t nf, uint64_t n, uint32_t* idx) {
+  switch (ppt) {
+    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx); break;
+    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx); break;
+    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx); break;
+    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx); break;
+  }
+}
+
+int ensure_tmp(kmc_ctx* c, size_t bytes) {
+  if (bytes <= c->tmp_cap) return KMC_OK;
+  if (c->d_tmp) {
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    KMC_HIP_TRY(c, hipFree(c->d_tmp));
+    c->d_tmp = nullptr;
+    c->tmp_cap = 0;
+  }
+  KMC_HIP_TRY(c, hipMalloc(&c->d_tmp, bytes));
+  c->tmp_cap = bytes;
+  return KMC_OK;
+}
+
+int ensure_pipeline(kmc_ctx* c) {
+  if (c->stage_cap) return KMC_OK;
+  const size_t bytes = kHostChunkPoints * sizeof(v4f);
+  for (int b = 0; b < 2; ++b) {
+    KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe[b], hipStreamNonBlocking));
+    KMC_HIP_TRY(c, hipMalloc(&c->d_stage_in[b], bytes));
+    KMC_HIP_TRY(c, hipMalloc(&c->d_stage_out[b], bytes));
+  }
+  c->stage_cap = bytes;
+  return KMC_OK;
+}
+
+struct CallTimer {
+  kmc_ctx* c;
+  explicit CallTimer(kmc_ctx* ctx) : c(ctx) {}
+  int begin_call() { return c->timing ? (hipEventRecord(c->ev_c0, c->stream) == hipSuccess ? KMC_OK : KMC_ERR_HIP) : KMC_OK; }
+  int begin_kernel() { return c->timing ? (hipEventRecord(c->ev_k0, c->stream) == hipSuccess ? KMC_OK : KMC_ERR_HIP) : KMC_OK; }
+  int end_kernel() { return c->timing ? (hipEventRecord(c->ev_k1, c->stream) == hipSuccess ? KMC_OK : KMC_ERR_HIP) : KMC_OK; }
+  int end_call(kmc_stats* st) {
+    if (!c->timing) return KMC_OK;
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_c1, c->stream));
+    KMC_HIP_TRY(c, hipEventSynchronize(c->ev_c1));
+    if (st) {
+      KMC_HIP_TRY(c, hipEventElapsedTime(&st->kernel_ms, c->ev_k0, c->ev_k1));
+      KMC_HIP_TRY(c, hipEventElapsedTime(&st->total_ms, c->ev_c0, c->ev_c1));
+    }
+    return KMC_OK;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int kmc_abi_version(void) { return KMC_ABI_VERSION; }
+
+const char* kmc_status_string(int status) {
+  switch (status) {
+    case KMC_OK: return "KMC_OK";
+    case KMC_ERR_INVALID_ARG: return "KMC_ERR_INVALID_ARG";
+    case KMC_ERR_HIP: return "KMC_ERR_HIP";
+    case KMC_ERR_NO_DEVICE: return "KMC_ERR_NO_DEVICE: no usable HIP device (the deskew path has no CPU fallback)";
+    case KMC_ERR_TIME_OUT_OF_RANGE: return "KMC_ERR_TIME_OUT_OF_RANGE: a time outside [stamp_start, stamp_end] (the reference asserts)";
+    case KMC_ERR_ALLOC: return "KMC_ERR_ALLOC";
+    case KMC_ERR_DEGENERATE: return "KMC_ERR_DEGENERATE";
+    default: return "KMC_ERR_UNKNOWN";
+  }
+}
+
+int kmc_hip_create(kmc_ctx** out, int device_id) {
+  if (!out) return KMC_ERR_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return KMC_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= count) return KMC_ERR_INVALID_ARG;
+  kmc_ctx* c = new (std::nothrow) kmc_ctx();
+  if (!c) return KMC_ERR_ALLOC;
+  c->device = device_id;
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  hipEvent_t* evs[] = {&c->ev_k0, &c->ev_k1, &c->ev_c0, &c->ev_c1, &c->ev_t0, &c->ev_t1};
+  for (hipEvent_t* ev : evs)
+    if (e == hipSuccess) e = hipEventCreate(ev);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    kmc_hip_destroy(c);
+    return KMC_ERR_NO_DEVICE;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return KMC_OK;
+}
+
+void kmc_hip_destroy(kmc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int b = 0; b < 2; ++b) {
+    if (c->pipe[b]) { (void)hipStreamSynchronize(c->pipe[b]); (void)hipStreamDestroy(c->pipe[b]); }
+    if (c->d_stage_in[b]) (void)hipFree(c->d_stage_in[b]);
+    if (c->d_stage_out[b]) (void)hipFree(c->d_stage_out[b]);
+  }
+  if (c->d_tmp) (void)hipFree(c->d_tmp);
+  if (c->d_recs) (void)hipFree(c->d_recs);
+  if (c->h_recs) (void)hipHostFree(c->h_recs);
+  if (c->d_tiles) (void)hipFree(c->d_tiles);
+  if (c->h_tiles) (void)hipHostFree(c->h_tiles);
+  if (c->d_counter) (void)hipFree(c->d_counter);
+  hipEvent_t evs[] = {c->ev_k0, c->ev_k1, c->ev_c0, c->ev_c1, c->ev_t0, c->ev_t1, c->ev_tables};
+  for (hipEvent_t ev : evs)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int kmc_hip_set_stream(kmc_ctx* c, void* hip_stream) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return KMC_OK;
+}
+
+int kmc_hip_synchronize(kmc_ctx* c) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return KMC_OK;
+}
+
+int kmc_hip_enable_timing(kmc_ctx* c, int enabled) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  c->timing = enabled != 0;
+  return KMC_OK;
+}
+
+const char* kmc_hip_last_error(kmc_ctx* c) { return c ? c->last_error.c_str() : "null ctx"; }
+
+int kmc_hip_device_info(kmc_ctx* c, kmc_device_info* out) {
+  if (!c || !out) return KMC_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  std::snprintf(out->name, sizeof(out->name), "%s", c->prop.name);
+  std::snprintf(out->arch, sizeof(out->arch), "%s", c->prop.gcnArchName);
+  out->device_id = c->device;
+  out->compute_units = c->prop.multiProcessorCount;
+  out->wavefront_size = c->prop.warpSize;
+  out->hbm_bytes = c->prop.totalGlobalMem;
+  out->clock_khz = c->prop.clockRate;
+  return KMC_OK;
+}
+
+int kmc_hip_set_launch_config(kmc_ctx* c, int blocks_per_cu, int points_per_thread) {
+  if (!c || blocks_per_cu < 0 || blocks_per_cu > 64) return KMC_ERR_INVALID_ARG;
+  if (!(points_per_thread == 0 || points_per_thread == 1 || points_per_thread == 2 || points_per_thread == 4 ||
+        points_per_thread == 8))
+    return KMC_ERR_INVALID_ARG;
+  c->blocks_per_cu = blocks_per_cu;
+  c->ppt = points_per_thread;
+  return KMC_OK;
+}
+
+int kmc_hip_force_tier(kmc_ctx* c, int tier) {
+  if (!c || tier < -1 || tier > 2) return KMC_ERR_INVALID_ARG;
+  c->force_tier = tier;
+  return KMC_OK;
+}
+
+int kmc_hip_timer_begin(kmc_ctx* c) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipEventRecord(c->ev_t0, c->stream));
+  return KMC_OK;
+}
+
+int kmc_hip_timer_end(kmc_ctx* c, float* elapsed_ms) {
+  if (!c || !elapsed_ms) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipEventRecord(c->ev_t1, c->stream));
+  KMC_HIP_TRY(c, hipEventSynchronize(c->ev_t1));
+  KMC_HIP_TRY(c, hipEventElapsedTime(elapsed_ms, c->ev_t0, c->ev_t1));
+  return KMC_OK;
+}
+
+// ---- host pre-step -------------------------------------------------------------------------------
+int kmc_frame_params_from_poses(const double T_start[12], const double T_end[12], double stamp_start, double stamp_end,
+                                double requested_time, kmc_frame_params* out) {
+  if (!T_start || !T_end || !out) return KMC_ERR_INVALID_ARG;
+  if (!(stamp_start < stamp_end)) return KMC_ERR_DEGENERATE;
+  // TimeIsInRange(requested_time): the reference asserts on it for every point (trajectory_interpolation.cpp:32)
+  if (!(requested_time >= stamp_start && requested_time <= stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  kmc_host::Twist f;
+  if (!kmc_host::relative_twist(kmc_host::Pose::from_rt12(T_start), kmc_host::Pose::from_rt12(T_end), &f)) return KMC_ERR_DEGENERATE;
+  out->twist[0] = f.rho.x; out->twist[1] = f.rho.y; out->twist[2] = f.rho.z;
+  out->twist[3] = f.phi.x; out->twist[4] = f.phi.y; out->twist[5] = f.phi.z;
+  out->x_req = (requested_time - stamp_start) / (stamp_end - stamp_start);
+  return params_ok(out) ? KMC_OK : KMC_ERR_DEGENERATE;
+}
+
+int kmc_oxts_to_pose(const kmc_oxts* o, double scale, double T_out[12]) {
+  if (!o || !T_out) return KMC_ERR_INVALID_ARG;
+  kmc_host::oxts_to_pose(o->lat, o->lon, o->alt, o->roll, o->pitch, o->yaw, scale).to_rt12(T_out);
+  return KMC_OK;
+}
+
+int kmc_interpolate_trajectory(const kmc_oxts* o1, const kmc_oxts* o2, double time, double T_out[12]) {
+  if (!o1 || !o2 || !T_out) return KMC_ERR_INVALID_ARG;
+  const kmc_host::Pose P1 = kmc_host::oxts_to_pose(o1->lat, o1->lon, o1->alt, o1->roll, o1->pitch, o1->yaw, 1.0);
+  const kmc_host::Pose P2 = kmc_host::oxts_to_pose(o2->lat, o2->lon, o2->alt, o2->roll, o2->pitch, o2->yaw, 1.0);
+  kmc_host::Pose P;
+  const int rc = kmc_host::pose_at_time(o1->stamp, P1, o2->stamp, P2, time, &P);
+  if (rc == -1) return KMC_ERR_TIME_OUT_OF_RANGE;
+  if (rc != 0) return KMC_ERR_DEGENERATE;
+  P.to_rt12(T_out);
+  return KMC_OK;
+}
+
+int kmc_make_frame_poses(const kmc_oxts* o_nm1, const kmc_oxts* o_n, const kmc_oxts* o_np1, double stamp_start,
+                         double stamp_end, double T_start_out[12], double T_end_out[12]) {
+  int rc = kmc_interpolate_trajectory(o_nm1, o_n, stamp_start, T_start_out);
+  if (rc != KMC_OK) return rc;
+  return kmc_interpolate_trajectory(o_n, o_np1, stamp_end, T_end_out);
+}
+
+// ---- hot path: single frame, f32 -----------------------------------------------------------------
+int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params,
+                       int mem_kind, kmc_stats* st) {
+  if (!c || !params || (n && (!xyzi_in || !xyzi_out))) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
+  if (!params_ok(params)) return KMC_ERR_INVALID_ARG;
+  if (!(params->x_req >= 0.0 && params->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  if (st) std::memset(st, 0, sizeof(*st));
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const int tier = pick_tier(c, params, 1);
+  FrameRec f;
+  std::memset(&f, 0, sizeof(f));
+  fill_rec(*params, &f);
+  if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
+  if (n == 0) return KMC_OK;
+  CallTimer tm(c);
+  if (mem_kind == KMC_MEM_DEVICE) {
+    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    launch_frame(c, c->stream, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f);
+    KMC_HIP_TRY(c, hipGetLastError());
+    if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    if (st) st->n_launches = 1;
+    return tm.end_call(st);
+  }
+  // KMC_MEM_HOST: two-slot H2D -> kernel -> D2H pipeline (PCIe-bound; see DESIGN.md "host buffers")
+  int rc = ensure_pipeline(c);
+  if (rc != KMC_OK) return rc;
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  uint32_t launches = 0;
+  for (uint64_t off = 0, k = 0; off < n; off += kHostChunkPoints, ++k) {
+    const int b = (int)(k & 1);
+    const uint64_t m = std::min<uint64_t>(kHostChunkPoints, n - off);
+    hipStream_t s = c->pipe[b];
+    KMC_HIP_TRY(c, hipMemcpyAsync(c->d_stage_in[b], xyzi_in + 4 * off, m * sizeof(v4f), hipMemcpyHostToDevice, s));
+    launch_frame(c, s, tier, (const v4f*)c->d_stage_in[b], (v4f*)c->d_stage_out[b], m, f);
+    KMC_HIP_TRY(c, hipGetLastError());
+    KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out + 4 * off, c->d_stage_out[b], m * sizeof(v4f), hipMemcpyDeviceToHost, s));
+    ++launches;
+  }
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[0]));
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[1]));
+  if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (st) st->n_launches = launches;
+  return tm.end_call(st);
+}
+
+// ---- hot path: batch of frames, f32 ---------------------------------------------------------------
+int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets, uint32_t n_frames,
+                             const kmc_frame_params* params, uint32_t* frame_idx_out, int mem_kind, kmc_stats* st) {
+  if (!c || !offsets || (n_frames && !params)) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (st) std::memset(st, 0, sizeof(*st));
+  if (offsets[0] != 0) return KMC_ERR_INVALID_ARG;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (offsets[f + 1] < offsets[f]) return KMC_ERR_INVALID_ARG;
+    if (!params_ok(&params[f])) return KMC_ERR_INVALID_ARG;
+    if (!(params[f].x_req >= 0.0 && params[f].x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  }
+  const uint64_t n = n_frames ? offsets[n_frames] : 0;
+  if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const int tier = pick_tier(c, params, n_frames);
+  if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
+  if (n == 0) return KMC_OK;
+
+  const int ppt = ppt_of(c);
+  const uint64_t tile = (uint64_t)kBlock * ppt;
+  const uint64_t n_tiles = (n + tile - 1) / tile;
+
+  // (re)allocate tables
+  if (n_frames > c->recs_cap) {
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_recs) (void)hipFree(c->d_recs);
+    if (c->h_recs) (void)hipHostFree(c->h_recs);
+    c->d_recs = nullptr; c->h_recs = nullptr; c->recs_cap = 0;
+    const size_t cap = std::max<size_t>(64, (size_t)n_frames * 2);
+    KMC_HIP_TRY(c, hipMalloc((void**)&c->d_recs, cap * sizeof(BatchRec)));
+    KMC_HIP_TRY(c, hipHostMalloc((void**)&c->h_recs, cap * sizeof(BatchRec), hipHostMallocDefault));
+    c->recs_cap = cap;
+  }
+  if (n_tiles > c->tiles_cap) {
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_tiles) (void)hipFree(c->d_tiles);
+    if (c->h_tiles) (void)hipHostFree(c->h_tiles);
+    c->d_tiles = nullptr; c->h_tiles = nullptr; c->tiles_cap = 0;
+    const size_t cap = std::max<size_t>(1024, (size_t)n_tiles * 2);
+    KMC_HIP_TRY(c, hipMalloc((void**)&c->d_tiles, cap * sizeof(uint32_t)));
+    KMC_HIP_TRY(c, hipHostMalloc((void**)&c->h_tiles, cap * sizeof(uint32_t), hipHostMallocDefault));
+    c->tiles_cap = cap;
+  }
+  // the pinned staging is reused: wait until the previous upload has been consumed
+  if (c->tables_in_flight) {
+    KMC_HIP_TRY(c, hipEventSynchronize(c->ev_tables));
+    c->tables_in_flight = false;
+  }
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    BatchRec* r = &c->h_recs[f];
+    fill_rec(params[f], r);
+    r->end_lo = (uint32_t)(offsets[f + 1] & 0xFFFFFFFFull);
+    r->end_hi = (uint32_t)(offsets[f + 1] >> 32);
+  }
+  {
+    uint32_t f = 0;
+    for (uint64_t t = 0; t < n_tiles; ++t) {
+      const uint64_t first = t * tile;
+      while (f + 1 < n_frames && offsets[f + 1] <= first) ++f;  // skips empty frames
+      c->h_tiles[t] = f;
+    }
+  }
+
+  CallTimer tm(c);
+  const v4f* d_in = (const v4f*)xyzi_in;
+  v4f* d_out = (v4f*)xyzi_out;
+  uint32_t* d_idx = frame_idx_out;
+  if (mem_kind == KMC_MEM_HOST) {
+    const size_t pts = n * sizeof(v4f);
+    const size_t idx_bytes = frame_idx_out ? n * sizeof(uint32_t) : 0;
+    int rc = ensure_tmp(c, 2 * pts + idx_bytes);
+    if (rc != KMC_OK) return rc;
+    d_in = (const v4f*)c->d_tmp;
+    d_out = (v4f*)((char*)c->d_tmp + pts);
+    d_idx = frame_idx_out ? (uint32_t*)((char*)c->d_tmp + 2 * pts) : nullptr;
+  }
+  if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (mem_kind == KMC_MEM_HOST)
+    KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, n * sizeof(v4f), hipMemcpyHostToDevice, c->stream));
+  KMC_HIP_TRY(c, hipMemcpyAsync(c->d_recs, c->h_recs, (size_t)n_frames * sizeof(BatchRec), hipMemcpyHostToDevice, c->stream));
+  KMC_HIP_TRY(c, hipMemcpyAsync(c->d_tiles, c->h_tiles, (size_t)n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  KMC_HIP_TRY(c, hipEventRecord(c->ev_tables, c->stream));
+  c->tables_in_flight = true;
+  if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  const int grid = grid_for(c, n_tiles);
+  switch (tier) {
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in, d_out, c->d_recs, c->d_tiles, n_frames, n, d_idx); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in, d_out, c->d_recs, c->d_tiles, n_frames, n, d_idx); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in, d_out, c->d_recs, c->d_tiles, n_frames, n, d_idx); break;
+  }
+  KMC_HIP_TRY(c, hipGetLastError());
+  if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (mem_kind == KMC_MEM_HOST) {
+    KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out, d_out, n * sizeof(v4f), hipMemcpyDeviceToHost, c->stream));
+    if (frame_idx_out) KMC_HIP_TRY(c, hipMemcpyAsync(frame_idx_out, d_idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (st) st->n_launches = 1;
+  return tm.end_call(st);
+}
+
+// ---- f64 Eigen-layout path ------------------------------------------------------------------------
+int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
+                           uint64_t n, double stamp_start, double stamp_end, const kmc_frame_params* params, double* ox,
+                           double* oy, double* oz, double* ow, int mem_kind, kmc_stats* st) {
+  if (!c || !params) return KMC_ERR_INVALID_ARG;
+  if (n && (!x || !y || !z || !stamps || !ox || !oy || !oz)) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (!(stamp_start < stamp_end)) return KMC_ERR_DEGENERATE;
+  if (!params_ok(params)) return KMC_ERR_INVALID_ARG;
+  if (!(params->x_req >= 0.0 && params->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  if (st) std::memset(st, 0, sizeof(*st));
+  if (st) { st->n_points = n; st->variant = 3; }
+  if (n == 0) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+
+  FrameRec64 f;
+  const kmc_host::Vec3 rho = {params->twist[0], params->twist[1], params->twist[2]};
+  const kmc_host::Vec3 phi = {params->twist[3], params->twist[4], params->twist[5]};
+  const kmc_host::Vec3 c1 = kmc_host::cross(phi, rho);
+  const kmc_host::Vec3 c2 = kmc_host::cross(phi, c1);
+  f.phi[0] = phi.x; f.phi[1] = phi.y; f.phi[2] = phi.z;
+  f.rho[0] = rho.x; f.rho[1] = rho.y; f.rho[2] = rho.z;
+  f.c1[0] = c1.x; f.c1[1] = c1.y; f.c1[2] = c1.z;
+  f.c2[0] = c2.x; f.c2[1] = c2.y; f.c2[2] = c2.z;
+  f.phi2 = kmc_host::dot(phi, phi);
+  f.x_req = params->x_req;
+  f.t_start = stamp_start;
+  f.t_end = stamp_end;
+  f.dur = stamp_end - stamp_start;
+
+  const double *dx = x, *dy = y, *dz = z, *dw = w, *ds = stamps;
+  double *dox = ox, *doy = oy, *doz = oz, *dow = ow;
+  const size_t col = n * sizeof(double);
+  if (mem_kind == KMC_MEM_HOST) {
+    int rc = ensure_tmp(c, 9 * col);
+    if (rc != KMC_OK) return rc;
+    double* base = (double*)c->d_tmp;
+    double* cols[9];
+    for (int i = 0; i < 9; ++i) cols[i] = base + (size_t)i * n;
+    KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, col, hipMemcpyHostToDevice, c->stream));
+    KMC_HIP_TRY(c, hipMemcpyAsync(cols[1], y, col, hipMemcpyHostToDevice, c->stream));
+    KMC_HIP_TRY(c, hipMemcpyAsync(cols[2], z, col, hipMemcpyHostToDevice, c->stream));
+    if (w) KMC_HIP_TRY(c, hipMemcpyAsync(cols[3], w, col, hipMemcpyHostToDevice, c->stream));
+    KMC_HIP_TRY(c, hipMemcpyAsync(cols[4], stamps, col, hipMemcpyHostToDevice, c->stream));
+    dx = cols[0]; dy = cols[1]; dz = cols[2]; dw = w ? cols[3] : nullptr; ds = cols[4];
+    dox = cols[5]; doy = cols[6]; doz = cols[7]; dow = ow ? cols[8] : nullptr;
+  }
+  CallTimer tm(c);
+  if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+  if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  const int grid = grid_for(c, (n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(deskew_f64cols, dim3(grid), dim3(kBlock), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter);
+  KMC_HIP_TRY(c, hipGetLastError());
+  if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  unsigned long long bad = 0;
+  KMC_HIP_TRY(c, hipMemcpyAsync(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+  if (mem_kind == KMC_MEM_HOST) {
+    KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, col, hipMemcpyDeviceToHost, c->stream));
+    KMC_HIP_TRY(c, hipMemcpyAsync(oy, doy, col, hipMemcpyDeviceToHost, c->stream));
+    KMC_HIP_TRY(c, hipMemcpyAsync(oz, doz, col, hipMemcpyDeviceToHost, c->stream));
+    if (ow) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
+  }
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the out-of-range verdict is part of the call's result
+  if (st) { st->n_launches = 1; st->n_out_of_range = bad; }
+  int rc = tm.end_call(st);
+  if (rc != KMC_OK) return rc;
+  return bad ? KMC_ERR_TIME_OUT_OF_RANGE : KMC_OK;
+}
+
+int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, uint64_t n, double scan_start, double scan_end,
+                                  double* stamps_out, int mem_kind) {
+  if (!c || (n && (!x || !y || !stamps_out))) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (n == 0) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const size_t col = n * sizeof(double);
+  const double *dx = x, *dy = y;
+  double* dout = stamps_out;
+  if (mem_kind == KMC_MEM_HOST) {
+    int rc = ensure_tmp(c, 3 * col);
+    if (rc != KMC_OK) return rc;
+    double* base = (double*)c->d_tmp;
+    KMC_HIP_TRY(c, hipMemcpyAsync(base, x, col, hipMemcpyHostToDevice, c->stream));
+    KMC_HIP_TRY(c, hipMemcpyAsync(base + n, y, col, hipMemcpyHostToDevice, c->stream));
+    dx = base; dy = base + n; dout = base + 2 * n;
+  }
+  const int grid = grid_for(c, (n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(pseudo_timestamps_f64, dim3(grid), dim3(kBlock), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
+  KMC_HIP_TRY(c, hipGetLastError());
+  if (mem_kind == KMC_MEM_HOST) {
+    KMC_HIP_TRY(c, hipMemcpyAsync(stamps_out, dout, col, hipMemcpyDeviceToHost, c->stream));
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return KMC_OK;
+}
+
+// ---- synthetic workload ----------------------------------------------------------------------------
+int kmc_hip_synth_points(kmc_ctx* c, float* xyzi_out_device, uint64_t n, uint64_t seed) {
+  if (!c || (n && !xyzi_out_device)) return KMC_ERR_INVALID_ARG;
+  if (n == 0) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const int grid = grid_for(c, (n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(synth_points, dim3(grid), dim3(kBlock), 0, c->stream, (v4f*)xyzi_out_device, n, seed);
+  KMC_HIP_TRY(c, hipGetLastError());
+  return KMC_OK;
+}
+
+int kmc_synth_points_host(float* out, uint64_t n, uint64_t seed) {
+  if (n && !out) return KMC_ERR_INVALID_ARG;
+  for (uint64_t i = 0; i < n; ++i) {
+    const kmc_synth::Point p = kmc_synth::make_point(i, n, seed);
+    out[4 * i + 0] = p.x;
+    out[4 * i + 1] = p.y;
+    out[4 * i + 2] = p.z;
+    out[4 * i + 3] = p.i;
+  }
+  return KMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+// kmc_kernels.hip.h -- the __global__ kernels of the deskew engine (gfx950 / CDNA4, wave64, no MFMA).
+//
+// Roofline: HBM.  32 algorithmic bytes per point (16 B v4f {x,y,z,intensity} read + 16 B written),
+// ~110 VALU ops per point -> 3.4 flop/B, far below the ~20 flop/B ridge.  Design rules applied
+// (cdna_hip_programming.md G2/G7/G11/G13, App. B "element-wise"):
+//   * one lane = one point, one global_load_dwordx4 / global_store_dwordx4 per point: a wave moves 1 KiB
+//     per instruction, perfectly coalesced;
+//   * PPT independent 16-B loads per lane are issued before the first use (memory-level parallelism:
+//     >= 32 KiB in flight per CU at 8 waves), arithmetic of tile t overlaps the loads of other waves;
+//   * grid = CUs x blocks_per_cu persistent workgroups, grid-stride over tiles, so consecutive workgroups
+//     (which the dispatcher places round-robin on the 8 XCDs) stream consecutive 4-16 KiB tiles: every
+//     XCD's L2 and every HBM channel sees the same uniform sequential load -- there is no inter-tile reuse
+//     to localise, so no XCD swizzle is needed (T1 gives 0 % on reuse-free kernels);
+//   * streamed-once data: non-temporal loads/stores keep the 4 MiB L2s / 256 MiB MALL from thrashing;
+//   * per-frame constants are wave-uniform: kernarg / scalar loads -> SGPRs (single-frame kernel), or a
+//     per-tile scalar-loaded record with an LDS-staged table for tiles that straddle frames (batched kernel).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmc_device_math.hip.h"
+#include "kmc_synth.h"
+
+namespace kmc_dev {
+
+constexpr int kBlock = 256;  // 4 waves: one per SIMD
+
+template <bool NT>
+__device__ __forceinline__ v4f load_point(const v4f* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void store_point(v4f* p, v4f v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-frame kernel: constants by value (kernarg segment -> s_load -> SGPRs)
+// ------------------------------------------------------------------------------------------------
+template <int TIER, int PPT, bool NT, bool OCML_ATAN>
+__global__ __launch_bounds__(kBlock) void deskew_frame_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
+                                                          uint64_t n, FrameRec f) {
+  constexpr uint64_t kTile = (uint64_t)kBlock * PPT;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_full = n / kTile;  // tiles that need no bounds checks
+  for (uint64_t t = blockIdx.x; t < n_full; t += gridDim.x) {
+    const v4f* __restrict__ tin = in + t * kTile;
+    v4f* __restrict__ tout = out + t * kTile;
+    v4f p[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * kBlock + tid);
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) store_point<NT>(tout + u * kBlock + tid, deskew_point<TIER, OCML_ATAN>(p[u], f));
+  }
+  // ragged tail (< kTile points): handled by the workgroup that would own tile n_full
+  if (blockIdx.x == n_full % gridDim.x) {
+    const uint64_t base = n_full * kTile;
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      const uint64_t i = base + (uint64_t)u * kBlock + tid;
+      if (i < n) store_point<NT>(out + i, deskew_point<TIER, OCML_ATAN>(load_point<NT>(in + i), f));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched kernel: many frames in one launch
+// ------------------------------------------------------------------------------------------------
+// Device-side frame record of the batch: FrameRec with the frame's END offset in the two pad words.
+struct alignas(16) BatchRec {
+  float phi_x, phi_y, phi_z, phi2;
+  float rho_x, rho_y, rho_z, s0;
+  float c1_x, c1_y, c1_z;
+  uint32_t end_lo;  // offsets[f+1], low / high 32 bits
+  float c2_x, c2_y, c2_z;
+  uint32_t end_hi;
+};
+static_assert(sizeof(BatchRec) == 64, "BatchRec must stay one 64-byte record");
+
+__device__ __forceinline__ uint64_t rec_end(const BatchRec& r) { return ((uint64_t)r.end_hi << 32) | r.end_lo; }
+
+__device__ __forceinline__ FrameRec to_frame(const BatchRec& r) {
+  FrameRec f;
+  f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
+  f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
+  f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pad0 = 0.f;
+  f.c2_x = r.c2_x; f.c2_y = r.c2_y; f.c2_z = r.c2_z; f.pad1 = 0.f;
+  return f;
+}
+
+constexpr int kLdsFrames = 16;  // records staged in LDS for a tile that straddles frame boundaries
+
+// tile_first[t] = index of the frame that owns the first point of tile t (host-computed, 4 B per tile).
+// A tile lies in ONE frame in all but ~F of the n/kTile tiles; then the record is fetched with scalar
+// loads (wave-uniform -> SGPRs) and the body is identical to the single-frame kernel.  A straddling tile
+// stages the next kLdsFrames records into LDS once per workgroup; each lane then walks to its own frame
+// (integer compares on the end offsets -- the per-point "timestamp index", bit-exact by construction) and
+// gathers its record from LDS; a wave whose lanes all landed in one frame broadcasts lane 0's record through
+// readfirstlane so it stays on the scalar path.
+template <int TIER, int PPT, bool NT, bool WRITE_IDX>
+__global__ __launch_bounds__(kBlock) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
+                                                          const BatchRec* __restrict__ recs,
+                                                          const uint32_t* __restrict__ tile_first, uint32_t n_frames,
+                                                          uint64_t n, uint32_t* __restrict__ frame_idx_out) {
+  constexpr uint64_t kTile = (uint64_t)kBlock * PPT;
+  __shared__ BatchRec lds_recs[kLdsFrames];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_tiles = (n + kTile - 1) / kTile;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t base = t * kTile;
+    const uint64_t tile_end = (base + kTile < n) ? base + kTile : n;
+    const uint32_t f0 = tile_first[t];           // uniform -> s_load_dword
+    const BatchRec r0 = recs[f0];                // uniform -> s_load_dwordx16
+    const bool uniform_tile = rec_end(r0) >= tile_end;
+    if (uniform_tile && tile_end - base == kTile) {
+      // fast path: full tile inside one frame
+      const FrameRec f = to_frame(r0);
+      const v4f* __restrict__ tin = in + base;
+      v4f* __restrict__ tout = out + base;
+      v4f p[PPT];
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * kBlock + tid);
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        store_point<NT>(tout + u * kBlock + tid, deskew_point<TIER, false>(p[u], f));
+        if constexpr (WRITE_IDX) __builtin_nontemporal_store(f0, frame_idx_out + base + u * kBlock + tid);
+      }
+    } else {
+      // slow path: ragged last tile and/or a tile that straddles frame boundaries
+      __syncthreads();  // previous iteration's LDS readers are done
+      if (tid < kLdsFrames * 4) {  // 16 records x 4 x 16 B: one ds_write_b128 per lane
+        const uint32_t fr = f0 + (tid >> 2);
+        if (fr < n_frames)
+          reinterpret_cast<v4f*>(lds_recs)[tid] = reinterpret_cast<const v4f*>(recs)[(uint64_t)f0 * 4 + tid];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) {
+        const uint64_t i = base + (uint64_t)u * kBlock + tid;
+        const bool live = i < tile_end;
+        // walk to the frame that owns point i (skips empty frames); dead lanes stay on f0
+        uint32_t fi = f0;
+        if (live) {
+          while (true) {
+            const uint32_t k = fi - f0;
+            const uint64_t e = (k < kLdsFrames) ? rec_end(lds_recs[k]) : rec_end(recs[fi]);
+            if (i < e || fi + 1 >= n_frames) break;
+            ++fi;
+          }
+        }
+        // wave-level broadcast when the whole wave sits in one frame
+        const uint32_t fi0 = __builtin_amdgcn_readfirstlane(fi);
+        const bool wave_uniform = __all(fi == fi0);
+        BatchRec r;
+        if (wave_uniform) {
+          const uint32_t k0 = fi0 - f0;
+          r = (k0 < kLdsFrames) ? lds_recs[k0] : recs[fi0];  // uniform address: LDS broadcast / scalar load
+        } else {
+          const uint32_t k = fi - f0;
+          r = (k < kLdsFrames) ? lds_recs[k] : recs[fi];     // per-lane gather
+        }
+        if (live) {
+          const FrameRec f = to_frame(r);
+          store_point<NT>(out + i, deskew_point<TIER, false>(load_point<NT>(in + i), f));
+          if constexpr (WRITE_IDX) frame_idx_out[i] = fi;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// f64 Eigen-layout kernel (compatibility path of MotionCompensateFrame(Frame const&, Time))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
+                                                        const double* __restrict__ z, const double* __restrict__ w,
+                                                        const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
+                                                        double* __restrict__ ox, double* __restrict__ oy,
+                                                        double* __restrict__ oz, double* __restrict__ ow,
+                                                        unsigned long long* __restrict__ n_bad) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double t = stamps[i];
+    const double px = x[i], py = y[i], pz = z[i], pw = w ? w[i] : 1.0;
+    const bool in_range = (t >= f.t_start) && (t <= f.t_end);  // TimeIsInRange, trajectory_interpolation.cpp:47
+    double rx, ry, rz;
+    if (in_range) {
+      const double xi = (t - f.t_start) / f.dur;  // FractionOfTrajectory, :49-51 (a true divide, like the reference)
+      deskew_point_f64(px, py, pz, pw, xi - f.x_req, f, rx, ry, rz);
+    } else {
+      rx = ry = rz = __builtin_nan("");
+    }
+    ox[i] = rx;
+    oy[i] = ry;
+    oz[i] = rz;
+    if (ow) ow[i] = pw;
+    const unsigned long long bad = __ballot(!in_range);
+    if (bad && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(bad)) atomicAdd(n_bad, (unsigned long long)__builtin_popcountll(bad));
+  }
+}
+
+// GetPseudoTimeStamps (timestamp_mocking.cpp:46-63) in f64
+__global__ __launch_bounds__(kBlock) void pseudo_timestamps_f64(const double* __restrict__ x, const double* __restrict__ y,
+                                                               uint64_t n, double start, double end,
+                                                               double* __restrict__ stamps) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  const double dur = end - start;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double frac = (3.14159265358979323846 - atan2(y[i], x[i])) / (2.0 * 3.14159265358979323846);
+    stamps[i] = start + (frac * dur);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic generator + a plain copy kernel (the measured same-hardware ceiling for the roofline table)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void synth_points(v4f* __restrict__ out, uint64_t n, uint64_t seed) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const kmc_synth::Point p = kmc_synth::make_point(i, n, seed);
+    out[i] = v4f{p.x, p.y, p.z, p.i};
+  }
+}
+
+template <int PPT, bool NT>
+__global__ __launch_bounds__(kBlock) void copy_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  constexpr uint64_t kTile = (uint64_t)kBlock * PPT;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_full = n / kTile;
+  for (uint64_t t = blockIdx.x; t < n_full; t += gridDim.x) {
+    const v4f* __restrict__ tin = in + t * kTile;
+    v4f* __restrict__ tout = out + t * kTile;
+    v4f p[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * kBlock + tid);
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) store_point<NT>(tout + u * kBlock + tid, p[u]);
+  }
+}
+
+}  // namespace kmc_dev

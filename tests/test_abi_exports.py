@@ -1,0 +1,74 @@
+"""The C-ABI library loads on a GPU-less box and exports every symbol include/kmc_hip.h declares; the product never
+touches the oracle.  No compute calls here."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from kitti_motion_compensation_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "kmc_hip.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kmc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    assert sorted(capi.SIGNATURES) == declared
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    for name in _declared_symbols():
+        assert hasattr(L, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\sT\s+(kmc_[a-z0-9_]+)", out))
+    assert set(_declared_symbols()) <= exported
+    assert L.kmc_abi_version() == 1
+
+
+def test_library_contains_gfx950_code_object():
+    out = subprocess.run(["strings", "-n", "6", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "gfx950" in out
+
+
+def test_status_strings():
+    assert capi.status_string(capi.OK) == "KMC_OK"
+    assert "no CPU fallback" in capi.status_string(capi.ERR_NO_DEVICE)
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.KmcError) as e:
+        capi.Context(0)
+    assert e.value.status == capi.ERR_NO_DEVICE
+
+
+def test_product_never_references_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    bad = []
+    pkg = os.path.join(ROOT, "kitti_motion_compensation_amd")
+    for base in (pkg, os.path.join(ROOT, "include")):
+        for dp, _, files in os.walk(base):
+            for fn in files:
+                if fn.endswith((".so", ".o", ".pyc")):
+                    continue
+                with open(os.path.join(dp, fn), errors="ignore") as f:
+                    txt = f.read()
+                if re.search(r"kmc_oracle|kmo_|from oracle|import oracle|libkmc_oracle", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    out = subprocess.run(["nm", "-D", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "kmo_" not in out
+    ldd = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd

@@ -1,0 +1,113 @@
+"""Host f64 pre-step of the product (libkmc_hip.so, no GPU needed) against the CPU oracle and the reference KATs:
+kmc_frame_params_from_poses, kmc_oxts_to_pose, kmc_interpolate_trajectory, kmc_make_frame_poses."""
+import os
+
+import numpy as np
+import pytest
+
+from kitti_motion_compensation_amd import capi
+from oracle import oracle as orc
+from tests import util
+
+
+def _rt(a: "orc.Affine"):
+    return a.rt12().reshape(3, 4)
+
+
+def _oracle_twist(P1, P2):
+    return orc.se3_log(orc.affine_mul(orc.affine_inverse(P1), P2))
+
+
+def _kitti_pose(golden_dir):
+    f = util.load_oxts_fields(os.path.join(golden_dir, "kitti_2011_09_26_drive_0005"), 0)
+    return f, orc.oxts_to_pose(orc.oxts(**f))
+
+
+@pytest.mark.parametrize("step", [
+    [1.3, 0.05, -0.02, 0.0, 0.0, 0.0],          # straight line: theta = 0 -> first-order branch
+    [1.3, 0.05, -0.02, 1e-7, -2e-7, 3e-7],      # below the 1e-6 branch point
+    [1.3, 0.05, -0.02, 0.001, -0.002, 0.03],    # gentle turn
+    [2.9, -0.3, 0.1, 0.02, 0.01, -0.1],         # hard turn
+    [0.4, 0.1, 0.0, 0.3, -0.9, 1.2],            # large rotation
+    [0.0, 0.0, 0.0, 0.0, 0.0, 0.0],             # stationary
+])
+def test_frame_params_match_oracle_log(step, golden_dir):
+    _, P1 = _kitti_pose(golden_dir)
+    P2 = orc.affine_mul(P1, orc.se3_exp(step))
+    t0, t1, tr = 47072.283701593, 47072.386973931, 47072.335337762
+    p = capi.frame_params_from_poses(_rt(P1), _rt(P2), t0, t1, tr)
+    want = _oracle_twist(P1, P2)
+    # the oracle's own noise floor here is ~2e-9 m (6e6 m Mercator cancellation)
+    assert np.allclose(p.twist_np()[:3], want[:3], atol=5e-9), (p.twist_np(), want)
+    assert np.allclose(p.twist_np()[3:], want[3:], atol=1e-12)
+    assert np.allclose(p.twist_np(), step, atol=5e-9)
+    assert p.x_req == (tr - t0) / (t1 - t0)
+
+
+def test_frame_params_reference_kat_constants(kats):
+    """test_motion_compensation.cpp fixture: lon 0 / 1e-5 / 2e-5 deg -> pure x translation, no rotation."""
+    k = kats["motion_compensate_frame"]
+    ox = [capi.Oxts(**{kk: vv for kk, vv in o.items()}) for o in k["oxts"]]
+    T_start, T_end = capi.make_frame_poses(ox[0], ox[1], ox[2], k["stamp_start"], k["stamp_end"])
+    oo = [orc.oxts(**o) for o in k["oxts"]]
+    rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], k["stamp_start"], k["stamp_end"])
+    assert rc == orc.OK
+    assert np.allclose(T_start, _rt(A), atol=1e-12) and np.allclose(T_end, _rt(B), atol=1e-12)
+    p = capi.frame_params_from_poses(T_start, T_end, k["stamp_start"], k["stamp_end"], k["requested_time"])
+    dx = 6378137.0 * np.pi * 1e-5 / 180.0  # metres per 1e-5 deg of longitude at scale 1
+    assert np.allclose(p.twist_np(), [dx, 0, 0, 0, 0, 0], atol=1e-12)
+    assert p.x_req == pytest.approx(0.5, abs=1e-15)
+
+
+def test_requested_time_out_of_range_is_rejected(golden_dir):
+    _, P1 = _kitti_pose(golden_dir)
+    P2 = orc.affine_mul(P1, orc.se3_exp([1, 0, 0, 0, 0, 0.01]))
+    with pytest.raises(capi.KmcError) as e:
+        capi.frame_params_from_poses(_rt(P1), _rt(P2), 10.0, 10.1, 9.99)
+    assert e.value.status == capi.ERR_TIME_OUT_OF_RANGE
+    with pytest.raises(capi.KmcError) as e:
+        capi.frame_params_from_poses(_rt(P1), _rt(P2), 10.0, 10.0, 10.0)
+    assert e.value.status == capi.ERR_DEGENERATE
+    # boundaries are inclusive (trajectory_interpolation.cpp:47)
+    assert capi.frame_params_from_poses(_rt(P1), _rt(P2), 10.0, 10.1, 10.0).x_req == 0.0
+    assert capi.frame_params_from_poses(_rt(P1), _rt(P2), 10.0, 10.1, 10.1).x_req == 1.0
+
+
+def test_oxts_to_pose_kat(kats, golden_dir):
+    k = kats["oxts_to_pose"]
+    f, P = _kitti_pose(golden_dir)
+    T = capi.oxts_to_pose(capi.Oxts(**f), k["scale"])
+    util.assert_float_eq(T[:, 3], k["expected_translation"])
+    util.assert_float_eq(np.linalg.det(T[:, :3]), k["expected_det"])
+    assert np.allclose(T, _rt(P), atol=1e-15, rtol=0) or np.allclose(T[:, :3], P.Rm(), atol=1e-15)
+    assert np.array_equal(T[:, 3], P.tv())
+
+
+def test_interpolate_trajectory_matches_oracle_and_midpoint_kat(kats, golden_dir):
+    f, _ = _kitti_pose(golden_dir)
+    o0 = dict(f)
+    o1 = dict(f, stamp=f["stamp"] + 0.1, lat=f["lat"] + 2e-6, lon=f["lon"] + 4e-6, yaw=f["yaw"] + 0.02, roll=f["roll"] - 0.003,
+              alt=f["alt"] + 0.05)
+    for frac in (0.0, 0.25, 0.5, 1.0):
+        t = o0["stamp"] + frac * 0.1
+        T = capi.interpolate_trajectory(capi.Oxts(**o0), capi.Oxts(**o1), t)
+        rc, A = orc.get_pose_at_time(orc.interpolator_from_oxts(orc.oxts(**o0), orc.oxts(**o1)), t)
+        assert rc == orc.OK
+        assert np.allclose(T[:, :3], A.Rm(), atol=1e-13)
+        assert np.allclose(T[:, 3], A.tv(), atol=5e-9)
+    with pytest.raises(capi.KmcError) as e:  # test_trajectory_interpolation.cpp:77-81
+        capi.interpolate_trajectory(capi.Oxts(**o0), capi.Oxts(**o1), kats["trajectory_out_of_range"]["query_time"])
+    assert e.value.status == capi.ERR_TIME_OUT_OF_RANGE
+
+
+def test_synth_points_host_is_deterministic_and_shaped():
+    a = capi.synth_points_host(100_000, 0x4B4D43)
+    b = capi.synth_points_host(100_000, 0x4B4D43)
+    c = capi.synth_points_host(100_000, 0x4B4D44)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    r = np.linalg.norm(a[:, :3].astype(np.float64), axis=1)
+    assert 2.0 <= r.min() and r.max() < 80.001
+    frac = (np.pi - np.arctan2(a[:, 1].astype(np.float64), a[:, 0].astype(np.float64))) / (2 * np.pi)
+    steps = (100_000 + 63) // 64
+    assert np.all(np.diff(frac[:steps]) > -1e-6)  # one ring sweeps the scan in order
+    assert set(np.round(a[:, 3] * 100).astype(int)) <= set(range(100))
