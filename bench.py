@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X deskew engine (contract: see the round prompt / DESIGN.md "Measurement").
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Metric (BASELINE.json): M points/s deskewed, with the achieved HBM GB/s of the per-point transform kernel.
+Workload = BASELINE.json configs[1]: synthetic 1 M-point frames, straight-line constant-velocity trajectory.  One STEP is
+one pass of the hot path over one batch of FRAMES_PER_STEP distinct such frames (64 x 1 M points = 1 GiB in + 1 GiB out,
+far beyond the 256 MiB Infinity Cache, so the GB/s are HBM GB/s) issued as ONE launch of the batched kernel through the
+C-ABI (kmc_hip_deskew_batch_f32, KMC_MEM_DEVICE: inputs resident in HBM before the timed region starts).
+Every rank processes its own batch (frame-sharded, weak scaling); RCCL is used only to reduce the counters.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured float4-copy ceiling
+BYTES_PER_POINT = 32    # algorithmic: 16 B {x,y,z,intensity} read + 16 B written
+POINTS_PER_FRAME = 1_000_000
+SEED = 0x4B4D43
+
+
+def make_workload(capi, n_frames, rank):
+    """configs[1] trajectory: yaw = roll = pitch = 0, 10 m/s east; OXTS at T0 + {.05,.15,.25}, scan T0 + {.10,.15,.20}."""
+    v = 10.0
+    dlon = v * 0.1 * 180.0 / (np.pi * 6378137.0)
+    params = []
+    for f in range(n_frames):
+        Tz = 47072.0 + 0.1 * (f + rank * n_frames)
+        k0 = f + rank * n_frames
+        ox = [capi.Oxts(stamp=Tz + 0.05 + 0.1 * i, lat=0.0, lon=dlon * (k0 + i), alt=0, roll=0, pitch=0, yaw=0) for i in range(3)]
+        t0, tm, t1 = Tz + 0.10, Tz + 0.15, Tz + 0.20
+        T_start, T_end = capi.make_frame_poses(ox[0], ox[1], ox[2], t0, t1)
+        params.append((capi.frame_params_from_poses(T_start, T_end, t0, t1, tm), (t0, tm, t1), (ox[0], ox[1], ox[2])))
+    return params
+
+
+def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)."""
+    from oracle import oracle as orc
+
+    cores = os.cpu_count() or 1
+    per = POINTS_PER_FRAME
+
+    def run(mode, threads, frames):
+        t = time.perf_counter()
+        pts = 0
+        for f in range(frames):
+            (t0, tm, t1), oxs = frame_meta[f]
+            oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
+            rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
+            r = orc.deskew_xyzi_f32(xyzi_sample[f * per:(f + 1) * per], t0, A, t1, B, tm, mode=mode, threads=threads,
+                                    want_f64=False, want_f32=True)
+            assert rc == orc.OK and r["rc"] == orc.OK
+            pts += per
+        return pts / (time.perf_counter() - t) / 1e6
+
+    b1 = run(orc.FAITHFUL, 1, n_frames_sample)            # B1: the reference's op sequence, 1 thread (it is single-threaded)
+    b2 = run(orc.FAITHFUL, cores, n_frames_sample)        # B2: same, OpenMP over points
+    b3 = run(orc.HOISTED, cores, n_frames_sample)         # B3: hoisted closed form, all cores
+    return {
+        "value": round(b1, 3), "unit": "Mpts/s", "cores": 1, "kind": "port",
+        "sample": f"{n_frames_sample} of the step's 1M-point frames ({n_frames_sample * per} points), oracle FAITHFUL mode "
+                  "(reference op sequence incl. per-point Log/Exp), f64, 1 thread like the reference",
+        "all_cores": {"cores": cores, "faithful_Mpts_s": round(b2, 3), "hoisted_closed_form_Mpts_s": round(b3, 3)},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=24)
+    args = ap.parse_args()
+
+    import torch
+
+    from kitti_motion_compensation_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # backend "nccl" IS RCCL on ROCm
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the deskew path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    F = args.frames_per_step
+    n = F * POINTS_PER_FRAME
+    ctx = capi.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    info = ctx.device_info()
+
+    # ---- workload: generated on the device (identical generator on the host for the oracle), resident in HBM ----
+    d_in = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    d_out = torch.empty_like(d_in)
+    for f in range(F):
+        ctx.synth_points(d_in[f * POINTS_PER_FRAME:(f + 1) * POINTS_PER_FRAME], POINTS_PER_FRAME, SEED + f + rank * F)
+    work = make_workload(capi, F, rank)
+    params = capi.params_array([w[0] for w in work])
+    offsets = np.arange(F + 1, dtype=np.uint64) * POINTS_PER_FRAME
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.deskew_batch_f32(d_in, d_out, offsets, params, None)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, HIP events on the launch stream ----
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_begin = time.perf_counter()
+    ctx.timer_begin()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_end()  # hipEventRecord + hipEventSynchronize on the same stream
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.perf_counter() - t_begin
+
+    t_max, pts_total, ev_max = wall, float(n * args.steps), ev_ms
+    if dist:
+        tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)          # RCCL: the only collective of the job
+        tsum = torch.tensor([float(n * args.steps)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        t_max, ev_max, pts_total = tmax[0].item(), tmax[1].item(), tsum[0].item()
+
+    # ---- parity spot check outside the timed region (a slice of the last output against the oracle) ----
+    parity = None
+    if rank == 0:
+        from oracle import oracle as orc
+
+        f = F - 1
+        sl = slice(f * POINTS_PER_FRAME, f * POINTS_PER_FRAME + 50_000)
+        xyzi = d_in[sl].cpu().numpy()
+        got = d_out[sl].cpu().numpy()
+        (t0, tm, t1), oxs = work[f][1], work[f][2]
+        oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
+        rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
+        ref = orc.deskew_xyzi_f32(xyzi, t0, A, t1, B, tm, mode=orc.FAITHFUL)
+        err = np.linalg.norm(got[:, :3] - ref["xyz_f64"], axis=1) / np.maximum(np.linalg.norm(ref["xyz_f64"], axis=1), 1e-3)
+        parity = {"max_rel_err": float(err.max()), "bar": 1e-5, "intensity_bit_identical": bool(np.array_equal(got[:, 3], xyzi[:, 3]))}
+        assert parity["max_rel_err"] <= 1e-5 and parity["intensity_bit_identical"], parity
+
+    if rank == 0:
+        kernel_ms = ev_ms / args.steps  # average launch duration of the dominant kernel, HIP events, this rank
+        achieved = BYTES_PER_POINT * n / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fjson:
+                traffic = json.load(fjson).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "M points/sec deskewed",
+            "value": round(pts_total / t_max / 1e6, 1),
+            "unit": "Mpts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(t_max / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[1]: synthetic 1M-point frames, straight-line constant-velocity trajectory; "
+                            f"{F} distinct frames per step in one batched launch (per GPU), device-resident",
+                "points_per_frame": POINTS_PER_FRAME, "frames_per_step_per_gpu": F, "points_per_step_per_gpu": n,
+                "parallelism": f"frame-sharded x{world} (no data-path collective)",
+                "kernel": "kmc_dev::deskew_batch_f32<series3, ppt=4, nt>", "device": info["name"], "arch": info["arch"],
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "bytes_per_point": BYTES_PER_POINT, "points_per_launch": n, "kernel_ms_avg": round(kernel_ms, 4),
+            },
+            "parity_spot_check": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            k = min(args.cpu_sample_frames, F)
+            sample = d_in[:k * POINTS_PER_FRAME].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

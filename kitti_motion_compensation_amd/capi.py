@@ -213,6 +213,14 @@ def synth_points_host(n: int, seed: int) -> np.ndarray:
     return out
 
 
+def params_array(params_list):
+    """list of FrameParams -> contiguous ctypes array (build once, reuse across steps)."""
+    arr = (FrameParams * max(len(params_list), 1))()
+    for i, p in enumerate(params_list):
+        arr[i] = p
+    return arr
+
+
 # ---- device context -----------------------------------------------------------------------------------
 class Context:
     """One kmc_ctx: one GPU, one stream.  Raises KmcError(ERR_NO_DEVICE) when there is no HIP device."""
@@ -291,11 +299,10 @@ class Context:
 
     def deskew_batch_f32(self, xyzi_in, xyzi_out, offsets, params_list, frame_idx_out=None) -> Stats:
         kind = _mem_kind(xyzi_in)
-        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        offs = offsets if (isinstance(offsets, np.ndarray) and offsets.dtype == np.uint64 and offsets.flags.c_contiguous) \
+            else np.ascontiguousarray(offsets, dtype=np.uint64)
         nf = len(offs) - 1
-        arr = (FrameParams * max(nf, 1))()
-        for i, p in enumerate(params_list):
-            arr[i] = p
+        arr = params_list if isinstance(params_list, C.Array) else params_array(params_list)
         st = Stats()
         rc = lib().kmc_hip_deskew_batch_f32(self._h, _ptr(xyzi_in), _ptr(xyzi_out),
                                             offs.ctypes.data_as(C.POINTER(C.c_uint64)), nf, arr, _ptr(frame_idx_out), kind,

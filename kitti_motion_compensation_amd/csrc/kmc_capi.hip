@@ -33,15 +33,23 @@ struct kmc_ctx {
   int force_tier = -1;
   // out-of-range counter (f64 path)
   unsigned long long* d_counter = nullptr;
-  // batch tables: device + pinned staging
-  BatchRec* d_recs = nullptr;
-  BatchRec* h_recs = nullptr;
-  size_t recs_cap = 0;
-  uint32_t* d_tiles = nullptr;
-  uint32_t* h_tiles = nullptr;
-  size_t tiles_cap = 0;
-  hipEvent_t ev_tables = nullptr;  // completion of the last table upload (guards the pinned staging)
-  bool tables_in_flight = false;
+  // batch tables: a ring of slots (device tables + pinned staging) uploaded on a side stream so that the
+  // per-step host preparation and the table H2D overlap the previous step's kernel
+  struct TableSlot {
+    BatchRec* d_recs = nullptr;
+    BatchRec* h_recs = nullptr;
+    size_t recs_cap = 0;
+    uint32_t* d_tiles = nullptr;
+    uint32_t* h_tiles = nullptr;
+    size_t tiles_cap = 0;
+    hipEvent_t uploaded = nullptr;  // tables are on the device (copy stream)
+    hipEvent_t consumed = nullptr;  // the kernel that read them has finished (compute stream)
+    bool busy = false;
+  };
+  static constexpr int kTableSlots = 3;
+  TableSlot slots[kTableSlots];
+  int next_slot = 0;
+  hipStream_t copy_stream = nullptr;
   // host-staging buffers
   hipStream_t pipe[2] = {nullptr, nullptr};
   void* d_stage_in[2] = {nullptr, nullptr};
@@ -239,7 +247,11 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   hipEvent_t* evs[] = {&c->ev_k0, &c->ev_k1, &c->ev_c0, &c->ev_c1, &c->ev_t0, &c->ev_t1};
   for (hipEvent_t* ev : evs)
     if (e == hipSuccess) e = hipEventCreate(ev);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  for (auto& sl : c->slots) {
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -261,12 +273,17 @@ void kmc_hip_destroy(kmc_ctx* c) {
     if (c->d_stage_out[b]) (void)hipFree(c->d_stage_out[b]);
   }
   if (c->d_tmp) (void)hipFree(c->d_tmp);
-  if (c->d_recs) (void)hipFree(c->d_recs);
-  if (c->h_recs) (void)hipHostFree(c->h_recs);
-  if (c->d_tiles) (void)hipFree(c->d_tiles);
-  if (c->h_tiles) (void)hipHostFree(c->h_tiles);
+  for (auto& sl : c->slots) {
+    if (sl.d_recs) (void)hipFree(sl.d_recs);
+    if (sl.h_recs) (void)hipHostFree(sl.h_recs);
+    if (sl.d_tiles) (void)hipFree(sl.d_tiles);
+    if (sl.h_tiles) (void)hipHostFree(sl.h_tiles);
+    if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+    if (sl.consumed) (void)hipEventDestroy(sl.consumed);
+  }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->d_counter) (void)hipFree(c->d_counter);
-  hipEvent_t evs[] = {c->ev_k0, c->ev_k1, c->ev_c0, c->ev_c1, c->ev_t0, c->ev_t1, c->ev_tables};
+  hipEvent_t evs[] = {c->ev_k0, c->ev_k1, c->ev_c0, c->ev_c1, c->ev_t0, c->ev_t1};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -448,34 +465,33 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const uint64_t tile = (uint64_t)kBlock * ppt;
   const uint64_t n_tiles = (n + tile - 1) / tile;
 
-  // (re)allocate tables
-  if (n_frames > c->recs_cap) {
-    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->d_recs) (void)hipFree(c->d_recs);
-    if (c->h_recs) (void)hipHostFree(c->h_recs);
-    c->d_recs = nullptr; c->h_recs = nullptr; c->recs_cap = 0;
+  // pick the next table slot; it was last used kTableSlots steps ago -- make sure that kernel is done
+  kmc_ctx::TableSlot& sl = c->slots[c->next_slot];
+  c->next_slot = (c->next_slot + 1) % kmc_ctx::kTableSlots;
+  if (sl.busy) {
+    KMC_HIP_TRY(c, hipEventSynchronize(sl.consumed));
+    sl.busy = false;
+  }
+  if (n_frames > sl.recs_cap) {
+    if (sl.d_recs) (void)hipFree(sl.d_recs);
+    if (sl.h_recs) (void)hipHostFree(sl.h_recs);
+    sl.d_recs = nullptr; sl.h_recs = nullptr; sl.recs_cap = 0;
     const size_t cap = std::max<size_t>(64, (size_t)n_frames * 2);
-    KMC_HIP_TRY(c, hipMalloc((void**)&c->d_recs, cap * sizeof(BatchRec)));
-    KMC_HIP_TRY(c, hipHostMalloc((void**)&c->h_recs, cap * sizeof(BatchRec), hipHostMallocDefault));
-    c->recs_cap = cap;
+    KMC_HIP_TRY(c, hipMalloc((void**)&sl.d_recs, cap * sizeof(BatchRec)));
+    KMC_HIP_TRY(c, hipHostMalloc((void**)&sl.h_recs, cap * sizeof(BatchRec), hipHostMallocDefault));
+    sl.recs_cap = cap;
   }
-  if (n_tiles > c->tiles_cap) {
-    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->d_tiles) (void)hipFree(c->d_tiles);
-    if (c->h_tiles) (void)hipHostFree(c->h_tiles);
-    c->d_tiles = nullptr; c->h_tiles = nullptr; c->tiles_cap = 0;
+  if (n_tiles > sl.tiles_cap) {
+    if (sl.d_tiles) (void)hipFree(sl.d_tiles);
+    if (sl.h_tiles) (void)hipHostFree(sl.h_tiles);
+    sl.d_tiles = nullptr; sl.h_tiles = nullptr; sl.tiles_cap = 0;
     const size_t cap = std::max<size_t>(1024, (size_t)n_tiles * 2);
-    KMC_HIP_TRY(c, hipMalloc((void**)&c->d_tiles, cap * sizeof(uint32_t)));
-    KMC_HIP_TRY(c, hipHostMalloc((void**)&c->h_tiles, cap * sizeof(uint32_t), hipHostMallocDefault));
-    c->tiles_cap = cap;
-  }
-  // the pinned staging is reused: wait until the previous upload has been consumed
-  if (c->tables_in_flight) {
-    KMC_HIP_TRY(c, hipEventSynchronize(c->ev_tables));
-    c->tables_in_flight = false;
+    KMC_HIP_TRY(c, hipMalloc((void**)&sl.d_tiles, cap * sizeof(uint32_t)));
+    KMC_HIP_TRY(c, hipHostMalloc((void**)&sl.h_tiles, cap * sizeof(uint32_t), hipHostMallocDefault));
+    sl.tiles_cap = cap;
   }
   for (uint32_t f = 0; f < n_frames; ++f) {
-    BatchRec* r = &c->h_recs[f];
+    BatchRec* r = &sl.h_recs[f];
     fill_rec(params[f], r);
     r->end_lo = (uint32_t)(offsets[f + 1] & 0xFFFFFFFFull);
     r->end_hi = (uint32_t)(offsets[f + 1] >> 32);
@@ -485,9 +501,13 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
     for (uint64_t t = 0; t < n_tiles; ++t) {
       const uint64_t first = t * tile;
       while (f + 1 < n_frames && offsets[f + 1] <= first) ++f;  // skips empty frames
-      c->h_tiles[t] = f;
+      sl.h_tiles[t] = f;
     }
   }
+  // table upload on the side stream: overlaps whatever the compute stream is still running
+  KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_recs, sl.h_recs, (size_t)n_frames * sizeof(BatchRec), hipMemcpyHostToDevice, c->copy_stream));
+  KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_tiles, sl.h_tiles, (size_t)n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+  KMC_HIP_TRY(c, hipEventRecord(sl.uploaded, c->copy_stream));
 
   CallTimer tm(c);
   const v4f* d_in = (const v4f*)xyzi_in;
@@ -505,18 +525,17 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST)
     KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, n * sizeof(v4f), hipMemcpyHostToDevice, c->stream));
-  KMC_HIP_TRY(c, hipMemcpyAsync(c->d_recs, c->h_recs, (size_t)n_frames * sizeof(BatchRec), hipMemcpyHostToDevice, c->stream));
-  KMC_HIP_TRY(c, hipMemcpyAsync(c->d_tiles, c->h_tiles, (size_t)n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  KMC_HIP_TRY(c, hipEventRecord(c->ev_tables, c->stream));
-  c->tables_in_flight = true;
+  KMC_HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.uploaded, 0));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, n_tiles);
   switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in, d_out, c->d_recs, c->d_tiles, n_frames, n, d_idx); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in, d_out, c->d_recs, c->d_tiles, n_frames, n, d_idx); break;
-    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in, d_out, c->d_recs, c->d_tiles, n_frames, n, d_idx); break;
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in, d_out, sl.d_recs, sl.d_tiles, n_frames, n, d_idx); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in, d_out, sl.d_recs, sl.d_tiles, n_frames, n, d_idx); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in, d_out, sl.d_recs, sl.d_tiles, n_frames, n, d_idx); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
+  KMC_HIP_TRY(c, hipEventRecord(sl.consumed, c->stream));
+  sl.busy = true;
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {
     KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out, d_out, n * sizeof(v4f), hipMemcpyDeviceToHost, c->stream));

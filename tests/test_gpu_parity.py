@@ -1,0 +1,434 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI (include/kmc_hip.h), against
+the CPU oracle on the same inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes --
+through size-independent properties.
+
+Parity bar (BASELINE.json north_star / SURVEY.md section 8(d)):
+  XYZ      : per point ||p_gpu - p_ref||_2 / max(||p_ref||_2, 1e-3) <= 1e-5        (REL_TOL below)
+  intensity: bit-identical
+  indices  : per-point integer indices (frame index) bit-exact
+  f64 path : <= 1e-11 relative (it computes in double like the reference)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from kitti_motion_compensation_amd import capi
+from oracle import oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5       # the bar north_star states
+REL_TOL_F64 = 1e-11  # f64 boundary mode
+
+T0, T1, TREQ = 47072.283701593, 47072.386973931, 47072.335337762
+
+TRAJECTORIES = {
+    "stationary": [0, 0, 0, 0, 0, 0],
+    "straight": [1.3, 0.05, -0.02, 0, 0, 0],
+    "gentle_turn": [1.3, 0.05, -0.02, 0.001, -0.002, 0.03],
+    "hard_turn": [2.9, -0.3, 0.1, 0.02, 0.01, -0.1],
+    "spin": [0.4, 0.1, 0.0, 0.1, -0.3, 0.6],       # series5 tier
+    "tumble": [0.4, 0.1, 0.0, 0.3, -0.9, 2.2],     # trig tier
+}
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the GPU: there is no CPU fallback to test"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ctx(torch_mod):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def kitti(golden_dir):
+    run = os.path.join(golden_dir, "kitti_2011_09_26_drive_0005")
+    xyzi = util.load_velodyne_bin(run, 0)
+    f = util.load_oxts_fields(run, 0)
+    return xyzi, orc.oxts_to_pose(orc.oxts(**f))
+
+
+def _poses(P1, step):
+    return P1, orc.affine_mul(P1, orc.se3_exp(step))
+
+
+def _params(P1, P2, t0=T0, t1=T1, treq=TREQ):
+    return capi.frame_params_from_poses(P1.rt12().reshape(3, 4), P2.rt12().reshape(3, 4), t0, t1, treq)
+
+
+def _oracle(xyzi, P1, P2, t0=T0, t1=T1, treq=TREQ, mode=orc.FAITHFUL):
+    r = orc.deskew_xyzi_f32(xyzi, t0, P1, t1, P2, treq, mode=mode, want_f32=True)
+    assert r["rc"] == orc.OK
+    return r
+
+
+def _check(got, xyzi, ref, tol=REL_TOL):
+    assert np.array_equal(got[:, 3].view(np.uint32), xyzi[:, 3].view(np.uint32)), "intensity not bit-identical"
+    err = util.rel_point_error(got[:, :3], ref["xyz_f64"])
+    assert np.isfinite(got[:, :3]).all()
+    assert err.max() <= tol, f"max rel err {err.max():.3e} > {tol}"
+    return err.max()
+
+
+def _run_device(torch, ctx, xyzi, params, in_place=False):
+    d_in = torch.from_numpy(np.ascontiguousarray(xyzi)).cuda()
+    d_out = d_in if in_place else torch.empty_like(d_in)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    st = ctx.deskew_f32(d_in, d_out, params)
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy(), st
+
+
+# ---- reference KAT through the HIP path ------------------------------------------------------------------------
+def test_reference_kat_through_hip(ctx, kats):
+    """test/test_motion_compensation.cpp:54-76 -- same fixture, same expected numbers, ASSERT_FLOAT_EQ semantics."""
+    k = kats["motion_compensate_frame"]
+    ox = [capi.Oxts(**o) for o in k["oxts"]]
+    T_start, T_end = capi.make_frame_poses(ox[0], ox[1], ox[2], k["stamp_start"], k["stamp_end"])
+    params = capi.frame_params_from_poses(T_start, T_end, k["stamp_start"], k["stamp_end"], k["requested_time"])
+    xyzi = np.array(k["cloud"], dtype=np.float32)
+    xyzi[:, 3] = [0.25, 0.5, 0.75]
+    out = np.empty_like(xyzi)
+    ctx.deskew_f32(xyzi, out, params)  # KMC_MEM_HOST
+    util.assert_float_eq(out[:, :3], np.array(k["expected"])[:, :3], "MotionCompensateFrame KAT on HIP")
+    assert np.array_equal(out[:, 3], xyzi[:, 3])
+
+
+# ---- real KITTI frame (BASELINE.json configs[0] data) ------------------------------------------------------------
+@pytest.mark.parametrize("name", list(TRAJECTORIES))
+def test_kitti_frame_vs_oracle_device(torch_mod, ctx, kitti, name):
+    xyzi, P1 = kitti
+    P1, P2 = _poses(P1, TRAJECTORIES[name])
+    params = _params(P1, P2)
+    got, st = _run_device(torch_mod, ctx, xyzi, params)
+    assert st.n_points == xyzi.shape[0] and st.n_launches == 1
+    expected_tier = {"spin": capi.TIER_SERIES5, "tumble": capi.TIER_TRIG}.get(name, capi.TIER_SERIES3)
+    assert st.variant == expected_tier
+    _check(got, xyzi, _oracle(xyzi, P1, P2))
+    if name == "stationary":  # zero twist: the transform is the identity, bit for bit
+        assert np.array_equal(got.view(np.uint32), xyzi.view(np.uint32))
+
+
+def test_kitti_frame_host_buffers_and_in_place(torch_mod, ctx, kitti):
+    xyzi, P1 = kitti
+    P1, P2 = _poses(P1, TRAJECTORIES["hard_turn"])
+    params = _params(P1, P2)
+    ref = _oracle(xyzi, P1, P2)
+    out = np.empty_like(xyzi)
+    ctx.deskew_f32(xyzi, out, params)  # host staging pipeline
+    _check(out, xyzi, ref)
+    dev, _ = _run_device(torch_mod, ctx, xyzi, params)
+    assert np.array_equal(out.view(np.uint32), dev.view(np.uint32)), "host-staged and device-resident results differ"
+    inplace, _ = _run_device(torch_mod, ctx, xyzi, params, in_place=True)
+    assert np.array_equal(inplace.view(np.uint32), dev.view(np.uint32))
+
+
+def test_every_tier_and_tiling_agree(torch_mod, ctx, kitti):
+    """All three coefficient tiers are valid below 0.25 rad and must agree with the oracle; tiling never changes bits."""
+    xyzi, P1 = kitti
+    P1, P2 = _poses(P1, TRAJECTORIES["hard_turn"])
+    params = _params(P1, P2)
+    ref = _oracle(xyzi, P1, P2)
+    base = None
+    try:
+        for tier in (capi.TIER_SERIES3, capi.TIER_SERIES5, capi.TIER_TRIG):
+            ctx.force_tier(tier)
+            got, st = _run_device(torch_mod, ctx, xyzi, params)
+            assert st.variant == tier
+            _check(got, xyzi, ref)
+        ctx.force_tier(-1)
+        for ppt in (1, 2, 4, 8):
+            for bpc in (1, 8):
+                ctx.set_launch_config(bpc, ppt)
+                got, _ = _run_device(torch_mod, ctx, xyzi, params)
+                if base is None:
+                    base = got
+                assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), (ppt, bpc)
+    finally:
+        ctx.force_tier(-1)
+        ctx.set_launch_config(0, 0)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 255, 256, 1023, 1024, 1025, 2047, 2048, 2049, 100_003])
+def test_ragged_sizes(torch_mod, ctx, kitti, n):
+    xyzi, P1 = kitti
+    xyzi = np.ascontiguousarray(xyzi[:n])
+    P1, P2 = _poses(P1, TRAJECTORIES["gentle_turn"])
+    params = _params(P1, P2)
+    if n == 0:
+        st = ctx.deskew_f32(np.empty((0, 4), np.float32), np.empty((0, 4), np.float32), params)
+        assert st.n_points == 0
+        return
+    # guard words after the buffer must stay untouched
+    import torch
+    d_in = torch.from_numpy(xyzi).cuda()
+    d_out = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.deskew_f32(d_in, d_out, params, n=n)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.all(out[n:] == 7.0), "wrote past the end"
+    _check(out[:n], xyzi, _oracle(xyzi, P1, P2))
+
+
+def test_edge_points_signed_zero_and_axes(ctx, kitti):
+    """timestamp_mocking.cpp:46 has no special cases; the kernel's azimuth must follow IEEE atan2 on zeros and axes."""
+    _, P1 = kitti
+    P1, P2 = _poses(P1, TRAJECTORIES["hard_turn"])
+    params = _params(P1, P2)
+    pts = np.array([
+        [0.0, 0.0, 0.0, 1], [0.0, 0.0, 1.5, 2], [-0.0, 0.0, 0.3, 3], [-0.0, -0.0, 0.3, 4], [0.0, -0.0, 0.3, 5],
+        [-1.0, 0.0, 0.0, 6], [-1.0, -0.0, 0.0, 7], [1.0, 0.0, 0.0, 8], [1.0, -0.0, 0.0, 9], [0.0, 5.0, 0.0, 10],
+        [0.0, -5.0, 0.0, 11], [-0.0, 5.0, 0.0, 12], [3.0, 3.0, 1.0, 13], [-3.0, 3.0, 1.0, 14], [-3.0, -3.0, 1.0, 15],
+        [3.0, -3.0, 1.0, 16], [1e-30, 1e-30, 0.0, 17], [-1e-38, 1e-39, 0.0, 18], [1e-42, -1e-44, 2.0, 19],
+        [79.9, -0.001, 1.0, 20], [-79.9, 1e-6, -3.0, 21], [-79.9, -1e-6, -3.0, 22],
+    ], dtype=np.float32)
+    out = np.empty_like(pts)
+    ctx.deskew_f32(pts, out, params)
+    ref = _oracle(pts, P1, P2)
+    _check(out, pts, ref)
+    # and an absolute bound: several points sit at the origin where the relative measure is capped by its 1e-3 floor
+    assert np.abs(out[:, :3].astype(np.float64) - ref["xyz_f64"]).max() < 1e-5
+
+
+def test_invalid_arguments(ctx, kitti):
+    xyzi, P1 = kitti
+    P1, P2 = _poses(P1, TRAJECTORIES["straight"])
+    params = _params(P1, P2)
+    buf = np.zeros(4 * 16 + 1, dtype=np.float32)
+    mis = buf[1:].reshape(-1, 4)  # 4-byte aligned only
+    with pytest.raises(capi.KmcError) as e:
+        ctx.deskew_f32(mis, np.empty_like(mis), params)
+    assert e.value.status == capi.ERR_INVALID_ARG
+    bad = capi.FrameParams.make(params.twist_np(), 1.5)  # requested time outside the scan
+    with pytest.raises(capi.KmcError) as e:
+        ctx.deskew_f32(xyzi[:8].copy(), np.empty((8, 4), np.float32), bad)
+    assert e.value.status == capi.ERR_TIME_OUT_OF_RANGE
+    nan = capi.FrameParams.make([np.nan, 0, 0, 0, 0, 0], 0.5)
+    with pytest.raises(capi.KmcError) as e:
+        ctx.deskew_f32(xyzi[:8].copy(), np.empty((8, 4), np.float32), nan)
+    assert e.value.status == capi.ERR_INVALID_ARG
+
+
+# ---- synthetic frames (BASELINE.json configs[1]) --------------------------------------------------------------------
+def test_device_generator_is_bit_identical_to_host(torch_mod, ctx):
+    torch = torch_mod
+    n = 1_000_000
+    d = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.synth_points(d, n, 0x4B4D43)
+    torch.cuda.synchronize()
+    h = capi.synth_points_host(n, 0x4B4D43)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), h.view(np.uint32))
+
+
+def test_config2_one_million_points_straight_line(torch_mod, ctx):
+    """BASELINE.json configs[1]: synthetic 1 M-point frame, straight-line constant-velocity trajectory.
+    OXTS exactly as SURVEY.md section 8(d) config 2; checked against the oracle AND the closed form x' = x + v (t_i - t_req)."""
+    n = 1_000_000
+    Tz = 47072.0
+    v = 10.0
+    dlon = v * 0.1 * 180.0 / (np.pi * 6378137.0)
+    ox = [capi.Oxts(stamp=Tz + 0.05 + 0.1 * i, lat=0.0, lon=dlon * i, alt=0, roll=0, pitch=0, yaw=0) for i in range(3)]
+    t0, tm, t1 = Tz + 0.10, Tz + 0.15, Tz + 0.20
+    T_start, T_end = capi.make_frame_poses(ox[0], ox[1], ox[2], t0, t1)
+    params = capi.frame_params_from_poses(T_start, T_end, t0, t1, tm)
+    assert np.allclose(params.twist_np(), [v * 0.1, 0, 0, 0, 0, 0], atol=1e-9)
+    xyzi = capi.synth_points_host(n, 0x4B4D43)
+    got, st = _run_device(torch_mod, ctx, xyzi, params)
+    assert st.variant == capi.TIER_SERIES3
+    oo = [orc.oxts(Tz + 0.05 + 0.1 * i, 0.0, dlon * i, 0, 0, 0, 0) for i in range(3)]
+    rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
+    assert rc == orc.OK
+    ref = orc.deskew_xyzi_f32(xyzi, t0, A, t1, B, tm, mode=orc.FAITHFUL, want_stamps=True)
+    assert ref["rc"] == orc.OK
+    _check(got, xyzi, ref)
+    closed = xyzi[:, :3].astype(np.float64).copy()
+    closed[:, 0] += v * (ref["stamps"] - tm)
+    assert util.rel_point_error(got[:, :3], closed).max() <= REL_TOL
+
+
+# ---- batched kernel ---------------------------------------------------------------------------------------------------
+def _batch_case(kitti, sizes, steps, seed=5):
+    xyzi, P1 = kitti
+    rng = np.random.default_rng(seed)
+    frames, params, refs = [], [], []
+    for n, step in zip(sizes, steps):
+        idx = rng.integers(0, xyzi.shape[0], size=n)
+        pts = np.ascontiguousarray(xyzi[idx])
+        A, B = _poses(P1, step)
+        xr = rng.uniform(0.2, 0.8)
+        treq = T0 + xr * (T1 - T0)
+        frames.append(pts)
+        params.append(_params(A, B, treq=treq))
+        refs.append(_oracle(pts, A, B, treq=treq, mode=orc.HOISTED)["xyz_f64"] if n else np.zeros((0, 3)))
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    return np.concatenate(frames) if sum(sizes) else np.zeros((0, 4), np.float32), offsets, params, np.concatenate(refs)
+
+
+@pytest.mark.parametrize("sizes", [
+    [5000, 1, 0, 0, 3000, 1023, 1025, 7, 0, 20000],        # ragged, with empty frames and tile-straddling frames
+    [100] * 40,                                             # many tiny frames inside single tiles (> LDS table of 16)
+    [123397, 120001, 118733],                               # KITTI-sized frames
+    [0, 0, 50, 0],
+])
+def test_batch_vs_per_frame_oracle_and_bit_exact_indices(torch_mod, ctx, kitti, sizes):
+    torch = torch_mod
+    names = list(TRAJECTORIES)[:5]  # below the trig tier so that the batch tier is series5 at most
+    steps = [TRAJECTORIES[names[i % len(names)]] for i in range(len(sizes))]
+    xyzi, offsets, params, ref = _batch_case(kitti, sizes, steps)
+    n = xyzi.shape[0]
+    want_idx = (np.searchsorted(offsets, np.arange(n, dtype=np.uint64), side="right") - 1).astype(np.uint32)
+    for ppt in (1, 4, 8):
+        ctx.set_launch_config(0, ppt)
+        # device-resident
+        d_in = torch.from_numpy(xyzi).cuda()
+        d_out = torch.empty_like(d_in)
+        d_idx = torch.full((max(n, 1),), -1, dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        st = ctx.deskew_batch_f32(d_in, d_out, offsets, params, d_idx)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        idx = d_idx.cpu().numpy().view(np.uint32)[:n]
+        assert st.n_points == n
+        assert np.array_equal(idx, want_idx), "per-point frame indices must be bit-exact"
+        assert np.array_equal(got[:, 3].view(np.uint32), xyzi[:, 3].view(np.uint32))
+        if n:
+            assert util.rel_point_error(got[:, :3], ref).max() <= REL_TOL
+        # host buffers, no index output
+        out = np.empty_like(xyzi)
+        ctx.deskew_batch_f32(xyzi, out, offsets, params, None)
+        assert np.array_equal(out.view(np.uint32), got.view(np.uint32))
+    ctx.set_launch_config(0, 0)
+
+
+def test_batch_equals_single_frame_kernel_bitwise(torch_mod, ctx, kitti):
+    """A one-frame batch must reduce bit-for-bit to kmc_hip_deskew_f32 (same arithmetic, different plumbing)."""
+    xyzi, P1 = kitti
+    P1, P2 = _poses(P1, TRAJECTORIES["hard_turn"])
+    params = _params(P1, P2)
+    single, _ = _run_device(torch_mod, ctx, xyzi, params)
+    out = np.empty_like(xyzi)
+    ctx.deskew_batch_f32(xyzi, out, np.array([0, xyzi.shape[0]], np.uint64), [params], None)
+    assert np.array_equal(out.view(np.uint32), single.view(np.uint32))
+
+
+# ---- f64 Eigen-layout path (the 2-argument MotionCompensateFrame contract) -------------------------------------------------
+def test_f64cols_vs_faithful_oracle(ctx, kitti, kats):
+    xyzi, P1 = kitti
+    xyzi = xyzi[::7]
+    n = xyzi.shape[0]
+    cloud = np.concatenate([xyzi[:, :3].astype(np.float64), np.ones((n, 1))], axis=1)
+    stamps = orc.pseudo_timestamps(cloud, T0, T1)
+    for name in ("straight", "hard_turn", "tumble"):
+        A, B = _poses(P1, TRAJECTORIES[name])
+        params = _params(A, B)
+        rc, nbad, want = orc.motion_compensate_frame(cloud, stamps, T0, A, T1, B, TREQ)
+        assert rc == orc.OK
+        cols = [np.ascontiguousarray(cloud[:, j]) for j in range(4)]
+        outs = [np.empty(n) for _ in range(4)]
+        rc2, st = ctx.deskew_f64cols(cols[0], cols[1], cols[2], cols[3], stamps, T0, T1, params, *outs)
+        assert rc2 == capi.OK and st.n_out_of_range == 0
+        got = np.stack(outs, axis=1)
+        assert np.array_equal(got[:, 3], cloud[:, 3])
+        # the faithful oracle itself carries ~2e-9 m of Mercator cancellation noise: 1e-9 relative at 2 m
+        assert util.rel_point_error(got[:, :3], want[:, :3]).max() <= 2e-9
+        hoisted = orc.deskew_xyzi_f32(xyzi, T0, A, T1, B, TREQ, mode=orc.HOISTED)["xyz_f64"]
+        assert util.rel_point_error(got[:, :3], hoisted).max() <= REL_TOL_F64
+    # reference KAT in the f64 layout
+    k = kats["motion_compensate_frame"]
+    ox = [capi.Oxts(**o) for o in k["oxts"]]
+    T_start, T_end = capi.make_frame_poses(ox[0], ox[1], ox[2], k["stamp_start"], k["stamp_end"])
+    params = capi.frame_params_from_poses(T_start, T_end, k["stamp_start"], k["stamp_end"], k["requested_time"])
+    c = np.array(k["cloud"])
+    st3 = orc.pseudo_timestamps(c, k["stamp_start"], k["stamp_end"])
+    outs = [np.empty(3) for _ in range(4)]
+    ctx.deskew_f64cols(*(np.ascontiguousarray(c[:, j]) for j in range(4)), st3, k["stamp_start"], k["stamp_end"], params, *outs)
+    util.assert_float_eq(np.stack(outs, axis=1), np.array(k["expected"]))
+
+
+def test_f64cols_out_of_range_stamps_are_reported(ctx, kitti):
+    """trajectory_interpolation.cpp:32 aborts; the ABI returns KMC_ERR_TIME_OUT_OF_RANGE and counts the offenders."""
+    xyzi, P1 = kitti
+    A, B = _poses(P1, TRAJECTORIES["gentle_turn"])
+    params = _params(A, B)
+    n = 1000
+    cloud = np.concatenate([xyzi[:n, :3].astype(np.float64), np.ones((n, 1))], axis=1)
+    stamps = orc.pseudo_timestamps(cloud, T0, T1)
+    stamps[[3, 500, 999]] = [T0 - 1e-6, T1 + 1e-6, 0.0]
+    outs = [np.empty(n) for _ in range(4)]
+    rc, st = ctx.deskew_f64cols(*(np.ascontiguousarray(cloud[:, j]) for j in range(4)), stamps, T0, T1, params, *outs,
+                                raise_on_range=False)
+    assert rc == capi.ERR_TIME_OUT_OF_RANGE and st.n_out_of_range == 3
+    assert np.isnan(outs[0][[3, 500, 999]]).all() and np.isfinite(np.delete(outs[0], [3, 500, 999])).all()
+    rc_o, nbad_o, _ = orc.motion_compensate_frame(cloud, stamps, T0, A, T1, B, TREQ)
+    assert rc_o == orc.ERR_TIME_OUT_OF_RANGE and nbad_o == 3
+
+
+def test_pseudo_timestamps_f64(ctx, kitti, kats):
+    xyzi, _ = kitti
+    x = xyzi[:, 0].astype(np.float64)
+    y = xyzi[:, 1].astype(np.float64)
+    out = np.empty_like(x)
+    ctx.pseudo_timestamps_f64(x, y, T0, T1, out)
+    cloud = np.stack([x, y, np.zeros_like(x), np.ones_like(x)], axis=1)
+    want = orc.pseudo_timestamps(cloud, T0, T1)
+    ulp = np.abs(out - want) / np.spacing(want)
+    assert ulp.max() <= 4, f"f64 stamps differ by {ulp.max()} ulp (ulp = {np.spacing(T0):.1e} s)"
+    k = kats["timestamp_mocking"]
+    c = np.array(k["cloud"])
+    o3 = np.empty(3)
+    ctx.pseudo_timestamps_f64(np.ascontiguousarray(c[:, 0]), np.ascontiguousarray(c[:, 1]), k["scan_start"], k["scan_end"], o3)
+    util.assert_float_eq(o3, k["expected_stamp"])
+
+
+# ---- full-size properties (BASELINE.json configs[3]: 10 M points per frame) --------------------------------------------
+def test_full_size_properties_10M(torch_mod, ctx):
+    torch = torch_mod
+    n = 10_000_000
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    ctx.synth_points(d_in, n, 0x4B4D43 + 3)
+    d_out = torch.empty_like(d_in)
+    # (1) zero twist is the identity, bit for bit
+    ctx.deskew_f32(d_in, d_out, capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5))
+    torch.cuda.synchronize()
+    assert torch.equal(d_in.view(torch.int32), d_out.view(torch.int32))
+    # (2) pure rotation preserves the range of every point; intensity untouched
+    ctx.deskew_f32(d_in, d_out, capi.FrameParams.make([0, 0, 0, 0.01, -0.02, 0.2], 0.37))
+    torch.cuda.synchronize()
+    r_in = d_in[:, :3].double().norm(dim=1)
+    r_out = d_out[:, :3].double().norm(dim=1)
+    assert ((r_out - r_in).abs() / r_in).max().item() < 5e-7
+    assert torch.equal(d_in[:, 3].view(torch.int32), d_out[:, 3].view(torch.int32))
+    # (3) pure translation moves every point along rho by s in [-x_req, 1 - x_req], monotone in the scan fraction
+    rho = torch.tensor([1.7, -0.4, 0.05], dtype=torch.float64, device="cuda")
+    x_req = 0.37
+    ctx.deskew_f32(d_in, d_out, capi.FrameParams.make([*rho.tolist(), 0, 0, 0], x_req))
+    torch.cuda.synchronize()
+    d = d_out[:, :3].double() - d_in[:, :3].double()
+    s = (d @ rho) / (rho @ rho)
+    perp = (d - s[:, None] * rho[None, :]).norm(dim=1)
+    assert perp.max().item() < 2e-5  # f32 ulp at 80 m is 7.6e-6
+    assert s.min().item() >= -x_req - 1e-5 and s.max().item() <= 1 - x_req + 1e-5
+    frac = (np.pi - torch.atan2(d_in[:, 1].double(), d_in[:, 0].double())) / (2 * np.pi)
+    assert (s - (frac - x_req)).abs().max().item() < 2e-5
+    # (4) a sampled slice agrees with the oracle
+    P1 = orc.oxts_to_pose(orc.oxts(T0, 49.011212804408, 8.4228850417969, 112.8, 0.022, 1e-5, -1.22))
+    A, B = _poses(P1, TRAJECTORIES["hard_turn"])
+    params = _params(A, B)
+    ctx.deskew_f32(d_in, d_out, params)
+    torch.cuda.synchronize()
+    sel = torch.arange(0, n, 97, device="cuda")
+    xyzi = d_in[sel].cpu().numpy()
+    got = d_out[sel].cpu().numpy()
+    _check(got, xyzi, _oracle(xyzi, A, B, mode=orc.HOISTED))

@@ -1,0 +1,158 @@
+// kmc_tune.hip -- on-GPU A/B harness for the deskew kernels (run through gpurun; writes CSV to stdout).
+//
+// All variants are timed in ONE process, interleaved over several rounds (cdna_hip_programming.md rule 24),
+// on a working set far beyond the 256 MiB Infinity Cache so that the GB/s are HBM GB/s.  The float4 copy kernel
+// is the same-hardware ceiling every deskew variant is compared with (rule 10).
+//
+// usage: kmc_tune [n_points=67108864] [rounds=5] [iters=10]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../kitti_motion_compensation_amd/csrc/kmc_kernels.hip.h"
+
+using namespace kmc_dev;
+
+#define CK(x)                                                                     \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      std::fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      std::exit(2);                                                               \
+    }                                                                             \
+  } while (0)
+
+struct Variant {
+  std::string name;
+  std::function<void(hipStream_t, const v4f*, v4f*, uint64_t, int)> launch;  // (stream, in, out, n, blocks_per_cu)
+  int ppt;
+};
+
+static int g_cus = 256;
+
+static int grid_for(uint64_t n, int ppt, int bpc) {
+  const uint64_t tiles = (n + (uint64_t)kBlock * ppt - 1) / ((uint64_t)kBlock * ppt);
+  if (bpc <= 0) return (int)std::min<uint64_t>(tiles, 0x7fffffff);  // one tile per workgroup
+  return (int)std::min<uint64_t>(tiles, (uint64_t)g_cus * bpc);
+}
+
+static FrameRec make_rec() {
+  FrameRec f;
+  std::memset(&f, 0, sizeof(f));
+  // a turning trajectory: |phi| ~ 0.1 rad, |rho| ~ 1.3 m
+  const double phi[3] = {0.02, 0.01, -0.1}, rho[3] = {1.3, 0.05, -0.02};
+  const double c1[3] = {phi[1] * rho[2] - phi[2] * rho[1], phi[2] * rho[0] - phi[0] * rho[2], phi[0] * rho[1] - phi[1] * rho[0]};
+  const double c2[3] = {phi[1] * c1[2] - phi[2] * c1[1], phi[2] * c1[0] - phi[0] * c1[2], phi[0] * c1[1] - phi[1] * c1[0]};
+  f.phi_x = phi[0]; f.phi_y = phi[1]; f.phi_z = phi[2]; f.phi2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+  f.rho_x = rho[0]; f.rho_y = rho[1]; f.rho_z = rho[2]; f.s0 = 0.0f;
+  f.c1_x = c1[0]; f.c1_y = c1[1]; f.c1_z = c1[2];
+  f.c2_x = c2[0]; f.c2_y = c2[1]; f.c2_z = c2[2];
+  return f;
+}
+
+template <int TIER, int PPT, bool NT, bool OCML>
+static Variant frame_variant(const char* label) {
+  Variant v;
+  v.name = label;
+  v.ppt = PPT;
+  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int bpc) {
+    static const FrameRec f = make_rec();
+    hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, NT, OCML>), dim3(grid_for(n, PPT, bpc)), dim3(kBlock), 0, s, in, out, n, f);
+  };
+  return v;
+}
+
+template <int PPT, bool NT>
+static Variant copy_variant(const char* label) {
+  Variant v;
+  v.name = label;
+  v.ppt = PPT;
+  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int bpc) {
+    hipLaunchKernelGGL((copy_points<PPT, NT>), dim3(grid_for(n, PPT, bpc)), dim3(kBlock), 0, s, in, out, n);
+  };
+  return v;
+}
+
+int main(int argc, char** argv) {
+  const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : (1ull << 26);
+  const int rounds = argc > 2 ? std::atoi(argv[2]) : 5;
+  const int iters = argc > 3 ? std::atoi(argv[3]) : 10;
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  g_cus = prop.multiProcessorCount;
+  std::fprintf(stderr, "# device %s (%s), %d CUs, n=%llu points (%.1f MiB in + same out), rounds=%d iters=%d\n", prop.name,
+               prop.gcnArchName, g_cus, (unsigned long long)n, n * 16.0 / (1 << 20), rounds, iters);
+
+  // rotating buffers: 3 input/output pairs so that consecutive launches never hit MALL-resident lines
+  constexpr int kBufs = 3;
+  v4f* in[kBufs];
+  v4f* out[kBufs];
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  for (int b = 0; b < kBufs; ++b) {
+    CK(hipMalloc((void**)&in[b], n * sizeof(v4f)));
+    CK(hipMalloc((void**)&out[b], n * sizeof(v4f)));
+    hipLaunchKernelGGL(synth_points, dim3(g_cus * 8), dim3(kBlock), 0, s, in[b], n, 0x4B4D43ull + b);
+    CK(hipMemsetAsync(out[b], 0, n * sizeof(v4f), s));
+  }
+  CK(hipStreamSynchronize(s));
+
+  std::vector<Variant> vs;
+  vs.push_back(copy_variant<4, true>("copy_ppt4_nt"));
+  vs.push_back(copy_variant<4, false>("copy_ppt4"));
+  vs.push_back(copy_variant<1, true>("copy_ppt1_nt"));
+  vs.push_back(copy_variant<8, true>("copy_ppt8_nt"));
+  vs.push_back(frame_variant<kSeries3, 1, true, false>("s3_ppt1_nt"));
+  vs.push_back(frame_variant<kSeries3, 2, true, false>("s3_ppt2_nt"));
+  vs.push_back(frame_variant<kSeries3, 4, true, false>("s3_ppt4_nt"));
+  vs.push_back(frame_variant<kSeries3, 8, true, false>("s3_ppt8_nt"));
+  vs.push_back(frame_variant<kSeries3, 4, false, false>("s3_ppt4"));
+  vs.push_back(frame_variant<kSeries3, 1, false, false>("s3_ppt1"));
+  vs.push_back(frame_variant<kSeries3, 4, true, true>("s3_ppt4_nt_ocml"));
+  vs.push_back(frame_variant<kSeries5, 4, true, false>("s5_ppt4_nt"));
+  vs.push_back(frame_variant<kTrig, 4, true, false>("trig_ppt4_nt"));
+  const int bpcs[] = {0, 4, 8, 16, 32};
+
+  struct Res { std::string name; int bpc; std::vector<float> ms; };
+  std::vector<Res> res;
+  for (auto& v : vs)
+    for (int bpc : bpcs) res.push_back({v.name, bpc, {}});
+
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  int rot = 0;
+  for (int r = 0; r < rounds + 1; ++r) {  // round 0 = warm-up
+    size_t k = 0;
+    for (auto& v : vs)
+      for (int bpc : bpcs) {
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) {
+          v.launch(s, in[rot % kBufs], out[rot % kBufs], n, bpc);
+          ++rot;
+        }
+        CK(hipEventRecord(e1, s));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) res[k].ms.push_back(ms / iters);
+        ++k;
+      }
+  }
+  std::printf("variant,blocks_per_cu,ms_median,ms_min,gbps_median,gbps_best,mpts_median,frac_of_8TBps\n");
+  for (auto& x : res) {
+    std::sort(x.ms.begin(), x.ms.end());
+    const float med = x.ms[x.ms.size() / 2], mn = x.ms.front();
+    const double bytes = 32.0 * n;
+    std::printf("%s,%d,%.4f,%.4f,%.1f,%.1f,%.1f,%.4f\n", x.name.c_str(), x.bpc, med, mn, bytes / med * 1e-6, bytes / mn * 1e-6,
+                n / med * 1e-3, bytes / med * 1e-6 / 8000.0);
+  }
+  return 0;
+}
