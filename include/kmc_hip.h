@@ -107,8 +107,8 @@ int kmc_hip_synchronize(kmc_ctx* ctx);
 int kmc_hip_enable_timing(kmc_ctx* ctx, int enabled);
 const char* kmc_hip_last_error(kmc_ctx* ctx);
 int kmc_hip_device_info(kmc_ctx* ctx, kmc_device_info* out);
-/* Launch-geometry override for tuning: blocks per CU (0 = default) and points per thread per tile
- * (1, 2, 4 or 8; 0 = default). */
+/* Launch-geometry override for tuning: blocks_per_cu > 0 makes the grid persistent (CUs x blocks_per_cu workgroups
+ * grid-striding over tiles), 0 = default = one tile per workgroup; points_per_thread = 1, 2, 4 or 8 (0 = default 1). */
 int kmc_hip_set_launch_config(kmc_ctx* ctx, int blocks_per_cu, int points_per_thread);
 
 /* Testing hook: force the series/trig tier of the f32 kernels (-1 = automatic selection from |phi|). */

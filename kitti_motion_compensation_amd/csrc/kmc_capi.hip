@@ -61,8 +61,7 @@ struct kmc_ctx {
 
 namespace {
 
-constexpr int kDefaultBlocksPerCu = 8;
-constexpr int kDefaultPpt = 4;
+constexpr int kDefaultPpt = 1;  // measured best on MI355X: 256-point tiles, one per workgroup (profiles/r01_tune.csv)
 constexpr uint64_t kHostChunkPoints = 1ull << 22;  // 64 MiB per direction per pipeline slot
 
 int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
@@ -113,8 +112,9 @@ bool params_ok(const kmc_frame_params* p) {
 }
 
 int grid_for(const kmc_ctx* c, uint64_t n_tiles) {
-  const int bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : kDefaultBlocksPerCu;
-  const uint64_t cap = (uint64_t)c->prop.multiProcessorCount * bpc;
+  // default: one tile per workgroup -- the hardware dispatcher streams 256-point tiles better than a persistent
+  // grid-stride loop does (6.66 vs 5.39 TB/s, profiles/r01_tune.csv); blocks_per_cu > 0 caps the grid instead.
+  const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu : 0x7fffffffull;
   return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, cap));
 }
 
@@ -126,7 +126,7 @@ int ppt_of(const kmc_ctx* c) {
 // ---- template dispatch ---------------------------------------------------------------------------
 template <int TIER, int PPT>
 void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
-  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, true, false>), dim3(grid), dim3(kBlock), 0, s, in, out, n, f);
+  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kNtBoth, false>), dim3(grid), dim3(kBlock), 0, s, in, out, n, f);
 }
 template <int TIER>
 void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
@@ -152,9 +152,9 @@ template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint32_t* tiles,
                      uint32_t nf, uint64_t n, uint32_t* idx) {
   if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, true, true>), dim3(grid), dim3(kBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kNtBoth, true>), dim3(grid), dim3(kBlock), 0, s, in, out, recs, tiles, nf, n, idx);
   else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, true, false>), dim3(grid), dim3(kBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kNtBoth, false>), dim3(grid), dim3(kBlock), 0, s, in, out, recs, tiles, nf, n, idx);
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,

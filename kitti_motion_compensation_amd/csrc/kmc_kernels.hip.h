@@ -26,24 +26,26 @@ namespace kmc_dev {
 
 constexpr int kBlock = 256;  // 4 waves: one per SIMD
 
-template <bool NT>
+// NT is a bit mask: bit 0 = non-temporal loads, bit 1 = non-temporal stores (3 = both, the default)
+constexpr int kNtLoad = 1, kNtStore = 2, kNtBoth = 3;
+template <int NT>
 __device__ __forceinline__ v4f load_point(const v4f* p) {
-  if constexpr (NT) return __builtin_nontemporal_load(p);
+  if constexpr (NT & kNtLoad) return __builtin_nontemporal_load(p);
   else return *p;
 }
-template <bool NT>
+template <int NT>
 __device__ __forceinline__ void store_point(v4f* p, v4f v) {
-  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  if constexpr (NT & kNtStore) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
 
 // ------------------------------------------------------------------------------------------------
 // single-frame kernel: constants by value (kernarg segment -> s_load -> SGPRs)
 // ------------------------------------------------------------------------------------------------
-template <int TIER, int PPT, bool NT, bool OCML_ATAN>
-__global__ __launch_bounds__(kBlock) void deskew_frame_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
-                                                          uint64_t n, FrameRec f) {
-  constexpr uint64_t kTile = (uint64_t)kBlock * PPT;
+template <int TIER, int PPT, int NT, bool OCML_ATAN, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void deskew_frame_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
+                                                         uint64_t n, FrameRec f) {
+  constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
   const uint32_t tid = threadIdx.x;
   const uint64_t n_full = n / kTile;  // tiles that need no bounds checks
   for (uint64_t t = blockIdx.x; t < n_full; t += gridDim.x) {
@@ -51,16 +53,16 @@ __global__ __launch_bounds__(kBlock) void deskew_frame_f32(const v4f* __restrict
     v4f* __restrict__ tout = out + t * kTile;
     v4f p[PPT];
 #pragma unroll
-    for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * kBlock + tid);
+    for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * BLOCK + tid);
 #pragma unroll
-    for (int u = 0; u < PPT; ++u) store_point<NT>(tout + u * kBlock + tid, deskew_point<TIER, OCML_ATAN>(p[u], f));
+    for (int u = 0; u < PPT; ++u) store_point<NT>(tout + u * BLOCK + tid, deskew_point<TIER, OCML_ATAN>(p[u], f));
   }
   // ragged tail (< kTile points): handled by the workgroup that would own tile n_full
   if (blockIdx.x == n_full % gridDim.x) {
     const uint64_t base = n_full * kTile;
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
-      const uint64_t i = base + (uint64_t)u * kBlock + tid;
+      const uint64_t i = base + (uint64_t)u * BLOCK + tid;
       if (i < n) store_point<NT>(out + i, deskew_point<TIER, OCML_ATAN>(load_point<NT>(in + i), f));
     }
   }
@@ -100,7 +102,7 @@ constexpr int kLdsFrames = 16;  // records staged in LDS for a tile that straddl
 // (integer compares on the end offsets -- the per-point "timestamp index", bit-exact by construction) and
 // gathers its record from LDS; a wave whose lanes all landed in one frame broadcasts lane 0's record through
 // readfirstlane so it stays on the scalar path.
-template <int TIER, int PPT, bool NT, bool WRITE_IDX>
+template <int TIER, int PPT, int NT, bool WRITE_IDX>
 __global__ __launch_bounds__(kBlock) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
                                                           const BatchRec* __restrict__ recs,
                                                           const uint32_t* __restrict__ tile_first, uint32_t n_frames,
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void synth_points(v4f* __restrict__ out, ui
   }
 }
 
-template <int PPT, bool NT>
+template <int PPT, int NT>
 __global__ __launch_bounds__(kBlock) void copy_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
   constexpr uint64_t kTile = (uint64_t)kBlock * PPT;
   const uint32_t tid = threadIdx.x;

@@ -56,25 +56,73 @@ static FrameRec make_rec() {
   return f;
 }
 
-template <int TIER, int PPT, bool NT, bool OCML>
+template <int TIER, int PPT, int NT, bool OCML, int BLOCK = kBlock>
 static Variant frame_variant(const char* label) {
   Variant v;
   v.name = label;
   v.ppt = PPT;
   v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int bpc) {
     static const FrameRec f = make_rec();
-    hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, NT, OCML>), dim3(grid_for(n, PPT, bpc)), dim3(kBlock), 0, s, in, out, n, f);
+    const uint64_t tiles = (n + (uint64_t)BLOCK * PPT - 1) / ((uint64_t)BLOCK * PPT);
+    const uint64_t cap = bpc <= 0 ? tiles : (uint64_t)g_cus * bpc * (kBlock / (BLOCK < kBlock ? BLOCK : kBlock));
+    hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, NT, OCML, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s, in, out, n, f);
   };
   return v;
 }
 
-template <int PPT, bool NT>
+template <int PPT, int NT>
 static Variant copy_variant(const char* label) {
   Variant v;
   v.name = label;
   v.ppt = PPT;
   v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int bpc) {
     hipLaunchKernelGGL((copy_points<PPT, NT>), dim3(grid_for(n, PPT, bpc)), dim3(kBlock), 0, s, in, out, n);
+  };
+  return v;
+}
+
+// batched kernel: tables for `frames` equal frames over n points
+struct BatchTables {
+  BatchRec* d_recs = nullptr;
+  uint32_t* d_tiles[9] = {nullptr};  // indexed by ppt
+  uint32_t n_frames = 0;
+};
+static BatchTables g_bt_big, g_bt_small;
+
+static void build_tables(BatchTables* bt, uint64_t n, uint64_t pts_per_frame) {
+  const uint32_t nf = (uint32_t)((n + pts_per_frame - 1) / pts_per_frame);
+  std::vector<BatchRec> recs(nf);
+  const FrameRec f = make_rec();
+  for (uint32_t i = 0; i < nf; ++i) {
+    BatchRec& r = recs[i];
+    r.phi_x = f.phi_x; r.phi_y = f.phi_y; r.phi_z = f.phi_z; r.phi2 = f.phi2;
+    r.rho_x = f.rho_x; r.rho_y = f.rho_y; r.rho_z = f.rho_z; r.s0 = f.s0;
+    r.c1_x = f.c1_x; r.c1_y = f.c1_y; r.c1_z = f.c1_z;
+    r.c2_x = f.c2_x; r.c2_y = f.c2_y; r.c2_z = f.c2_z;
+    const uint64_t end = std::min<uint64_t>(n, (uint64_t)(i + 1) * pts_per_frame);
+    r.end_lo = (uint32_t)end; r.end_hi = (uint32_t)(end >> 32);
+  }
+  CK(hipMalloc((void**)&bt->d_recs, nf * sizeof(BatchRec)));
+  CK(hipMemcpy(bt->d_recs, recs.data(), nf * sizeof(BatchRec), hipMemcpyHostToDevice));
+  for (int ppt : {1, 2, 4}) {
+    const uint64_t tile = (uint64_t)kBlock * ppt, nt = (n + tile - 1) / tile;
+    std::vector<uint32_t> tf(nt);
+    for (uint64_t t = 0; t < nt; ++t) tf[t] = (uint32_t)((t * tile) / pts_per_frame);
+    CK(hipMalloc((void**)&bt->d_tiles[ppt], nt * sizeof(uint32_t)));
+    CK(hipMemcpy(bt->d_tiles[ppt], tf.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  bt->n_frames = nf;
+}
+
+template <int PPT, bool SMALL>
+static Variant batch_variant(const char* label) {
+  Variant v;
+  v.name = label;
+  v.ppt = PPT;
+  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int bpc) {
+    const BatchTables& bt = SMALL ? g_bt_small : g_bt_big;
+    hipLaunchKernelGGL((deskew_batch_f32<kSeries3, PPT, kNtBoth, false>), dim3(grid_for(n, PPT, bpc)), dim3(kBlock), 0, s, in, out,
+                       bt.d_recs, bt.d_tiles[PPT], bt.n_frames, n, (uint32_t*)nullptr);
   };
   return v;
 }
@@ -103,48 +151,63 @@ int main(int argc, char** argv) {
   }
   CK(hipStreamSynchronize(s));
 
-  std::vector<Variant> vs;
-  vs.push_back(copy_variant<4, true>("copy_ppt4_nt"));
-  vs.push_back(copy_variant<4, false>("copy_ppt4"));
-  vs.push_back(copy_variant<1, true>("copy_ppt1_nt"));
-  vs.push_back(copy_variant<8, true>("copy_ppt8_nt"));
-  vs.push_back(frame_variant<kSeries3, 1, true, false>("s3_ppt1_nt"));
-  vs.push_back(frame_variant<kSeries3, 2, true, false>("s3_ppt2_nt"));
-  vs.push_back(frame_variant<kSeries3, 4, true, false>("s3_ppt4_nt"));
-  vs.push_back(frame_variant<kSeries3, 8, true, false>("s3_ppt8_nt"));
-  vs.push_back(frame_variant<kSeries3, 4, false, false>("s3_ppt4"));
-  vs.push_back(frame_variant<kSeries3, 1, false, false>("s3_ppt1"));
-  vs.push_back(frame_variant<kSeries3, 4, true, true>("s3_ppt4_nt_ocml"));
-  vs.push_back(frame_variant<kSeries5, 4, true, false>("s5_ppt4_nt"));
-  vs.push_back(frame_variant<kTrig, 4, true, false>("trig_ppt4_nt"));
-  const int bpcs[] = {0, 4, 8, 16, 32};
+  build_tables(&g_bt_big, n, 1000000);
+  build_tables(&g_bt_small, n, 123397);
+  struct Entry { Variant v; std::vector<int> bpcs; };
+  std::vector<Entry> es;
+  const std::vector<int> kAll = {0, 8, 32}, kZero = {0};
+  es.push_back({copy_variant<1, kNtBoth>("copy_ppt1_nt"), kAll});
+  es.push_back({copy_variant<1, kNtLoad>("copy_ppt1_ntload"), kZero});
+  es.push_back({copy_variant<1, kNtStore>("copy_ppt1_ntstore"), kZero});
+  es.push_back({copy_variant<1, 0>("copy_ppt1_plain"), kZero});
+  es.push_back({copy_variant<4, kNtBoth>("copy_ppt4_nt"), kAll});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth, false>("s3_ppt1_nt"), kAll});
+  es.push_back({frame_variant<kSeries3, 1, kNtLoad, false>("s3_ppt1_ntload"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtStore, false>("s3_ppt1_ntstore"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, 0, false>("s3_ppt1_plain"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth, false, 64>("s3_ppt1_nt_b64"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth, false, 128>("s3_ppt1_nt_b128"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth, false, 512>("s3_ppt1_nt_b512"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth, false, 1024>("s3_ppt1_nt_b1024"), kZero});
+  es.push_back({frame_variant<kSeries3, 2, kNtBoth, false>("s3_ppt2_nt"), kZero});
+  es.push_back({frame_variant<kSeries3, 2, kNtBoth, false, 128>("s3_ppt2_nt_b128"), kZero});
+  es.push_back({frame_variant<kSeries3, 4, kNtBoth, false>("s3_ppt4_nt"), kAll});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth, true>("s3_ppt1_nt_ocml"), kZero});
+  es.push_back({frame_variant<kSeries5, 1, kNtBoth, false>("s5_ppt1_nt"), kZero});
+  es.push_back({frame_variant<kTrig, 1, kNtBoth, false>("trig_ppt1_nt"), kZero});
+  es.push_back({batch_variant<1, false>("batch1M_ppt1"), kAll});
+  es.push_back({batch_variant<2, false>("batch1M_ppt2"), kZero});
+  es.push_back({batch_variant<4, false>("batch1M_ppt4"), kAll});
+  es.push_back({batch_variant<1, true>("batch123k_ppt1"), kAll});
+  es.push_back({batch_variant<4, true>("batch123k_ppt4"), kAll});
+
+  std::vector<Variant> vs;  // flattened (variant, bpc) pairs
+  std::vector<int> vb;
+  for (auto& e : es)
+    for (int b : e.bpcs) { vs.push_back(e.v); vb.push_back(b); }
 
   struct Res { std::string name; int bpc; std::vector<float> ms; };
   std::vector<Res> res;
-  for (auto& v : vs)
-    for (int bpc : bpcs) res.push_back({v.name, bpc, {}});
+  for (size_t i = 0; i < vs.size(); ++i) res.push_back({vs[i].name, vb[i], {}});
 
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   int rot = 0;
   for (int r = 0; r < rounds + 1; ++r) {  // round 0 = warm-up
-    size_t k = 0;
-    for (auto& v : vs)
-      for (int bpc : bpcs) {
-        CK(hipEventRecord(e0, s));
-        for (int i = 0; i < iters; ++i) {
-          v.launch(s, in[rot % kBufs], out[rot % kBufs], n, bpc);
-          ++rot;
-        }
-        CK(hipEventRecord(e1, s));
-        CK(hipEventSynchronize(e1));
-        CK(hipGetLastError());
-        float ms = 0;
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        if (r > 0) res[k].ms.push_back(ms / iters);
-        ++k;
+    for (size_t k = 0; k < vs.size(); ++k) {
+      CK(hipEventRecord(e0, s));
+      for (int i = 0; i < iters; ++i) {
+        vs[k].launch(s, in[rot % kBufs], out[rot % kBufs], n, vb[k]);
+        ++rot;
       }
+      CK(hipEventRecord(e1, s));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0) res[k].ms.push_back(ms / iters);
+    }
   }
   std::printf("variant,blocks_per_cu,ms_median,ms_min,gbps_median,gbps_best,mpts_median,frac_of_8TBps\n");
   for (auto& x : res) {
