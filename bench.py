@@ -6,7 +6,7 @@
 
 Metric (BASELINE.json): M points/s deskewed, with the achieved HBM GB/s of the per-point transform kernel.
 Workload = BASELINE.json configs[1]: synthetic 1 M-point frames, straight-line constant-velocity trajectory.  One STEP is
-one pass of the hot path over one batch of FRAMES_PER_STEP distinct such frames (64 x 1 M points = 1 GiB in + 1 GiB out,
+one pass of the hot path over one batch of FRAMES_PER_STEP distinct such frames (256 x 1 M points = 4 GB in + 4 GB out,
 far beyond the 256 MiB Infinity Cache, so the GB/s are HBM GB/s) issued as ONE launch of the batched kernel through the
 C-ABI (kmc_hip_deskew_batch_f32, KMC_MEM_DEVICE: inputs resident in HBM before the timed region starts).
 Every rank processes its own batch (frame-sharded, weak scaling); RCCL is used only to reduce the counters.
@@ -80,11 +80,12 @@ def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-step", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames-per-step", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=24)
+    ap.add_argument("--cpu-sample-frames", type=int, default=32)
+    ap.add_argument("--rotate", type=int, default=1, help="number of in/out buffer pairs cycled through by the steps")
     args = ap.parse_args()
 
     import torch
@@ -115,17 +116,24 @@ def main():
     info = ctx.device_info()
 
     # ---- workload: generated on the device (identical generator on the host for the oracle), resident in HBM ----
-    d_in = torch.empty((n, 4), dtype=torch.float32, device=dev)
-    d_out = torch.empty_like(d_in)
+    R = max(1, args.rotate)
+    d_ins = [torch.empty((n, 4), dtype=torch.float32, device=dev) for _ in range(R)]
+    d_outs = [torch.empty_like(d_ins[0]) for _ in range(R)]
     for f in range(F):
-        ctx.synth_points(d_in[f * POINTS_PER_FRAME:(f + 1) * POINTS_PER_FRAME], POINTS_PER_FRAME, SEED + f + rank * F)
+        ctx.synth_points(d_ins[0][f * POINTS_PER_FRAME:(f + 1) * POINTS_PER_FRAME], POINTS_PER_FRAME, SEED + f + rank * F)
+    for r in range(1, R):
+        d_ins[r].copy_(d_ins[0])
+    d_in, d_out = d_ins[0], d_outs[0]
+    state = {"k": 0}
     work = make_workload(capi, F, rank)
     params = capi.params_array([w[0] for w in work])
     offsets = np.arange(F + 1, dtype=np.uint64) * POINTS_PER_FRAME
     torch.cuda.synchronize()
 
     def step():
-        ctx.deskew_batch_f32(d_in, d_out, offsets, params, None)
+        k = state["k"] % R
+        state["k"] += 1
+        ctx.deskew_batch_f32(d_ins[k], d_outs[k], offsets, params, None)
 
     for _ in range(args.warmup):
         step()
@@ -161,7 +169,7 @@ def main():
         f = F - 1
         sl = slice(f * POINTS_PER_FRAME, f * POINTS_PER_FRAME + 50_000)
         xyzi = d_in[sl].cpu().numpy()
-        got = d_out[sl].cpu().numpy()
+        got = d_outs[(state["k"] - 1) % R][sl].cpu().numpy()
         (t0, tm, t1), oxs = work[f][1], work[f][2]
         oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
         rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
@@ -196,7 +204,7 @@ def main():
                             f"{F} distinct frames per step in one batched launch (per GPU), device-resident",
                 "points_per_frame": POINTS_PER_FRAME, "frames_per_step_per_gpu": F, "points_per_step_per_gpu": n,
                 "parallelism": f"frame-sharded x{world} (no data-path collective)",
-                "kernel": "kmc_dev::deskew_batch_f32<series3, ppt=1, nt>, one 256-point tile per workgroup", "device": info["name"], "arch": info["arch"],
+                "kernel": "kmc_dev::deskew_batch_f32<series3, ppt=1, nt, block=64>, one 64-point tile (one wave) per workgroup", "device": info["name"], "arch": info["arch"],
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

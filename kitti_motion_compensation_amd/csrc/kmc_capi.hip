@@ -33,21 +33,22 @@ struct kmc_ctx {
   int force_tier = -1;
   // out-of-range counter (f64 path)
   unsigned long long* d_counter = nullptr;
-  // batch tables: a ring of slots (device tables + pinned staging) uploaded on a side stream so that the
-  // per-step host preparation and the table H2D overlap the previous step's kernel
+  // batch tables: a ring of slots, each one device buffer + one pinned staging buffer holding
+  // [BatchRec x n_frames | coarse x (n_chunks + 1)], uploaded with ONE copy on a side stream so that the per-step host
+  // preparation and the table H2D overlap the previous step's kernel.  The compute stream sees no event between two
+  // launches except one "consumed" marker per group of kSlotsPerGroup launches (a marker between kernels costs ~3 us).
   struct TableSlot {
-    BatchRec* d_recs = nullptr;
-    BatchRec* h_recs = nullptr;
-    size_t recs_cap = 0;
-    uint32_t* d_tiles = nullptr;
-    uint32_t* h_tiles = nullptr;
-    size_t tiles_cap = 0;
+    char* d_buf = nullptr;
+    char* h_buf = nullptr;
+    size_t cap = 0;
     hipEvent_t uploaded = nullptr;  // tables are on the device (copy stream)
-    hipEvent_t consumed = nullptr;  // the kernel that read them has finished (compute stream)
-    bool busy = false;
   };
-  static constexpr int kTableSlots = 3;
+  static constexpr int kSlotsPerGroup = 4;
+  static constexpr int kSlotGroups = 4;
+  static constexpr int kTableSlots = kSlotsPerGroup * kSlotGroups;
   TableSlot slots[kTableSlots];
+  hipEvent_t group_consumed[kSlotGroups] = {nullptr, nullptr, nullptr, nullptr};  // kernels of the group finished
+  bool group_busy[kSlotGroups] = {false, false, false, false};
   int next_slot = 0;
   hipStream_t copy_stream = nullptr;
   // host-staging buffers
@@ -61,6 +62,8 @@ struct kmc_ctx {
 
 namespace {
 
+// measured best on MI355X (profiles/r01_tune.csv): one wave per workgroup, one point per lane, one tile per workgroup
+constexpr int kLaunchBlock = 64;
 constexpr int kDefaultPpt = 1;  // measured best on MI355X: 256-point tiles, one per workgroup (profiles/r01_tune.csv)
 constexpr uint64_t kHostChunkPoints = 1ull << 22;  // 64 MiB per direction per pipeline slot
 
@@ -114,7 +117,7 @@ bool params_ok(const kmc_frame_params* p) {
 int grid_for(const kmc_ctx* c, uint64_t n_tiles) {
   // default: one tile per workgroup -- the hardware dispatcher streams 256-point tiles better than a persistent
   // grid-stride loop does (6.66 vs 5.39 TB/s, profiles/r01_tune.csv); blocks_per_cu > 0 caps the grid instead.
-  const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu : 0x7fffffffull;
+  const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu * (kBlock / kLaunchBlock) : 0x7fffffffull;
   return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, cap));
 }
 
@@ -126,7 +129,7 @@ int ppt_of(const kmc_ctx* c) {
 // ---- template dispatch ---------------------------------------------------------------------------
 template <int TIER, int PPT>
 void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
-  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kNtBoth, false>), dim3(grid), dim3(kBlock), 0, s, in, out, n, f);
+  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kNtBoth, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f);
 }
 template <int TIER>
 void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
@@ -139,7 +142,7 @@ void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, u
 }
 void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
   const int ppt = ppt_of(c);
-  const uint64_t n_tiles = (n + (uint64_t)kBlock * ppt - 1) / ((uint64_t)kBlock * ppt);
+  const uint64_t n_tiles = (n + (uint64_t)kLaunchBlock * ppt - 1) / ((uint64_t)kLaunchBlock * ppt);
   const int grid = grid_for(c, n_tiles);
   switch (tier) {
     case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f); break;
@@ -152,9 +155,9 @@ template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint32_t* tiles,
                      uint32_t nf, uint64_t n, uint32_t* idx) {
   if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kNtBoth, true>), dim3(grid), dim3(kBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kNtBoth, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
   else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kNtBoth, false>), dim3(grid), dim3(kBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kNtBoth, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
@@ -248,10 +251,10 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   for (hipEvent_t* ev : evs)
     if (e == hipSuccess) e = hipEventCreate(ev);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
-  for (auto& sl : c->slots) {
+  for (auto& sl : c->slots)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming);
-  }
+  for (auto& ev : c->group_consumed)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -274,13 +277,12 @@ void kmc_hip_destroy(kmc_ctx* c) {
   }
   if (c->d_tmp) (void)hipFree(c->d_tmp);
   for (auto& sl : c->slots) {
-    if (sl.d_recs) (void)hipFree(sl.d_recs);
-    if (sl.h_recs) (void)hipHostFree(sl.h_recs);
-    if (sl.d_tiles) (void)hipFree(sl.d_tiles);
-    if (sl.h_tiles) (void)hipHostFree(sl.h_tiles);
+    if (sl.d_buf) (void)hipFree(sl.d_buf);
+    if (sl.h_buf) (void)hipHostFree(sl.h_buf);
     if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
-    if (sl.consumed) (void)hipEventDestroy(sl.consumed);
   }
+  for (auto& ev : c->group_consumed)
+    if (ev) (void)hipEventDestroy(ev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->d_counter) (void)hipFree(c->d_counter);
   hipEvent_t evs[] = {c->ev_k0, c->ev_k1, c->ev_c0, c->ev_c1, c->ev_t0, c->ev_t1};
@@ -462,51 +464,63 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (n == 0) return KMC_OK;
 
   const int ppt = ppt_of(c);
-  const uint64_t tile = (uint64_t)kBlock * ppt;
+  const uint64_t tile = (uint64_t)kLaunchBlock * ppt;
   const uint64_t n_tiles = (n + tile - 1) / tile;
+  const uint64_t chunk = 1ull << kChunkShift;
+  const uint64_t n_chunks = (n + chunk - 1) / chunk;
+  const uint64_t n_coarse = n_chunks + 1;
 
-  // pick the next table slot; it was last used kTableSlots steps ago -- make sure that kernel is done
-  kmc_ctx::TableSlot& sl = c->slots[c->next_slot];
+  // pick the next table slot; its group's kernels were launched >= kTableSlots - kSlotsPerGroup steps ago
+  const int slot_id = c->next_slot;
+  const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
+  kmc_ctx::TableSlot& sl = c->slots[slot_id];
   c->next_slot = (c->next_slot + 1) % kmc_ctx::kTableSlots;
-  if (sl.busy) {
-    KMC_HIP_TRY(c, hipEventSynchronize(sl.consumed));
-    sl.busy = false;
+  if (slot_id % kmc_ctx::kSlotsPerGroup == 0 && c->group_busy[group_id]) {
+    KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
+    c->group_busy[group_id] = false;
   }
-  if (n_frames > sl.recs_cap) {
-    if (sl.d_recs) (void)hipFree(sl.d_recs);
-    if (sl.h_recs) (void)hipHostFree(sl.h_recs);
-    sl.d_recs = nullptr; sl.h_recs = nullptr; sl.recs_cap = 0;
-    const size_t cap = std::max<size_t>(64, (size_t)n_frames * 2);
-    KMC_HIP_TRY(c, hipMalloc((void**)&sl.d_recs, cap * sizeof(BatchRec)));
-    KMC_HIP_TRY(c, hipHostMalloc((void**)&sl.h_recs, cap * sizeof(BatchRec), hipHostMallocDefault));
-    sl.recs_cap = cap;
+  const size_t recs_bytes = ((size_t)n_frames * sizeof(BatchRec) + 255) & ~(size_t)255;
+  const size_t need = recs_bytes + (size_t)n_coarse * sizeof(uint32_t);
+  if (need > sl.cap) {
+    // grow EVERY slot at once (so that steady state never allocates again); slots may still be referenced by
+    // kernels in flight: drain first
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    const size_t cap = std::max<size_t>(64 * 1024, need * 2);
+    for (auto& each : c->slots) {
+      if (each.cap >= cap) continue;
+      if (each.d_buf) (void)hipFree(each.d_buf);
+      if (each.h_buf) (void)hipHostFree(each.h_buf);
+      each.d_buf = nullptr; each.h_buf = nullptr; each.cap = 0;
+      KMC_HIP_TRY(c, hipMalloc((void**)&each.d_buf, cap));
+      KMC_HIP_TRY(c, hipHostMalloc((void**)&each.h_buf, cap, hipHostMallocDefault));
+      each.cap = cap;
+    }
+    for (auto& busy : c->group_busy) busy = false;
   }
-  if (n_tiles > sl.tiles_cap) {
-    if (sl.d_tiles) (void)hipFree(sl.d_tiles);
-    if (sl.h_tiles) (void)hipHostFree(sl.h_tiles);
-    sl.d_tiles = nullptr; sl.h_tiles = nullptr; sl.tiles_cap = 0;
-    const size_t cap = std::max<size_t>(1024, (size_t)n_tiles * 2);
-    KMC_HIP_TRY(c, hipMalloc((void**)&sl.d_tiles, cap * sizeof(uint32_t)));
-    KMC_HIP_TRY(c, hipHostMalloc((void**)&sl.h_tiles, cap * sizeof(uint32_t), hipHostMallocDefault));
-    sl.tiles_cap = cap;
-  }
+  BatchRec* h_recs = reinterpret_cast<BatchRec*>(sl.h_buf);
+  uint32_t* h_coarse = reinterpret_cast<uint32_t*>(sl.h_buf + recs_bytes);
+  const BatchRec* d_recs = reinterpret_cast<const BatchRec*>(sl.d_buf);
+  const uint32_t* d_coarse = reinterpret_cast<const uint32_t*>(sl.d_buf + recs_bytes);
   for (uint32_t f = 0; f < n_frames; ++f) {
-    BatchRec* r = &sl.h_recs[f];
+    BatchRec* r = &h_recs[f];
     fill_rec(params[f], r);
     r->end_lo = (uint32_t)(offsets[f + 1] & 0xFFFFFFFFull);
     r->end_hi = (uint32_t)(offsets[f + 1] >> 32);
   }
   {
+    // coarse[c] = frame that owns point c * chunk (empty frames skipped); coarse[n_chunks] = frame of the last point
     uint32_t f = 0;
-    for (uint64_t t = 0; t < n_tiles; ++t) {
-      const uint64_t first = t * tile;
-      while (f + 1 < n_frames && offsets[f + 1] <= first) ++f;  // skips empty frames
-      sl.h_tiles[t] = f;
+    for (uint64_t ci = 0; ci < n_chunks; ++ci) {
+      const uint64_t first = ci * chunk;
+      while (f + 1 < n_frames && offsets[f + 1] <= first) ++f;
+      h_coarse[ci] = f;
     }
+    while (f + 1 < n_frames && offsets[f + 1] <= n - 1) ++f;
+    h_coarse[n_chunks] = f;
   }
-  // table upload on the side stream: overlaps whatever the compute stream is still running
-  KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_recs, sl.h_recs, (size_t)n_frames * sizeof(BatchRec), hipMemcpyHostToDevice, c->copy_stream));
-  KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_tiles, sl.h_tiles, (size_t)n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+  // one table upload on the side stream: overlaps whatever the compute stream is still running
+  KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, need, hipMemcpyHostToDevice, c->copy_stream));
   KMC_HIP_TRY(c, hipEventRecord(sl.uploaded, c->copy_stream));
 
   CallTimer tm(c);
@@ -525,17 +539,21 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST)
     KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, n * sizeof(v4f), hipMemcpyHostToDevice, c->stream));
-  KMC_HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.uploaded, 0));
+  // wait for the (tiny) table upload on the HOST: the launch below then has no cross-stream dependency, so
+  // back-to-back steps keep the ~2 us same-stream kernel boundary instead of a ~10 us barrier packet
+  KMC_HIP_TRY(c, hipEventSynchronize(sl.uploaded));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, n_tiles);
   switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in, d_out, sl.d_recs, sl.d_tiles, n_frames, n, d_idx); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in, d_out, sl.d_recs, sl.d_tiles, n_frames, n, d_idx); break;
-    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in, d_out, sl.d_recs, sl.d_tiles, n_frames, n, d_idx); break;
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in, d_out, d_recs, d_coarse, n_frames, n, d_idx); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in, d_out, d_recs, d_coarse, n_frames, n, d_idx); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in, d_out, d_recs, d_coarse, n_frames, n, d_idx); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
-  KMC_HIP_TRY(c, hipEventRecord(sl.consumed, c->stream));
-  sl.busy = true;
+  if (slot_id % kmc_ctx::kSlotsPerGroup == kmc_ctx::kSlotsPerGroup - 1) {
+    KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
+    c->group_busy[group_id] = true;
+  }
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {
     KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out, d_out, n * sizeof(v4f), hipMemcpyDeviceToHost, c->stream));

@@ -93,42 +93,58 @@ __device__ __forceinline__ FrameRec to_frame(const BatchRec& r) {
   return f;
 }
 
-constexpr int kLdsFrames = 16;  // records staged in LDS for a tile that straddles frame boundaries
+constexpr int kLdsFrames = 16;   // records staged in LDS for a tile that straddles frame boundaries
+constexpr int kChunkShift = 14;  // coarse frame table: one entry per 16384 points
 
-// tile_first[t] = index of the frame that owns the first point of tile t (host-computed, 4 B per tile).
-// A tile lies in ONE frame in all but ~F of the n/kTile tiles; then the record is fetched with scalar
-// loads (wave-uniform -> SGPRs) and the body is identical to the single-frame kernel.  A straddling tile
-// stages the next kLdsFrames records into LDS once per workgroup; each lane then walks to its own frame
-// (integer compares on the end offsets -- the per-point "timestamp index", bit-exact by construction) and
-// gathers its record from LDS; a wave whose lanes all landed in one frame broadcasts lane 0's record through
-// readfirstlane so it stays on the scalar path.
-template <int TIER, int PPT, int NT, bool WRITE_IDX>
-__global__ __launch_bounds__(kBlock) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
-                                                          const BatchRec* __restrict__ recs,
-                                                          const uint32_t* __restrict__ tile_first, uint32_t n_frames,
-                                                          uint64_t n, uint32_t* __restrict__ frame_idx_out) {
-  constexpr uint64_t kTile = (uint64_t)kBlock * PPT;
+// coarse[c] = index of the frame that owns point c << kChunkShift (host-computed, 4 B per 16384 points, so the
+// table and the 64-B records stay resident in the scalar cache / L2).  Per tile, wave-uniform scalar code:
+//   1. the tile's point loads are issued FIRST (their addresses do not depend on the tables), so the table
+//      look-ups below overlap the HBM latency of the points instead of preceding it;
+//   2. [coarse[c], coarse[c+1]] brackets the frame of the tile's first point; a scalar binary search over the
+//      records' end offsets narrows it (zero iterations unless a frame boundary falls into this 16384-point chunk);
+//   3. a tile that lies in ONE frame -- all but ~F of the n/kTile tiles -- takes the record through scalar loads
+//      (SGPRs) and runs the same body as the single-frame kernel;
+//   4. a straddling tile stages the next kLdsFrames records into LDS once per workgroup; each lane walks to its
+//      own frame (integer compares on the end offsets: the per-point "timestamp index", bit-exact by construction)
+//      and gathers its record from LDS; a wave whose lanes all landed in one frame broadcasts the index through
+//      readfirstlane and stays on the uniform path.
+template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
+                                                         const BatchRec* __restrict__ recs,
+                                                         const uint32_t* __restrict__ coarse, uint32_t n_frames,
+                                                         uint64_t n, uint32_t* __restrict__ frame_idx_out) {
+  static_assert(BLOCK >= kLdsFrames * 4, "the LDS staging uses one lane per 16 bytes of the record table");
+  constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
   __shared__ BatchRec lds_recs[kLdsFrames];
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + kTile - 1) / kTile;
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const uint64_t base = t * kTile;
-    const uint64_t tile_end = (base + kTile < n) ? base + kTile : n;
-    const uint32_t f0 = tile_first[t];           // uniform -> s_load_dword
-    const BatchRec r0 = recs[f0];                // uniform -> s_load_dwordx16
-    const bool uniform_tile = rec_end(r0) >= tile_end;
-    if (uniform_tile && tile_end - base == kTile) {
-      // fast path: full tile inside one frame
-      const FrameRec f = to_frame(r0);
-      const v4f* __restrict__ tin = in + base;
-      v4f* __restrict__ tout = out + base;
-      v4f p[PPT];
+    const bool full = base + kTile <= n;
+    const uint64_t tile_end = full ? base + kTile : n;
+    const v4f* __restrict__ tin = in + base;
+    v4f* __restrict__ tout = out + base;
+    v4f p[PPT];
+    if (full) {
 #pragma unroll
-      for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * kBlock + tid);
+      for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * BLOCK + tid);
+    }
+    // frame of the tile's first point (uniform -> SALU + scalar loads)
+    const uint64_t c = base >> kChunkShift;
+    uint32_t lo = coarse[c], hi = coarse[c + 1];
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (rec_end(recs[mid]) > base) hi = mid;
+      else lo = mid + 1;
+    }
+    const uint32_t f0 = lo;
+    const BatchRec r0 = recs[f0];
+    if (full && rec_end(r0) >= tile_end) {
+      const FrameRec f = to_frame(r0);
 #pragma unroll
       for (int u = 0; u < PPT; ++u) {
-        store_point<NT>(tout + u * kBlock + tid, deskew_point<TIER, false>(p[u], f));
-        if constexpr (WRITE_IDX) __builtin_nontemporal_store(f0, frame_idx_out + base + u * kBlock + tid);
+        store_point<NT>(tout + u * BLOCK + tid, deskew_point<TIER, false>(p[u], f));
+        if constexpr (WRITE_IDX) __builtin_nontemporal_store(f0, frame_idx_out + base + u * BLOCK + tid);
       }
     } else {
       // slow path: ragged last tile and/or a tile that straddles frame boundaries
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void deskew_batch_f32(const v4f* __restrict
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < PPT; ++u) {
-        const uint64_t i = base + (uint64_t)u * kBlock + tid;
+        const uint64_t i = base + (uint64_t)u * BLOCK + tid;
         const bool live = i < tile_end;
         // walk to the frame that owns point i (skips empty frames); dead lanes stay on f0
         uint32_t fi = f0;
@@ -166,7 +182,8 @@ __global__ __launch_bounds__(kBlock) void deskew_batch_f32(const v4f* __restrict
         }
         if (live) {
           const FrameRec f = to_frame(r);
-          store_point<NT>(out + i, deskew_point<TIER, false>(load_point<NT>(in + i), f));
+          const v4f pt = full ? p[u] : load_point<NT>(in + i);
+          store_point<NT>(out + i, deskew_point<TIER, false>(pt, f));
           if constexpr (WRITE_IDX) frame_idx_out[i] = fi;
         }
       }

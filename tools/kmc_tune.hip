@@ -84,7 +84,7 @@ static Variant copy_variant(const char* label) {
 // batched kernel: tables for `frames` equal frames over n points
 struct BatchTables {
   BatchRec* d_recs = nullptr;
-  uint32_t* d_tiles[9] = {nullptr};  // indexed by ppt
+  uint32_t* d_coarse = nullptr;
   uint32_t n_frames = 0;
 };
 static BatchTables g_bt_big, g_bt_small;
@@ -104,25 +104,28 @@ static void build_tables(BatchTables* bt, uint64_t n, uint64_t pts_per_frame) {
   }
   CK(hipMalloc((void**)&bt->d_recs, nf * sizeof(BatchRec)));
   CK(hipMemcpy(bt->d_recs, recs.data(), nf * sizeof(BatchRec), hipMemcpyHostToDevice));
-  for (int ppt : {1, 2, 4}) {
-    const uint64_t tile = (uint64_t)kBlock * ppt, nt = (n + tile - 1) / tile;
-    std::vector<uint32_t> tf(nt);
-    for (uint64_t t = 0; t < nt; ++t) tf[t] = (uint32_t)((t * tile) / pts_per_frame);
-    CK(hipMalloc((void**)&bt->d_tiles[ppt], nt * sizeof(uint32_t)));
-    CK(hipMemcpy(bt->d_tiles[ppt], tf.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice));
+  {
+    const uint64_t chunk = 1ull << kChunkShift, nc = (n + chunk - 1) / chunk;
+    std::vector<uint32_t> co(nc + 1);
+    for (uint64_t c = 0; c < nc; ++c) co[c] = (uint32_t)((c * chunk) / pts_per_frame);
+    co[nc] = (uint32_t)((n - 1) / pts_per_frame);
+    CK(hipMalloc((void**)&bt->d_coarse, (nc + 1) * sizeof(uint32_t)));
+    CK(hipMemcpy(bt->d_coarse, co.data(), (nc + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   bt->n_frames = nf;
 }
 
-template <int PPT, bool SMALL>
+template <int PPT, bool SMALL, int BLOCK = kBlock>
 static Variant batch_variant(const char* label) {
   Variant v;
   v.name = label;
   v.ppt = PPT;
   v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int bpc) {
     const BatchTables& bt = SMALL ? g_bt_small : g_bt_big;
-    hipLaunchKernelGGL((deskew_batch_f32<kSeries3, PPT, kNtBoth, false>), dim3(grid_for(n, PPT, bpc)), dim3(kBlock), 0, s, in, out,
-                       bt.d_recs, bt.d_tiles[PPT], bt.n_frames, n, (uint32_t*)nullptr);
+    const uint64_t tiles = (n + (uint64_t)BLOCK * PPT - 1) / ((uint64_t)BLOCK * PPT);
+    const uint64_t cap = bpc <= 0 ? tiles : (uint64_t)g_cus * bpc * (kBlock / (BLOCK < kBlock ? BLOCK : kBlock));
+    hipLaunchKernelGGL((deskew_batch_f32<kSeries3, PPT, kNtBoth, false, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s,
+                       in, out, bt.d_recs, bt.d_coarse, bt.n_frames, n, (uint32_t*)nullptr);
   };
   return v;
 }
@@ -176,10 +179,14 @@ int main(int argc, char** argv) {
   es.push_back({frame_variant<kSeries5, 1, kNtBoth, false>("s5_ppt1_nt"), kZero});
   es.push_back({frame_variant<kTrig, 1, kNtBoth, false>("trig_ppt1_nt"), kZero});
   es.push_back({batch_variant<1, false>("batch1M_ppt1"), kAll});
+  es.push_back({batch_variant<1, false, 64>("batch1M_ppt1_b64"), kZero});
+  es.push_back({batch_variant<1, false, 128>("batch1M_ppt1_b128"), kZero});
+  es.push_back({batch_variant<2, false, 64>("batch1M_ppt2_b64"), kZero});
   es.push_back({batch_variant<2, false>("batch1M_ppt2"), kZero});
-  es.push_back({batch_variant<4, false>("batch1M_ppt4"), kAll});
-  es.push_back({batch_variant<1, true>("batch123k_ppt1"), kAll});
-  es.push_back({batch_variant<4, true>("batch123k_ppt4"), kAll});
+  es.push_back({batch_variant<4, false>("batch1M_ppt4"), kZero});
+  es.push_back({batch_variant<1, true>("batch123k_ppt1"), kZero});
+  es.push_back({batch_variant<1, true, 64>("batch123k_ppt1_b64"), kZero});
+  es.push_back({batch_variant<1, true, 128>("batch123k_ppt1_b128"), kZero});
 
   std::vector<Variant> vs;  // flattened (variant, bpc) pairs
   std::vector<int> vb;
