@@ -181,11 +181,15 @@ def main():
     if rank == 0:
         kernel_ms = ev_ms / args.steps  # average launch duration of the dominant kernel, HIP events, this rank
         achieved = BYTES_PER_POINT * n / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of
+        # this same command, corrected as MI355X_MICROARCH.md section HBM prescribes; tools/summarize_profiles.py).
+        # Counters cannot be read from inside the process, so the figure is per-point and scaled to this launch size.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fjson:
-                traffic = json.load(fjson).get("hbm_bytes_per_launch")
+                tj = json.load(fjson)
+            traffic = round(tj["hbm_bytes_per_point"] * n)
         out = {
             "metric": "M points/sec deskewed",
             "value": round(pts_total / t_max / 1e6, 1),

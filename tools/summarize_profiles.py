@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of one profiling session (gpurun_out/<tag>/, scratch) into the small tracked summaries
+under profiles/ that bench.py and DESIGN.md cite.
+
+  python tools/summarize_profiles.py gpurun_out/r01 r01
+
+Inputs expected in the session directory (see profiles/README.md for the exact gpurun command):
+  kt/bench_kernel_stats.csv                rocprofv3 --kernel-trace --stats            -- python bench.py
+  pmc_fetch/bench_counter_collection.csv   rocprofv3 --pmc FETCH_SIZE                  -- python bench.py --steps 4 --warmup 1
+  pmc_write/bench_counter_collection.csv   rocprofv3 --pmc WRITE_SIZE                  -- python bench.py --steps 4 --warmup 1
+  cal_fetch/, cal_write/                   the same two counters on tools/kmc_tune (copy kernel of known byte count)
+
+HBM-byte derivation (MI355X_MICROARCH.md section HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+exactly 1/2 of the bytes of a wide coalesced stream, WRITE_SIZE must be calibrated -- both factors are re-derived here from
+the float4 copy kernel whose byte count is known, in the same access pattern as the deskew kernel.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def counters(path, name):
+    d = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == name:
+                d[(r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(float(r["Counter_Value"]))
+    return d
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(os.path.join(src, "kt", "bench_kernel_stats.csv"), os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
+
+    # calibration on the copy kernel: 64 Mi points x 16 B each way
+    cal_f = counters(os.path.join(src, "cal_fetch", "tune_counter_collection.csv"), "FETCH_SIZE")
+    cal_w = counters(os.path.join(src, "cal_write", "tune_counter_collection.csv"), "WRITE_SIZE")
+
+    def pick(d, frag):
+        for (k, grid, wg), v in d.items():
+            if frag in k and grid == 67108864 and wg == 256:
+                return sum(v) / len(v)
+        raise KeyError(frag)
+
+    known_kib = 67108864 * 16 / 1024.0
+    fetch_factor = known_kib / pick(cal_f, "copy_points<1, 3>")
+    write_factor = known_kib / pick(cal_w, "copy_points<1, 3>")
+
+    f = counters(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"), "FETCH_SIZE")
+    w = counters(os.path.join(src, "pmc_write", "bench_counter_collection.csv"), "WRITE_SIZE")
+    (kname, grid, wg), fv = next((k, v) for k, v in f.items() if "deskew_batch_f32" in k[0])
+    wv = next(v for k, v in w.items() if "deskew_batch_f32" in k[0])
+    fetch_kib, write_kib = sum(fv) / len(fv), sum(wv) / len(wv)
+    points = grid  # one lane per point, one tile per workgroup: Grid_Size == points (rounded up to the 64-lane tile)
+    hbm_bytes = (fetch_kib * fetch_factor + write_kib * write_factor) * 1024.0
+
+    stats = {}
+    with open(os.path.join(src, "kt", "bench_kernel_stats.csv")) as fh:
+        for r in csv.DictReader(fh):
+            if "deskew_batch_f32" in r["Name"]:
+                stats = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                         "max_ns": float(r["MaxNs"])}
+    summary = {
+        "tag": tag,
+        "kernel": kname,
+        "points_per_launch": points,
+        "algorithmic_bytes_per_launch": 32 * points,
+        "FETCH_SIZE_KiB_raw": fetch_kib,
+        "WRITE_SIZE_KiB_raw": write_kib,
+        "fetch_correction_factor": fetch_factor,
+        "write_correction_factor": write_factor,
+        "calibration": "kmc_dev::copy_points<1,3> over 67108864 points (1 GiB read + 1 GiB written), same 16 B/lane nt access pattern",
+        "hbm_bytes_per_launch": hbm_bytes,
+        "hbm_bytes_per_point": hbm_bytes / points,
+        "traffic_over_algorithmic": hbm_bytes / (32.0 * points),
+        "kernel_trace_stats": stats,
+    }
+    with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:  # the one bench.py reads
+        json.dump(summary, fh, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
