@@ -1,0 +1,54 @@
+// motion_compensation.hpp -- THE drop-in: same two functions, same signatures, same semantics as the reference
+// (include/kitti_motion_compensation/motion_compensation.hpp:10-13), executed on an MI355X through libkmc_hip.so.
+//
+//   * MotionCompensateFrame(frame, t): per point i, row(i) = RelativePoseBetweenTimes(t, timestamps(i)) * cloud.row(i)
+//     (motion_compensation.cpp:16-28).  The caller's per-point stamps are honoured (f64 device kernel); the result is a
+//     fresh N x 4 f64 cloud returned by value; inputs are never mutated; pure and re-entrant (one device context per thread).
+//   * errors: the reference aborts (assert kept in release, trajectory_interpolation.cpp:9,:32) when requested_time or
+//     any point stamp lies outside [stamp_start, stamp_end].  So does this: message on stderr, then std::abort().
+//   * no GPU -> std::runtime_error.  There is NO CPU fallback for the frame path.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "kitti_motion_compensation/data_types.hpp"
+#include "kitti_motion_compensation/trajectory_interpolation.hpp"
+
+namespace kmc {
+
+using TrajectoryInterpolator = trajectory_interpolation::TrajectoryInterpolator;
+
+Vector4d MotionCompensatePoint(TrajectoryInterpolator const& trajectory_interpolator, Time const point_stamp,
+                               Vector4d const& point, Time const requested_time);
+
+Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Extensions (not in the reference): the f32 KITTI-layout fast path that the roofline numbers are quoted on.
+// ---------------------------------------------------------------------------------------------------------------
+namespace hip {
+
+// Which HIP device the calling thread's context uses (default 0 or $KMC_DEVICE).  Must be called before the first
+// deskew call of the thread.
+void SetDevice(int device_id);
+int GetDevice();
+
+// One frame in the on-disk KITTI layout (f32 AoS x,y,z,intensity): fuses GetPseudoTimeStamps (data_io.cpp:163),
+// MotionCompensateFrame (handlers.cpp:60) and WritePointcloud's f64->f32 cast (data_io.cpp:300-310) in one kernel.
+// xyzi_in / xyzi_out are HOST pointers here (16-byte aligned); use the C-ABI directly for device-resident buffers.
+void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t num_points, Affine3d const& T_start, Affine3d const& T_end,
+                                Time stamp_start, Time stamp_end, Time requested_time, float* xyzi_out);
+
+// Many frames in one launch; frame f owns points [offsets[f], offsets[f+1]).
+struct FramePoses {
+  Affine3d T_start, T_end;
+  Time stamp_start, stamp_end, requested_time;
+};
+void MotionCompensateKittiClouds(float const* xyzi_in, std::vector<std::uint64_t> const& offsets,
+                                 std::vector<FramePoses> const& frames, float* xyzi_out,
+                                 std::uint32_t* frame_index_out = nullptr);
+
+}  // namespace hip
+}  // namespace kmc

@@ -1,0 +1,129 @@
+// kmc_api_deskew.cpp -- kmc::MotionCompensateFrame / MotionCompensatePoint / GetPseudoTimeStamps on the GPU.
+//
+// Everything per-point goes through the C-ABI (libkmc_hip.so).  No CPU fallback: without a HIP device the first call
+// throws std::runtime_error.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "kitti_motion_compensation/motion_compensation.hpp"
+#include "kitti_motion_compensation/timestamp_mocking.hpp"
+#include "kmc_api_internal.hpp"
+
+namespace kmc {
+namespace detail {
+
+namespace {
+struct CtxDeleter {
+  void operator()(kmc_ctx* c) const { kmc_hip_destroy(c); }
+};
+thread_local std::unique_ptr<kmc_ctx, CtxDeleter> t_ctx;
+thread_local int t_device = -1;
+
+int default_device() {
+  if (const char* e = std::getenv("KMC_DEVICE")) return std::atoi(e);
+  return 0;
+}
+}  // namespace
+
+kmc_ctx* thread_context() {
+  if (!t_ctx) {
+    if (t_device < 0) t_device = default_device();
+    kmc_ctx* c = nullptr;
+    int const rc = kmc_hip_create(&c, t_device);
+    if (rc != KMC_OK) throw_status(rc, "kmc: cannot create the HIP deskew context");
+    t_ctx.reset(c);
+  }
+  return t_ctx.get();
+}
+
+static kmc_frame_params frame_params(Affine3d const& T_start, Affine3d const& T_end, Time t0, Time t1, Time t_req, const char* where) {
+  double a[12], b[12];
+  T_start.to_rt12(a);
+  T_end.to_rt12(b);
+  kmc_frame_params p;
+  int const rc = kmc_frame_params_from_poses(a, b, t0, t1, t_req, &p);
+  if (rc == KMC_ERR_TIME_OUT_OF_RANGE) die_time_out_of_range(where);  // the reference asserts on requested_time for every point
+  if (rc != KMC_OK) throw_status(rc, where);
+  return p;
+}
+
+}  // namespace detail
+
+namespace hip {
+
+void SetDevice(int device_id) {
+  if (detail::t_ctx && detail::t_device != device_id) detail::t_ctx.reset();
+  detail::t_device = device_id;
+}
+
+int GetDevice() { return detail::t_device < 0 ? detail::default_device() : detail::t_device; }
+
+void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t n, Affine3d const& T_start, Affine3d const& T_end, Time stamp_start,
+                                Time stamp_end, Time requested_time, float* xyzi_out) {
+  kmc_frame_params const p = detail::frame_params(T_start, T_end, stamp_start, stamp_end, requested_time, "kmc::hip::MotionCompensateKittiCloud");
+  kmc_ctx* c = detail::thread_context();
+  int const rc = kmc_hip_deskew_f32(c, xyzi_in, xyzi_out, n, &p, KMC_MEM_HOST, nullptr);
+  if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_f32", c);
+}
+
+void MotionCompensateKittiClouds(float const* xyzi_in, std::vector<std::uint64_t> const& offsets, std::vector<FramePoses> const& frames,
+                                 float* xyzi_out, std::uint32_t* frame_index_out) {
+  if (offsets.size() != frames.size() + 1) throw std::invalid_argument("kmc::hip::MotionCompensateKittiClouds: offsets.size() != frames.size() + 1");
+  std::vector<kmc_frame_params> params(frames.size());
+  for (std::size_t f = 0; f < frames.size(); ++f)
+    params[f] = detail::frame_params(frames[f].T_start, frames[f].T_end, frames[f].stamp_start, frames[f].stamp_end, frames[f].requested_time,
+                                     "kmc::hip::MotionCompensateKittiClouds");
+  kmc_ctx* c = detail::thread_context();
+  int const rc = kmc_hip_deskew_batch_f32(c, xyzi_in, xyzi_out, offsets.data(), static_cast<std::uint32_t>(frames.size()), params.data(),
+                                          frame_index_out, KMC_MEM_HOST, nullptr);
+  if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_batch_f32", c);
+}
+
+}  // namespace hip
+
+// motion_compensation.cpp:16-28
+Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time) {
+  Index const n = frame.scan.cloud.rows();
+  if (frame.scan.timestamps.size() != n) throw std::invalid_argument("kmc::MotionCompensateFrame: timestamps.size() != cloud.rows()");
+  kmc_frame_params const p = detail::frame_params(frame.T_start, frame.T_end, frame.scan.stamp_start, frame.scan.stamp_end, requested_time,
+                                                  "kmc::MotionCompensateFrame");
+  Pointcloud out{MatrixX4d(n, 4)};
+  if (n == 0) return out;
+  kmc_ctx* c = detail::thread_context();
+  kmc_stats st;
+  Pointcloud const& in = frame.scan.cloud;
+  int const rc = kmc_hip_deskew_f64cols(c, in.col(0), in.col(1), in.col(2), in.col(3), frame.scan.timestamps.data(), static_cast<std::uint64_t>(n),
+                                        frame.scan.stamp_start, frame.scan.stamp_end, &p, out.col(0), out.col(1), out.col(2), out.col(3),
+                                        KMC_MEM_HOST, &st);
+  if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::MotionCompensateFrame");
+  if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_f64cols", c);
+  return out;
+}
+
+// motion_compensation.cpp:9-14 -- one point: the same device kernel with n = 1 (latency-bound by construction; callers
+// with many points should hand a Frame to MotionCompensateFrame, which is what the reference's own loop does).
+Vector4d MotionCompensatePoint(TrajectoryInterpolator const& ti, Time const point_stamp, Vector4d const& point, Time const requested_time) {
+  kmc_frame_params const p =
+      detail::frame_params(ti.pose_1(), ti.pose_2(), ti.time_1(), ti.time_2(), requested_time, "kmc::MotionCompensatePoint");
+  kmc_ctx* c = detail::thread_context();
+  double const x = point(0), y = point(1), z = point(2), w = point(3), t = point_stamp;
+  double ox, oy, oz, ow;
+  int const rc = kmc_hip_deskew_f64cols(c, &x, &y, &z, &w, &t, 1, ti.time_1(), ti.time_2(), &p, &ox, &oy, &oz, &ow, KMC_MEM_HOST, nullptr);
+  if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::MotionCompensatePoint");
+  if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_f64cols", c);
+  return {ox, oy, oz, ow};
+}
+
+// timestamp_mocking.cpp:56-63
+VectorXd GetPseudoTimeStamps(Pointcloud const& cloud, Time const start_time, Time const end_time) {
+  VectorXd stamps(cloud.rows());
+  if (cloud.rows() == 0) return stamps;
+  kmc_ctx* c = detail::thread_context();
+  int const rc = kmc_hip_pseudo_timestamps_f64(c, cloud.col(0), cloud.col(1), static_cast<std::uint64_t>(cloud.rows()), start_time, end_time,
+                                               stamps.data(), KMC_MEM_HOST);
+  if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_pseudo_timestamps_f64", c);
+  return stamps;
+}
+
+}  // namespace kmc

@@ -1,0 +1,369 @@
+// test_dropin_api.cpp -- the reference's own gtest cases for the hot path, restated against the drop-in C++ API
+// (include/kitti_motion_compensation/*.hpp, libkitti_motion_compensation_lib.so).  Same fixtures, same expected numbers,
+// same comparison rule (ASSERT_FLOAT_EQ = equal as float within 4 ULP).  No gtest in this image: a 30-line harness.
+//
+//   kmc_api_tests host <golden_dir>      -- cases that need no GPU  (test_lie_algebra.cpp, test_trajectory_interpolation.cpp
+//                                           artificial poses, test_oxts_to_pose.cpp, test_data_io.cpp values)
+//   kmc_api_tests gpu <golden_dir> <tmp> -- cases that run the deskew path (test_motion_compensation.cpp,
+//                                           test_timestamp_mocking.cpp, the run driver)
+//   kmc_api_tests death_pose | death_frame | death_point   -- must die with SIGABRT like the reference's assert
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "kitti_motion_compensation/data_io.hpp"
+#include "kitti_motion_compensation/data_types.hpp"
+#include "kitti_motion_compensation/handlers.hpp"
+#include "kitti_motion_compensation/lie_algebra.hpp"
+#include "kitti_motion_compensation/motion_compensation.hpp"
+#include "kitti_motion_compensation/timestamp_mocking.hpp"
+#include "kitti_motion_compensation/trajectory_interpolation.hpp"
+#include "kitti_motion_compensation/utilities_for_testing.hpp"
+#include "kitti_motion_compensation/utils.hpp"
+
+using namespace kmc;
+
+static int g_failures = 0, g_checks = 0;
+static const char* g_case = "";
+
+static std::int64_t ordered(float f) {
+  std::int32_t i;
+  std::memcpy(&i, &f, sizeof(i));
+  return i < 0 ? -static_cast<std::int64_t>(i & 0x7fffffff) : i;
+}
+static bool float_eq(double a, double b) {  // gtest's AlmostEquals: 4 ULP as float
+  float const fa = static_cast<float>(a), fb = static_cast<float>(b);
+  if (std::isnan(fa) || std::isnan(fb)) return false;
+  return std::llabs(ordered(fa) - ordered(fb)) <= 4;
+}
+#define ASSERT_FLOAT_EQ(a, b)                                                                        \
+  do {                                                                                               \
+    ++g_checks;                                                                                      \
+    if (!float_eq((a), (b))) {                                                                       \
+      ++g_failures;                                                                                  \
+      std::printf("FAIL %s: %s:%d  %s = %.9g  vs  %s = %.9g\n", g_case, __FILE__, __LINE__, #a, (double)(a), #b, (double)(b)); \
+    }                                                                                                \
+  } while (0)
+#define ASSERT_TRUE(c)                                                              \
+  do {                                                                              \
+    ++g_checks;                                                                     \
+    if (!(c)) {                                                                     \
+      ++g_failures;                                                                 \
+      std::printf("FAIL %s: %s:%d  %s\n", g_case, __FILE__, __LINE__, #c);          \
+    }                                                                               \
+  } while (0)
+#define ASSERT_EQ(a, b) ASSERT_TRUE((a) == (b))
+#define CASE(name) g_case = name
+
+// ---- fixtures (test_motion_compensation.cpp:12-49 / test_timestamp_mocking.cpp:10-46) -----------------------
+static Frame MakeMotionCompensationTestFrame() {
+  Oxts const odometry_0{Time(0.05), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  Oxts const odometry_1{Time(0.15), 0.0, 0.00001, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  Oxts const odometry_2{Time(0.25), 0.0, 0.00002, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  Pointcloud cloud_1 = MatrixX4d(3, 4);
+  cloud_1.row(0) = Vector4d{0.0, 5.0, 0.0, 1.0};
+  cloud_1.row(1) = Vector4d{5.0, 0.0, 0.0, 1.0};
+  cloud_1.row(2) = Vector4d{0.0, -5.0, 0.0, 1.0};
+  Time const stamp_start{Time(0.1)};
+  Time const stamp_middle{Time(0.15)};
+  Time const stamp_end{Time(0.2)};
+  VectorXd const intensities_1{VectorXd(3)};
+  VectorXd const timestamps_1{GetPseudoTimeStamps(cloud_1, stamp_start, stamp_end)};
+  LidarScan const scan_1{stamp_start, stamp_middle, stamp_end, cloud_1, intensities_1, timestamps_1};
+  return MakeFrame(odometry_0, odometry_1, odometry_2, scan_1);
+}
+
+static Affine3d ArtificialPose(double const x_rotation, double const x_translation) {  // test_trajectory_interpolation.cpp:24-30
+  Affine3d pose{Affine3d::Identity()};
+  pose.rotate(AngleAxisd{x_rotation, Vector3d::UnitX()});
+  pose.translation() = Vector3d{x_translation, 0, 0};
+  return pose;
+}
+
+// ---- host cases ---------------------------------------------------------------------------------------------------
+static void host_cases(std::string const& golden) {
+  Path const data_folder{golden + "/kitti_2011_09_26_drive_0005"};
+
+  CASE("LieAlgebraTest.HatAndVeeInverses");  // test_lie_algebra.cpp:5-12
+  {
+    Vector3d const phi_in{0.1, 0.2, 0.3};
+    Vector3d const phi_out{lie::Vee(lie::Hat(phi_in))};
+    for (int i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(phi_in(i), phi_out(i));
+  }
+  CASE("LieAlgebraTest.So3LogAndExpInverse");  // :14-21
+  {
+    Vector3d const phi_in{0.1, 0.2, 0.3};
+    Vector3d const phi_out{lie::Log(lie::Exp(phi_in))};
+    for (int i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(phi_in(i), phi_out(i));
+  }
+  CASE("LieAlgebraTest.So3LeftJacobiansInverse");  // :23-34
+  {
+    Vector3d const phi_in{0.1, 0.2, 0.3};
+    Matrix3d const I{lie::LeftJacobian(phi_in) * lie::InverseLeftJacobian(phi_in)};
+    ASSERT_FLOAT_EQ(I.trace(), 3.0);
+    ASSERT_TRUE(std::fabs(static_cast<float>(I.sum() - I.trace())) < 1e-6f);
+  }
+  CASE("LieAlgebraTest.Se3LogAndExpInverse");  // :36-47
+  {
+    Twist xi_in{0.1, 0.2, 0.3, 0.4, 0.5, 0.6};
+    Twist const xi_out{lie::Log(lie::Exp(xi_in))};
+    for (int i = 0; i < 6; ++i) ASSERT_FLOAT_EQ(xi_in(i), xi_out(i));
+  }
+  CASE("TrajectoryInterpolationFixtureArtificialPoses.TestInterpolationClassPoseConstructor");  // test_trajectory_interpolation.cpp:43-50
+  {
+    Affine3d const pose_0{ArtificialPose(0, 0)}, pose_1{ArtificialPose(0.5, 0.5)}, pose_2{ArtificialPose(1.0, 1.0)};
+    auto const ti{trajectory_interpolation::TrajectoryInterpolator(0, pose_0, 100, pose_2)};
+    Affine3d const interpolated_pose_1{ti.GetPoseAtTime(50)};
+    ASSERT_TRUE(utilities_for_testing::TransformationMatricesAreTheSame(interpolated_pose_1, pose_1));
+  }
+  CASE("TrajectoryInterpolationFixtureArtificialPoses.TestRelativePoseBetweenTimes");  // :52-60
+  {
+    Affine3d const pose_0{ArtificialPose(0, 0)}, pose_2{ArtificialPose(1.0, 1.0)};
+    auto const ti{trajectory_interpolation::TrajectoryInterpolator(0, pose_0, 100, pose_2)};
+    auto const tf_0_1{ti.RelativePoseBetweenTimes(0, 50)};
+    auto const tf_1_2{ti.RelativePoseBetweenTimes(50, 100)};
+    ASSERT_TRUE(utilities_for_testing::TransformationMatricesAreTheSame(tf_0_1, tf_1_2));
+  }
+  CASE("OxtsToPoseTest.LoadKnownPoseProperly");  // test_oxts_to_pose.cpp:9-20
+  {
+    Oxts const oxts{LoadOxts(data_folder, 0)};
+    auto const pose{OxtsToPose(oxts, 1.0)};
+    ASSERT_FLOAT_EQ(pose.rotation().determinant(), 1.0);
+    ASSERT_FLOAT_EQ(pose.translation().x(), 937631.25);
+    ASSERT_FLOAT_EQ(pose.translation().y(), 6276764);
+    ASSERT_FLOAT_EQ(pose.translation().z(), 112.83492);
+  }
+  CASE("DataIoTest.LoadOdometryProperly");  // test_data_io.cpp:10-30
+  {
+    Oxts const o{LoadOxts(data_folder, 0)};
+    ASSERT_EQ(o.stamp, 47072.349659964);
+    ASSERT_EQ(o.lat, 49.011212804408);
+    ASSERT_EQ(o.lon, 8.4228850417969);
+    ASSERT_EQ(o.alt, 112.83492279053);
+    ASSERT_EQ(o.roll, 0.022447);
+    ASSERT_EQ(o.pitch, 1e-05);
+    ASSERT_EQ(o.yaw, -1.2219096732051);
+    ASSERT_EQ(o.vf, 3.5147680214713);
+    ASSERT_EQ(o.vl, 0.037625160413037);
+    ASSERT_EQ(o.vu, -0.03878884255623);
+  }
+  CASE("DataIoTest.LoadPointCloudProperly(host part)");  // test_data_io.cpp:53-76 on the shipped frame 0
+  {
+    ASSERT_EQ(LoadTimeStamp(data_folder / "velodyne_points/timestamps_start.txt", 0), 47072.283701593);
+    ASSERT_EQ(LoadTimeStamp(data_folder / "velodyne_points/timestamps.txt", 0), 47072.335337762);
+    ASSERT_EQ(LoadTimeStamp(data_folder / "velodyne_points/timestamps_end.txt", 0), 47072.386973931);
+    KittiPclLoader loader;
+    auto const [cloud, intensities] = loader.LoadPointcloud(data_folder / "velodyne_points/data/0000000000.bin");
+    ASSERT_EQ(cloud.rows(), 123397);
+    ASSERT_EQ(intensities.rows(), 123397);
+    ASSERT_FLOAT_EQ(cloud(0, 0), 22.7189998626709);
+    ASSERT_FLOAT_EQ(cloud(0, 1), 0.0309999994933605);
+    ASSERT_FLOAT_EQ(cloud(0, 2), 0.976999998092651);
+    ASSERT_FLOAT_EQ(cloud(0, 3), 1.0);
+    ASSERT_FLOAT_EQ(intensities(0), 0.319999992847443);
+    ASSERT_FLOAT_EQ(cloud(123396, 0), 5.63399982452393);
+    ASSERT_FLOAT_EQ(cloud(123396, 1), -1.39499998092651);
+    ASSERT_FLOAT_EQ(cloud(123396, 2), -2.58999991416931);
+    ASSERT_FLOAT_EQ(intensities(123396), 0.0);
+  }
+  CASE("utils");  // utils.cpp:10-38
+  {
+    ASSERT_TRUE(IdToZeroPaddedString(42) == "0000000042");
+    ASSERT_TRUE(IdToZeroPaddedString(7, 3) == "007");
+    ASSERT_EQ(MmHhSsToSeconds("13:04:32.283701593"), 47072.283701593);
+    auto const tok = TokenizeString("2011-09-26 13:04:32.283701593");
+    ASSERT_EQ(tok.size(), 2u);
+  }
+}
+
+// ---- gpu cases ---------------------------------------------------------------------------------------------------------
+static std::vector<float> read_bin(Path const& f) { return KittiPclLoader::LoadRaw(f); }
+
+static void gpu_cases(std::string const& golden, std::string const& tmp) {
+  Path const data_folder{golden + "/kitti_2011_09_26_drive_0005"};
+
+  CASE("FractionOfScanCompletedTest");  // test_timestamp_mocking.cpp:48-58
+  {
+    Frame const test_frame{MakeMotionCompensationTestFrame()};
+    Pointcloud const& c{test_frame.scan.cloud};
+    ASSERT_FLOAT_EQ(FractionOfScanCompleted(c.row(0)), 0.25);
+    ASSERT_FLOAT_EQ(FractionOfScanCompleted(c.row(1)), 0.5);
+    ASSERT_FLOAT_EQ(FractionOfScanCompleted(c.row(2)), 0.75);
+  }
+  CASE("PsuedoTimeStampTest");  // :60-74
+  {
+    Frame const f{MakeMotionCompensationTestFrame()};
+    ASSERT_FLOAT_EQ(GetPseudoTimeStamp(f.scan.cloud.row(0), f.scan.stamp_start, f.scan.stamp_end), 0.125);
+    ASSERT_FLOAT_EQ(GetPseudoTimeStamp(f.scan.cloud.row(1), f.scan.stamp_start, f.scan.stamp_end), 0.15);
+    ASSERT_FLOAT_EQ(GetPseudoTimeStamp(f.scan.cloud.row(2), f.scan.stamp_start, f.scan.stamp_end), 0.175);
+  }
+  CASE("PsuedoTimeStampFrameInitializationTest");  // :76-87 (GetPseudoTimeStamps ran on the GPU inside the fixture)
+  {
+    Frame const f{MakeMotionCompensationTestFrame()};
+    ASSERT_FLOAT_EQ(f.scan.timestamps(0), 0.125);
+    ASSERT_FLOAT_EQ(f.scan.timestamps(1), 0.15);
+    ASSERT_FLOAT_EQ(f.scan.timestamps(2), 0.175);
+  }
+  CASE("TestFrameFixture.MotionCompensateFrame");  // test_motion_compensation.cpp:54-76
+  {
+    Frame const frame{MakeMotionCompensationTestFrame()};
+    Time const requested_time{frame.scan.stamp_middle};
+    Pointcloud const mc{MotionCompensateFrame(frame, requested_time)};
+    Vector4d const point_1{mc.row(0)};
+    ASSERT_FLOAT_EQ(point_1(0), -0.27829874);
+    ASSERT_FLOAT_EQ(point_1(1), 5.0);
+    ASSERT_FLOAT_EQ(point_1(2), 0.0);
+    ASSERT_FLOAT_EQ(point_1(3), 1.0);
+    Vector4d const point_2{mc.row(1)};
+    for (int j = 0; j < 4; ++j) ASSERT_FLOAT_EQ(point_2(j), frame.scan.cloud(1, j));
+    Vector4d const point_3{mc.row(2)};
+    ASSERT_FLOAT_EQ(point_3(0), 0.27829874);
+    ASSERT_FLOAT_EQ(point_3(1), -5.0);
+    ASSERT_FLOAT_EQ(point_3(2), 0.0);
+    ASSERT_FLOAT_EQ(point_3(3), 1.0);
+    // inputs are never mutated; MotionCompensatePoint agrees with the frame call
+    ASSERT_FLOAT_EQ(frame.scan.cloud(0, 1), 5.0);
+    TrajectoryInterpolator const ti(frame.scan.stamp_start, frame.T_start, frame.scan.stamp_end, frame.T_end);
+    for (Index i = 0; i < 3; ++i) {
+      Vector4d const p{MotionCompensatePoint(ti, frame.scan.timestamps(i), frame.scan.cloud.row(i), requested_time)};
+      for (int j = 0; j < 4; ++j) ASSERT_TRUE(std::fabs(p(j) - mc(i, j)) <= 1e-12);
+    }
+  }
+  CASE("DataIoTest.LoadPointCloudProperly(stamps)");  // test_data_io.cpp:68, :78 via LoadLidarScan
+  {
+    LidarScan const scan{LoadLidarScan(data_folder, 0)};
+    ASSERT_EQ(scan.timestamps.rows(), 123397);
+    ASSERT_FLOAT_EQ(scan.timestamps(0), 47072.336);
+    ASSERT_FLOAT_EQ(scan.timestamps(123396), 47072.332);
+  }
+  CASE("f32 KITTI-layout path == f64 Eigen-layout path (to f32 rounding) on the shipped frame");
+  {
+    LidarScan const scan{LoadLidarScan(data_folder, 0)};
+    Oxts const o{LoadOxts(data_folder, 0)};
+    Affine3d const P1{OxtsToPose(o)};
+    Affine3d const P2{P1 * lie::Exp(Twist{1.3, 0.05, -0.02, 0.02, 0.01, -0.1})};
+    Frame const frame(P1, P2, scan);
+    Pointcloud const ref{MotionCompensateFrame(frame, scan.stamp_middle)};
+    std::vector<float> const raw = read_bin(data_folder / "velodyne_points/data/0000000000.bin");
+    std::vector<float> out(raw.size());
+    hip::MotionCompensateKittiCloud(raw.data(), raw.size() / 4, P1, P2, scan.stamp_start, scan.stamp_end, scan.stamp_middle, out.data());
+    double worst = 0;
+    for (Index i = 0; i < ref.rows(); ++i) {
+      double d2 = 0, n2 = 0;
+      for (int j = 0; j < 3; ++j) {
+        double const d = out[4 * i + j] - ref(i, j);
+        d2 += d * d;
+        n2 += ref(i, j) * ref(i, j);
+      }
+      worst = std::fmax(worst, std::sqrt(d2) / std::fmax(std::sqrt(n2), 1e-3));
+      if (out[4 * i + 3] != raw[4 * i + 3]) ++g_failures;
+    }
+    std::printf("  f32 vs f64 path: max rel err %.3e (bar 1e-5)\n", worst);
+    ASSERT_TRUE(worst <= 1e-5);
+  }
+  CASE("MotionCompensateRun on a synthesised 5-frame run");  // handlers.cpp:41-65
+  {
+    namespace fs = std::filesystem;
+    Path const run{tmp + "/run_0005_sync"};
+    fs::remove_all(run);
+    fs::create_directories(run / "velodyne_points/data");
+    fs::create_directories(run / "oxts/data");
+    std::vector<float> const raw = read_bin(data_folder / "velodyne_points/data/0000000000.bin");
+    std::ifstream oxf(data_folder / "oxts/data/0000000000.txt");
+    std::string oxline;
+    std::getline(oxf, oxline);
+    auto tok = TokenizeString(oxline);
+    std::size_t const n_frames = 5;
+    std::ofstream ts(run / "velodyne_points/timestamps_start.txt"), tm(run / "velodyne_points/timestamps.txt"),
+        te(run / "velodyne_points/timestamps_end.txt"), to(run / "oxts/timestamps.txt");
+    for (std::size_t i = 0; i < n_frames; ++i) {
+      // frame i: a strided sub-cloud so that frames differ in size
+      std::vector<float> sub;
+      for (std::size_t k = i; k < raw.size() / 4; k += 3 + i)
+        for (int j = 0; j < 4; ++j) sub.push_back(raw[4 * k + j]);
+      WriteRaw(run / "velodyne_points/data", i, sub.data(), sub.size() / 4);
+      char buf[64];
+      auto stamp = [&](double s) {
+        std::snprintf(buf, sizeof(buf), "2011-09-26 13:04:%012.9f", s);
+        return std::string(buf);
+      };
+      double const base = 32.0 + 0.1 * static_cast<double>(i);
+      ts << stamp(base + 0.283701593) << "\n";
+      tm << stamp(base + 0.335337762) << "\n";
+      te << stamp(base + 0.386973931) << "\n";
+      to << stamp(base + 0.349659964) << "\n";
+      // OXTS: drive north-east with a yaw rate; rewrite lat/lon/yaw of the shipped packet
+      auto t2 = tok;
+      char num[64];
+      std::snprintf(num, sizeof(num), "%.13f", 49.011212804408 + 1.1e-5 * static_cast<double>(i));
+      t2[0] = num;
+      std::snprintf(num, sizeof(num), "%.13f", 8.4228850417969 + 0.7e-5 * static_cast<double>(i));
+      t2[1] = num;
+      std::snprintf(num, sizeof(num), "%.13f", -1.2219096732051 + 0.03 * static_cast<double>(i));
+      t2[5] = num;
+      std::ofstream ox(run / ("oxts/data/" + IdToZeroPaddedString(i) + ".txt"));
+      for (std::size_t k = 0; k < t2.size(); ++k) ox << (k ? " " : "") << t2[k];
+      ox << "\n";
+    }
+    ts.close(); tm.close(); te.close(); to.close();
+    MotionCompensateRun(run);
+    Path const out_dir{run / "velodyne_points/data_motion_compensated"};
+    ASSERT_EQ(NumberOfFilesInDirectory(out_dir), n_frames);
+    // first frame copied through; last frame = the reference's slip (first frame's points)
+    ASSERT_TRUE(read_bin(out_dir / "0000000000.bin") == read_bin(run / "velodyne_points/data/0000000000.bin"));
+    ASSERT_TRUE(read_bin(out_dir / "0000000004.bin") == read_bin(run / "velodyne_points/data/0000000000.bin"));
+    // interior frames equal the f64 drop-in API applied frame by frame, cast like WritePointcloud
+    for (std::size_t i = 1; i + 1 < n_frames; ++i) {
+      Frame const frame{LoadSingleFrame(run, i)};
+      Pointcloud const ref{MotionCompensateFrame(frame, frame.scan.stamp_middle)};
+      std::vector<float> const got = read_bin(out_dir / (IdToZeroPaddedString(i) + ".bin"));
+      ASSERT_EQ(static_cast<Index>(got.size() / 4), ref.rows());
+      double worst = 0;
+      for (Index k = 0; k < ref.rows(); ++k) {
+        double d2 = 0, n2 = 0;
+        for (int j = 0; j < 3; ++j) {
+          double const d = got[4 * k + j] - ref(k, j);
+          d2 += d * d;
+          n2 += ref(k, j) * ref(k, j);
+        }
+        worst = std::fmax(worst, std::sqrt(d2) / std::fmax(std::sqrt(n2), 1e-3));
+        if (got[4 * k + 3] != static_cast<float>(frame.scan.intensities(k))) ++g_failures;
+      }
+      std::printf("  run frame %zu: %td points, max rel err vs f64 API %.3e\n", i, ref.rows(), worst);
+      ASSERT_TRUE(worst <= 1e-5);
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  std::string const mode = argc > 1 ? argv[1] : "";
+  if (mode == "host" && argc > 2) {
+    host_cases(argv[2]);
+  } else if (mode == "gpu" && argc > 3) {
+    gpu_cases(argv[2], argv[3]);
+  } else if (mode == "death_pose") {  // test_trajectory_interpolation.cpp:77-81  EXPECT_DEATH(GetPoseAtTime(0))
+    auto const ti{trajectory_interpolation::TrajectoryInterpolator(47072.35, Affine3d::Identity(), 47072.56, ArtificialPose(0.1, 1.0))};
+    (void)ti.GetPoseAtTime(0);
+    return 0;  // not reached
+  } else if (mode == "death_frame") {  // a point stamp outside the scan: MotionCompensateFrame must abort
+    Frame frame{MakeMotionCompensationTestFrame()};
+    frame.scan.timestamps(1) = 0.25;
+    (void)MotionCompensateFrame(frame, frame.scan.stamp_middle);
+    return 0;
+  } else if (mode == "death_point") {  // requested_time outside the trajectory
+    Frame const frame{MakeMotionCompensationTestFrame()};
+    TrajectoryInterpolator const ti(frame.scan.stamp_start, frame.T_start, frame.scan.stamp_end, frame.T_end);
+    (void)MotionCompensatePoint(ti, 0.15, Vector4d{1, 2, 3, 1}, 0.5);
+    return 0;
+  } else {
+    std::fprintf(stderr, "usage: kmc_api_tests host <golden> | gpu <golden> <tmp> | death_pose | death_frame | death_point\n");
+    return 2;
+  }
+  std::printf("%d checks, %d failures\n", g_checks, g_failures);
+  return g_failures ? 1 : 0;
+}
