@@ -90,7 +90,7 @@ def main():
 
     import torch
 
-    from kitti_motion_compensation_amd import capi
+    from kitti_motion_compensation_amd import capi, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -153,13 +153,8 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t_begin
 
-    t_max, pts_total, ev_max = wall, float(n * args.steps), ev_ms
-    if dist:
-        tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)          # RCCL: the only collective of the job
-        tsum = torch.tensor([float(n * args.steps)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        t_max, ev_max, pts_total = tmax[0].item(), tmax[1].item(), tsum[0].item()
+    # the job's ONLY collective: SUM of points, MAX of times (RCCL all-reduce when N > 1)
+    pts_total, t_max, ev_max_s = sharding.reduce_throughput(dist, dev, float(n * args.steps), wall, ev_ms * 1e-3)
 
     # ---- parity spot check outside the timed region (a slice of the last output against the oracle) ----
     parity = None

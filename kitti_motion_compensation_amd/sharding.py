@@ -1,0 +1,80 @@
+"""Frame-range sharding for the one-process-per-GPU launch.
+
+The deskew path shards trivially: points within a frame are independent and frames are independent given their own
+(T_start, T_end).  A drive is split into CONTIGUOUS frame ranges, one per rank; no point data ever crosses GPUs and the
+only collective of a job is the reduction of the throughput counters (RCCL all-reduce on the GPU box, gloo in the CPU
+tests).  Plumbing only -- no compute here.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+
+def frame_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) of frames owned by `rank`; sizes differ by at most one frame, earlier ranks get the extra."""
+    if world <= 0 or not (0 <= rank < world) or n_frames < 0:
+        raise ValueError((n_frames, rank, world))
+    base, extra = divmod(n_frames, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def frame_range_balanced(frame_sizes: Sequence[int], rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous range chosen on POINT counts (mixed frame sizes, BASELINE.json configs[4]): rank r owns the frames whose
+    point-prefix midpoint falls into [r, r+1) * total / world.  Ranges are contiguous, disjoint and cover every frame."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError((rank, world))
+    total = sum(frame_sizes)
+    if total == 0:
+        return frame_range(len(frame_sizes), rank, world)
+    bounds = [0] * (world + 1)
+    bounds[world] = len(frame_sizes)
+    acc, r = 0, 1
+    for i, s in enumerate(frame_sizes):
+        mid = acc + s / 2.0
+        while r < world and mid >= r * total / world:
+            bounds[r] = i
+            r += 1
+        acc += s
+    while r < world:
+        bounds[r] = len(frame_sizes)
+        r += 1
+    return bounds[rank], bounds[rank + 1]
+
+
+def multi_drive_ranges(drive_frame_counts: Sequence[int], rank: int, world: int) -> List[Tuple[int, int, int]]:
+    """configs[4] (several drives at once): every drive is split into contiguous ranges per rank.
+    Returns [(drive_index, begin, end), ...] for this rank, empty ranges dropped."""
+    out = []
+    for d, n in enumerate(drive_frame_counts):
+        b, e = frame_range(n, rank, world)
+        if e > b:
+            out.append((d, b, e))
+    return out
+
+
+def make_batches(frame_sizes: Sequence[int], begin: int, end: int, max_points: int, max_frames: int = 1 << 16):
+    """Greedy packing of the frames [begin, end) into batches of at most max_points points / max_frames frames (a frame
+    larger than max_points travels alone).  Yields (first_frame, last_frame_exclusive)."""
+    i = begin
+    while i < end:
+        j, pts = i, 0
+        while j < end and j - i < max_frames and (j == i or pts + frame_sizes[j] <= max_points):
+            pts += frame_sizes[j]
+            j += 1
+        yield i, j
+        i = j
+
+
+def reduce_throughput(dist, device, points: float, seconds: float, kernel_seconds: float = 0.0):
+    """The job's only collective: SUM of points, MAX of times.  `dist` is torch.distributed (backend nccl == RCCL on the
+    GPU box, gloo on CPU) or None for a single process.  Returns (total_points, max_seconds, max_kernel_seconds)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(points), float(seconds), float(kernel_seconds)
+    import torch
+
+    tmax = torch.tensor([seconds, kernel_seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = torch.tensor([float(points)], dtype=torch.float64, device=device)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    return tsum[0].item(), tmax[0].item(), tmax[1].item()
