@@ -1,8 +1,8 @@
 """ctypes binding of the CPU oracle (oracle/libkmc_oracle.so).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
-Nothing under kitti_motion_compensation_amd/ may import this module (tests/test_no_oracle_in_product.py
-enforces it).  See oracle/kmc_oracle.h for the reference file:line each function restates.
+Nothing under kitti_motion_compensation_amd/ may import this module
+(tests/test_abi_exports.py::test_product_never_references_the_oracle enforces it).  See oracle/kmc_oracle.h for the reference file:line each function restates.
 """
 from __future__ import annotations
 
@@ -293,14 +293,20 @@ HOISTED = 1
 
 
 def deskew_xyzi_f32(xyzi, stamp_start, T_start: Affine, stamp_end, T_end: Affine, requested, mode=HOISTED,
-                    threads=0, want_f64=True, want_f32=False, want_stamps=False):
-    """KITTI-layout pipeline: (N,4) f32 AoS in -> dict(xyz_f64 (N,3), xyzi_f32 (N,4), stamps, rc, n_bad)."""
+                    threads=0, want_f64=True, want_f32=False, want_stamps=False, out_f32=None):
+    """KITTI-layout pipeline: (N,4) f32 AoS in -> dict(xyz_f64 (N,3), xyzi_f32 (N,4), stamps, rc, n_bad).
+    out_f32: optional preallocated (N,4) float32 array to write into (implies want_f32)."""
     a = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
     n = a.shape[0]
     if threads <= 0:
         threads = lib().kmo_num_threads()
     o64 = np.empty((n, 3), dtype=np.float64) if want_f64 else None
-    o32 = np.empty((n, 4), dtype=np.float32) if want_f32 else None
+    if out_f32 is not None:
+        assert out_f32.dtype == np.float32 and out_f32.shape == (n, 4) and out_f32.flags.c_contiguous
+        want_f32 = True
+        o32 = out_f32
+    else:
+        o32 = np.empty((n, 4), dtype=np.float32) if want_f32 else None
     st = np.empty(n, dtype=np.float64) if want_stamps else None
     nbad = C.c_size_t(0)
     rc = lib().kmo_deskew_xyzi_f32(

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Measures the secondary configurations DESIGN.md / BASELINE.md quote (run on the GPU box):
+BASELINE.json configs 2-5 shapes, the f64 Eigen-layout kernel, and the PCIe-inclusive (host-buffer) rate.
+Prints one JSON object.  `python tools/measure_configs.py [--quick]`"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    import torch
+
+    from kitti_motion_compensation_amd import capi, sharding
+
+    dev = torch.device("cuda", 0)
+    ctx = capi.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    res = {"device": ctx.device_info()}
+    rng = np.random.default_rng(1)
+    turn = capi.FrameParams.make([1.3, 0.05, -0.02, 0.002, -0.004, 0.03], 0.5)
+
+    def timed(fn, iters, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ctx.timer_begin()
+        for _ in range(iters):
+            fn()
+        ms = ctx.timer_end()
+        return ms / iters
+
+    # ---- config 2 literal: ONE 1 M-point frame per launch (launch-latency / MALL regime, reported as such) ----
+    n = 1_000_000
+    bufs = []
+    for k in range(24):  # 24 x 32 MB > 256 MiB MALL
+        a = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        ctx.synth_points(a, n, 100 + k)
+        bufs.append((a, torch.empty_like(a)))
+    state = {"k": 0}
+
+    def one_frame():
+        a, b = bufs[state["k"] % len(bufs)]
+        state["k"] += 1
+        ctx.deskew_f32(a, b, turn)
+
+    ms = timed(one_frame, 480)
+    res["config2_single_1M_frame_per_launch"] = {"ms_per_launch": ms, "Mpts_s": n / ms / 1e3, "GBps": 32 * n / ms / 1e6,
+                                                  "note": "24 rotating buffer pairs (768 MB) so data comes from HBM; includes launch gaps"}
+    del bufs
+
+    # ---- config 4 unit: 10 M-point frames, single-frame kernel, rotating pairs ----
+    n = 10_000_000
+    bufs = []
+    for k in range(4):
+        a = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        ctx.synth_points(a, n, 200 + k)
+        bufs.append((a, torch.empty_like(a)))
+    state["k"] = 0
+    ms = timed(one_frame, 40 if args.quick else 400)
+    res["config4_10M_point_frame_per_launch"] = {"ms_per_frame": ms, "Mpts_s": n / ms / 1e3, "GBps": 32 * n / ms / 1e6,
+                                                 "frac_of_8TBps": 32 * n / ms / 1e6 / 8000}
+    a10, b10 = bufs[0]
+
+    # ---- PCIe-inclusive: host buffers through the staging pipeline (pageable numpy and pinned torch) ----
+    h_in = a10.cpu().numpy()
+    h_out = np.empty_like(h_in)
+    t = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        ctx.deskew_f32(h_in, h_out, turn)
+    dt = (time.perf_counter() - t) / reps
+    res["pcie_inclusive_pageable_host"] = {"Mpts_s": n / dt / 1e6, "GBps_algorithmic": 32 * n / dt / 1e9}
+    p_in = torch.from_numpy(h_in).pin_memory()
+    p_out = torch.empty_like(p_in).pin_memory()
+    ctx.deskew_f32(p_in.numpy(), p_out.numpy(), turn)
+    t = time.perf_counter()
+    for _ in range(reps):
+        ctx.deskew_f32(p_in.numpy(), p_out.numpy(), turn)
+    dt = (time.perf_counter() - t) / reps
+    res["pcie_inclusive_pinned_host"] = {"Mpts_s": n / dt / 1e6, "GBps_algorithmic": 32 * n / dt / 1e9}
+    del bufs, a10, b10, p_in, p_out
+
+    # ---- config 3: one KITTI-like drive (108 frames ~ N(121k, 3k) points), ONE batched launch ----
+    sizes = np.clip(rng.normal(121_000, 3_000, size=108), 90_000, 140_000).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    ntot = int(offs[-1])
+    params = capi.params_array([capi.FrameParams.make([1.3, 0.02, -0.01, 0.001 * (i % 5), -0.002, 0.03], 0.5) for i in range(108)])
+    sets = []
+    for k in range(3):
+        a = torch.empty((ntot, 4), dtype=torch.float32, device=dev)
+        ctx.synth_points(a, ntot, 300 + k)
+        sets.append((a, torch.empty_like(a)))
+    state["k"] = 0
+
+    def drive():
+        a, b = sets[state["k"] % 3]
+        state["k"] += 1
+        ctx.deskew_batch_f32(a, b, offs, params, None)
+
+    ms = timed(drive, 300)
+    res["config3_drive_108_frames_one_launch"] = {"points": ntot, "ms_per_drive": ms, "Mpts_s": ntot / ms / 1e3, "GBps": 32 * ntot / ms / 1e6,
+                                                  "note": "13 M points = 418 MB traffic per launch (3 rotating sets); fixed ~5 us launch cost is 8 % of 62 us"}
+    # the same drive frame by frame (what a per-frame caller pays)
+    def per_frame():
+        a, b = sets[0]
+        for f in range(108):
+            s, e = int(offs[f]), int(offs[f + 1])
+            ctx.deskew_f32(a[s:e], b[s:e], turn)
+
+    ms_pf = timed(per_frame, 20)
+    res["config3_drive_frame_by_frame"] = {"ms_per_drive": ms_pf, "Mpts_s": ntot / ms_pf / 1e3}
+    del sets
+
+    # ---- config 5 shape: five drives, mixed frame sizes 90k-130k, batches of <= 64 M points ----
+    counts = [108, 154, 340, 312, 660]
+    sizes5 = rng.integers(90_000, 130_001, size=sum(counts))
+    offs5 = np.concatenate([[0], np.cumsum(sizes5)]).astype(np.uint64)
+    n5 = int(offs5[-1])
+    a = torch.empty((n5, 4), dtype=torch.float32, device=dev)
+    ctx.synth_points(a, n5, 500)
+    b = torch.empty_like(a)
+    batches = list(sharding.make_batches(sizes5.tolist(), 0, len(sizes5), max_points=64_000_000))
+    prepared = []
+    for (i, j) in batches:
+        o = (offs5[i:j + 1] - offs5[i]).astype(np.uint64)
+        prepared.append((int(offs5[i]), int(offs5[j]), o, capi.params_array([turn] * (j - i))))
+
+    def soak():
+        for s, e, o, p in prepared:
+            ctx.deskew_batch_f32(a[s:e], b[s:e], o, p, None)
+
+    ms = timed(soak, 10 if args.quick else 60)
+    res["config5_five_drives_mixed_sizes"] = {"frames": int(sum(counts)), "points": n5, "batches": len(batches), "ms_per_pass": ms,
+                                              "Mpts_s": n5 / ms / 1e3, "GBps": 32 * n5 / ms / 1e6}
+    del a, b
+
+    # ---- f64 Eigen-layout kernel, device resident: 40 B read (x,y,z,w,stamp) + 32 B written per point ----
+    n = 16_000_000
+    cols = [torch.rand(n, dtype=torch.float64, device=dev) * 80 - 40 for _ in range(3)]
+    w = torch.ones(n, dtype=torch.float64, device=dev)
+    stamps = torch.rand(n, dtype=torch.float64, device=dev) * 0.1 + 100.0
+    outs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)]
+
+    def f64():
+        ctx.deskew_f64cols(cols[0], cols[1], cols[2], w, stamps, 100.0, 100.1, turn, *outs)
+
+    ms = timed(f64, 20)
+    res["f64cols_device_resident"] = {"ms": ms, "Mpts_s": n / ms / 1e3, "GBps_algorithmic_72B": 72 * n / ms / 1e6,
+                                      "note": "each call ends with a stream sync (the out-of-range verdict is part of its result)"}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
