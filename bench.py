@@ -46,11 +46,31 @@ def make_workload(capi, n_frames, rank):
     return params
 
 
+def effective_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box exposes 256
+    logical CPUs but grants 16 through cpu.max; OpenMP beyond the quota only oversubscribes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except OSError:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except OSError:
+            pass
+    return n
+
+
 def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample):
     """The oracle timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)."""
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     per = POINTS_PER_FRAME
 
     out = np.zeros((per, 4), dtype=np.float32)  # preallocated and touched: no page faults inside the timed loops
@@ -76,7 +96,8 @@ def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample):
         "value": round(b1, 3), "unit": "Mpts/s", "cores": 1, "kind": "port",
         "sample": f"{n_frames_sample} of the step's 1M-point frames ({n_frames_sample * per} points), oracle FAITHFUL mode "
                   "(reference op sequence incl. per-point Log/Exp), f64, 1 thread like the reference",
-        "all_cores": {"cores": cores, "faithful_Mpts_s": round(b2, 3), "hoisted_closed_form_Mpts_s": round(b3, 3)},
+        "all_cores": {"cores": cores, "logical_cpus_visible": os.cpu_count(), "faithful_Mpts_s": round(b2, 3),
+                      "hoisted_closed_form_Mpts_s": round(b3, 3)},
     }
 
 
@@ -101,10 +122,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("KMC_BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist  # backend "nccl" IS RCCL on ROCm
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the deskew path has no CPU fallback"
