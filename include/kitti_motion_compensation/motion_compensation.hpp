@@ -26,6 +26,20 @@ Vector4d MotionCompensatePoint(TrajectoryInterpolator const& trajectory_interpol
 Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time);
 
 // ---------------------------------------------------------------------------------------------------------------
+// The 3-argument form BASELINE.json's north_star names.  NOT in the reference (which has no Trajectory type and always
+// interpolates along the single geodesic T_start -> T_end): a piecewise SE(3) geodesic through time-stamped poses, e.g.
+// the three bracketing OXTS poses used directly instead of being reduced to two by MakeFrame.
+//   T(t) = P_k * Exp(x * Log(P_k^-1 P_{k+1})) on [t_k, t_{k+1}];   row(i) = T(requested_time)^-1 * T(timestamps(i)) * cloud.row(i)
+// Trajectory{{stamp_start, stamp_end}, {T_start, T_end}} gives results BIT-IDENTICAL to the 2-argument function.
+// Aborts like the reference's assert when requested_time or a point stamp is outside [times.front(), times.back()].
+// ---------------------------------------------------------------------------------------------------------------
+struct Trajectory {
+  std::vector<Time> times;      // strictly increasing, 2 .. 17 knots
+  std::vector<Affine3d> poses;  // pose at each knot
+};
+Pointcloud MotionCompensateFrame(Frame const& frame, Trajectory const& trajectory, Time const requested_time);
+
+// ---------------------------------------------------------------------------------------------------------------
 // Extensions (not in the reference): the f32 KITTI-layout fast path that the roofline numbers are quoted on.
 // ---------------------------------------------------------------------------------------------------------------
 namespace hip {
@@ -40,6 +54,10 @@ int GetDevice();
 // xyzi_in / xyzi_out are HOST pointers here (16-byte aligned); use the C-ABI directly for device-resident buffers.
 void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t num_points, Affine3d const& T_start, Affine3d const& T_end,
                                 Time stamp_start, Time stamp_end, Time requested_time, float* xyzi_out);
+
+// Same on an N-knot trajectory; bracket_index_out (optional) receives each point's segment index.
+void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t num_points, Trajectory const& trajectory, Time stamp_start,
+                                Time stamp_end, Time requested_time, float* xyzi_out, std::uint32_t* bracket_index_out = nullptr);
 
 // Many frames in one launch; frame f owns points [offsets[f], offsets[f+1]).
 struct FramePoses {

@@ -169,6 +169,26 @@ int kmc_hip_deskew_f64cols(kmc_ctx* ctx, const double* x, const double* y, const
                            const kmc_frame_params* params, double* ox, double* oy, double* oz, double* ow,
                            int mem_kind, kmc_stats* out_stats);
 
+/* ---- N-knot trajectories: the 3-argument MotionCompensateFrame(Frame, Trajectory, Time) of BASELINE.json's north_star ----
+ * The reference interpolates along ONE geodesic between the two scan poses.  These entry points generalise that to a
+ * piecewise SE(3) geodesic through n_knots time-stamped poses (e.g. the three bracketing OXTS poses directly):
+ *     T(t) = P_k * Exp(x * Log(P_k^-1 P_{k+1})),  t in [t_k, t_{k+1}],  x = (t - t_k)/(t_{k+1} - t_k)
+ *     p'   = T(requested_time)^-1 * T(t_i) * p
+ * knot_times[n_knots] strictly increasing; knot_poses[12 * n_knots] row-major 3x4; 2 <= n_knots <= 17.
+ * The trajectory must cover requested_time and every point stamp (else KMC_ERR_TIME_OUT_OF_RANGE).
+ * With n_knots == 2 and knots = {(stamp_start, T_start), (stamp_end, T_end)} the results are BIT-IDENTICAL to
+ * kmc_hip_deskew_f32 / kmc_hip_deskew_f64cols.
+ * bracket_idx_out (optional, NULL to skip; same mem_kind as the points): per-point segment index k -- the integer
+ * "timestamp index".  In the f32 entry point it is decided by trig-free half-plane tests on (x, y) so that it is bit-exact
+ * against the CPU oracle; in the f64 entry point by f64 compares of the caller's stamps against the knot times. */
+int kmc_hip_deskew_traj_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint64_t n, const double* knot_times,
+                            const double* knot_poses, uint32_t n_knots, double stamp_start, double stamp_end,
+                            double requested_time, uint32_t* bracket_idx_out, int mem_kind, kmc_stats* out_stats);
+int kmc_hip_deskew_traj_f64cols(kmc_ctx* ctx, const double* x, const double* y, const double* z, const double* w,
+                                const double* stamps, uint64_t n, const double* knot_times, const double* knot_poses,
+                                uint32_t n_knots, double requested_time, double* ox, double* oy, double* oz, double* ow,
+                                uint32_t* bracket_idx_out, int mem_kind, kmc_stats* out_stats);
+
 /* GetPseudoTimeStamps (timestamp_mocking.cpp:56-63) on the device, f64: stamps[i] = start + frac_i*(end-start). */
 int kmc_hip_pseudo_timestamps_f64(kmc_ctx* ctx, const double* x, const double* y, uint64_t n, double scan_start,
                                   double scan_end, double* stamps_out, int mem_kind);

@@ -114,16 +114,46 @@ SIGNATURES = {
         [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, C.POINTER(FrameParams), _vp, _vp, _vp, _vp,
          C.c_int, C.POINTER(Stats)],
     ),
+    "kmc_hip_deskew_traj_f32": (
+        C.c_int,
+        [_vp, _vp, _vp, C.c_uint64, _dp, _dp, C.c_uint32, C.c_double, C.c_double, C.c_double, _vp, C.c_int, C.POINTER(Stats)],
+    ),
+    "kmc_hip_deskew_traj_f64cols": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _dp, _dp, C.c_uint32, C.c_double, _vp, _vp, _vp, _vp, _vp, C.c_int,
+         C.POINTER(Stats)],
+    ),
     "kmc_hip_pseudo_timestamps_f64": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, _vp, C.c_int]),
     "kmc_hip_synth_points": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "kmc_synth_points_host": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
 }
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in one process
+    do not both see the GPU, so whichever is loaded first must be the only one: if torch is installed but not imported
+    yet, load ITS runtime now; libkmc_hip.so's DT_NEEDED libamdhip64.so.7 then binds to it by SONAME, and a later
+    `import torch` finds the very same file.  (Pure C/C++ users link /opt/rocm's runtime as usual.)"""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib() -> C.CDLL:
     """Loads libkmc_hip.so (built by `make -C kitti_motion_compensation_amd/csrc` / __graft_entry__.build())."""
     global _lib
     if _lib is None:
+        _preload_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -321,6 +351,34 @@ class Context:
         if rc == ERR_TIME_OUT_OF_RANGE and not raise_on_range:
             return rc, st
         self._check(rc, "kmc_hip_deskew_f64cols")
+        return rc, st
+
+    def deskew_traj_f32(self, xyzi_in, xyzi_out, knot_times, knot_poses, stamp_start, stamp_end, requested_time,
+                        bracket_idx_out=None, n=None) -> Stats:
+        """knot_poses: (K, 3, 4) or (K, 12) row-major [R|t]."""
+        kind = _mem_kind(xyzi_in)
+        if n is None:
+            n = int(xyzi_in.shape[0])
+        t = np.ascontiguousarray(knot_times, dtype=np.float64)
+        P = np.ascontiguousarray(np.asarray(knot_poses, dtype=np.float64).reshape(len(t), 12))
+        st = Stats()
+        rc = lib().kmc_hip_deskew_traj_f32(self._h, _ptr(xyzi_in), _ptr(xyzi_out), n, t.ctypes.data_as(_dp), P.ctypes.data_as(_dp),
+                                           len(t), stamp_start, stamp_end, requested_time, _ptr(bracket_idx_out), kind, C.byref(st))
+        self._check(rc, "kmc_hip_deskew_traj_f32")
+        return st
+
+    def deskew_traj_f64cols(self, x, y, z, w, stamps, knot_times, knot_poses, requested_time, ox, oy, oz, ow=None,
+                            bracket_idx_out=None, raise_on_range=True):
+        kind = _mem_kind(x)
+        t = np.ascontiguousarray(knot_times, dtype=np.float64)
+        P = np.ascontiguousarray(np.asarray(knot_poses, dtype=np.float64).reshape(len(t), 12))
+        st = Stats()
+        rc = lib().kmc_hip_deskew_traj_f64cols(self._h, _ptr(x), _ptr(y), _ptr(z), _ptr(w), _ptr(stamps), int(x.shape[0]),
+                                               t.ctypes.data_as(_dp), P.ctypes.data_as(_dp), len(t), requested_time, _ptr(ox),
+                                               _ptr(oy), _ptr(oz), _ptr(ow), _ptr(bracket_idx_out), kind, C.byref(st))
+        if rc == ERR_TIME_OUT_OF_RANGE and not raise_on_range:
+            return rc, st
+        self._check(rc, "kmc_hip_deskew_traj_f64cols")
         return rc, st
 
     def pseudo_timestamps_f64(self, x, y, scan_start, scan_end, out):

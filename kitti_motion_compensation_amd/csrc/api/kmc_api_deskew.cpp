@@ -67,6 +67,25 @@ void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t n, Affine3d co
   if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_f32", c);
 }
 
+namespace {
+void flatten(Trajectory const& tr, std::vector<double>* poses12) {
+  if (tr.times.size() != tr.poses.size()) throw std::invalid_argument("kmc::Trajectory: times.size() != poses.size()");
+  poses12->resize(12 * tr.poses.size());
+  for (std::size_t k = 0; k < tr.poses.size(); ++k) tr.poses[k].to_rt12(poses12->data() + 12 * k);
+}
+}  // namespace
+
+void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t n, Trajectory const& tr, Time stamp_start, Time stamp_end,
+                                Time requested_time, float* xyzi_out, std::uint32_t* bracket_index_out) {
+  std::vector<double> poses;
+  flatten(tr, &poses);
+  kmc_ctx* c = detail::thread_context();
+  int const rc = kmc_hip_deskew_traj_f32(c, xyzi_in, xyzi_out, n, tr.times.data(), poses.data(), static_cast<std::uint32_t>(tr.times.size()),
+                                         stamp_start, stamp_end, requested_time, bracket_index_out, KMC_MEM_HOST, nullptr);
+  if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::hip::MotionCompensateKittiCloud(Trajectory)");
+  if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_traj_f32", c);
+}
+
 void MotionCompensateKittiClouds(float const* xyzi_in, std::vector<std::uint64_t> const& offsets, std::vector<FramePoses> const& frames,
                                  float* xyzi_out, std::uint32_t* frame_index_out) {
   if (offsets.size() != frames.size() + 1) throw std::invalid_argument("kmc::hip::MotionCompensateKittiClouds: offsets.size() != frames.size() + 1");
@@ -98,6 +117,25 @@ Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time) 
                                         KMC_MEM_HOST, &st);
   if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::MotionCompensateFrame");
   if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_f64cols", c);
+  return out;
+}
+
+// north_star's 3-argument form (see the header): piecewise geodesic through the trajectory's knots
+Pointcloud MotionCompensateFrame(Frame const& frame, Trajectory const& tr, Time const requested_time) {
+  Index const n = frame.scan.cloud.rows();
+  if (frame.scan.timestamps.size() != n) throw std::invalid_argument("kmc::MotionCompensateFrame: timestamps.size() != cloud.rows()");
+  if (tr.times.size() != tr.poses.size()) throw std::invalid_argument("kmc::Trajectory: times.size() != poses.size()");
+  std::vector<double> poses(12 * tr.poses.size());
+  for (std::size_t k = 0; k < tr.poses.size(); ++k) tr.poses[k].to_rt12(poses.data() + 12 * k);
+  Pointcloud out{MatrixX4d(n, 4)};
+  kmc_ctx* c = detail::thread_context();
+  Pointcloud const& in = frame.scan.cloud;
+  int const rc = kmc_hip_deskew_traj_f64cols(c, in.col(0), in.col(1), in.col(2), in.col(3), frame.scan.timestamps.data(),
+                                             static_cast<std::uint64_t>(n), tr.times.data(), poses.data(),
+                                             static_cast<std::uint32_t>(tr.times.size()), requested_time, out.col(0), out.col(1), out.col(2),
+                                             out.col(3), nullptr, KMC_MEM_HOST, nullptr);
+  if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::MotionCompensateFrame(Frame, Trajectory, Time)");
+  if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_traj_f64cols", c);
   return out;
 }
 

@@ -120,11 +120,9 @@ __device__ __forceinline__ Coef se3_coefficients(float s, float phi2) {
   return c;
 }
 
-// p' = Exp(s * f) * p  in the cross-product form; (x, y, z) in, (x', y', z') out.
-template <int TIER, bool OCML_ATAN = false>
-__device__ __forceinline__ v4f deskew_point(const v4f p, const FrameRec& f) {
-  const float a = OCML_ATAN ? azimuth_turns_ocml(p.x, p.y) : azimuth_turns(p.x, p.y);
-  const float s = f.s0 - a;  // = frac - x_req
+// p' = Exp(s * f) * p  in the cross-product form, for a given s = x_i - x_anchor; (x, y, z) in, (x', y', z') out.
+template <int TIER>
+__device__ __forceinline__ v4f deskew_point_s(const v4f p, const float s, const FrameRec& f) {
   const Coef k = se3_coefficients<TIER>(s, f.phi2);
   // q1 = phi x p
   const float q1x = __builtin_fmaf(f.phi_y, p.z, -(f.phi_z * p.y));
@@ -142,12 +140,70 @@ __device__ __forceinline__ v4f deskew_point(const v4f p, const FrameRec& f) {
   return o;
 }
 
+// fused: azimuth -> scan fraction -> s -> Exp(s f) p
+template <int TIER, bool OCML_ATAN = false>
+__device__ __forceinline__ v4f deskew_point(const v4f p, const FrameRec& f) {
+  const float a = OCML_ATAN ? azimuth_turns_ocml(p.x, p.y) : azimuth_turns(p.x, p.y);
+  return deskew_point_s<TIER>(p, f.s0 - a, f);  // s = frac - x_req
+}
+
+// ---- N-knot trajectories (piecewise SE(3) geodesic through time-stamped poses) ------------------------------------
+// One record per trajectory segment k = [knot k, knot k+1]; 128 B, staged into LDS by the workgroup.
+//   p' = M_k * ( Exp((x_i - a_k) f_k) * p ),   x_i = position of the point's stamp inside the segment
+// The segment that contains requested_time has M = I and a = x_req (the reference's single-geodesic case, bit for bit);
+// every other segment has a = 0 and M_k = T(requested)^-1 * P_k, computed on the host in f64.
+struct alignas(16) TrajSeg32 {
+  float phi_x, phi_y, phi_z, phi2;
+  float rho_x, rho_y, rho_z, s0;     // s = s0 - turns * g
+  float c1_x, c1_y, c1_z, g;         // g = scan duration / segment duration
+  float c2_x, c2_y, c2_z, knot_c;    // knot_c: scan fraction c_k of the segment's START knot
+  float m00, m01, m02, tx;           // M_k rows with the translation in the 4th column
+  float m10, m11, m12, ty;
+  float m20, m21, m22, tz;
+  float knot_cos, knot_sin;          // direction of the start knot's azimuth alpha_k = pi - 2 pi c_k
+  uint32_t flags;                    // kSegIdentity | kKnotAlwaysGe | kKnotNeverGe
+  uint32_t pad;
+};
+static_assert(sizeof(TrajSeg32) == 128, "TrajSeg32 must stay one 128-byte record");
+constexpr uint32_t kSegIdentity = 1u, kKnotAlwaysGe = 2u, kKnotNeverGe = 4u;
+constexpr int kMaxSegments = 16;
+
+// Integer bracket test "scan fraction of (x, y) >= c_k" WITHOUT trig: half-plane tests against the knot's direction.
+// Pure IEEE f32 mul/sub/add/compare in a fixed order with contraction off, so that the CPU restatement in the oracle
+// executes the identical operations and the per-point bracket index is bit-exact.
+__device__ __forceinline__ bool knot_ge(float x, float y, float knot_c, float ck, float sk, uint32_t flags) {
+#pragma clang fp contract(off)
+  if (flags & kKnotAlwaysGe) return true;
+  if (flags & kKnotNeverGe) return false;
+  const bool xneg = (__float_as_uint(x) >> 31) != 0;
+  const bool yneg = (__float_as_uint(y) >> 31) != 0;
+  bool lt;
+  if (x == 0.0f && y == 0.0f) {  // atan2 on signed zeros: (+-0, +0) -> frac 0.5, (+0, -0) -> 0, (-0, -0) -> 1
+    const float fs = xneg ? (yneg ? 1.0f : 0.0f) : 0.5f;
+    lt = fs < knot_c;
+  } else {
+    const float cross = ck * y - sk * x;
+    const float dot = ck * x + sk * y;
+    if (knot_c <= 0.5f) lt = !yneg && (cross > 0.0f || (cross == 0.0f && dot < 0.0f));
+    else lt = !yneg || cross > 0.0f || (cross == 0.0f && dot < 0.0f);
+  }
+  return !lt;
+}
+
 // ---- f64 path (Eigen-layout API): closed form in double, series below theta^2 = 0.04 -----------------
 struct FrameRec64 {
   double phi[3], rho[3], c1[3], c2[3];
   double phi2;
   double x_req;
   double t_start, t_end, dur;
+};
+
+// f64 trajectory segment (global-memory table, read by the f64 Eigen-layout trajectory kernel)
+struct TrajSeg64 {
+  FrameRec64 f;      // twist of the segment; f.x_req holds the anchor a_k, f.t_start/f.dur the segment's time span
+  double M[12];      // row-major 3x4 [R | t] applied after the exponential (identity for the anchor segment)
+  int identity;
+  int pad;
 };
 
 __device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, double& alpha, double& beta, double& gamma) {

@@ -234,6 +234,98 @@ __global__ __launch_bounds__(kBlock) void pseudo_timestamps_f64(const double* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// N-knot trajectory kernels (the 3-argument MotionCompensateFrame(Frame, Trajectory, Time) overload)
+// ------------------------------------------------------------------------------------------------
+// The workgroup stages the segment records -- the twists of the bracketing poses -- into LDS once; each lane finds its
+// bracket with the trig-free knot tests (an integer, bit-exact against the oracle), a wave whose lanes share one
+// bracket broadcasts it through readfirstlane and reads the record at a uniform LDS address, other waves gather per
+// lane; then the fused exp-map + rotate + translate runs per lane exactly like the single-geodesic kernels.
+template <int TIER, int NT, bool WRITE_IDX>
+__global__ __launch_bounds__(kBlock) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+                                                         const TrajSeg32* __restrict__ segs, uint32_t n_seg,
+                                                         uint32_t* __restrict__ bracket_out) {
+  __shared__ TrajSeg32 lds[kMaxSegments];
+  const uint32_t tid = threadIdx.x;
+  if (tid < n_seg * 8) reinterpret_cast<v4f*>(lds)[tid] = reinterpret_cast<const v4f*>(segs)[tid];  // 8 x 16 B per record
+  __syncthreads();
+  const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t i = t * kBlock + tid;
+    const bool live = i < n;
+    v4f p = {0.f, 0.f, 0.f, 0.f};
+    if (live) p = load_point<NT>(in + i);
+    uint32_t k = 0;
+    for (uint32_t j = 1; j < n_seg; ++j)  // interior knots; uniform LDS addresses -> broadcast reads
+      k += knot_ge(p.x, p.y, lds[j].knot_c, lds[j].knot_cos, lds[j].knot_sin, lds[j].flags) ? 1u : 0u;
+    const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
+    const bool wave_uniform = __all(k == k0);
+    const TrajSeg32 r = wave_uniform ? lds[k0] : lds[k];
+    if (live) {
+      FrameRec f;
+      f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
+      f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
+      f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pad0 = 0.f;
+      f.c2_x = r.c2_x; f.c2_y = r.c2_y; f.c2_z = r.c2_z; f.pad1 = 0.f;
+      const float turns = azimuth_turns(p.x, p.y);
+      const float s = __builtin_fmaf(-turns, r.g, r.s0);
+      v4f q = deskew_point_s<TIER>(p, s, f);
+      if (!(r.flags & kSegIdentity)) {
+        v4f o;
+        o.x = __builtin_fmaf(r.m02, q.z, __builtin_fmaf(r.m01, q.y, __builtin_fmaf(r.m00, q.x, r.tx)));
+        o.y = __builtin_fmaf(r.m12, q.z, __builtin_fmaf(r.m11, q.y, __builtin_fmaf(r.m10, q.x, r.ty)));
+        o.z = __builtin_fmaf(r.m22, q.z, __builtin_fmaf(r.m21, q.y, __builtin_fmaf(r.m20, q.x, r.tz)));
+        o.w = q.w;
+        q = o;
+      }
+      store_point<NT>(out + i, q);
+      if constexpr (WRITE_IDX) bracket_out[i] = k;
+    }
+  }
+}
+
+// f64 Eigen-layout variant: honours the caller's per-point stamps; the bracket is found by f64 time compares.
+__global__ __launch_bounds__(kBlock) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
+                                                             const double* __restrict__ z, const double* __restrict__ w,
+                                                             const double* __restrict__ stamps, uint64_t n,
+                                                             const TrajSeg64* __restrict__ segs, uint32_t n_seg,
+                                                             double t_first, double t_last, double* __restrict__ ox,
+                                                             double* __restrict__ oy, double* __restrict__ oz,
+                                                             double* __restrict__ ow, uint32_t* __restrict__ bracket_out,
+                                                             unsigned long long* __restrict__ n_bad) {
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double t = stamps[i];
+    const double px = x[i], py = y[i], pz = z[i], pw = w ? w[i] : 1.0;
+    const bool in_range = (t >= t_first) && (t <= t_last);
+    double rx, ry, rz;
+    uint32_t k = 0;
+    if (in_range) {
+      while (k + 1 < n_seg && t >= segs[k + 1].f.t_start) ++k;  // t_k <= t < t_{k+1}; the last knot belongs to the last segment
+      const TrajSeg64& sg = segs[k];
+      const double xi = (t - sg.f.t_start) / sg.f.dur;
+      double qx, qy, qz;
+      deskew_point_f64(px, py, pz, pw, xi - sg.f.x_req, sg.f, qx, qy, qz);
+      if (sg.identity) {
+        rx = qx; ry = qy; rz = qz;
+      } else {  // M_k * (q, w): rotation on the point, translation scaled by the homogeneous coordinate
+        rx = sg.M[0] * qx + sg.M[1] * qy + sg.M[2] * qz + sg.M[3] * pw;
+        ry = sg.M[4] * qx + sg.M[5] * qy + sg.M[6] * qz + sg.M[7] * pw;
+        rz = sg.M[8] * qx + sg.M[9] * qy + sg.M[10] * qz + sg.M[11] * pw;
+      }
+    } else {
+      rx = ry = rz = __builtin_nan("");
+    }
+    ox[i] = rx;
+    oy[i] = ry;
+    oz[i] = rz;
+    if (ow) ow[i] = pw;
+    if (bracket_out) bracket_out[i] = k;
+    const unsigned long long bad = __ballot(!in_range);
+    if (bad && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(bad)) atomicAdd(n_bad, (unsigned long long)__builtin_popcountll(bad));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic generator + a plain copy kernel (the measured same-hardware ceiling for the roofline table)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void synth_points(v4f* __restrict__ out, uint64_t n, uint64_t seed) {

@@ -573,3 +573,149 @@ int kmo_deskew_xyzi_f32(const float* xyzi, size_t n, double stamp_start, const k
   if (n_bad) *n_bad = bad;
   return bad ? KMO_ERR_TIME_OUT_OF_RANGE : KMO_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * N-knot trajectory: the reference's two-pose interpolator chained over consecutive knots (see kmc_oracle.h)
+ * ---------------------------------------------------------------------------------------------- */
+static size_t traj_segment(const double* times, size_t n_knots, double t) {
+  size_t k = 0;
+  while (k + 2 < n_knots && t >= times[k + 1]) ++k;
+  return k;
+}
+
+int kmo_traj_pose_at_time(const double* times, const kmo_affine* poses, size_t n_knots, double t, kmo_affine* out) {
+  if (n_knots < 2 || !(t >= times[0] && t <= times[n_knots - 1])) return KMO_ERR_TIME_OUT_OF_RANGE;
+  size_t k = traj_segment(times, n_knots, t);
+  kmo_interpolator ti;
+  kmo_interpolator_from_poses(times[k], &poses[k], times[k + 1], &poses[k + 1], &ti);
+  return kmo_get_pose_at_time(&ti, t, out); /* trajectory_interpolation.cpp:31-41 on the bracketing pair */
+}
+
+static int traj_correct_point(const double* times, const kmo_affine* poses, size_t n_knots, const kmo_affine* Treq_inv,
+                              double stamp, const double p[4], double q[4], uint32_t* bracket) {
+  kmo_affine Tq, corr;
+  int rc = kmo_traj_pose_at_time(times, poses, n_knots, stamp, &Tq);
+  if (rc != KMO_OK) return rc;
+  if (bracket) *bracket = (uint32_t)traj_segment(times, n_knots, stamp);
+  kmo_affine_mul(Treq_inv, &Tq, &corr); /* GetPoseAtTime(anchor)^-1 * GetPoseAtTime(query), :43-45 */
+  kmo_affine_apply4(&corr, p, q);       /* motion_compensation.cpp:13 */
+  return KMO_OK;
+}
+
+int kmo_deskew_xyzi_f32_traj(const float* xyzi, size_t n, double stamp_start, double stamp_end, const double* times,
+                             const kmo_affine* poses, size_t n_knots, double requested_time, int threads,
+                             double* out_xyz_f64, uint32_t* bracket_by_time_out, size_t* n_bad) {
+  kmo_affine Treq, Treq_inv;
+  int rc0 = kmo_traj_pose_at_time(times, poses, n_knots, requested_time, &Treq);
+  if (rc0 != KMO_OK) {
+    if (n_bad) *n_bad = n;
+    return rc0;
+  }
+  kmo_affine_inverse(&Treq, &Treq_inv);
+  size_t bad = 0;
+  long long nn = (long long)n;
+#ifdef _OPENMP
+  if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) reduction(+ : bad) schedule(static)
+#else
+  (void)threads;
+#endif
+  for (long long i = 0; i < nn; ++i) {
+    double p[4] = {(double)xyzi[4 * i + 0], (double)xyzi[4 * i + 1], (double)xyzi[4 * i + 2], 1.0};
+    double stamp = kmo_pseudo_timestamp(p, stamp_start, stamp_end);
+    double q[4];
+    uint32_t b = 0;
+    if (traj_correct_point(times, poses, n_knots, &Treq_inv, stamp, p, q, &b) != KMO_OK) {
+      ++bad;
+      q[0] = q[1] = q[2] = NAN;
+    }
+    if (out_xyz_f64) {
+      out_xyz_f64[3 * i + 0] = q[0];
+      out_xyz_f64[3 * i + 1] = q[1];
+      out_xyz_f64[3 * i + 2] = q[2];
+    }
+    if (bracket_by_time_out) bracket_by_time_out[i] = b;
+  }
+  if (n_bad) *n_bad = bad;
+  return bad ? KMO_ERR_TIME_OUT_OF_RANGE : KMO_OK;
+}
+
+int kmo_motion_compensate_frame_traj(const double* cloud, const double* stamps, size_t n, const double* times,
+                                     const kmo_affine* poses, size_t n_knots, double requested_time, double* out,
+                                     uint32_t* bracket_out, size_t* n_bad) {
+  kmo_affine Treq, Treq_inv;
+  int rc0 = kmo_traj_pose_at_time(times, poses, n_knots, requested_time, &Treq);
+  if (rc0 != KMO_OK) {
+    if (n_bad) *n_bad = n;
+    return rc0;
+  }
+  kmo_affine_inverse(&Treq, &Treq_inv);
+  size_t bad = 0;
+  for (size_t i = 0; i < n; ++i) {
+    double p[4] = {cloud[i], cloud[n + i], cloud[2 * n + i], cloud[3 * n + i]};
+    double q[4];
+    uint32_t b = 0;
+    if (traj_correct_point(times, poses, n_knots, &Treq_inv, stamps[i], p, q, &b) != KMO_OK) {
+      ++bad;
+      q[0] = q[1] = q[2] = q[3] = NAN;
+    }
+    out[i] = q[0];
+    out[n + i] = q[1];
+    out[2 * n + i] = q[2];
+    out[3 * n + i] = q[3];
+    if (bracket_out) bracket_out[i] = b;
+  }
+  if (n_bad) *n_bad = bad;
+  return bad ? KMO_ERR_TIME_OUT_OF_RANGE : KMO_OK;
+}
+
+/* trig-free bracket index: see the specification in kmc_oracle.h */
+static int knot_ge_f32(float x, float y, float knot_c, float ck, float sk, int always_ge, int never_ge) {
+  if (always_ge) return 1; /* c_k <= 0, decided on the f64 fraction */
+  if (never_ge) return 0;  /* c_k > 1 */
+  int xneg = signbit(x) != 0, yneg = signbit(y) != 0;
+  int lt;
+  if (x == 0.0f && y == 0.0f) {
+    float fs = xneg ? (yneg ? 1.0f : 0.0f) : 0.5f;
+    lt = fs < knot_c;
+  } else {
+    float a = ck * y;
+    float b = sk * x;
+    float cross = a - b;
+    float c = ck * x;
+    float d = sk * y;
+    float dot = c + d;
+    if (knot_c <= 0.5f) lt = !yneg && (cross > 0.0f || (cross == 0.0f && dot < 0.0f));
+    else lt = !yneg || cross > 0.0f || (cross == 0.0f && dot < 0.0f);
+  }
+  return !lt;
+}
+
+void kmo_bracket_indices_f32(const float* xyzi, size_t n, const double* times, size_t n_knots, double stamp_start,
+                             double stamp_end, uint32_t* out) {
+  float kc[64], kcos[64], ksin[64];
+  int always_ge[64], never_ge[64];
+  size_t n_int = 0;
+  for (size_t k = 1; k + 1 < n_knots && n_int < 64; ++k, ++n_int) {
+    double c = (times[k] - stamp_start) / (stamp_end - stamp_start);
+    double q = 4.0 * c;
+    kc[n_int] = (float)c;
+    always_ge[n_int] = c <= 0.0;
+    never_ge[n_int] = c > 1.0;
+    if (q == floor(q) && q >= 0.0 && q <= 4.0) { /* exact directions on the quarter turns */
+      static const float tc[5] = {-1.f, 0.f, 1.f, 0.f, -1.f};
+      static const float ts[5] = {0.f, 1.f, 0.f, -1.f, -0.f};
+      kcos[n_int] = tc[(int)q];
+      ksin[n_int] = ts[(int)q];
+    } else {
+      double alpha = M_PI - 2.0 * M_PI * c;
+      kcos[n_int] = (float)cos(alpha);
+      ksin[n_int] = (float)sin(alpha);
+    }
+  }
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t k = 0;
+    for (size_t j = 0; j < n_int; ++j) k += (uint32_t)knot_ge_f32(xyzi[4 * i], xyzi[4 * i + 1], kc[j], kcos[j], ksin[j], always_ge[j], never_ge[j]);
+    out[i] = k;
+  }
+}

@@ -112,6 +112,31 @@ int kmo_deskew_xyzi_f32(const float* xyzi, size_t n, double stamp_start, const k
                         int threads, double* out_xyz_f64, float* out_xyzi_f32, double* stamps_out,
                         size_t* n_bad);
 
+/* ---- N-knot trajectory (this project's generalisation of the reference's single geodesic; NOT in the reference) ----
+ * T(t) is the reference's own GetPoseAtTime (trajectory_interpolation.cpp:31-41) applied to the knot pair that brackets t
+ * (t_k <= t < t_{k+1}; the last knot belongs to the last segment); correction_i = T(requested)^-1 * T(stamp_i), formed
+ * exactly like RelativePoseBetweenTimes (:43-45).  With 2 knots it IS the reference algorithm. */
+int kmo_traj_pose_at_time(const double* times, const kmo_affine* poses, size_t n_knots, double t, kmo_affine* out);
+int kmo_deskew_xyzi_f32_traj(const float* xyzi, size_t n, double stamp_start, double stamp_end, const double* times,
+                             const kmo_affine* poses, size_t n_knots, double requested_time, int threads,
+                             double* out_xyz_f64, uint32_t* bracket_by_time_out, size_t* n_bad);
+/* Eigen-layout variant with explicit per-point stamps (N x 4 column-major in/out). */
+int kmo_motion_compensate_frame_traj(const double* cloud_colmajor, const double* stamps, size_t n, const double* times,
+                                     const kmo_affine* poses, size_t n_knots, double requested_time,
+                                     double* out_colmajor, uint32_t* bracket_out, size_t* n_bad);
+
+/* Per-point integer bracket index decided WITHOUT trig: for every interior knot k with scan
+ * fraction c_k = (t_k - stamp_start)/(stamp_end - stamp_start) and direction (ck, sk) = f32(cos, sin)(pi - 2 pi c_k),
+ *   ge_k(x, y) = !lt_k,  lt_k = (c_k <= 0) ? false : (c_k > 1) ? true :
+ *                 (x == 0 && y == 0) ? (frac_of_signed_zeros < c_k) :
+ *                 (c_k <= 0.5) ? (!signbit(y) && (cross > 0 || (cross == 0 && dot < 0)))
+ *                               : (!signbit(y) || cross > 0 || (cross == 0 && dot < 0))     [cross == 0 && dot < 0: the point is
+ *                                 exactly opposite the knot direction, i.e. half a turn EARLIER in the scan]
+ *   cross = ck*y - sk*x, dot = ck*x + sk*y   in f32, every operation rounded, no contraction
+ * index = sum over interior knots of ge_k.  The device executes the same IEEE operations -> bit-exact. */
+void kmo_bracket_indices_f32(const float* xyzi, size_t n, const double* times, size_t n_knots, double stamp_start,
+                             double stamp_end, uint32_t* out);
+
 int kmo_num_threads(void); /* omp_get_max_threads() or 1 */
 
 #ifdef __cplusplus

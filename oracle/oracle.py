@@ -120,6 +120,17 @@ def lib() -> C.CDLL:
              C.POINTER(C.c_size_t)],
         ),
         "kmo_num_threads": (C.c_int, []),
+        "kmo_traj_pose_at_time": (C.c_int, [dp, ap, C.c_size_t, C.c_double, ap]),
+        "kmo_deskew_xyzi_f32_traj": (
+            C.c_int,
+            [fp, C.c_size_t, C.c_double, C.c_double, dp, ap, C.c_size_t, C.c_double, C.c_int, dp, C.POINTER(C.c_uint32),
+             C.POINTER(C.c_size_t)],
+        ),
+        "kmo_motion_compensate_frame_traj": (
+            C.c_int,
+            [dp, dp, C.c_size_t, dp, ap, C.c_size_t, C.c_double, dp, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)],
+        ),
+        "kmo_bracket_indices_f32": (None, [fp, C.c_size_t, dp, C.c_size_t, C.c_double, C.c_double, C.POINTER(C.c_uint32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -321,3 +332,58 @@ def deskew_xyzi_f32(xyzi, stamp_start, T_start: Affine, stamp_end, T_end: Affine
 
 def num_threads() -> int:
     return lib().kmo_num_threads()
+
+
+# ---- N-knot trajectory (this project's generalisation; see kmc_oracle.h) ------------------------------
+def _affine_array(poses):
+    arr = (Affine * len(poses))()
+    for i, p in enumerate(poses):
+        arr[i] = p
+    return arr
+
+
+def traj_pose_at_time(times, poses, t):
+    t_, tp = _d(times)
+    out = Affine()
+    rc = lib().kmo_traj_pose_at_time(tp, _affine_array(poses), len(poses), t, C.byref(out))
+    return rc, out
+
+
+def deskew_xyzi_f32_traj(xyzi, stamp_start, stamp_end, times, poses, requested, threads=0):
+    """-> dict(rc, n_bad, xyz_f64 (N,3), bracket_by_time (N,) uint32)"""
+    a = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    n = a.shape[0]
+    if threads <= 0:
+        threads = lib().kmo_num_threads()
+    t_, tp = _d(times)
+    o64 = np.empty((n, 3), dtype=np.float64)
+    br = np.empty(n, dtype=np.uint32)
+    nbad = C.c_size_t(0)
+    rc = lib().kmo_deskew_xyzi_f32_traj(a.ctypes.data_as(C.POINTER(C.c_float)), n, stamp_start, stamp_end, tp,
+                                        _affine_array(poses), len(poses), requested, threads,
+                                        o64.ctypes.data_as(C.POINTER(C.c_double)), br.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        C.byref(nbad))
+    return {"rc": rc, "n_bad": nbad.value, "xyz_f64": o64, "bracket_by_time": br}
+
+
+def motion_compensate_frame_traj(cloud_nx4, stamps, times, poses, requested):
+    cm = np.asfortranarray(np.asarray(cloud_nx4, dtype=np.float64))
+    n = cm.shape[0]
+    st_, sp = _d(stamps)
+    t_, tp = _d(times)
+    out = np.zeros((n, 4), order="F")
+    br = np.empty(n, dtype=np.uint32)
+    nbad = C.c_size_t(0)
+    rc = lib().kmo_motion_compensate_frame_traj(cm.ctypes.data_as(C.POINTER(C.c_double)), sp, n, tp, _affine_array(poses),
+                                                len(poses), requested, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                                br.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nbad))
+    return rc, nbad.value, np.ascontiguousarray(out), br
+
+
+def bracket_indices_f32(xyzi, times, stamp_start, stamp_end):
+    a = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    t_, tp = _d(times)
+    out = np.empty(a.shape[0], dtype=np.uint32)
+    lib().kmo_bracket_indices_f32(a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0], tp, len(t_), stamp_start, stamp_end,
+                                  out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out

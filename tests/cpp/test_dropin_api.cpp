@@ -266,6 +266,46 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
     std::printf("  f32 vs f64 path: max rel err %.3e (bar 1e-5)\n", worst);
     ASSERT_TRUE(worst <= 1e-5);
   }
+  CASE("MotionCompensateFrame(Frame, Trajectory, Time): 2 knots == the 2-argument function, bit for bit");
+  {
+    Frame const frame{MakeMotionCompensationTestFrame()};
+    Trajectory const two{{frame.scan.stamp_start, frame.scan.stamp_end}, {frame.T_start, frame.T_end}};
+    Pointcloud const a{MotionCompensateFrame(frame, frame.scan.stamp_middle)};
+    Pointcloud const b{MotionCompensateFrame(frame, two, frame.scan.stamp_middle)};
+    for (Index i = 0; i < a.rows(); ++i)
+      for (int j = 0; j < 4; ++j) ASSERT_TRUE(std::memcmp(&a.col(j)[i], &b.col(j)[i], sizeof(double)) == 0);
+    ASSERT_FLOAT_EQ(b(0, 0), -0.27829874);
+    ASSERT_FLOAT_EQ(b(2, 0), 0.27829874);
+  }
+  CASE("MotionCompensateFrame(Frame, Trajectory, Time): the three bracketing OXTS poses used directly");
+  {
+    // constant velocity along a straight line: the 3-knot trajectory and the reference's 2-pose reduction describe the
+    // same motion, so both must give the reference's expected numbers (test_motion_compensation.cpp:59-75)
+    Oxts const o0{Time(0.05), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    Oxts const o1{Time(0.15), 0.0, 0.00001, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    Oxts const o2{Time(0.25), 0.0, 0.00002, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    Frame const frame{MakeMotionCompensationTestFrame()};
+    Trajectory const three{{o0.stamp, o1.stamp, o2.stamp}, {OxtsToPose(o0), OxtsToPose(o1), OxtsToPose(o2)}};
+    Pointcloud const mc{MotionCompensateFrame(frame, three, frame.scan.stamp_middle)};
+    ASSERT_FLOAT_EQ(mc(0, 0), -0.27829874);
+    ASSERT_FLOAT_EQ(mc(0, 1), 5.0);
+    ASSERT_FLOAT_EQ(mc(1, 0), 5.0);
+    ASSERT_FLOAT_EQ(mc(2, 0), 0.27829874);
+    ASSERT_FLOAT_EQ(mc(2, 1), -5.0);
+    // f32 KITTI-layout entry point with bracket indices: point 0 (frac 0.25) in segment 0, point 2 (frac 0.75) in segment 1
+    float const in[12] = {0.f, 5.f, 0.f, 0.1f, 5.f, 0.f, 0.f, 0.2f, 0.f, -5.f, 0.f, 0.3f};
+    alignas(16) float buf_in[12];
+    alignas(16) float buf_out[12];
+    std::memcpy(buf_in, in, sizeof(in));
+    std::uint32_t idx[3] = {9, 9, 9};
+    hip::MotionCompensateKittiCloud(buf_in, 3, three, frame.scan.stamp_start, frame.scan.stamp_end, frame.scan.stamp_middle, buf_out, idx);
+    ASSERT_FLOAT_EQ(buf_out[0], -0.27829874);
+    ASSERT_FLOAT_EQ(buf_out[8], 0.27829874);
+    ASSERT_EQ(idx[0], 0u);
+    ASSERT_EQ(idx[1], 1u);  // frac == 0.5 == the knot: belongs to the later segment
+    ASSERT_EQ(idx[2], 1u);
+    ASSERT_TRUE(buf_out[3] == 0.1f && buf_out[7] == 0.2f && buf_out[11] == 0.3f);
+  }
   CASE("MotionCompensateRun on a synthesised 5-frame run");  // handlers.cpp:41-65
   {
     namespace fs = std::filesystem;

@@ -1,0 +1,215 @@
+"""N-knot trajectories: the 3-argument MotionCompensateFrame(Frame, Trajectory, Time) that BASELINE.json's north_star names.
+The reference has only the 2-pose geodesic; the N-knot form chains the reference's own interpolator over consecutive
+knots (oracle/kmc_oracle.h).  Checked here: (CPU) the oracle's chain reduces to the reference algorithm for 2 knots and
+is continuous across knots; (GPU) the HIP kernels match it, reduce BIT-FOR-BIT to the 2-argument kernels for 2 knots, and
+emit per-point bracket indices that are BIT-EXACT against the oracle's trig-free definition."""
+import os
+
+import numpy as np
+import pytest
+
+from kitti_motion_compensation_amd import capi
+from oracle import oracle as orc
+from tests import util
+
+T0, T1, TREQ = 47072.283701593, 47072.386973931, 47072.335337762
+REL_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def kitti(golden_dir):
+    run = os.path.join(golden_dir, "kitti_2011_09_26_drive_0005")
+    return util.load_velodyne_bin(run, 0), orc.oxts_to_pose(orc.oxts(**util.load_oxts_fields(run, 0)))
+
+
+def _chain(P0, steps):
+    poses = [P0]
+    for s in steps:
+        poses.append(orc.affine_mul(poses[-1], orc.se3_exp(s)))
+    return poses
+
+
+def _rt(poses):
+    return np.stack([p.rt12().reshape(3, 4) for p in poses])
+
+
+def _oxts_like_trajectory(P0):
+    """Three bracketing poses at T0-0.05 / mid / T1+0.05: the boundary between the two segments sits inside the scan."""
+    times = [T0 - 0.0520, 0.5 * (T0 + T1) + 0.0031, T1 + 0.0490]
+    poses = _chain(P0, [[1.31, 0.04, -0.015, 0.002, -0.004, 0.035], [1.36, -0.02, 0.01, -0.003, 0.002, 0.05]])
+    return times, poses
+
+
+# ---- CPU: the oracle's chain --------------------------------------------------------------------------------------
+def test_oracle_two_knots_is_the_reference_algorithm(kitti):
+    xyzi, P1 = kitti
+    xyzi = xyzi[::23]
+    P2 = orc.affine_mul(P1, orc.se3_exp([2.9, -0.3, 0.1, 0.02, 0.01, -0.1]))
+    a = orc.deskew_xyzi_f32(xyzi, T0, P1, T1, P2, TREQ, mode=orc.FAITHFUL, threads=1)
+    b = orc.deskew_xyzi_f32_traj(xyzi, T0, T1, [T0, T1], [P1, P2], TREQ, threads=1)
+    assert a["rc"] == orc.OK and b["rc"] == orc.OK
+    assert np.array_equal(a["xyz_f64"], b["xyz_f64"])  # same operations, bit for bit
+    assert np.all(b["bracket_by_time"] == 0)
+
+
+def test_oracle_chain_is_continuous_and_in_range(kitti):
+    _, P1 = kitti
+    times, poses = _oxts_like_trajectory(P1)
+    eps = 1e-9
+    rc1, A = orc.traj_pose_at_time(times, poses, times[1] - eps)
+    rc2, B = orc.traj_pose_at_time(times, poses, times[1])
+    assert rc1 == orc.OK and rc2 == orc.OK
+    assert np.allclose(A.matrix(), B.matrix(), atol=1e-6)
+    assert np.allclose(B.matrix(), poses[1].matrix(), atol=1e-8)  # a knot reproduces its pose
+    assert orc.traj_pose_at_time(times, poses, times[0] - 1e-3)[0] == orc.ERR_TIME_OUT_OF_RANGE
+    assert orc.traj_pose_at_time(times, poses, times[2] + 1e-3)[0] == orc.ERR_TIME_OUT_OF_RANGE
+    assert orc.traj_pose_at_time(times, poses, times[2])[0] == orc.OK
+
+
+def test_trig_free_bracket_matches_time_bracket_away_from_knots(kitti):
+    xyzi, P1 = kitti
+    times, poses = _oxts_like_trajectory(P1)
+    r = orc.deskew_xyzi_f32_traj(xyzi, T0, T1, times, poses, TREQ)
+    idx = orc.bracket_indices_f32(xyzi, times, T0, T1)
+    frac = (np.pi - np.arctan2(xyzi[:, 1].astype(np.float64), xyzi[:, 0].astype(np.float64))) / (2 * np.pi)
+    c1 = (times[1] - T0) / (T1 - T0)
+    away = np.abs(frac - c1) > 1e-6
+    assert np.array_equal(idx[away], r["bracket_by_time"][away])
+    assert set(np.unique(idx)) == {0, 1}
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available()
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_two_knots_reduce_bit_for_bit_to_the_two_argument_kernels(ctx, kitti):
+    xyzi, P1 = kitti
+    for step in ([1.3, 0.05, -0.02, 0, 0, 0], [2.9, -0.3, 0.1, 0.02, 0.01, -0.1], [0.4, 0.1, 0.0, 0.1, -0.3, 0.6], [0.4, 0.1, 0.0, 0.3, -0.9, 2.2]):
+        P2 = orc.affine_mul(P1, orc.se3_exp(step))
+        params = capi.frame_params_from_poses(_rt([P1])[0], _rt([P2])[0], T0, T1, TREQ)
+        a = np.empty_like(xyzi)
+        b = np.empty_like(xyzi)
+        br = np.full(xyzi.shape[0], 99, dtype=np.uint32)
+        ctx.deskew_f32(xyzi, a, params)
+        ctx.deskew_traj_f32(xyzi, b, [T0, T1], _rt([P1, P2]), T0, T1, TREQ, br)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), step
+        assert np.all(br == 0)
+        # f64 Eigen layout
+        n = 5000
+        cloud = np.concatenate([xyzi[:n, :3].astype(np.float64), np.ones((n, 1))], axis=1)
+        stamps = orc.pseudo_timestamps(cloud, T0, T1)
+        cols = [np.ascontiguousarray(cloud[:, j]) for j in range(4)]
+        o1 = [np.empty(n) for _ in range(4)]
+        o2 = [np.empty(n) for _ in range(4)]
+        ctx.deskew_f64cols(*cols, stamps, T0, T1, params, *o1)
+        ctx.deskew_traj_f64cols(*cols, stamps, [T0, T1], _rt([P1, P2]), TREQ, *o2)
+        for u, v in zip(o1, o2):
+            assert np.array_equal(u.view(np.uint64), v.view(np.uint64)), step
+
+
+@pytest.mark.gpu
+def test_three_bracketing_poses_vs_oracle_and_bit_exact_indices(ctx, kitti):
+    xyzi, P1 = kitti
+    times, poses = _oxts_like_trajectory(P1)
+    out = np.empty_like(xyzi)
+    br = np.empty(xyzi.shape[0], dtype=np.uint32)
+    st = ctx.deskew_traj_f32(xyzi, out, times, _rt(poses), T0, T1, TREQ, br)
+    assert st.n_points == xyzi.shape[0]
+    ref = orc.deskew_xyzi_f32_traj(xyzi, T0, T1, times, poses, TREQ)
+    assert ref["rc"] == orc.OK
+    assert np.array_equal(out[:, 3].view(np.uint32), xyzi[:, 3].view(np.uint32))
+    assert util.rel_point_error(out[:, :3], ref["xyz_f64"]).max() <= REL_TOL
+    assert np.array_equal(br, orc.bracket_indices_f32(xyzi, times, T0, T1)), "bracket indices must be bit-exact"
+    # without the index output, and device-resident: same bits
+    import torch
+
+    d_in = torch.from_numpy(xyzi).cuda()
+    d_out = torch.empty_like(d_in)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.deskew_traj_f32(d_in, d_out, times, _rt(poses), T0, T1, TREQ, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), out.view(np.uint32))
+    ctx.set_stream(None)
+
+
+@pytest.mark.gpu
+def test_many_knots_quarter_turn_boundaries_and_edge_points(ctx, kitti):
+    """Knots exactly on the quarter turns (exact directions), knots outside the scan, and points on the axes / signed zeros."""
+    xyzi, P1 = kitti
+    D = T1 - T0
+    times = [T0 - 0.3 * D, T0 - 0.1 * D, T0 + 0.25 * D, T0 + 0.4 * D, T0 + 0.5 * D, T0 + 0.75 * D, T0 + 0.9 * D, T1, T1 + 0.2 * D]
+    steps = [[0.3 + 0.02 * i, 0.01 * (-1) ** i, 0.0, 0.001 * i, -0.002, 0.01 + 0.004 * i] for i in range(len(times) - 1)]
+    poses = _chain(P1, steps)
+    edge = np.array([
+        [0, 0, 1, 1], [-0.0, 0.0, 1, 2], [-0.0, -0.0, 1, 3], [0.0, -0.0, 1, 4], [-1, 0, 0, 5], [-1, -0.0, 0, 6], [1, 0, 0, 7],
+        [1, -0.0, 0, 8], [0, 5, 0, 9], [0, -5, 0, 10], [-0.0, 5, 0, 11], [-0.0, -5, 0, 12], [3, 3, 1, 13], [-3, 3, 1, 14],
+        [-3, -3, 1, 15], [3, -3, 1, 16], [1e-30, 1e-30, 0, 17], [-5, 1e-7, 0, 18], [-5, -1e-7, 0, 19], [5, 1e-7, 0, 20], [5, -1e-7, 0, 21],
+    ], dtype=np.float32)
+    pts = np.concatenate([edge, xyzi[::3]])
+    out = np.empty_like(pts)
+    br = np.empty(pts.shape[0], dtype=np.uint32)
+    treq = T0 + 0.62 * D
+    ctx.deskew_traj_f32(pts, out, times, _rt(poses), T0, T1, treq, br)
+    want_idx = orc.bracket_indices_f32(pts, times, T0, T1)
+    assert np.array_equal(br, want_idx)
+    assert br.min() >= 1 and br.max() <= 7  # knots 0,1 lie before the scan (always >=), knot 8 after it
+    ref = orc.deskew_xyzi_f32_traj(pts, T0, T1, times, poses, treq)
+    assert ref["rc"] == orc.OK
+    err = util.rel_point_error(out[:, :3], ref["xyz_f64"])
+    assert err.max() <= REL_TOL, err.max()
+    # the bracket the oracle derives from f64 stamps agrees wherever the point is not within rounding of a knot
+    frac = (np.pi - np.arctan2(pts[:, 1].astype(np.float64), pts[:, 0].astype(np.float64))) / (2 * np.pi)
+    cs = (np.array(times) - T0) / D
+    away = np.min(np.abs(frac[:, None] - cs[None, :]), axis=1) > 1e-6
+    assert np.array_equal(br[away], ref["bracket_by_time"][away])
+
+
+@pytest.mark.gpu
+def test_f64_trajectory_vs_oracle(ctx, kitti):
+    xyzi, _ = kitti
+    xyzi = xyzi[::9]
+    n = xyzi.shape[0]
+    P_local = orc.Affine.from_Rt(orc.so3_exp([0.01, -0.02, 0.7]), [12.5, -3.0, 0.4])
+    times, poses = _oxts_like_trajectory(P_local)
+    cloud = np.concatenate([xyzi[:, :3].astype(np.float64), np.ones((n, 1))], axis=1)
+    stamps = orc.pseudo_timestamps(cloud, T0, T1)
+    cols = [np.ascontiguousarray(cloud[:, j]) for j in range(4)]
+    outs = [np.empty(n) for _ in range(4)]
+    br = np.empty(n, dtype=np.uint32)
+    rc, st = ctx.deskew_traj_f64cols(*cols, stamps, times, _rt(poses), TREQ, *outs, bracket_idx_out=br)
+    assert rc == capi.OK and st.n_out_of_range == 0
+    rc_o, nbad, want, br_o = orc.motion_compensate_frame_traj(cloud, stamps, times, poses, TREQ)
+    assert rc_o == orc.OK
+    assert np.array_equal(br, br_o)  # f64 compares of the same stamps: exact
+    got = np.stack(outs, axis=1)
+    assert util.rel_point_error(got[:, :3], want[:, :3]).max() <= 1e-11
+    # a stamp beyond the last knot is reported like the reference's assert
+    stamps2 = stamps.copy()
+    stamps2[7] = times[-1] + 1e-3
+    rc, st = ctx.deskew_traj_f64cols(*cols, stamps2, times, _rt(poses), TREQ, *outs, raise_on_range=False)
+    assert rc == capi.ERR_TIME_OUT_OF_RANGE and st.n_out_of_range == 1
+
+
+@pytest.mark.gpu
+def test_trajectory_argument_checks(ctx, kitti):
+    xyzi, P1 = kitti
+    pts = np.ascontiguousarray(xyzi[:64])
+    out = np.empty_like(pts)
+    times, poses = _oxts_like_trajectory(P1)
+    with pytest.raises(capi.KmcError) as e:  # trajectory does not cover the scan
+        ctx.deskew_traj_f32(pts, out, [T0 + 0.01, T1], _rt(poses[:2]), T0, T1, TREQ)
+    assert e.value.status == capi.ERR_TIME_OUT_OF_RANGE
+    with pytest.raises(capi.KmcError) as e:  # knots not increasing
+        ctx.deskew_traj_f32(pts, out, [times[1], times[0], times[2]], _rt(poses), T0, T1, TREQ)
+    assert e.value.status == capi.ERR_DEGENERATE
+    with pytest.raises(capi.KmcError) as e:  # too many knots
+        ctx.deskew_traj_f32(pts, out, np.linspace(T0 - 1, T1 + 1, 19), _rt(poses * 7)[:19], T0, T1, TREQ)
+    assert e.value.status == capi.ERR_INVALID_ARG

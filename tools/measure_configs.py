@@ -71,6 +71,27 @@ def main():
                                                  "frac_of_8TBps": 32 * n / ms / 1e6 / 8000}
     a10, b10 = bufs[0]
 
+    # ---- N-knot trajectory kernel: the three bracketing poses used directly, 10 M-point frames ----
+    Tz = 47072.0
+    knot_t = [Tz + 0.05, Tz + 0.15, Tz + 0.25]
+    eye = np.eye(4)[:3]
+    P = []
+    for k in range(3):
+        M = eye.copy()
+        c, s_ = np.cos(0.03 * k), np.sin(0.03 * k)
+        M[:2, :2] = [[c, -s_], [s_, c]]
+        M[:, 3] = [1.3 * k, 0.02 * k * k, 0.0]
+        P.append(M)
+    state["k"] = 0
+
+    def traj():
+        a, b = bufs[state["k"] % len(bufs)]
+        state["k"] += 1
+        ctx.deskew_traj_f32(a, b, knot_t, np.stack(P), Tz + 0.10, Tz + 0.20, Tz + 0.15, None)
+
+    ms = timed(traj, 40 if args.quick else 200)
+    res["traj_3_knots_10M_point_frame_per_launch"] = {"ms_per_frame": ms, "Mpts_s": n / ms / 1e3, "GBps": 32 * n / ms / 1e6}
+
     # ---- PCIe-inclusive: host buffers through the staging pipeline (pageable numpy and pinned torch) ----
     h_in = a10.cpu().numpy()
     h_out = np.empty_like(h_in)
