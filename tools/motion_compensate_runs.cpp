@@ -1,0 +1,37 @@
+// motion_compensate_runs -- same command line as the reference's examples/motion_compensate_runs.cpp:9-46:
+//     motion_compensate_runs <DATA_DIR> [RUN ...]
+// With no RUN arguments every "*_sync" directory under DATA_DIR is processed.  Thin argv wrapper around
+// kmc::MotionCompensateRun (handlers.cpp:41-65); the frames are deskewed on the GPU in batches.
+#include <algorithm>
+#include <filesystem>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "kitti_motion_compensation/handlers.hpp"
+
+int main(int argc, char** argv) {
+  namespace fs = std::filesystem;
+  if (argc < 2) {
+    std::cerr << "usage: " << argv[0] << " <DATA_DIR> [RUN ...]\n";
+    return 2;
+  }
+  fs::path const data_dir{argv[1]};
+  std::vector<std::string> runs;
+  for (int i = 2; i < argc; ++i) runs.emplace_back(argv[i]);
+  if (runs.empty()) {
+    for (auto const& e : fs::directory_iterator(data_dir))
+      if (e.is_directory() && e.path().filename().string().find("_sync") != std::string::npos) runs.push_back(e.path().filename().string());
+    std::sort(runs.begin(), runs.end());
+  }
+  for (auto const& run : runs) {
+    std::cout << "Motion compensating run: " << run << std::endl;
+    try {
+      kmc::MotionCompensateRun(data_dir / run);
+    } catch (std::exception const& e) {
+      std::cerr << "error: " << e.what() << "\n";
+      return 1;
+    }
+  }
+  return 0;
+}
