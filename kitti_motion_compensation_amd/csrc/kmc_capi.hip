@@ -833,12 +833,13 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   rc = upload_traj(c, segs, 0, th.n_seg * sizeof(TrajSeg32));
   if (rc != KMC_OK) return rc;
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (n + kBlock - 1) / kBlock);
+  static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
+  const int grid = grid_for(c, (n + 63) / 64);
   const TrajSeg32* d_segs = (const TrajSeg32*)c->d_traj;
 #define KMC_LAUNCH_TRAJ(T)                                                                                                          \
   do {                                                                                                                              \
-    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kNtBoth, true>), dim3(grid), dim3(kBlock), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx); \
-    else hipLaunchKernelGGL((deskew_traj_f32<T, kNtBoth, false>), dim3(grid), dim3(kBlock), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx);      \
+    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kNtBoth, true>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx); \
+    else hipLaunchKernelGGL((deskew_traj_f32<T, kNtBoth, false>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx);      \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ(kSeries3); break;

@@ -156,13 +156,14 @@ struct alignas(16) TrajSeg32 {
   float phi_x, phi_y, phi_z, phi2;
   float rho_x, rho_y, rho_z, s0;     // s = s0 - turns * g
   float c1_x, c1_y, c1_z, g;         // g = scan duration / segment duration
-  float c2_x, c2_y, c2_z, knot_c;    // knot_c: scan fraction c_k of the segment's START knot
+  float c2_x, c2_y, c2_z, pad;
   float m00, m01, m02, tx;           // M_k rows with the translation in the 4th column
   float m10, m11, m12, ty;
   float m20, m21, m22, tz;
-  float knot_cos, knot_sin;          // direction of the start knot's azimuth alpha_k = pi - 2 pi c_k
+  // the START knot of the segment, one 16-byte slot so that a bracket test costs one ds_read_b128:
+  float knot_cos, knot_sin;          // direction of the knot's azimuth alpha_k = pi - 2 pi c_k
   uint32_t flags;                    // kSegIdentity | kKnotAlwaysGe | kKnotNeverGe
-  uint32_t pad;
+  float knot_c;                      // scan fraction c_k of the knot
 };
 static_assert(sizeof(TrajSeg32) == 128, "TrajSeg32 must stay one 128-byte record");
 constexpr uint32_t kSegIdentity = 1u, kKnotAlwaysGe = 2u, kKnotNeverGe = 4u;

@@ -236,49 +236,66 @@ __global__ __launch_bounds__(kBlock) void pseudo_timestamps_f64(const double* __
 // ------------------------------------------------------------------------------------------------
 // N-knot trajectory kernels (the 3-argument MotionCompensateFrame(Frame, Trajectory, Time) overload)
 // ------------------------------------------------------------------------------------------------
-// The workgroup stages the segment records -- the twists of the bracketing poses -- into LDS once; each lane finds its
-// bracket with the trig-free knot tests (an integer, bit-exact against the oracle), a wave whose lanes share one
-// bracket broadcasts it through readfirstlane and reads the record at a uniform LDS address, other waves gather per
-// lane; then the fused exp-map + rotate + translate runs per lane exactly like the single-geodesic kernels.
+// One wave per workgroup.  Every lane finds its bracket with the trig-free knot tests (an integer, bit-exact against the
+// oracle; the knot slots are wave-uniform scalar loads).  A wave whose lanes share one bracket -- all but the few waves that
+// contain a knot's azimuth -- broadcasts it through readfirstlane and takes the segment record through scalar loads, so its
+// body is the single-geodesic kernel plus one 3x4 transform.  A wave that straddles a knot stages the segment records -- the
+// twists of the bracketing poses -- into LDS and every lane gathers its own record from there.
+template <int TIER>
+__device__ __forceinline__ v4f traj_point(const v4f p, const TrajSeg32& r) {
+  FrameRec f;
+  f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
+  f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
+  f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pad0 = 0.f;
+  f.c2_x = r.c2_x; f.c2_y = r.c2_y; f.c2_z = r.c2_z; f.pad1 = 0.f;
+  const float turns = azimuth_turns(p.x, p.y);
+  const float s = __builtin_fmaf(-turns, r.g, r.s0);
+  v4f q = deskew_point_s<TIER>(p, s, f);
+  if (!(r.flags & kSegIdentity)) {
+    v4f o;
+    o.x = __builtin_fmaf(r.m02, q.z, __builtin_fmaf(r.m01, q.y, __builtin_fmaf(r.m00, q.x, r.tx)));
+    o.y = __builtin_fmaf(r.m12, q.z, __builtin_fmaf(r.m11, q.y, __builtin_fmaf(r.m10, q.x, r.ty)));
+    o.z = __builtin_fmaf(r.m22, q.z, __builtin_fmaf(r.m21, q.y, __builtin_fmaf(r.m20, q.x, r.tz)));
+    o.w = q.w;
+    q = o;
+  }
+  return q;
+}
+
 template <int TIER, int NT, bool WRITE_IDX>
-__global__ __launch_bounds__(kBlock) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
-                                                         const TrajSeg32* __restrict__ segs, uint32_t n_seg,
-                                                         uint32_t* __restrict__ bracket_out) {
+__global__ __launch_bounds__(64) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+                                                     const TrajSeg32* __restrict__ segs, uint32_t n_seg,
+                                                     uint32_t* __restrict__ bracket_out) {
+  constexpr int BLOCK = 64;
   __shared__ TrajSeg32 lds[kMaxSegments];
   const uint32_t tid = threadIdx.x;
-  if (tid < n_seg * 8) reinterpret_cast<v4f*>(lds)[tid] = reinterpret_cast<const v4f*>(segs)[tid];  // 8 x 16 B per record
-  __syncthreads();
-  const uint64_t n_tiles = (n + kBlock - 1) / kBlock;
+  const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;
+  bool staged = false;
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t i = t * kBlock + tid;
+    const uint64_t i = t * BLOCK + tid;
     const bool live = i < n;
     v4f p = {0.f, 0.f, 0.f, 0.f};
     if (live) p = load_point<NT>(in + i);
     uint32_t k = 0;
-    for (uint32_t j = 1; j < n_seg; ++j)  // interior knots; uniform LDS addresses -> broadcast reads
-      k += knot_ge(p.x, p.y, lds[j].knot_c, lds[j].knot_cos, lds[j].knot_sin, lds[j].flags) ? 1u : 0u;
+    for (uint32_t j = 1; j < n_seg; ++j) {  // interior knots: uniform address -> s_load_dwordx4 of the knot slot
+      const TrajSeg32& kn = segs[j];
+      k += knot_ge(p.x, p.y, kn.knot_c, kn.knot_cos, kn.knot_sin, kn.flags) ? 1u : 0u;
+    }
     const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
-    const bool wave_uniform = __all(k == k0);
-    const TrajSeg32 r = wave_uniform ? lds[k0] : lds[k];
-    if (live) {
-      FrameRec f;
-      f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
-      f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
-      f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pad0 = 0.f;
-      f.c2_x = r.c2_x; f.c2_y = r.c2_y; f.c2_z = r.c2_z; f.pad1 = 0.f;
-      const float turns = azimuth_turns(p.x, p.y);
-      const float s = __builtin_fmaf(-turns, r.g, r.s0);
-      v4f q = deskew_point_s<TIER>(p, s, f);
-      if (!(r.flags & kSegIdentity)) {
-        v4f o;
-        o.x = __builtin_fmaf(r.m02, q.z, __builtin_fmaf(r.m01, q.y, __builtin_fmaf(r.m00, q.x, r.tx)));
-        o.y = __builtin_fmaf(r.m12, q.z, __builtin_fmaf(r.m11, q.y, __builtin_fmaf(r.m10, q.x, r.ty)));
-        o.z = __builtin_fmaf(r.m22, q.z, __builtin_fmaf(r.m21, q.y, __builtin_fmaf(r.m20, q.x, r.tz)));
-        o.w = q.w;
-        q = o;
+    v4f q;
+    if (__all(k == k0)) {
+      q = traj_point<TIER>(p, segs[k0]);  // wave-uniform: record through scalar loads -> SGPRs
+    } else {
+      if (!staged) {  // single-wave workgroup: the wave stages for itself
+        for (uint32_t w = tid; w < n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs)[w];
+        __syncthreads();
+        staged = true;
       }
+      q = traj_point<TIER>(p, lds[k]);  // per-lane gather from LDS
+    }
+    if (live) {
       store_point<NT>(out + i, q);
-      if constexpr (WRITE_IDX) bracket_out[i] = k;
+      if constexpr (WRITE_IDX) __builtin_nontemporal_store(k, bracket_out + i);
     }
   }
 }
