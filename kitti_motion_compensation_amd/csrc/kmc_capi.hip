@@ -52,9 +52,14 @@ struct kmc_ctx {
   int next_slot = 0;
   hipStream_t copy_stream = nullptr;
   // host-staging buffers
-  hipStream_t pipe[2] = {nullptr, nullptr};
-  void* d_stage_in[2] = {nullptr, nullptr};
-  void* d_stage_out[2] = {nullptr, nullptr};
+  // host-buffer pipeline: dedicated upload / compute / download streams over a ring of device slots
+  static constexpr int kPipeSlots = 4;
+  hipStream_t pipe[3] = {nullptr, nullptr, nullptr};  // [0] H2D, [1] kernels, [2] D2H
+  void* d_stage_in[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  void* d_stage_out[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_h2d[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_kernel[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_d2h[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_cap = 0;  // bytes per buffer
   void* d_traj = nullptr; // segment tables of the N-knot trajectory kernels (16 x TrajSeg32 + 16 x TrajSeg64)
   void* h_traj = nullptr; // pinned staging of the same size
@@ -69,7 +74,7 @@ namespace {
 // measured best on MI355X (profiles/r01_tune.csv): one wave per workgroup, one point per lane, one tile per workgroup
 constexpr int kLaunchBlock = 64;
 constexpr int kDefaultPpt = 1;  // measured best on MI355X: 256-point tiles, one per workgroup (profiles/r01_tune.csv)
-constexpr uint64_t kHostChunkPoints = 1ull << 22;  // 64 MiB per direction per pipeline slot
+constexpr uint64_t kHostChunkPoints = 1ull << 21;  // 32 MiB per direction per pipeline slot
 
 int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
   if (c) {
@@ -190,10 +195,13 @@ int ensure_tmp(kmc_ctx* c, size_t bytes) {
 int ensure_pipeline(kmc_ctx* c) {
   if (c->stage_cap) return KMC_OK;
   const size_t bytes = kHostChunkPoints * sizeof(v4f);
-  for (int b = 0; b < 2; ++b) {
-    KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe[b], hipStreamNonBlocking));
+  for (int b = 0; b < 3; ++b) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe[b], hipStreamNonBlocking));
+  for (int b = 0; b < kmc_ctx::kPipeSlots; ++b) {
     KMC_HIP_TRY(c, hipMalloc(&c->d_stage_in[b], bytes));
     KMC_HIP_TRY(c, hipMalloc(&c->d_stage_out[b], bytes));
+    KMC_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming));
+    KMC_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_kernel[b], hipEventDisableTiming));
+    KMC_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_d2h[b], hipEventDisableTiming));
   }
   c->stage_cap = bytes;
   return KMC_OK;
@@ -377,10 +385,14 @@ void kmc_hip_destroy(kmc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < 3; ++b)
     if (c->pipe[b]) { (void)hipStreamSynchronize(c->pipe[b]); (void)hipStreamDestroy(c->pipe[b]); }
+  for (int b = 0; b < kmc_ctx::kPipeSlots; ++b) {
     if (c->d_stage_in[b]) (void)hipFree(c->d_stage_in[b]);
     if (c->d_stage_out[b]) (void)hipFree(c->d_stage_out[b]);
+    if (c->ev_h2d[b]) (void)hipEventDestroy(c->ev_h2d[b]);
+    if (c->ev_kernel[b]) (void)hipEventDestroy(c->ev_kernel[b]);
+    if (c->ev_d2h[b]) (void)hipEventDestroy(c->ev_d2h[b]);
   }
   if (c->d_tmp) (void)hipFree(c->d_tmp);
   if (c->d_traj) (void)hipFree(c->d_traj);
@@ -530,24 +542,33 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     if (st) st->n_launches = 1;
     return tm.end_call(st);
   }
-  // KMC_MEM_HOST: two-slot H2D -> kernel -> D2H pipeline (PCIe-bound; see DESIGN.md "host buffers")
+  // KMC_MEM_HOST: upload / compute / download on three streams over a ring of device slots, so that the H2D of chunk
+  // k+1, the kernel of chunk k and the D2H of chunk k-1 run concurrently (PCIe is full duplex; DESIGN.md "host buffers")
   int rc = ensure_pipeline(c);
   if (rc != KMC_OK) return rc;
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   uint32_t launches = 0;
   for (uint64_t off = 0, k = 0; off < n; off += kHostChunkPoints, ++k) {
-    const int b = (int)(k & 1);
+    const int b = (int)(k % kmc_ctx::kPipeSlots);
+    const bool reused = k >= (uint64_t)kmc_ctx::kPipeSlots;
     const uint64_t m = std::min<uint64_t>(kHostChunkPoints, n - off);
-    hipStream_t s = c->pipe[b];
-    KMC_HIP_TRY(c, hipMemcpyAsync(c->d_stage_in[b], xyzi_in + 4 * off, m * sizeof(v4f), hipMemcpyHostToDevice, s));
-    launch_frame(c, s, tier, (const v4f*)c->d_stage_in[b], (v4f*)c->d_stage_out[b], m, f);
+    if (reused) KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[0], c->ev_kernel[b], 0));  // the slot's input was consumed
+    KMC_HIP_TRY(c, hipMemcpyAsync(c->d_stage_in[b], xyzi_in + 4 * off, m * sizeof(v4f), hipMemcpyHostToDevice, c->pipe[0]));
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_h2d[b], c->pipe[0]));
+    KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[1], c->ev_h2d[b], 0));
+    if (reused) KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[1], c->ev_d2h[b], 0));     // the slot's output was downloaded
+    launch_frame(c, c->pipe[1], tier, (const v4f*)c->d_stage_in[b], (v4f*)c->d_stage_out[b], m, f);
     KMC_HIP_TRY(c, hipGetLastError());
-    KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out + 4 * off, c->d_stage_out[b], m * sizeof(v4f), hipMemcpyDeviceToHost, s));
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_kernel[b], c->pipe[1]));
+    KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[2], c->ev_kernel[b], 0));
+    KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out + 4 * off, c->d_stage_out[b], m * sizeof(v4f), hipMemcpyDeviceToHost, c->pipe[2]));
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_d2h[b], c->pipe[2]));
     ++launches;
   }
-  KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[0]));
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[2]));
   KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[1]));
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[0]));
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (st) st->n_launches = launches;
   return tm.end_call(st);

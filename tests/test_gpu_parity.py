@@ -132,6 +132,28 @@ def test_kitti_frame_host_buffers_and_in_place(torch_mod, ctx, kitti):
     assert np.array_equal(inplace.view(np.uint32), dev.view(np.uint32))
 
 
+def test_host_pipeline_many_chunks_matches_device_path(torch_mod, ctx, kitti):
+    """KMC_MEM_HOST streams 2 M-point chunks through a 4-slot upload/compute/download pipeline: more chunks than slots
+    (slot reuse, ragged last chunk) must give the same bits as the device-resident launch."""
+    torch = torch_mod
+    _, P1 = kitti
+    P1, P2 = _poses(P1, TRAJECTORIES["hard_turn"])
+    params = _params(P1, P2)
+    n = 5 * (1 << 21) + 12345
+    xyzi = capi.synth_points_host(n, 77)
+    out = np.empty_like(xyzi)
+    st = ctx.deskew_f32(xyzi, out, params)
+    assert st.n_launches == 6 and st.n_points == n
+    dev, _ = _run_device(torch, ctx, xyzi, params)
+    assert np.array_equal(out.view(np.uint32), dev.view(np.uint32))
+    pinned_in = torch.from_numpy(xyzi).pin_memory()
+    pinned_out = torch.empty_like(pinned_in).pin_memory()
+    ctx.deskew_f32(pinned_in.numpy(), pinned_out.numpy(), params)
+    assert np.array_equal(pinned_out.numpy().view(np.uint32), dev.view(np.uint32))
+    sel = np.arange(0, n, 1013)
+    _check(out[sel], xyzi[sel], _oracle(xyzi[sel], P1, P2, mode=orc.HOISTED))
+
+
 def test_every_tier_and_tiling_agree(torch_mod, ctx, kitti):
     """All three coefficient tiers are valid below 0.25 rad and must agree with the oracle; tiling never changes bits."""
     xyzi, P1 = kitti
