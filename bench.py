@@ -230,7 +230,7 @@ def main():
                             f"{F} distinct frames per step in one batched launch (per GPU), device-resident",
                 "points_per_frame": POINTS_PER_FRAME, "frames_per_step_per_gpu": F, "points_per_step_per_gpu": n,
                 "parallelism": f"frame-sharded x{world} (no data-path collective)",
-                "kernel": "kmc_dev::deskew_batch_f32<series3, ppt=1, nt, block=64>, one 64-point tile (one wave) per workgroup", "device": info["name"], "arch": info["arch"],
+                "kernel": "kmc_dev::deskew_batch_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64>, one 64-point tile (one wave) per workgroup", "device": info["name"], "arch": info["arch"],
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -138,7 +138,7 @@ int ppt_of(const kmc_ctx* c) {
 // ---- template dispatch ---------------------------------------------------------------------------
 template <int TIER, int PPT>
 void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
-  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kNtBoth, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f);
+  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f);
 }
 template <int TIER>
 void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
@@ -164,9 +164,9 @@ template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint32_t* tiles,
                      uint32_t nf, uint64_t n, uint32_t* idx) {
   if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kNtBoth, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
   else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kNtBoth, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,

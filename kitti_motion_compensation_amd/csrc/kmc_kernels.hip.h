@@ -26,8 +26,14 @@ namespace kmc_dev {
 
 constexpr int kBlock = 256;  // 4 waves: one per SIMD
 
-// NT is a bit mask: bit 0 = non-temporal loads, bit 1 = non-temporal stores (3 = both, the default)
-constexpr int kNtLoad = 1, kNtStore = 2, kNtBoth = 3;
+// NT is a bit mask of memory-access policies:
+//   bit 0 (1): non-temporal loads            bit 1 (2): non-temporal stores
+//   bit 2 (4): stores also carry sc1 (write-through past the XCD's L2: the line is dropped instead of kept -- measured
+//              +1.4 % on this streaming kernel, profiles/r01_tune_policies.csv); implies buffer stores
+//   bit 3 (8): loads go through a buffer descriptor too (SRSRC + 32-bit offset instead of 64-bit VGPR addresses)
+constexpr int kNtLoad = 1, kNtStore = 2, kNtBoth = 3, kStoreSc1 = 4, kBufLoad = 8;
+constexpr int kPolicyDefault = kNtBoth | kStoreSc1;
+
 template <int NT>
 __device__ __forceinline__ v4f load_point(const v4f* p) {
   if constexpr (NT & kNtLoad) return __builtin_nontemporal_load(p);
@@ -39,6 +45,25 @@ __device__ __forceinline__ void store_point(v4f* p, v4f v) {
   else *p = v;
 }
 
+// Buffer-descriptor access to one tile: base = first point of the tile (wave-uniform -> SGPRs), `bytes` = extent from
+// there; out-of-range lanes are clipped by the hardware (loads return 0, stores are dropped), which also covers a ragged
+// last tile.  aux bits (gfx940+): 1 = sc0, 2 = nt, 16 = sc1.
+using v4u = uint32_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, uint64_t bytes) {
+  const uint32_t clipped = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, clipped, 0x00020000);
+}
+template <int NT>
+__device__ __forceinline__ v4f tile_load(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  constexpr int aux = (NT & kNtLoad) ? 2 : 0;
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, aux));
+}
+template <int NT>
+__device__ __forceinline__ void tile_store(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, v4f v) {
+  constexpr int aux = ((NT & kNtStore) ? 2 : 0) | ((NT & kStoreSc1) ? 16 : 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, byte_off, 0, aux);
+}
+
 // ------------------------------------------------------------------------------------------------
 // single-frame kernel: constants by value (kernarg segment -> s_load -> SGPRs)
 // ------------------------------------------------------------------------------------------------
@@ -47,6 +72,31 @@ __global__ __launch_bounds__(BLOCK) void deskew_frame_f32(const v4f* __restrict_
                                                          uint64_t n, FrameRec f) {
   constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
   const uint32_t tid = threadIdx.x;
+  if constexpr ((NT & (kStoreSc1 | kBufLoad)) != 0) {
+    // descriptor path: every tile, ragged or not, through hardware-clipped buffer accesses
+    const uint64_t n_tiles = (n + kTile - 1) / kTile;
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+      const uint64_t base = t * kTile;
+      const uint64_t bytes = (n - base) * sizeof(v4f);
+      const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, bytes);
+      v4f p[PPT];
+      if constexpr (NT & kBufLoad) {
+        const __amdgpu_buffer_rsrc_t rin = tile_rsrc(in + base, bytes);
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) p[u] = tile_load<NT>(rin, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)));
+      } else {
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+          const uint64_t i = base + (uint64_t)u * BLOCK + tid;
+          p[u] = load_point<NT>(in + (i < n ? i : n - 1));  // clamp: the store of a dead lane is clipped anyway
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PPT; ++u)
+        tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), deskew_point<TIER, OCML_ATAN>(p[u], f));
+    }
+    return;
+  }
   const uint64_t n_full = n / kTile;  // tiles that need no bounds checks
   for (uint64_t t = blockIdx.x; t < n_full; t += gridDim.x) {
     const v4f* __restrict__ tin = in + t * kTile;
@@ -141,10 +191,18 @@ __global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict_
     const BatchRec r0 = recs[f0];
     if (full && rec_end(r0) >= tile_end) {
       const FrameRec f = to_frame(r0);
+      if constexpr (NT & kStoreSc1) {
+        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(tout, kTile * sizeof(v4f));
 #pragma unroll
-      for (int u = 0; u < PPT; ++u) {
-        store_point<NT>(tout + u * BLOCK + tid, deskew_point<TIER, false>(p[u], f));
-        if constexpr (WRITE_IDX) __builtin_nontemporal_store(f0, frame_idx_out + base + u * BLOCK + tid);
+        for (int u = 0; u < PPT; ++u)
+          tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), deskew_point<TIER, false>(p[u], f));
+      } else {
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) store_point<NT>(tout + u * BLOCK + tid, deskew_point<TIER, false>(p[u], f));
+      }
+      if constexpr (WRITE_IDX) {
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) __builtin_nontemporal_store(f0, frame_idx_out + base + u * BLOCK + tid);
       }
     } else {
       // slow path: ragged last tile and/or a tile that straddles frame boundaries

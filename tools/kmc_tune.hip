@@ -56,6 +56,69 @@ static FrameRec make_rec() {
   return f;
 }
 
+// ---- experiments (tuner only) -------------------------------------------------------------------------------
+// XCD-contiguous tile mapping: workgroup b runs on XCD b % 8 (observed, not contractual); give every XCD one contiguous
+// eighth of the buffer instead of every eighth tile.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void deskew_frame_xcd(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, FrameRec f) {
+  const uint64_t n_tiles = n / BLOCK;  // tuner sizes are multiples of the tile
+  const uint64_t per_xcd = n_tiles / 8;
+  const uint64_t b = blockIdx.x;
+  const uint64_t t = (b % 8) * per_xcd + b / 8;
+  const uint64_t i = t * BLOCK + threadIdx.x;
+  if (b < per_xcd * 8) store_point<kNtBoth>(out + i, deskew_point<kSeries3, false>(load_point<kNtBoth>(in + i), f));
+}
+
+// explicit cache-policy bits through inline asm (loads: LP, stores: SP)
+//   0: (none)   1: nt   2: sc1   3: sc0 sc1   4: sc1 nt   5: sc0 sc1 nt   6: sc0
+template <int LP, int SP>
+__global__ __launch_bounds__(64) void deskew_frame_policy(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, FrameRec f) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  v4f p;
+  const v4f* src = in + i;
+  v4f* dst = out + i;
+  if constexpr (LP == 0) asm volatile("global_load_dwordx4 %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
+  if constexpr (LP == 1) asm volatile("global_load_dwordx4 %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
+  if constexpr (LP == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
+  if constexpr (LP == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
+  if constexpr (LP == 4) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
+  if constexpr (LP == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
+  if constexpr (LP == 6) asm volatile("global_load_dwordx4 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(p) : "v"(src) : "memory");
+  const v4f q = deskew_point<kSeries3, false>(p, f);
+  if constexpr (SP == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(q) : "memory");
+  if constexpr (SP == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(q) : "memory");
+  if constexpr (SP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(q) : "memory");
+  if constexpr (SP == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(q) : "memory");
+  if constexpr (SP == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(q) : "memory");
+  if constexpr (SP == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(q) : "memory");
+  if constexpr (SP == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(dst), "v"(q) : "memory");
+}
+
+template <int BLOCK>
+static Variant xcd_variant(const char* label) {
+  Variant v;
+  v.name = label;
+  v.ppt = 1;
+  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+    static const FrameRec f = make_rec();
+    hipLaunchKernelGGL((deskew_frame_xcd<BLOCK>), dim3((unsigned)(n / BLOCK)), dim3(BLOCK), 0, s, in, out, n, f);
+  };
+  return v;
+}
+
+template <int LP, int SP>
+static Variant policy_variant(const char* label) {
+  Variant v;
+  v.name = label;
+  v.ppt = 1;
+  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+    static const FrameRec f = make_rec();
+    hipLaunchKernelGGL((deskew_frame_policy<LP, SP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in, out, n, f);
+  };
+  return v;
+}
+
 template <int TIER, int PPT, int NT, bool OCML, int BLOCK = kBlock>
 static Variant frame_variant(const char* label) {
   Variant v;
@@ -115,7 +178,7 @@ static void build_tables(BatchTables* bt, uint64_t n, uint64_t pts_per_frame) {
   bt->n_frames = nf;
 }
 
-template <int PPT, bool SMALL, int BLOCK = kBlock>
+template <int PPT, bool SMALL, int BLOCK = kBlock, int NT = kNtBoth>
 static Variant batch_variant(const char* label) {
   Variant v;
   v.name = label;
@@ -124,7 +187,7 @@ static Variant batch_variant(const char* label) {
     const BatchTables& bt = SMALL ? g_bt_small : g_bt_big;
     const uint64_t tiles = (n + (uint64_t)BLOCK * PPT - 1) / ((uint64_t)BLOCK * PPT);
     const uint64_t cap = bpc <= 0 ? tiles : (uint64_t)g_cus * bpc * (kBlock / (BLOCK < kBlock ? BLOCK : kBlock));
-    hipLaunchKernelGGL((deskew_batch_f32<kSeries3, PPT, kNtBoth, false, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s,
+    hipLaunchKernelGGL((deskew_batch_f32<kSeries3, PPT, NT, false, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s,
                        in, out, bt.d_recs, bt.d_coarse, bt.n_frames, n, (uint32_t*)nullptr);
   };
   return v;
@@ -172,6 +235,26 @@ int main(int argc, char** argv) {
   es.push_back({frame_variant<kSeries3, 1, kNtBoth, false, 128>("s3_ppt1_nt_b128"), kZero});
   es.push_back({frame_variant<kSeries3, 1, kNtBoth, false, 512>("s3_ppt1_nt_b512"), kZero});
   es.push_back({frame_variant<kSeries3, 1, kNtBoth, false, 1024>("s3_ppt1_nt_b1024"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth | kStoreSc1, false, 64>("s3_b64_gld_bufst_sc1nt"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth | kStoreSc1 | kBufLoad, false, 64>("s3_b64_bufld_bufst_sc1nt"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth | kBufLoad, false, 64>("s3_b64_bufld_bufst_nt"), kZero});
+  es.push_back({frame_variant<kSeries3, 1, kNtBoth | kStoreSc1, false, 256>("s3_b256_gld_bufst_sc1nt"), kZero});
+  es.push_back({frame_variant<kSeries3, 2, kNtBoth | kStoreSc1 | kBufLoad, false, 64>("s3_b64_ppt2_buf_sc1nt"), kZero});
+  es.push_back({xcd_variant<64>("x_xcdcontig_b64"), kZero});
+  es.push_back({xcd_variant<256>("x_xcdcontig_b256"), kZero});
+  es.push_back({policy_variant<1, 1>("x_pol_nt_nt"), kZero});
+  es.push_back({policy_variant<0, 0>("x_pol_plain_plain"), kZero});
+  es.push_back({policy_variant<1, 0>("x_pol_nt_plain"), kZero});
+  es.push_back({policy_variant<1, 2>("x_pol_nt_sc1"), kZero});
+  es.push_back({policy_variant<1, 4>("x_pol_nt_sc1nt"), kZero});
+  es.push_back({policy_variant<1, 3>("x_pol_nt_sc0sc1"), kZero});
+  es.push_back({policy_variant<1, 5>("x_pol_nt_sc0sc1nt"), kZero});
+  es.push_back({policy_variant<1, 6>("x_pol_nt_sc0"), kZero});
+  es.push_back({policy_variant<4, 1>("x_pol_sc1nt_nt"), kZero});
+  es.push_back({policy_variant<2, 1>("x_pol_sc1_nt"), kZero});
+  es.push_back({policy_variant<5, 1>("x_pol_sc0sc1nt_nt"), kZero});
+  es.push_back({policy_variant<6, 1>("x_pol_sc0_nt"), kZero});
+  es.push_back({policy_variant<5, 5>("x_pol_sc0sc1nt_both"), kZero});
   es.push_back({frame_variant<kSeries3, 2, kNtBoth, false>("s3_ppt2_nt"), kZero});
   es.push_back({frame_variant<kSeries3, 2, kNtBoth, false, 128>("s3_ppt2_nt_b128"), kZero});
   es.push_back({frame_variant<kSeries3, 4, kNtBoth, false>("s3_ppt4_nt"), kAll});
@@ -180,6 +263,7 @@ int main(int argc, char** argv) {
   es.push_back({frame_variant<kTrig, 1, kNtBoth, false>("trig_ppt1_nt"), kZero});
   es.push_back({batch_variant<1, false>("batch1M_ppt1"), kAll});
   es.push_back({batch_variant<1, false, 64>("batch1M_ppt1_b64"), kZero});
+  es.push_back({batch_variant<1, false, 64, kPolicyDefault>("batch1M_ppt1_b64_sc1nt"), kZero});
   es.push_back({batch_variant<1, false, 128>("batch1M_ppt1_b128"), kZero});
   es.push_back({batch_variant<2, false, 64>("batch1M_ppt2_b64"), kZero});
   es.push_back({batch_variant<2, false>("batch1M_ppt2"), kZero});
