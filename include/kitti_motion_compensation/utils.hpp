@@ -1,15 +1,4 @@
-// utils.hpp -- string helpers the KITTI readers need (reference include/.../utils.hpp, src/.../utils.cpp:10-38).
+// utils.hpp -- kept so that `#include "kitti_motion_compensation/utils.hpp"` written against the reference still resolves.
+// The declarations (kmc::IdToZeroPaddedString, TokenizeString, MmHhSsToSeconds) live in host_math.hpp.
 #pragma once
-
-#include <string>
-#include <vector>
-
-#include "kitti_motion_compensation/data_types.hpp"
-
-namespace kmc {
-
-std::string IdToZeroPaddedString(std::size_t const id, std::size_t const pad = 10);  // utils.cpp:10-15
-std::vector<std::string> TokenizeString(std::string raw_string);                     // :17-29
-double MmHhSsToSeconds(std::string const mm_hh_ss);                                  // :31-38
-
-}  // namespace kmc
+#include "kitti_motion_compensation/host_math.hpp"

@@ -23,10 +23,20 @@
 #include "kitti_motion_compensation/motion_compensation.hpp"
 #include "kitti_motion_compensation/timestamp_mocking.hpp"
 #include "kitti_motion_compensation/trajectory_interpolation.hpp"
-#include "kitti_motion_compensation/utilities_for_testing.hpp"
 #include "kitti_motion_compensation/utils.hpp"
 
 using namespace kmc;
+
+// The reference's pose-equality criterion (include/.../utilities_for_testing.hpp:4-11), restated for the harness:
+// tf1 * tf2^-1 must be the identity -- trace 4 and every off-diagonal entry summing to 0 -- compared as float with eps 1e-10.
+namespace utilities_for_testing {
+static bool NearlyEqualAsFloat(double a, double b, float eps = 1e-10f) { return std::fabs(static_cast<float>(a) - static_cast<float>(b)) <= eps; }
+static bool TransformationMatricesAreTheSame(Affine3d const& tf1, Affine3d const& tf2) {
+  Matrix4d const product{(tf1 * tf2.inverse()).matrix()};
+  double const tr = product.trace();
+  return NearlyEqualAsFloat(tr, 4.0) && NearlyEqualAsFloat(product.sum() - tr, 0.0);
+}
+}  // namespace utilities_for_testing
 
 static int g_failures = 0, g_checks = 0;
 static const char* g_case = "";
