@@ -333,6 +333,42 @@ def test_batch_vs_per_frame_oracle_and_bit_exact_indices(torch_mod, ctx, kitti, 
     ctx.set_launch_config(0, 0)
 
 
+def test_batch_soak_many_random_frames(torch_mod, ctx, kitti):
+    """BASELINE.json configs[4] in miniature: hundreds of frames of mixed (incl. zero) sizes, each with its own random
+    trajectory and request time, one launch; every point against the oracle, every frame index bit-exact."""
+    torch = torch_mod
+    xyzi, P0 = kitti
+    rng = np.random.default_rng(2024)
+    n_frames = 300
+    sizes = rng.integers(0, 20001, size=n_frames)
+    sizes[rng.integers(0, n_frames, size=12)] = 0
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(offsets[-1])
+    pts = np.ascontiguousarray(xyzi[rng.integers(0, xyzi.shape[0], size=n)])
+    params, ref = [], np.empty((n, 3))
+    for f in range(n_frames):
+        step = np.concatenate([rng.normal(0, 1.5, 3), rng.normal(0, 0.05, 3)])
+        A = orc.affine_mul(P0, orc.se3_exp(np.concatenate([rng.normal(0, 30, 3), rng.normal(0, 0.3, 3)])))
+        B = orc.affine_mul(A, orc.se3_exp(step))
+        treq = T0 + rng.uniform(0, 1) * (T1 - T0)
+        params.append(_params(A, B, treq=treq))
+        s, e = int(offsets[f]), int(offsets[f + 1])
+        if e > s:
+            ref[s:e] = _oracle(pts[s:e], A, B, treq=treq, mode=orc.HOISTED)["xyz_f64"]
+    d_in = torch.from_numpy(pts).cuda()
+    d_out = torch.empty_like(d_in)
+    d_idx = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    st = ctx.deskew_batch_f32(d_in, d_out, offsets, params, d_idx)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    want_idx = (np.searchsorted(offsets, np.arange(n, dtype=np.uint64), side="right") - 1).astype(np.uint32)
+    assert st.n_points == n and st.variant == capi.TIER_SERIES3
+    assert np.array_equal(d_idx.cpu().numpy().view(np.uint32), want_idx)
+    assert np.array_equal(got[:, 3].view(np.uint32), pts[:, 3].view(np.uint32))
+    assert util.rel_point_error(got[:, :3], ref).max() <= REL_TOL
+
+
 def test_batch_equals_single_frame_kernel_bitwise(torch_mod, ctx, kitti):
     """A one-frame batch must reduce bit-for-bit to kmc_hip_deskew_f32 (same arithmetic, different plumbing)."""
     xyzi, P1 = kitti
