@@ -1,19 +1,19 @@
 // kmc_kernels.hip.h -- the __global__ kernels of the deskew engine (gfx950 / CDNA4, wave64, no MFMA).
 //
 // Roofline: HBM.  32 algorithmic bytes per point (16 B v4f {x,y,z,intensity} read + 16 B written),
-// ~110 VALU ops per point -> 3.4 flop/B, far below the ~20 flop/B ridge.  Design rules applied
-// (cdna_hip_programming.md G2/G7/G11/G13, App. B "element-wise"):
-//   * one lane = one point, one global_load_dwordx4 / global_store_dwordx4 per point: a wave moves 1 KiB
-//     per instruction, perfectly coalesced;
-//   * PPT independent 16-B loads per lane are issued before the first use (memory-level parallelism:
-//     >= 32 KiB in flight per CU at 8 waves), arithmetic of tile t overlaps the loads of other waves;
-//   * grid = CUs x blocks_per_cu persistent workgroups, grid-stride over tiles, so consecutive workgroups
-//     (which the dispatcher places round-robin on the 8 XCDs) stream consecutive 4-16 KiB tiles: every
-//     XCD's L2 and every HBM channel sees the same uniform sequential load -- there is no inter-tile reuse
-//     to localise, so no XCD swizzle is needed (T1 gives 0 % on reuse-free kernels);
-//   * streamed-once data: non-temporal loads/stores keep the 4 MiB L2s / 256 MiB MALL from thrashing;
-//   * per-frame constants are wave-uniform: kernarg / scalar loads -> SGPRs (single-frame kernel), or a
-//     per-tile scalar-loaded record with an LDS-staged table for tiles that straddle frames (batched kernel).
+// ~80 VALU ops per point -> ~3 flop/B, far below the ~20 flop/B ridge.  What the measurements on MI355X settled
+// (profiles/r01_tune.csv):
+//   * one lane = one point, one 16-byte load and one 16-byte store per point: a wave moves 1 KiB per instruction,
+//     perfectly coalesced;
+//   * ONE TILE PER WORKGROUP, one wave per workgroup (the shipped geometry): the hardware dispatcher streaming 64-point
+//     tiles reaches 6.75-6.8 TB/s where a persistent grid-stride loop of the same body stays at 5.2-5.8 TB/s, and one
+//     point per lane beats 2/4/8 (with 8 waves per SIMD resident, TLP already covers the HBM latency).  The kernels keep
+//     their grid-stride loops and the PPT parameter so that any grid is still correct (kmc_hip_set_launch_config);
+//   * consecutive workgroups land round-robin on the 8 XCDs, so every XCD streams an interleaved eighth of the buffer;
+//     there is no inter-tile reuse to localise and an XCD-contiguous mapping measured 3-5 % slower;
+//   * streamed-once data: non-temporal loads; stores carry nt + sc1 (the written line is dropped from the XCD's L2);
+//   * per-frame constants are wave-uniform: kernarg / scalar loads -> SGPRs (single-frame kernel), or a per-tile
+//     scalar-loaded record with an LDS-staged table for the tiles that straddle frames (batched kernel).
 #pragma once
 
 #include <hip/hip_runtime.h>
