@@ -99,8 +99,12 @@ const char* kmc_status_string(int status);
 /* Creates a context on HIP device `device_id`.  Fails with KMC_ERR_NO_DEVICE when there is none. */
 int kmc_hip_create(kmc_ctx** out, int device_id);
 void kmc_hip_destroy(kmc_ctx* ctx);
-/* Use the caller's hipStream_t (e.g. torch's current stream) for all launches; NULL = the ctx's own stream. */
+/* Use the caller's hipStream_t (e.g. torch's current stream) for all launches.  The handle is taken literally: NULL is
+ * HIP's legacy default stream (which is what torch.cuda.current_stream().cuda_stream returns unless a side stream is
+ * active), so work issued through the ctx stays ordered with the caller's own work on that stream. */
 int kmc_hip_set_stream(kmc_ctx* ctx, void* hip_stream);
+/* Go back to the context's private non-blocking stream (the state after kmc_hip_create). */
+int kmc_hip_use_own_stream(kmc_ctx* ctx);
 int kmc_hip_synchronize(kmc_ctx* ctx);
 /* When enabled every call brackets its launches with hipEvents on the ctx stream, synchronizes, and fills
  * kmc_stats.kernel_ms / total_ms.  Off by default (calls are then fully asynchronous for KMC_MEM_DEVICE). */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "kmc_hip_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "kmc_hip_destroy": (None, [_vp]),
     "kmc_hip_set_stream": (C.c_int, [_vp, _vp]),
+    "kmc_hip_use_own_stream": (C.c_int, [_vp]),
     "kmc_hip_synchronize": (C.c_int, [_vp]),
     "kmc_hip_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_last_error": (C.c_char_p, [_vp]),
@@ -287,8 +288,12 @@ class Context:
             raise KmcError(rc, where, detail)
 
     def set_stream(self, stream):
-        """stream: an int hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None for the ctx's own."""
-        self._check(lib().kmc_hip_set_stream(self._h, stream if stream else None), "kmc_hip_set_stream")
+        """stream: an int hipStream_t handle, taken literally -- 0 is HIP's legacy default stream, which is what
+        torch.cuda.current_stream().cuda_stream returns unless a side stream is active; None = the ctx's own stream."""
+        if stream is None:
+            self._check(lib().kmc_hip_use_own_stream(self._h), "kmc_hip_use_own_stream")
+        else:
+            self._check(lib().kmc_hip_set_stream(self._h, C.c_void_p(int(stream))), "kmc_hip_set_stream")
 
     def synchronize(self):
         self._check(lib().kmc_hip_synchronize(self._h), "kmc_hip_synchronize")

@@ -384,7 +384,8 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
 void kmc_hip_destroy(kmc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (int b = 0; b < 3; ++b)
     if (c->pipe[b]) { (void)hipStreamSynchronize(c->pipe[b]); (void)hipStreamDestroy(c->pipe[b]); }
   for (int b = 0; b < kmc_ctx::kPipeSlots; ++b) {
@@ -416,7 +417,13 @@ void kmc_hip_destroy(kmc_ctx* c) {
 
 int kmc_hip_set_stream(kmc_ctx* c, void* hip_stream) {
   if (!c) return KMC_ERR_INVALID_ARG;
-  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  c->stream = (hipStream_t)hip_stream;  // literally: NULL is HIP's legacy default stream
+  return KMC_OK;
+}
+
+int kmc_hip_use_own_stream(kmc_ctx* c) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  c->stream = c->own_stream;
   return KMC_OK;
 }
 

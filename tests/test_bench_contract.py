@@ -27,8 +27,9 @@ def test_bench_prints_one_contract_line():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    # value and achieved describe the same launches: value [Mpts/s] * 32 B ~= achieved [GB/s] (wall vs event time)
-    assert abs(d["value"] * 32 / 1e3 - rf["achieved"]) / rf["achieved"] < 0.05
+    # value and achieved describe the same launches: value [Mpts/s] * 32 B ~= achieved [GB/s]; on this 6-step toy run the
+    # wall clock (value) also carries the Python launch overhead of the first steps, hence the loose band
+    assert 0.7 < (d["value"] * 32 / 1e3) / rf["achieved"] <= 1.02
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert d["parity_spot_check"]["max_rel_err"] <= 1e-5 and d["parity_spot_check"]["intensity_bit_identical"]

@@ -494,3 +494,64 @@ def test_full_size_properties_10M(torch_mod, ctx):
     xyzi = d_in[sel].cpu().numpy()
     got = d_out[sel].cpu().numpy()
     _check(got, xyzi, _oracle(xyzi, A, B, mode=orc.HOISTED))
+
+
+# ---- scale and speed guards ------------------------------------------------------------------------------------------
+def test_beyond_4GiB_buffers_use_64bit_indexing(torch_mod, ctx):
+    """300 M points = 4.8 GB per buffer (> 2^32 bytes): tiles past the 4 GiB mark must be addressed correctly by the
+    single-frame and the batched kernel (per-tile descriptors carry a 64-bit base)."""
+    torch = torch_mod
+    n = 300_000_000
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    ctx.synth_points(d_in, n, 4242)
+    d_out = torch.zeros_like(d_in)
+    rho = [1.7, -0.4, 0.05]
+    params = capi.FrameParams.make([*rho, 0, 0, 0], 0.25)
+    ctx.deskew_f32(d_in, d_out, params)
+    torch.cuda.synchronize()
+
+    def check(out):
+        for lo in (0, (1 << 28) - 50_000, n - 100_000):  # start, across the 4 GiB byte mark, end
+            a = d_in[lo:lo + 100_000].double()
+            b = out[lo:lo + 100_000].double()
+            frac = (np.pi - torch.atan2(a[:, 1], a[:, 0])) / (2 * np.pi)
+            want = a[:, :3] + (frac - 0.25)[:, None] * torch.tensor(rho, dtype=torch.float64, device="cuda")[None, :]
+            assert (b[:, :3] - want).abs().max().item() < 2e-5
+            assert torch.equal(a[:, 3], b[:, 3])
+
+    check(d_out)
+    d_out.zero_()
+    offsets = np.array([0, 100_000_000, 100_000_000, 268_435_456 + 7, n], dtype=np.uint64)  # a boundary right after 2^28 points
+    d_idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.deskew_batch_f32(d_in, d_out, offsets, [params] * 4, d_idx)
+    torch.cuda.synchronize()
+    check(d_out)
+    for pos, want in ((0, 0), (99_999_999, 0), (100_000_000, 2), (268_435_462, 2), (268_435_463, 3), (n - 1, 3)):
+        assert int(d_idx[pos].item()) == want, pos
+
+
+def test_throughput_guard_batched_kernel(torch_mod, ctx):
+    """Regression guard, not a benchmark: the batched kernel on 64 x 1 M points must stay above 5.5 TB/s
+    (69 % of the 8 TB/s HBM peak; bench.py measures 6.8-6.9 TB/s on 256 M points)."""
+    torch = torch_mod
+    F, per = 64, 1_000_000
+    n = F * per
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    ctx.synth_points(d_in, n, 99)
+    d_out = torch.empty_like(d_in)
+    offsets = np.arange(F + 1, dtype=np.uint64) * per
+    params = capi.params_array([capi.FrameParams.make([1.0, 0.01 * f, 0, 0.001, -0.002, 0.01 + 0.0005 * f], 0.5) for f in range(F)])
+    for _ in range(10):
+        ctx.deskew_batch_f32(d_in, d_out, offsets, params, None)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        ctx.timer_begin()
+        for _ in range(30):
+            ctx.deskew_batch_f32(d_in, d_out, offsets, params, None)
+        best = min(best, ctx.timer_end() / 30)
+    gbps = 32.0 * n / (best * 1e-3) / 1e9
+    print(f"batched kernel: {best * 1e3:.1f} us per 64 M points = {gbps:.0f} GB/s")
+    assert gbps > 5500, gbps
