@@ -207,6 +207,58 @@ int ensure_pipeline(kmc_ctx* c) {
   return KMC_OK;
 }
 
+// ---- ring of table slots (batch tables and trajectory segment tables) ---------------------------------------------------
+// slot_begin : picks the next slot, waits (host) until the kernels of its group from the previous lap are done, grows every
+//              slot if `need` bytes do not fit;
+// slot_upload: one H2D copy of the slot's pinned staging on the side stream, then a HOST wait for that tiny copy -- the
+//              launch that follows has no cross-stream dependency, so back-to-back launches keep the ~2 us same-stream boundary;
+// slot_end   : after the launch; records one "consumed" marker per group of launches on the compute stream.
+int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
+  const int slot_id = c->next_slot;
+  const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
+  c->next_slot = (c->next_slot + 1) % kmc_ctx::kTableSlots;
+  if (slot_id % kmc_ctx::kSlotsPerGroup == 0 && c->group_busy[group_id]) {
+    KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
+    c->group_busy[group_id] = false;
+  }
+  if (need > c->slots[slot_id].cap) {
+    // grow EVERY slot at once (so that steady state never allocates again); slots may still be referenced by kernels in
+    // flight: drain first
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    const size_t cap = std::max<size_t>(64 * 1024, need * 2);
+    for (auto& each : c->slots) {
+      if (each.cap >= cap) continue;
+      if (each.d_buf) (void)hipFree(each.d_buf);
+      if (each.h_buf) (void)hipHostFree(each.h_buf);
+      each.d_buf = nullptr; each.h_buf = nullptr; each.cap = 0;
+      KMC_HIP_TRY(c, hipMalloc((void**)&each.d_buf, cap));
+      KMC_HIP_TRY(c, hipHostMalloc((void**)&each.h_buf, cap, hipHostMallocDefault));
+      each.cap = cap;
+    }
+    for (auto& busy : c->group_busy) busy = false;
+  }
+  *slot_id_out = slot_id;
+  return KMC_OK;
+}
+
+int slot_upload(kmc_ctx* c, int slot_id, size_t bytes) {
+  kmc_ctx::TableSlot& sl = c->slots[slot_id];
+  KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  KMC_HIP_TRY(c, hipEventRecord(sl.uploaded, c->copy_stream));
+  KMC_HIP_TRY(c, hipEventSynchronize(sl.uploaded));
+  return KMC_OK;
+}
+
+int slot_end(kmc_ctx* c, int slot_id) {
+  if (slot_id % kmc_ctx::kSlotsPerGroup == kmc_ctx::kSlotsPerGroup - 1) {
+    const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
+    KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
+    c->group_busy[group_id] = true;
+  }
+  return KMC_OK;
+}
+
 struct CallTimer {
   kmc_ctx* c;
   explicit CallTimer(kmc_ctx* ctx) : c(ctx) {}
@@ -608,34 +660,14 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const uint64_t n_chunks = (n + chunk - 1) / chunk;
   const uint64_t n_coarse = n_chunks + 1;
 
-  // pick the next table slot; its group's kernels were launched >= kTableSlots - kSlotsPerGroup steps ago
-  const int slot_id = c->next_slot;
-  const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
-  kmc_ctx::TableSlot& sl = c->slots[slot_id];
-  c->next_slot = (c->next_slot + 1) % kmc_ctx::kTableSlots;
-  if (slot_id % kmc_ctx::kSlotsPerGroup == 0 && c->group_busy[group_id]) {
-    KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
-    c->group_busy[group_id] = false;
-  }
   const size_t recs_bytes = ((size_t)n_frames * sizeof(BatchRec) + 255) & ~(size_t)255;
   const size_t need = recs_bytes + (size_t)n_coarse * sizeof(uint32_t);
-  if (need > sl.cap) {
-    // grow EVERY slot at once (so that steady state never allocates again); slots may still be referenced by
-    // kernels in flight: drain first
-    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-    const size_t cap = std::max<size_t>(64 * 1024, need * 2);
-    for (auto& each : c->slots) {
-      if (each.cap >= cap) continue;
-      if (each.d_buf) (void)hipFree(each.d_buf);
-      if (each.h_buf) (void)hipHostFree(each.h_buf);
-      each.d_buf = nullptr; each.h_buf = nullptr; each.cap = 0;
-      KMC_HIP_TRY(c, hipMalloc((void**)&each.d_buf, cap));
-      KMC_HIP_TRY(c, hipHostMalloc((void**)&each.h_buf, cap, hipHostMallocDefault));
-      each.cap = cap;
-    }
-    for (auto& busy : c->group_busy) busy = false;
+  int slot_id = 0;
+  {
+    const int rc_slot = slot_begin(c, need, &slot_id);
+    if (rc_slot != KMC_OK) return rc_slot;
   }
+  kmc_ctx::TableSlot& sl = c->slots[slot_id];
   BatchRec* h_recs = reinterpret_cast<BatchRec*>(sl.h_buf);
   uint32_t* h_coarse = reinterpret_cast<uint32_t*>(sl.h_buf + recs_bytes);
   const BatchRec* d_recs = reinterpret_cast<const BatchRec*>(sl.d_buf);
@@ -657,9 +689,11 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
     while (f + 1 < n_frames && offsets[f + 1] <= n - 1) ++f;
     h_coarse[n_chunks] = f;
   }
-  // one table upload on the side stream: overlaps whatever the compute stream is still running
-  KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, need, hipMemcpyHostToDevice, c->copy_stream));
-  KMC_HIP_TRY(c, hipEventRecord(sl.uploaded, c->copy_stream));
+  // one table upload on the side stream (overlaps whatever the compute stream is still running), awaited on the host
+  {
+    const int rc_up = slot_upload(c, slot_id, need);
+    if (rc_up != KMC_OK) return rc_up;
+  }
 
   CallTimer tm(c);
   const v4f* d_in = (const v4f*)xyzi_in;
@@ -677,9 +711,6 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST)
     KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, n * sizeof(v4f), hipMemcpyHostToDevice, c->stream));
-  // wait for the (tiny) table upload on the HOST: the launch below then has no cross-stream dependency, so
-  // back-to-back steps keep the ~2 us same-stream kernel boundary instead of a ~10 us barrier packet
-  KMC_HIP_TRY(c, hipEventSynchronize(sl.uploaded));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, n_tiles);
   switch (tier) {
@@ -688,9 +719,9 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
     default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in, d_out, d_recs, d_coarse, n_frames, n, d_idx); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
-  if (slot_id % kmc_ctx::kSlotsPerGroup == kmc_ctx::kSlotsPerGroup - 1) {
-    KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
-    c->group_busy[group_id] = true;
+  {
+    const int rc_end = slot_end(c, slot_id);
+    if (rc_end != KMC_OK) return rc_end;
   }
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {
@@ -841,7 +872,11 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
     knot_direction(ck, &r.knot_cos, &r.knot_sin);
     r.flags = (k == th.r ? kSegIdentity : 0u) | (ck <= 0.0 ? kKnotAlwaysGe : 0u) | (ck > 1.0 ? kKnotNeverGe : 0u);
   }
-  rc = ensure_traj(c);
+  int slot_id = 0;
+  rc = slot_begin(c, sizeof(segs), &slot_id);
+  if (rc != KMC_OK) return rc;
+  std::memcpy(c->slots[slot_id].h_buf, segs, th.n_seg * sizeof(TrajSeg32));
+  rc = slot_upload(c, slot_id, th.n_seg * sizeof(TrajSeg32));
   if (rc != KMC_OK) return rc;
 
   const v4f* d_in = (const v4f*)xyzi_in;
@@ -858,16 +893,14 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   }
   CallTimer tm(c);
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  rc = upload_traj(c, segs, 0, th.n_seg * sizeof(TrajSeg32));
-  if (rc != KMC_OK) return rc;
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
   const int grid = grid_for(c, (n + 63) / 64);
-  const TrajSeg32* d_segs = (const TrajSeg32*)c->d_traj;
+  const TrajSeg32* d_segs = (const TrajSeg32*)c->slots[slot_id].d_buf;
 #define KMC_LAUNCH_TRAJ(T)                                                                                                          \
   do {                                                                                                                              \
-    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kNtBoth, true>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx); \
-    else hipLaunchKernelGGL((deskew_traj_f32<T, kNtBoth, false>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx);      \
+    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx); \
+    else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx);      \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ(kSeries3); break;
@@ -876,6 +909,8 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   }
 #undef KMC_LAUNCH_TRAJ
   KMC_HIP_TRY(c, hipGetLastError());
+  rc = slot_end(c, slot_id);
+  if (rc != KMC_OK) return rc;
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {
     KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out, d_out, n * sizeof(v4f), hipMemcpyDeviceToHost, c->stream));

@@ -294,11 +294,16 @@ __global__ __launch_bounds__(kBlock) void pseudo_timestamps_f64(const double* __
 // ------------------------------------------------------------------------------------------------
 // N-knot trajectory kernels (the 3-argument MotionCompensateFrame(Frame, Trajectory, Time) overload)
 // ------------------------------------------------------------------------------------------------
-// One wave per workgroup.  Every lane finds its bracket with the trig-free knot tests (an integer, bit-exact against the
-// oracle; the knot slots are wave-uniform scalar loads).  A wave whose lanes share one bracket -- all but the few waves that
-// contain a knot's azimuth -- broadcasts it through readfirstlane and takes the segment record through scalar loads, so its
-// body is the single-geodesic kernel plus one 3x4 transform.  A wave that straddles a knot stages the segment records -- the
-// twists of the bracketing poses -- into LDS and every lane gathers its own record from there.
+// One wave per workgroup (measured best, profiles/r01_tune.csv rows traj_*: 6.68 TB/s against 6.12 for records fetched
+// through scalar loads after the bracket is known, and 5.9-6.2 for 256-thread workgroups):
+//   1. the wave issues its point load first;
+//   2. it stages the segment records -- the twists of the bracketing poses and their anchor transforms, 128 B each --
+//      into LDS (one 16-byte slot per lane; the table round trip hides under the HBM latency of the points);
+//   3. every lane finds its bracket with the trig-free knot tests (an integer, bit-exact against the oracle); each test
+//      reads the knot's 16-byte slot at a uniform LDS address, i.e. one broadcast ds_read_b128;
+//   4. a wave whose lanes share one bracket -- all but the few waves that contain a knot's azimuth -- broadcasts it through
+//      readfirstlane and reads its record at a uniform LDS address; a wave that straddles a knot gathers per lane;
+//   5. fused exp-map + rotate + translate per lane, then the 3x4 anchor transform unless the segment is the anchor's own.
 template <int TIER>
 __device__ __forceinline__ v4f traj_point(const v4f p, const TrajSeg32& r) {
   FrameRec f;
@@ -330,30 +335,30 @@ __global__ __launch_bounds__(64) void deskew_traj_f32(const v4f* __restrict__ in
   const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;
   bool staged = false;
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t i = t * BLOCK + tid;
-    const bool live = i < n;
-    v4f p = {0.f, 0.f, 0.f, 0.f};
-    if (live) p = load_point<NT>(in + i);
+    const uint64_t base = t * BLOCK;
+    const uint64_t i = base + tid;
+    const v4f p = load_point<NT>(in + (i < n ? i : n - 1));  // dead lanes of a ragged tile re-read the last point
+    if (!staged) {
+      for (uint32_t w = tid; w < n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs)[w];
+      __syncthreads();  // single-wave workgroup: orders the wave's own LDS writes before its reads
+      staged = true;
+    }
     uint32_t k = 0;
-    for (uint32_t j = 1; j < n_seg; ++j) {  // interior knots: uniform address -> s_load_dwordx4 of the knot slot
-      const TrajSeg32& kn = segs[j];
-      k += knot_ge(p.x, p.y, kn.knot_c, kn.knot_cos, kn.knot_sin, kn.flags) ? 1u : 0u;
+    for (uint32_t j = 1; j < n_seg; ++j) {  // interior knots
+      const v4f kn = reinterpret_cast<const v4f*>(&lds[j])[7];  // {knot_cos, knot_sin, flags, knot_c}
+      k += knot_ge(p.x, p.y, kn.w, kn.x, kn.y, __float_as_uint(kn.z)) ? 1u : 0u;
     }
     const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
-    v4f q;
-    if (__all(k == k0)) {
-      q = traj_point<TIER>(p, segs[k0]);  // wave-uniform: record through scalar loads -> SGPRs
+    const uint32_t ks = __all(k == k0) ? k0 : k;  // uniform bracket -> uniform LDS address (broadcast), else per-lane gather
+    const v4f q = traj_point<TIER>(p, lds[ks]);
+    if constexpr (NT & kStoreSc1) {
+      const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
+      tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
     } else {
-      if (!staged) {  // single-wave workgroup: the wave stages for itself
-        for (uint32_t w = tid; w < n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs)[w];
-        __syncthreads();
-        staged = true;
-      }
-      q = traj_point<TIER>(p, lds[k]);  // per-lane gather from LDS
+      if (i < n) store_point<NT>(out + i, q);
     }
-    if (live) {
-      store_point<NT>(out + i, q);
-      if constexpr (WRITE_IDX) __builtin_nontemporal_store(k, bracket_out + i);
+    if constexpr (WRITE_IDX) {
+      if (i < n) __builtin_nontemporal_store(k, bracket_out + i);
     }
   }
 }
