@@ -95,6 +95,64 @@ __global__ __launch_bounds__(64) void deskew_frame_policy(const v4f* __restrict_
   if constexpr (SP == 6) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(dst), "v"(q) : "memory");
 }
 
+// dynamic tile grabbing: persistent one-wave workgroups pull chunks of CHUNK consecutive tiles from per-XCD counters
+// (counter x hands out global chunks x, x+8, x+16, ... so the set of tiles in flight stays one compact window, like the
+// hardware dispatcher's order, but without re-launching a wave per tile).  The next grab is issued before the current
+// chunk is processed, so its latency is hidden.
+static unsigned long long* g_dyn_counters = nullptr;  // 8 x 128-byte-spaced counters
+
+template <int CHUNK>
+__global__ __launch_bounds__(64) void deskew_frame_dyn(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, FrameRec f,
+                                                       unsigned long long* __restrict__ counters) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t xcd = blockIdx.x & 7u;
+  unsigned long long* ctr = counters + xcd * 16;
+  const uint64_t n_tiles = n / 64;  // tuner sizes are multiples of the tile
+  const uint64_t n_chunks = n_tiles / CHUNK;
+  unsigned long long g = 0;
+  if (lane == 0) g = atomicAdd(ctr, 1ull);
+  uint64_t chunk = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)g) * 8 + xcd;
+  while (chunk < n_chunks) {
+    unsigned long long gn = 0;
+    if (lane == 0) gn = atomicAdd(ctr, 1ull);  // prefetch the next grab
+    const uint64_t first = chunk * CHUNK * 64;
+    v4f p[CHUNK];
+#pragma unroll
+    for (int u = 0; u < CHUNK; ++u) p[u] = load_point<kNtBoth>(in + first + u * 64 + lane);
+    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + first, (uint64_t)CHUNK * 64 * sizeof(v4f));
+#pragma unroll
+    for (int u = 0; u < CHUNK; ++u) tile_store<kPolicyDefault>(rout, (uint32_t)((u * 64 + lane) * sizeof(v4f)), deskew_point<kSeries3, false>(p[u], f));
+    chunk = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)gn) * 8 + xcd;
+  }
+}
+
+template <int CHUNK, int WAVES_PER_CU>
+static Variant dyn_variant(const char* label) {
+  Variant v;
+  v.name = label;
+  v.ppt = CHUNK;
+  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+    static const FrameRec f = make_rec();
+    if (!g_dyn_counters) CK(hipMalloc((void**)&g_dyn_counters, 8 * 128));
+    CK(hipMemsetAsync(g_dyn_counters, 0, 8 * 128, s));
+    hipLaunchKernelGGL((deskew_frame_dyn<CHUNK>), dim3((unsigned)(g_cus * WAVES_PER_CU)), dim3(64), 0, s, in, out, n, f, g_dyn_counters);
+  };
+  return v;
+}
+
+// occupancy sensitivity: the same one-wave kernel with a dynamic-LDS reservation that caps the workgroups per CU
+template <int LDS_BYTES>
+static Variant occ_variant(const char* label) {
+  Variant v;
+  v.name = label;
+  v.ppt = 1;
+  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+    static const FrameRec f = make_rec();
+    hipLaunchKernelGGL((deskew_frame_f32<kSeries3, 1, kPolicyDefault, false, 64>), dim3((unsigned)((n + 63) / 64)), dim3(64), LDS_BYTES, s, in, out, n, f);
+  };
+  return v;
+}
+
 template <int BLOCK>
 static Variant xcd_variant(const char* label) {
   Variant v;
@@ -328,6 +386,19 @@ int main(int argc, char** argv) {
   es.push_back({traj_lds_variant<256, 2>("traj_lds_b256_t2"), kZero});
   es.push_back({traj_lds_variant<256, 4>("traj_lds_b256_t4"), kZero});
   es.push_back({traj_lds_variant<1024, 1>("traj_lds_b1024_t1"), kZero});
+  es.push_back({dyn_variant<1, 32>("dyn_c1_w32"), kZero});
+  es.push_back({dyn_variant<2, 32>("dyn_c2_w32"), kZero});
+  es.push_back({dyn_variant<4, 32>("dyn_c4_w32"), kZero});
+  es.push_back({dyn_variant<8, 32>("dyn_c8_w32"), kZero});
+  es.push_back({dyn_variant<2, 64>("dyn_c2_w64"), kZero});
+  es.push_back({dyn_variant<4, 16>("dyn_c4_w16"), kZero});
+  es.push_back({occ_variant<0>("occ_32_per_cu"), kZero});
+  es.push_back({occ_variant<5800>("occ_28_per_cu"), kZero});
+  es.push_back({occ_variant<6800>("occ_24_per_cu"), kZero});
+  es.push_back({occ_variant<8100>("occ_20_per_cu"), kZero});
+  es.push_back({occ_variant<10200>("occ_16_per_cu"), kZero});
+  es.push_back({occ_variant<13600>("occ_12_per_cu"), kZero});
+  es.push_back({occ_variant<20400>("occ_8_per_cu"), kZero});
   es.push_back({xcd_variant<64>("x_xcdcontig_b64"), kZero});
   es.push_back({xcd_variant<256>("x_xcdcontig_b256"), kZero});
   es.push_back({policy_variant<1, 1>("x_pol_nt_nt"), kZero});
