@@ -172,15 +172,24 @@ def status_string(status: int) -> str:
     return lib().kmc_status_string(status).decode()
 
 
-def _ptr(a):
-    """numpy array / torch tensor / int / None -> void* value."""
+def _ptr(a, dtype=None):
+    """numpy array / torch tensor / int / None -> void* value.  Arrays must be C-contiguous (and of `dtype` if given):
+    the C-ABI takes bare pointers, a strided view would silently be read as if it were dense."""
     if a is None:
         return None
     if isinstance(a, int):
         return a
     if isinstance(a, np.ndarray):
+        if not a.flags.c_contiguous:
+            raise ValueError("kmc: array must be C-contiguous")
+        if dtype is not None and a.dtype != np.dtype(dtype):
+            raise TypeError(f"kmc: expected {np.dtype(dtype)}, got {a.dtype}")
         return a.ctypes.data
     if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise ValueError("kmc: tensor must be contiguous")
+        if dtype is not None and str(a.dtype).replace("torch.", "") != np.dtype(dtype).name:
+            raise TypeError(f"kmc: expected {np.dtype(dtype).name}, got {a.dtype}")
         return a.data_ptr()
     raise TypeError(type(a))
 
@@ -328,7 +337,7 @@ class Context:
         if n is None:
             n = int(xyzi_in.shape[0])
         st = Stats()
-        rc = lib().kmc_hip_deskew_f32(self._h, _ptr(xyzi_in), _ptr(xyzi_out), n, C.byref(params), kind, C.byref(st))
+        rc = lib().kmc_hip_deskew_f32(self._h, _ptr(xyzi_in, np.float32), _ptr(xyzi_out, np.float32), n, C.byref(params), kind, C.byref(st))
         self._check(rc, "kmc_hip_deskew_f32")
         return st
 
@@ -339,7 +348,7 @@ class Context:
         nf = len(offs) - 1
         arr = params_list if isinstance(params_list, C.Array) else params_array(params_list)
         st = Stats()
-        rc = lib().kmc_hip_deskew_batch_f32(self._h, _ptr(xyzi_in), _ptr(xyzi_out),
+        rc = lib().kmc_hip_deskew_batch_f32(self._h, _ptr(xyzi_in, np.float32), _ptr(xyzi_out, np.float32),
                                             offs.ctypes.data_as(C.POINTER(C.c_uint64)), nf, arr, _ptr(frame_idx_out), kind,
                                             C.byref(st))
         self._check(rc, "kmc_hip_deskew_batch_f32")
@@ -350,8 +359,10 @@ class Context:
         kind = _mem_kind(x)
         n = int(x.shape[0])
         st = Stats()
-        rc = lib().kmc_hip_deskew_f64cols(self._h, _ptr(x), _ptr(y), _ptr(z), _ptr(w), _ptr(stamps), n, stamp_start,
-                                          stamp_end, C.byref(params), _ptr(ox), _ptr(oy), _ptr(oz), _ptr(ow), kind,
+        rc = lib().kmc_hip_deskew_f64cols(self._h, _ptr(x, np.float64), _ptr(y, np.float64), _ptr(z, np.float64),
+                                          _ptr(w, np.float64), _ptr(stamps, np.float64), n, stamp_start,
+                                          stamp_end, C.byref(params), _ptr(ox, np.float64), _ptr(oy, np.float64),
+                                          _ptr(oz, np.float64), _ptr(ow, np.float64), kind,
                                           C.byref(st))
         if rc == ERR_TIME_OUT_OF_RANGE and not raise_on_range:
             return rc, st
@@ -367,7 +378,7 @@ class Context:
         t = np.ascontiguousarray(knot_times, dtype=np.float64)
         P = np.ascontiguousarray(np.asarray(knot_poses, dtype=np.float64).reshape(len(t), 12))
         st = Stats()
-        rc = lib().kmc_hip_deskew_traj_f32(self._h, _ptr(xyzi_in), _ptr(xyzi_out), n, t.ctypes.data_as(_dp), P.ctypes.data_as(_dp),
+        rc = lib().kmc_hip_deskew_traj_f32(self._h, _ptr(xyzi_in, np.float32), _ptr(xyzi_out, np.float32), n, t.ctypes.data_as(_dp), P.ctypes.data_as(_dp),
                                            len(t), stamp_start, stamp_end, requested_time, _ptr(bracket_idx_out), kind, C.byref(st))
         self._check(rc, "kmc_hip_deskew_traj_f32")
         return st

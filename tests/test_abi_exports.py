@@ -72,3 +72,16 @@ def test_product_never_references_the_oracle():
     assert "kmo_" not in out
     ldd = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in ldd
+
+
+def test_python_plumbing_rejects_strided_or_mistyped_buffers():
+    """The C-ABI takes bare pointers; the ctypes layer must refuse views it would misread."""
+    import numpy as np
+
+    a = np.zeros((16, 8), dtype=np.float32)[:, :4]  # strided view
+    with pytest.raises(ValueError):
+        capi._ptr(a, np.float32)
+    with pytest.raises(TypeError):
+        capi._ptr(np.zeros((4, 4), dtype=np.float64), np.float32)
+    assert capi._ptr(np.zeros((4, 4), dtype=np.float32), np.float32) != 0
+    assert capi._ptr(None) is None

@@ -140,6 +140,34 @@ static Variant dyn_variant(const char* label) {
   return v;
 }
 
+// sequential multi-tile: one wave handles SEQ adjacent tiles one after the other (load, compute, store, then the next load),
+// so the wave lives SEQ times longer per dispatch without holding more loads in flight
+template <int SEQ>
+__global__ __launch_bounds__(64) void deskew_frame_seq(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, FrameRec f) {
+  const uint64_t first = (uint64_t)blockIdx.x * SEQ * 64;
+  const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + first, (n - first) * sizeof(v4f));
+#pragma unroll
+  for (int u = 0; u < SEQ; ++u) {
+    const uint64_t i = first + u * 64 + threadIdx.x;
+    const v4f p = load_point<kNtBoth>(in + (i < n ? i : n - 1));
+    tile_store<kPolicyDefault>(rout, (uint32_t)((u * 64 + threadIdx.x) * sizeof(v4f)), deskew_point<kSeries3, false>(p, f));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep the next load behind this store
+  }
+}
+
+template <int SEQ>
+static Variant seq_variant(const char* label) {
+  Variant v;
+  v.name = label;
+  v.ppt = SEQ;
+  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+    static const FrameRec f = make_rec();
+    const uint64_t per = 64ull * SEQ;
+    hipLaunchKernelGGL((deskew_frame_seq<SEQ>), dim3((unsigned)((n + per - 1) / per)), dim3(64), 0, s, in, out, n, f);
+  };
+  return v;
+}
+
 // occupancy sensitivity: the same one-wave kernel with a dynamic-LDS reservation that caps the workgroups per CU
 template <int LDS_BYTES>
 static Variant occ_variant(const char* label) {
@@ -392,6 +420,9 @@ int main(int argc, char** argv) {
   es.push_back({dyn_variant<8, 32>("dyn_c8_w32"), kZero});
   es.push_back({dyn_variant<2, 64>("dyn_c2_w64"), kZero});
   es.push_back({dyn_variant<4, 16>("dyn_c4_w16"), kZero});
+  es.push_back({seq_variant<1>("seq1"), kZero});
+  es.push_back({seq_variant<2>("seq2"), kZero});
+  es.push_back({seq_variant<4>("seq4"), kZero});
   es.push_back({occ_variant<0>("occ_32_per_cu"), kZero});
   es.push_back({occ_variant<5800>("occ_28_per_cu"), kZero});
   es.push_back({occ_variant<6800>("occ_24_per_cu"), kZero});
