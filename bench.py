@@ -47,23 +47,11 @@ def make_workload(capi, n_frames, rank):
 
 
 def effective_cores():
-    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box exposes 256
-    logical CPUs but grants 16 through cpu.max; OpenMP beyond the quota only oversubscribes)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except OSError:
-        try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
-                q, p = int(f.read()), int(g.read())
-            if q > 0:
-                n = min(n, max(1, q // p))
-        except OSError:
-            pass
-    return n
+    """CPU cores this process may actually use (affinity mask capped by the cgroup CPU quota; the GPU box exposes 256
+    logical CPUs but grants 16 through cpu.max, and OpenMP beyond the quota only oversubscribes)."""
+    from oracle import oracle as orc
+
+    return orc.default_threads()
 
 
 def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample):

@@ -140,6 +140,20 @@ def lib() -> C.CDLL:
     return L
 
 
+def default_threads() -> int:
+    """OpenMP team size for the oracle helpers: the cores this process may really use (affinity mask capped by the cgroup
+    CPU quota -- GPU boxes expose hundreds of logical CPUs but grant far fewer; oversubscribed OpenMP teams crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def _d(a):
     a = np.ascontiguousarray(a, dtype=np.float64)
     return a, a.ctypes.data_as(C.POINTER(C.c_double))
@@ -310,7 +324,7 @@ def deskew_xyzi_f32(xyzi, stamp_start, T_start: Affine, stamp_end, T_end: Affine
     a = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
     n = a.shape[0]
     if threads <= 0:
-        threads = lib().kmo_num_threads()
+        threads = default_threads() if n >= 20000 else 1
     o64 = np.empty((n, 3), dtype=np.float64) if want_f64 else None
     if out_f32 is not None:
         assert out_f32.dtype == np.float32 and out_f32.shape == (n, 4) and out_f32.flags.c_contiguous
@@ -354,7 +368,7 @@ def deskew_xyzi_f32_traj(xyzi, stamp_start, stamp_end, times, poses, requested, 
     a = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
     n = a.shape[0]
     if threads <= 0:
-        threads = lib().kmo_num_threads()
+        threads = default_threads() if n >= 20000 else 1
     t_, tp = _d(times)
     o64 = np.empty((n, 3), dtype=np.float64)
     br = np.empty(n, dtype=np.uint32)

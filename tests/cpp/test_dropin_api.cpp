@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kitti_motion_compensation/data_io.hpp"
@@ -315,6 +316,28 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
     ASSERT_EQ(idx[1], 1u);  // frac == 0.5 == the knot: belongs to the later segment
     ASSERT_EQ(idx[2], 1u);
     ASSERT_TRUE(buf_out[3] == 0.1f && buf_out[7] == 0.2f && buf_out[11] == 0.3f);
+  }
+  CASE("re-entrancy: MotionCompensateFrame from four threads at once (one device context per thread)");
+  {
+    LidarScan const scan{LoadLidarScan(data_folder, 0)};
+    Affine3d const P1{OxtsToPose(LoadOxts(data_folder, 0))};
+    std::vector<Affine3d> ends;
+    std::vector<Pointcloud> serial;
+    for (int t = 0; t < 4; ++t) {
+      ends.push_back(P1 * lie::Exp(Twist{1.0 + 0.3 * t, 0.05, -0.02, 0.01 * t, 0.01, -0.05 - 0.02 * t}));
+      serial.push_back(MotionCompensateFrame(Frame(P1, ends.back(), scan), scan.stamp_middle));
+    }
+    std::vector<Pointcloud> parallel(4);
+    std::vector<std::thread> workers;
+    for (int t = 0; t < 4; ++t)
+      workers.emplace_back([&, t] {
+        for (int rep = 0; rep < 3; ++rep) parallel[t] = MotionCompensateFrame(Frame(P1, ends[t], scan), scan.stamp_middle);
+      });
+    for (auto& w : workers) w.join();
+    for (int t = 0; t < 4; ++t) {
+      ASSERT_EQ(parallel[t].rows(), serial[t].rows());
+      ASSERT_TRUE(std::memcmp(parallel[t].data(), serial[t].data(), sizeof(double) * 4 * static_cast<std::size_t>(serial[t].rows())) == 0);
+    }
   }
   CASE("MotionCompensateRun on a synthesised 5-frame run");  // handlers.cpp:41-65
   {
