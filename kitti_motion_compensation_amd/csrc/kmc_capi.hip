@@ -73,7 +73,7 @@ namespace {
 
 // measured best on MI355X (profiles/r01_tune.csv): one wave per workgroup, one point per lane, one tile per workgroup
 constexpr int kLaunchBlock = 64;
-constexpr int kDefaultPpt = 1;  // measured best on MI355X: 256-point tiles, one per workgroup (profiles/r01_tune.csv)
+constexpr int kDefaultPpt = 1;
 constexpr uint64_t kHostChunkPoints = 1ull << 21;  // 32 MiB per direction per pipeline slot
 
 int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
@@ -124,8 +124,8 @@ bool params_ok(const kmc_frame_params* p) {
 }
 
 int grid_for(const kmc_ctx* c, uint64_t n_tiles) {
-  // default: one tile per workgroup -- the hardware dispatcher streams 256-point tiles better than a persistent
-  // grid-stride loop does (6.66 vs 5.39 TB/s, profiles/r01_tune.csv); blocks_per_cu > 0 caps the grid instead.
+  // default: one tile per workgroup -- the hardware dispatcher streaming 64-point tiles beats a persistent grid-stride loop
+  // (6.8 vs 5.2-5.8 TB/s, profiles/r01_tune.csv); blocks_per_cu > 0 caps the grid instead (in units of 256 threads per CU).
   const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu * (kBlock / kLaunchBlock) : 0x7fffffffull;
   return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, cap));
 }
