@@ -310,8 +310,8 @@ def test_batch_vs_per_frame_oracle_and_bit_exact_indices(torch_mod, ctx, kitti, 
     xyzi, offsets, params, ref = _batch_case(kitti, sizes, steps)
     n = xyzi.shape[0]
     want_idx = (np.searchsorted(offsets, np.arange(n, dtype=np.uint64), side="right") - 1).astype(np.uint32)
-    for ppt in (1, 4, 8):
-        ctx.set_launch_config(0, ppt)
+    for bpc, ppt in ((0, 1), (0, 4), (0, 8), (1, 1), (2, 2)):  # bpc > 0: persistent grid-stride workgroups
+        ctx.set_launch_config(bpc, ppt)
         # device-resident
         d_in = torch.from_numpy(xyzi).cuda()
         d_out = torch.empty_like(d_in)
