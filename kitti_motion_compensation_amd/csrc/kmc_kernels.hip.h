@@ -260,8 +260,9 @@ __global__ __launch_bounds__(kBlock) void deskew_f64cols(const double* __restric
                                                         unsigned long long* __restrict__ n_bad) {
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const double t = stamps[i];
-    const double px = x[i], py = y[i], pz = z[i], pw = w ? w[i] : 1.0;
+    const double t = __builtin_nontemporal_load(stamps + i);
+    const double px = __builtin_nontemporal_load(x + i), py = __builtin_nontemporal_load(y + i), pz = __builtin_nontemporal_load(z + i);
+    const double pw = w ? __builtin_nontemporal_load(w + i) : 1.0;
     const bool in_range = (t >= f.t_start) && (t <= f.t_end);  // TimeIsInRange, trajectory_interpolation.cpp:47
     double rx, ry, rz;
     if (in_range) {
@@ -270,10 +271,10 @@ __global__ __launch_bounds__(kBlock) void deskew_f64cols(const double* __restric
     } else {
       rx = ry = rz = __builtin_nan("");
     }
-    ox[i] = rx;
-    oy[i] = ry;
-    oz[i] = rz;
-    if (ow) ow[i] = pw;
+    __builtin_nontemporal_store(rx, ox + i);
+    __builtin_nontemporal_store(ry, oy + i);
+    __builtin_nontemporal_store(rz, oz + i);
+    if (ow) __builtin_nontemporal_store(pw, ow + i);
     const unsigned long long bad = __ballot(!in_range);
     if (bad && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(bad)) atomicAdd(n_bad, (unsigned long long)__builtin_popcountll(bad));
   }
