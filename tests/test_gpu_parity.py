@@ -532,8 +532,9 @@ def test_beyond_4GiB_buffers_use_64bit_indexing(torch_mod, ctx):
 
 
 def test_throughput_guard_batched_kernel(torch_mod, ctx):
-    """Regression guard, not a benchmark: the batched kernel on 64 x 1 M points must stay above 5.5 TB/s
-    (69 % of the 8 TB/s HBM peak; bench.py measures 6.8-6.9 TB/s on 256 M points)."""
+    """Regression guard, not a benchmark: the batched kernel on 64 x 1 M points must stay above 5.0 TB/s
+    (bench.py measures 6.8-6.9 TB/s on 256 M points; a persistent-loop or un-hinted variant would land at 5.2-6.4 and a
+    lost vectorisation far below; the margin absorbs a noisy or throttled box)."""
     torch = torch_mod
     F, per = 64, 1_000_000
     n = F * per
@@ -554,4 +555,4 @@ def test_throughput_guard_batched_kernel(torch_mod, ctx):
         best = min(best, ctx.timer_end() / 30)
     gbps = 32.0 * n / (best * 1e-3) / 1e9
     print(f"batched kernel: {best * 1e3:.1f} us per 64 M points = {gbps:.0f} GB/s")
-    assert gbps > 5500, gbps
+    assert gbps > 5000, gbps
