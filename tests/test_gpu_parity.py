@@ -314,12 +314,13 @@ def test_batch_vs_per_frame_oracle_and_bit_exact_indices(torch_mod, ctx, kitti, 
         ctx.set_launch_config(bpc, ppt)
         # device-resident
         d_in = torch.from_numpy(xyzi).cuda()
-        d_out = torch.empty_like(d_in)
-        d_idx = torch.full((max(n, 1),), -1, dtype=torch.int32, device="cuda")
+        d_out = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")  # 64 guard rows behind the batch
+        d_idx = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         st = ctx.deskew_batch_f32(d_in, d_out, offsets, params, d_idx)
         torch.cuda.synchronize()
-        got = d_out.cpu().numpy()
+        assert bool((d_out[n:] == 7.0).all()) and bool((d_idx[n:] == -1).all()), "wrote past the end of the batch"
+        got = d_out[:n].cpu().numpy()
         idx = d_idx.cpu().numpy().view(np.uint32)[:n]
         assert st.n_points == n
         assert np.array_equal(idx, want_idx), "per-point frame indices must be bit-exact"

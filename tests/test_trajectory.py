@@ -138,12 +138,14 @@ def test_three_bracketing_poses_vs_oracle_and_bit_exact_indices(ctx, kitti):
     # without the index output, and device-resident: same bits
     import torch
 
+    n = xyzi.shape[0]
     d_in = torch.from_numpy(xyzi).cuda()
-    d_out = torch.empty_like(d_in)
+    d_out = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")  # guard rows: 123397 is not a multiple of 64
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.deskew_traj_f32(d_in, d_out, times, _rt(poses), T0, T1, TREQ, None)
+    ctx.deskew_traj_f32(d_in, d_out, times, _rt(poses), T0, T1, TREQ, None, n=n)
     torch.cuda.synchronize()
-    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), out.view(np.uint32))
+    assert bool((d_out[n:] == 7.0).all()), "wrote past the end"
+    assert np.array_equal(d_out[:n].cpu().numpy().view(np.uint32), out.view(np.uint32))
     ctx.set_stream(None)
 
 
