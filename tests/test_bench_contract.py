@@ -34,3 +34,14 @@ def test_bench_prints_one_contract_line():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert d["parity_spot_check"]["max_rel_err"] <= 1e-5 and d["parity_spot_check"]["intensity_bit_identical"]
     assert d["value"] > 50_000  # > 50 G points/s even on a short, cold run
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_initialises_and_reduces_on_one_gpu():
+    """WORLD_SIZE = 1 with the RCCL process group forced on: barrier + the two all-reduces of the counters run through RCCL."""
+    env = dict(os.environ, KMC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                        "--frames-per-step", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 10_000
