@@ -154,6 +154,21 @@ def test_host_pipeline_many_chunks_matches_device_path(torch_mod, ctx, kitti):
     _check(out[sel], xyzi[sel], _oracle(xyzi[sel], P1, P2, mode=orc.HOISTED))
 
 
+@pytest.mark.parametrize("theta,tier", [(0.2499, 0), (0.2501, 1), (0.9999, 1), (1.0001, 2), (3.0, 2)])
+def test_tier_boundaries_keep_the_bar(torch_mod, ctx, kitti, theta, tier):
+    """The host picks the series/trig tier from |phi| * max|s|; at the edges of each tier's validity (0.25 rad, 1 rad) the
+    truncated series must still sit far inside the 1e-5 bar.  requested_time = stamp_start makes max|s| = 1."""
+    xyzi, P1 = kitti
+    axis = np.array([0.3, -0.5, 0.81])
+    axis /= np.linalg.norm(axis)
+    P1, P2 = _poses(P1, [2.0, -0.4, 0.1, *(theta * axis)])
+    params = _params(P1, P2, treq=T0)
+    got, st = _run_device(torch_mod, ctx, xyzi, params)
+    assert st.variant == tier
+    err = _check(got, xyzi, _oracle(xyzi, P1, P2, treq=T0, mode=orc.HOISTED))
+    assert err < 2e-6, err
+
+
 def test_every_tier_and_tiling_agree(torch_mod, ctx, kitti):
     """All three coefficient tiers are valid below 0.25 rad and must agree with the oracle; tiling never changes bits."""
     xyzi, P1 = kitti
