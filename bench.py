@@ -55,8 +55,10 @@ def effective_cores():
     return orc.default_threads()
 
 
-def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample):
-    """The oracle timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)."""
+def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample, gpu_out_frame0):
+    """The oracle timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).  The same leg
+    also checks the GPU's output of the sample's first frame against the oracle's (parity spot check, outside any timing).
+    This function is the ONLY place bench.py touches oracle/."""
     from oracle import oracle as orc
 
     cores = effective_cores()
@@ -78,6 +80,17 @@ def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample):
         return pts / (time.perf_counter() - t) / 1e6
 
     run(orc.HOISTED, cores, 1)  # spin the OpenMP team up once
+    # parity spot check: the reference's op sequence (FAITHFUL) on frame 0 against what the GPU wrote for frame 0
+    (t0, tm, t1), oxs = frame_meta[0]
+    oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
+    rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
+    sel = slice(0, 100_000)
+    ref = orc.deskew_xyzi_f32(xyzi_sample[sel], t0, A, t1, B, tm, mode=orc.FAITHFUL)
+    assert rc == orc.OK and ref["rc"] == orc.OK
+    err = np.linalg.norm(gpu_out_frame0[sel, :3] - ref["xyz_f64"], axis=1) / np.maximum(np.linalg.norm(ref["xyz_f64"], axis=1), 1e-3)
+    parity = {"max_rel_err": float(err.max()), "bar": 1e-5,
+              "intensity_bit_identical": bool(np.array_equal(gpu_out_frame0[sel, 3], xyzi_sample[sel, 3]))}
+    assert parity["max_rel_err"] <= 1e-5 and parity["intensity_bit_identical"], parity
     b1 = run(orc.FAITHFUL, 1, n_frames_sample)            # B1: the reference's op sequence, 1 thread (it is single-threaded)
     b2 = run(orc.FAITHFUL, cores, n_frames_sample)        # B2: same, OpenMP over points
     b3 = run(orc.HOISTED, cores, n_frames_sample)         # B3: hoisted closed form, all cores
@@ -87,7 +100,7 @@ def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample):
                   "(reference op sequence incl. per-point Log/Exp), f64, 1 thread like the reference",
         "all_cores": {"cores": cores, "logical_cpus_visible": os.cpu_count(), "faithful_Mpts_s": round(b2, 3),
                       "hoisted_closed_form_Mpts_s": round(b3, 3)},
-    }
+    }, parity
 
 
 def main():
@@ -177,23 +190,6 @@ def main():
     # the job's ONLY collective: SUM of points, MAX of times (RCCL all-reduce when N > 1)
     pts_total, t_max, ev_max_s = sharding.reduce_throughput(dist, dev, float(n * args.steps), wall, ev_ms * 1e-3)
 
-    # ---- parity spot check outside the timed region (a slice of the last output against the oracle) ----
-    parity = None
-    if rank == 0:
-        from oracle import oracle as orc
-
-        f = F - 1
-        sl = slice(f * POINTS_PER_FRAME, f * POINTS_PER_FRAME + 50_000)
-        xyzi = d_in[sl].cpu().numpy()
-        got = d_outs[(state["k"] - 1) % R][sl].cpu().numpy()
-        (t0, tm, t1), oxs = work[f][1], work[f][2]
-        oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
-        rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
-        ref = orc.deskew_xyzi_f32(xyzi, t0, A, t1, B, tm, mode=orc.FAITHFUL)
-        err = np.linalg.norm(got[:, :3] - ref["xyz_f64"], axis=1) / np.maximum(np.linalg.norm(ref["xyz_f64"], axis=1), 1e-3)
-        parity = {"max_rel_err": float(err.max()), "bar": 1e-5, "intensity_bit_identical": bool(np.array_equal(got[:, 3], xyzi[:, 3]))}
-        assert parity["max_rel_err"] <= 1e-5 and parity["intensity_bit_identical"], parity
-
     if rank == 0:
         kernel_ms = ev_ms / args.steps  # average launch duration of the dominant kernel, HIP events, this rank
         achieved = BYTES_PER_POINT * n / (kernel_ms * 1e-3) / 1e9
@@ -231,12 +227,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "bytes_per_point": BYTES_PER_POINT, "points_per_launch": n, "kernel_ms_avg": round(kernel_ms, 4),
             },
-            "parity_spot_check": parity,
         }
         if world == 1 and not args.no_cpu_baseline:
             k = min(args.cpu_sample_frames, F)
             sample = d_in[:k * POINTS_PER_FRAME].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k)
+            gpu_frame0 = d_outs[(state["k"] - 1) % R][:POINTS_PER_FRAME].cpu().numpy()
+            out["cpu_baseline"], out["parity_spot_check"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k, gpu_frame0)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist:
