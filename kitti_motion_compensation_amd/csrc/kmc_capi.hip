@@ -161,7 +161,7 @@ void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f*
 }
 
 template <int TIER, int PPT>
-void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint32_t* tiles,
+void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
                      uint32_t nf, uint64_t n, uint32_t* idx) {
   if (idx)
     hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
@@ -170,7 +170,7 @@ void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const Bat
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
-                    const uint32_t* tiles, uint32_t nf, uint64_t n, uint32_t* idx) {
+                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx) {
   switch (ppt) {
     case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx); break;
     case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx); break;
@@ -661,7 +661,7 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const uint64_t n_coarse = n_chunks + 1;
 
   const size_t recs_bytes = ((size_t)n_frames * sizeof(BatchRec) + 255) & ~(size_t)255;
-  const size_t need = recs_bytes + (size_t)n_coarse * sizeof(uint32_t);
+  const size_t need = recs_bytes + (size_t)n_coarse * sizeof(uint2);
   int slot_id = 0;
   {
     const int rc_slot = slot_begin(c, need, &slot_id);
@@ -669,9 +669,9 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   }
   kmc_ctx::TableSlot& sl = c->slots[slot_id];
   BatchRec* h_recs = reinterpret_cast<BatchRec*>(sl.h_buf);
-  uint32_t* h_coarse = reinterpret_cast<uint32_t*>(sl.h_buf + recs_bytes);
+  uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + recs_bytes);
   const BatchRec* d_recs = reinterpret_cast<const BatchRec*>(sl.d_buf);
-  const uint32_t* d_coarse = reinterpret_cast<const uint32_t*>(sl.d_buf + recs_bytes);
+  const uint2* d_coarse = reinterpret_cast<const uint2*>(sl.d_buf + recs_bytes);
   for (uint32_t f = 0; f < n_frames; ++f) {
     BatchRec* r = &h_recs[f];
     fill_rec(params[f], r);
@@ -679,15 +679,23 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
     r->end_hi = (uint32_t)(offsets[f + 1] >> 32);
   }
   {
-    // coarse[c] = frame that owns point c * chunk (empty frames skipped); coarse[n_chunks] = frame of the last point
+    // coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point
     uint32_t f = 0;
     for (uint64_t ci = 0; ci < n_chunks; ++ci) {
       const uint64_t first = ci * chunk;
+      const uint64_t chunk_end = std::min<uint64_t>(first + chunk, n);
       while (f + 1 < n_frames && offsets[f + 1] <= first) ++f;
-      h_coarse[ci] = f;
+      uint32_t split = kSplitNone;
+      const uint64_t e = offsets[f + 1];
+      if (e < chunk_end) {  // frame f ends inside this chunk
+        // a second boundary inside the chunk (frame f+1 ends here too, e.g. it is tiny or empty) -> search on the device
+        const bool second = (f + 2 <= n_frames) && (f + 1 < n_frames) && offsets[f + 2] < chunk_end;
+        split = second ? kSplitSearch : (uint32_t)(e - first);
+      }
+      h_coarse[ci] = make_uint2(f, split);
     }
     while (f + 1 < n_frames && offsets[f + 1] <= n - 1) ++f;
-    h_coarse[n_chunks] = f;
+    h_coarse[n_chunks] = make_uint2(f, kSplitNone);
   }
   // one table upload on the side stream (overlaps whatever the compute stream is still running), awaited on the host
   {

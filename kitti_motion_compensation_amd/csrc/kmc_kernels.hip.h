@@ -145,23 +145,30 @@ __device__ __forceinline__ FrameRec to_frame(const BatchRec& r) {
 
 constexpr int kLdsFrames = 16;   // records staged in LDS for a tile that straddles frame boundaries
 constexpr int kChunkShift = 14;  // coarse frame table: one entry per 16384 points
+constexpr uint32_t kSplitNone = 0xFFFFFFFEu;    // no frame boundary inside the chunk
+constexpr uint32_t kSplitSearch = 0xFFFFFFFFu;  // two or more boundaries (tiny or empty frames): search
 
-// coarse[c] = index of the frame that owns point c << kChunkShift (host-computed, 4 B per 16384 points, so the
-// table and the 64-B records stay resident in the scalar cache / L2).  Per tile, wave-uniform scalar code:
-//   1. the tile's point loads are issued FIRST (their addresses do not depend on the tables), so the table
-//      look-ups below overlap the HBM latency of the points instead of preceding it;
-//   2. [coarse[c], coarse[c+1]] brackets the frame of the tile's first point; a scalar binary search over the
-//      records' end offsets narrows it (zero iterations unless a frame boundary falls into this 16384-point chunk);
-//   3. a tile that lies in ONE frame -- all but ~F of the n/kTile tiles -- takes the record through scalar loads
-//      (SGPRs) and runs the same body as the single-frame kernel;
-//   4. a straddling tile stages the next kLdsFrames records into LDS once per workgroup; each lane walks to its
-//      own frame (integer compares on the end offsets: the per-point "timestamp index", bit-exact by construction)
-//      and gathers its record from LDS; a wave whose lanes all landed in one frame broadcasts the index through
-//      readfirstlane and stays on the uniform path.
+// Coarse table, host-computed, 8 B per 16384 points (so it and the 64-B records stay resident in the scalar cache / L2):
+//   coarse[c].x = index of the frame that owns point c << kChunkShift
+//   coarse[c].y = `split`: how many points of the chunk still belong to that frame -- the ONE frame boundary that may lie
+//                 inside the chunk -- or kSplitNone, or kSplitSearch when several boundaries fall into the chunk.
+// Per tile, wave-uniform scalar code:
+//   1. the tile's point loads are issued FIRST (their addresses do not depend on the tables), so the table look-ups
+//      overlap the HBM latency of the points instead of preceding it;
+//   2. ONE 8-byte scalar load gives the frame of the tile's first point: coarse[c].x, plus one if the tile starts at or
+//      past the split.  (A dependent scalar load costs up to ~1 us under full streaming load, so the look-up chain is kept
+//      at two loads -- entry, then record -- also for the chunks that contain a boundary; the first version searched the
+//      records' end offsets there and lost 2-5 % on KITTI-sized frames.)  Only kSplitSearch chunks run a binary search;
+//   3. a tile that lies in ONE frame -- all but ~F of the n/kTile tiles -- takes the record through scalar loads (SGPRs)
+//      and runs the same body as the single-frame kernel;
+//   4. a straddling tile stages the next kLdsFrames records into LDS once per workgroup; each lane walks to its own frame
+//      (integer compares on the end offsets: the per-point "timestamp index", bit-exact by construction) and gathers its
+//      record from LDS; a wave whose lanes all landed in one frame broadcasts the index through readfirstlane and stays on
+//      the uniform path.
 template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock>
 __global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
                                                          const BatchRec* __restrict__ recs,
-                                                         const uint32_t* __restrict__ coarse, uint32_t n_frames,
+                                                         const uint2* __restrict__ coarse, uint32_t n_frames,
                                                          uint64_t n, uint32_t* __restrict__ frame_idx_out) {
   static_assert(BLOCK >= kLdsFrames * 4, "the LDS staging uses one lane per 16 bytes of the record table");
   constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
@@ -181,13 +188,19 @@ __global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict_
     }
     // frame of the tile's first point (uniform -> SALU + scalar loads)
     const uint64_t c = base >> kChunkShift;
-    uint32_t lo = coarse[c], hi = coarse[c + 1];
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (rec_end(recs[mid]) > base) hi = mid;
-      else lo = mid + 1;
+    const uint2 entry = coarse[c];  // one s_load_dwordx2
+    uint32_t f0;
+    if (entry.y != kSplitSearch) {
+      f0 = entry.x + ((uint32_t)(base - (c << kChunkShift)) >= entry.y ? 1u : 0u);
+    } else {
+      uint32_t lo = entry.x, hi = coarse[c + 1].x;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rec_end(recs[mid]) > base) hi = mid;
+        else lo = mid + 1;
+      }
+      f0 = lo;
     }
-    const uint32_t f0 = lo;
     const BatchRec r0 = recs[f0];
     if (full && rec_end(r0) >= tile_end) {
       const FrameRec f = to_frame(r0);

@@ -313,7 +313,7 @@ static Variant copy_variant(const char* label) {
 // batched kernel: tables for `frames` equal frames over n points
 struct BatchTables {
   BatchRec* d_recs = nullptr;
-  uint32_t* d_coarse = nullptr;
+  uint2* d_coarse = nullptr;
   uint32_t n_frames = 0;
 };
 static BatchTables g_bt_big, g_bt_small;
@@ -335,11 +335,18 @@ static void build_tables(BatchTables* bt, uint64_t n, uint64_t pts_per_frame) {
   CK(hipMemcpy(bt->d_recs, recs.data(), nf * sizeof(BatchRec), hipMemcpyHostToDevice));
   {
     const uint64_t chunk = 1ull << kChunkShift, nc = (n + chunk - 1) / chunk;
-    std::vector<uint32_t> co(nc + 1);
-    for (uint64_t c = 0; c < nc; ++c) co[c] = (uint32_t)((c * chunk) / pts_per_frame);
-    co[nc] = (uint32_t)((n - 1) / pts_per_frame);
-    CK(hipMalloc((void**)&bt->d_coarse, (nc + 1) * sizeof(uint32_t)));
-    CK(hipMemcpy(bt->d_coarse, co.data(), (nc + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::vector<uint2> co(nc + 1);
+    for (uint64_t c = 0; c < nc; ++c) {
+      const uint64_t first = c * chunk, chunk_end = std::min<uint64_t>(first + chunk, n);
+      const uint32_t f = (uint32_t)(first / pts_per_frame);
+      const uint64_t e = std::min<uint64_t>(n, (uint64_t)(f + 1) * pts_per_frame);
+      uint32_t split = kSplitNone;
+      if (e < chunk_end) split = (std::min<uint64_t>(n, (uint64_t)(f + 2) * pts_per_frame) < chunk_end) ? kSplitSearch : (uint32_t)(e - first);
+      co[c] = make_uint2(f, split);
+    }
+    co[nc] = make_uint2((uint32_t)((n - 1) / pts_per_frame), kSplitNone);
+    CK(hipMalloc((void**)&bt->d_coarse, (nc + 1) * sizeof(uint2)));
+    CK(hipMemcpy(bt->d_coarse, co.data(), (nc + 1) * sizeof(uint2), hipMemcpyHostToDevice));
   }
   bt->n_frames = nf;
 }
