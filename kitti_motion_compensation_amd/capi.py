@@ -101,6 +101,8 @@ SIGNATURES = {
     "kmc_hip_force_tier": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_timer_begin": (C.c_int, [_vp]),
     "kmc_hip_timer_end": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "kmc_hip_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "kmc_hip_host_free": (C.c_int, [_vp, _vp]),
     "kmc_frame_params_from_poses": (C.c_int, [_dp, _dp, C.c_double, C.c_double, C.c_double, C.POINTER(FrameParams)]),
     "kmc_oxts_to_pose": (C.c_int, [C.POINTER(Oxts), C.c_double, _dp]),
     "kmc_interpolate_trajectory": (C.c_int, [C.POINTER(Oxts), C.POINTER(Oxts), C.c_double, _dp]),

@@ -25,6 +25,7 @@
 #include "kitti_motion_compensation/timestamp_mocking.hpp"
 #include "kitti_motion_compensation/trajectory_interpolation.hpp"
 #include "kitti_motion_compensation/utils.hpp"
+#include "kmc_api_internal.hpp"
 
 namespace kmc {
 
@@ -203,17 +204,38 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
   std::vector<Oxts> oxts(n_frames);
   for (std::size_t i = 0; i < n_frames; ++i) oxts[i] = LoadOxtsWithStamp(run_folder, i, t_oxts[i]);
 
+  // Batches of <= 64 frames; the .bin payloads are read STRAIGHT into page-locked memory (the on-disk layout is the
+  // kernel's layout, so there is no conversion and no extra copy) and the results are written from page-locked memory.
   constexpr std::size_t kMaxBatchFrames = 64;
-  std::vector<float> in, out;
+  struct Pinned {
+    kmc_ctx* ctx = nullptr;
+    float* p = nullptr;
+    std::size_t floats = 0;
+    ~Pinned() { if (p) kmc_hip_host_free(ctx, p); }
+    void reserve(kmc_ctx* c, std::size_t n_floats) {
+      if (n_floats <= floats) return;
+      if (p) kmc_hip_host_free(ctx, p);
+      ctx = c; p = nullptr; floats = 0;
+      void* q = nullptr;
+      int const rc = kmc_hip_host_alloc(c, n_floats * sizeof(float), &q);
+      if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_host_alloc", c);
+      p = static_cast<float*>(q);
+      floats = n_floats;
+    }
+  } in, out;
+  kmc_ctx* ctx = detail::thread_context();
   for (std::size_t b0 = 1; b0 + 1 < n_frames; b0 += kMaxBatchFrames) {
     std::size_t const b1 = std::min(b0 + kMaxBatchFrames, n_frames - 1);
     std::vector<std::uint64_t> offsets{0};
     std::vector<hip::FramePoses> frames;
-    in.clear();
+    std::vector<Path> files;
     for (std::size_t i = b0; i < b1; ++i) {
-      std::vector<float> const raw = KittiPclLoader::LoadRaw(velodyne / Path("data/" + IdToZeroPaddedString(i) + ".bin"));
-      in.insert(in.end(), raw.begin(), raw.end());
-      offsets.push_back(in.size() / 4);
+      files.push_back(velodyne / Path("data/" + IdToZeroPaddedString(i) + ".bin"));
+      std::error_code ec;
+      auto const bytes = fs::file_size(files.back(), ec);
+      if (ec) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + files.back().string());
+      if (bytes % 4 != 0) throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + files.back().string());
+      offsets.push_back(offsets.back() + bytes / 16);
       // MakeFrame (data_io.cpp:253-269) + requested_time = stamp_middle (handlers.cpp:59)
       hip::FramePoses fp;
       fp.T_start = trajectory_interpolation::InterpolateTrajectory(oxts[i - 1], oxts[i], t_start[i]);
@@ -223,11 +245,18 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
       fp.requested_time = t_mid[i];
       frames.push_back(fp);
     }
-    out.resize(in.size());
-    hip::MotionCompensateKittiClouds(in.data(), offsets, frames, out.data());
+    std::size_t const total = static_cast<std::size_t>(offsets.back());
+    in.reserve(ctx, 4 * total + 16);
+    out.reserve(ctx, 4 * total + 16);
+    for (std::size_t k = 0; k < files.size(); ++k) {
+      std::ifstream is{files[k], std::ios::in | std::ios::binary};
+      if (!is.is_open()) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + files[k].string());
+      is.read(reinterpret_cast<char*>(in.p + 4 * offsets[k]), static_cast<std::streamsize>((offsets[k + 1] - offsets[k]) * 16));
+    }
+    hip::MotionCompensateKittiClouds(in.p, offsets, frames, out.p);
     for (std::size_t i = b0; i < b1; ++i) {
       std::size_t const k = i - b0;
-      WriteRaw(out_dir, i, out.data() + 4 * offsets[k], static_cast<std::size_t>(offsets[k + 1] - offsets[k]));
+      WriteRaw(out_dir, i, out.p + 4 * offsets[k], static_cast<std::size_t>(offsets[k + 1] - offsets[k]));
       std::cout << "Motion compensated pointcloud number: " << i << std::endl;  // handlers.cpp:63
     }
   }

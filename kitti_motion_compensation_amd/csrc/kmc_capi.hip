@@ -536,6 +536,21 @@ int kmc_hip_timer_end(kmc_ctx* c, float* elapsed_ms) {
   return KMC_OK;
 }
 
+int kmc_hip_host_alloc(kmc_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return KMC_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (bytes == 0) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_HIP_TRY(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return KMC_OK;
+}
+
+int kmc_hip_host_free(kmc_ctx* c, void* ptr) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  if (ptr) KMC_HIP_TRY(c, hipHostFree(ptr));
+  return KMC_OK;
+}
+
 // ---- host pre-step -------------------------------------------------------------------------------
 int kmc_frame_params_from_poses(const double T_start[12], const double T_end[12], double stamp_start, double stamp_end,
                                 double requested_time, kmc_frame_params* out) {
