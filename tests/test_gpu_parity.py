@@ -572,3 +572,67 @@ def test_throughput_guard_batched_kernel(torch_mod, ctx):
     gbps = 32.0 * n / (best * 1e-3) / 1e9
     print(f"batched kernel: {best * 1e3:.1f} us per 64 M points = {gbps:.0f} GB/s")
     assert gbps > 5000, gbps
+
+
+def test_config3_drive_twin_with_real_cadence(torch_mod, ctx, golden_dir):
+    """BASELINE.json configs[2] twin: 108 frames at the REAL cadence of the shipped
+    timestamps*.txt, OXTS packets along a constant-twist track (13 m/s, 0.3 rad/s yaw rate, small roll/pitch rates), every
+    interior frame through the whole host pre-step (OxtsToPose -> InterpolateTrajectory -> MakeFrame -> Log) and ONE batched
+    launch; checked frame by frame against the oracle's own MakeFrame + faithful loop."""
+    torch = torch_mod
+    run = os.path.join(golden_dir, "kitti_2011_09_26_drive_0005")
+    n_frames = 108
+    vp = os.path.join(run, "velodyne_points")
+    t_start = [util.load_timestamp(os.path.join(vp, "timestamps_start.txt"), i) for i in range(n_frames)]
+    t_mid = [util.load_timestamp(os.path.join(vp, "timestamps.txt"), i) for i in range(n_frames)]
+    t_end = [util.load_timestamp(os.path.join(vp, "timestamps_end.txt"), i) for i in range(n_frames)]
+    t_oxts = [util.load_timestamp(os.path.join(run, "oxts", "timestamps.txt"), i) for i in range(n_frames)]
+    f0 = util.load_oxts_fields(run, 0)
+    # constant-twist track integrated at the OXTS stamps (Mercator inverse of a local east/north path)
+    R_E = 6378137.0
+    lat0, lon0, yaw0 = f0["lat"], f0["lon"], f0["yaw"]
+    north0 = R_E * np.log(np.tan(np.pi * (90.0 + lat0) / 360.0))
+    east0 = R_E * np.pi * lon0 / 180.0
+    oxts = []
+    for i in range(n_frames):
+        dt = t_oxts[i] - t_oxts[0]
+        yaw = yaw0 + 0.3 * dt
+        # arc of radius v / omega
+        east = east0 + (13.0 / 0.3) * (np.sin(yaw) - np.sin(yaw0))
+        north = north0 - (13.0 / 0.3) * (np.cos(yaw) - np.cos(yaw0))
+        lat = 360.0 / np.pi * np.arctan(np.exp(north / R_E)) - 90.0
+        lon = east * 180.0 / (np.pi * R_E)
+        oxts.append(dict(stamp=t_oxts[i], lat=lat, lon=lon, alt=f0["alt"] + 0.02 * dt, roll=f0["roll"] + 0.01 * dt, pitch=f0["pitch"] - 0.008 * dt, yaw=yaw))
+    rng = np.random.default_rng(11)
+    xyzi_all = util.load_velodyne_bin(run, 0)
+    frames, params, refs, sizes = [], [], [], []
+    for i in range(1, n_frames - 1):  # handlers.cpp:55: frames 1 .. n-2
+        n = int(np.clip(rng.normal(12_100, 300), 9_000, 14_000))  # a tenth of KITTI's ~121 k so that the oracle stays quick
+        pts = np.ascontiguousarray(xyzi_all[rng.integers(0, xyzi_all.shape[0], size=n)])
+        co = [capi.Oxts(**oxts[i + d]) for d in (-1, 0, 1)]
+        T_s, T_e = capi.make_frame_poses(co[0], co[1], co[2], t_start[i], t_end[i])
+        params.append(capi.frame_params_from_poses(T_s, T_e, t_start[i], t_end[i], t_mid[i]))  # requested = stamp_middle, handlers.cpp:59
+        oo = [orc.oxts(**oxts[i + d]) for d in (-1, 0, 1)]
+        rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t_start[i], t_end[i])
+        assert rc == orc.OK
+        r = orc.deskew_xyzi_f32(pts, t_start[i], A, t_end[i], B, t_mid[i], mode=orc.FAITHFUL)
+        assert r["rc"] == orc.OK
+        frames.append(pts)
+        refs.append(r["xyz_f64"])
+        sizes.append(n)
+    xyzi = np.concatenate(frames)
+    ref = np.concatenate(refs)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    d_in = torch.from_numpy(xyzi).cuda()
+    d_out = torch.empty_like(d_in)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    st = ctx.deskew_batch_f32(d_in, d_out, offsets, params, None)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert st.n_points == xyzi.shape[0] and st.variant == capi.TIER_SERIES3
+    err = util.rel_point_error(got[:, :3], ref)
+    assert err.max() <= REL_TOL, err.max()
+    assert np.array_equal(got[:, 3], xyzi[:, 3])
+    # the vehicle really moves: the correction is far above the tolerance (so the test cannot pass vacuously)
+    moved = np.linalg.norm(got[:, :3].astype(np.float64) - xyzi[:, :3], axis=1)
+    assert moved.max() > 0.5
