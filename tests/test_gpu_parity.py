@@ -582,27 +582,7 @@ def test_config3_drive_twin_with_real_cadence(torch_mod, ctx, golden_dir):
     torch = torch_mod
     run = os.path.join(golden_dir, "kitti_2011_09_26_drive_0005")
     n_frames = 108
-    vp = os.path.join(run, "velodyne_points")
-    t_start = [util.load_timestamp(os.path.join(vp, "timestamps_start.txt"), i) for i in range(n_frames)]
-    t_mid = [util.load_timestamp(os.path.join(vp, "timestamps.txt"), i) for i in range(n_frames)]
-    t_end = [util.load_timestamp(os.path.join(vp, "timestamps_end.txt"), i) for i in range(n_frames)]
-    t_oxts = [util.load_timestamp(os.path.join(run, "oxts", "timestamps.txt"), i) for i in range(n_frames)]
-    f0 = util.load_oxts_fields(run, 0)
-    # constant-twist track integrated at the OXTS stamps (Mercator inverse of a local east/north path)
-    R_E = 6378137.0
-    lat0, lon0, yaw0 = f0["lat"], f0["lon"], f0["yaw"]
-    north0 = R_E * np.log(np.tan(np.pi * (90.0 + lat0) / 360.0))
-    east0 = R_E * np.pi * lon0 / 180.0
-    oxts = []
-    for i in range(n_frames):
-        dt = t_oxts[i] - t_oxts[0]
-        yaw = yaw0 + 0.3 * dt
-        # arc of radius v / omega
-        east = east0 + (13.0 / 0.3) * (np.sin(yaw) - np.sin(yaw0))
-        north = north0 - (13.0 / 0.3) * (np.cos(yaw) - np.cos(yaw0))
-        lat = 360.0 / np.pi * np.arctan(np.exp(north / R_E)) - 90.0
-        lon = east * 180.0 / (np.pi * R_E)
-        oxts.append(dict(stamp=t_oxts[i], lat=lat, lon=lon, alt=f0["alt"] + 0.02 * dt, roll=f0["roll"] + 0.01 * dt, pitch=f0["pitch"] - 0.008 * dt, yaw=yaw))
+    t_start, t_mid, t_end, oxts = util.real_cadence_drive(run, n_frames)
     rng = np.random.default_rng(11)
     xyzi_all = util.load_velodyne_bin(run, 0)
     frames, params, refs, sizes = [], [], [], []

@@ -111,3 +111,25 @@ def test_synth_points_host_is_deterministic_and_shaped():
     steps = (100_000 + 63) // 64
     assert np.all(np.diff(frac[:steps]) > -1e-6)  # one ring sweeps the scan in order
     assert set(np.round(a[:, 3] * 100).astype(int)) <= set(range(100))
+
+
+def test_make_frame_and_twist_on_a_real_cadence_drive(golden_dir):
+    """Every interior frame of the config-3 twin (real KITTI cadence, OXTS on a 13 m/s, 0.3 rad/s arc): the product's
+    OxtsToPose -> InterpolateTrajectory -> MakeFrame -> Log chain against the oracle's, frame by frame."""
+    run = os.path.join(golden_dir, "kitti_2011_09_26_drive_0005")
+    t_start, t_mid, t_end, oxts = util.real_cadence_drive(run, 108)
+    for i in range(1, 107):
+        co = [capi.Oxts(**oxts[i + d]) for d in (-1, 0, 1)]
+        T_s, T_e = capi.make_frame_poses(co[0], co[1], co[2], t_start[i], t_end[i])
+        p = capi.frame_params_from_poses(T_s, T_e, t_start[i], t_end[i], t_mid[i])
+        oo = [orc.oxts(**oxts[i + d]) for d in (-1, 0, 1)]
+        rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t_start[i], t_end[i])
+        assert rc == orc.OK
+        assert np.allclose(T_s[:, :3], A.Rm(), atol=1e-12) and np.allclose(T_e[:, :3], B.Rm(), atol=1e-12)
+        assert np.allclose(T_s[:, 3], A.tv(), atol=5e-9) and np.allclose(T_e[:, 3], B.tv(), atol=5e-9)
+        want = _oracle_twist(A, B)
+        assert np.allclose(p.twist_np()[:3], want[:3], atol=1e-8), i
+        assert np.allclose(p.twist_np()[3:], want[3:], atol=1e-11), i
+        # the scan lasts ~0.1033 s on a 13 m/s, 0.3 rad/s arc
+        assert 1.2 < np.linalg.norm(p.twist_np()[:3]) < 1.5 and 0.028 < np.linalg.norm(p.twist_np()[3:]) < 0.034
+        assert 0.45 < p.x_req < 0.55

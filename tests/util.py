@@ -67,3 +67,27 @@ def rel_point_error(p, ref):
     p = np.asarray(p, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     return np.linalg.norm(p - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-3)
+
+
+def real_cadence_drive(run_dir, n_frames=108, speed=13.0, yaw_rate=0.3):
+    """SURVEY.md section 8(d) config 3 twin: the shipped timestamps*.txt (real KITTI cadence) and OXTS packets placed on a
+    constant-twist track (arc of radius speed / yaw_rate, small roll / pitch / altitude rates), through the inverse of the
+    Mercator map that OxtsToPose applies.  Returns (t_start, t_mid, t_end, oxts_dicts)."""
+    vp = os.path.join(run_dir, "velodyne_points")
+    t_start = [load_timestamp(os.path.join(vp, "timestamps_start.txt"), i) for i in range(n_frames)]
+    t_mid = [load_timestamp(os.path.join(vp, "timestamps.txt"), i) for i in range(n_frames)]
+    t_end = [load_timestamp(os.path.join(vp, "timestamps_end.txt"), i) for i in range(n_frames)]
+    t_oxts = [load_timestamp(os.path.join(run_dir, "oxts", "timestamps.txt"), i) for i in range(n_frames)]
+    f0 = load_oxts_fields(run_dir, 0)
+    R_E = 6378137.0
+    north0 = R_E * np.log(np.tan(np.pi * (90.0 + f0["lat"]) / 360.0))
+    east0 = R_E * np.pi * f0["lon"] / 180.0
+    oxts = []
+    for i in range(n_frames):
+        dt = t_oxts[i] - t_oxts[0]
+        yaw = f0["yaw"] + yaw_rate * dt
+        east = east0 + (speed / yaw_rate) * (np.sin(yaw) - np.sin(f0["yaw"]))
+        north = north0 - (speed / yaw_rate) * (np.cos(yaw) - np.cos(f0["yaw"]))
+        oxts.append(dict(stamp=t_oxts[i], lat=360.0 / np.pi * np.arctan(np.exp(north / R_E)) - 90.0, lon=east * 180.0 / (np.pi * R_E),
+                         alt=f0["alt"] + 0.02 * dt, roll=f0["roll"] + 0.01 * dt, pitch=f0["pitch"] - 0.008 * dt, yaw=yaw))
+    return t_start, t_mid, t_end, oxts
