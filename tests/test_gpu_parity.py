@@ -616,3 +616,40 @@ def test_config3_drive_twin_with_real_cadence(torch_mod, ctx, golden_dir):
     # the vehicle really moves: the correction is far above the tolerance (so the test cannot pass vacuously)
     moved = np.linalg.norm(got[:, :3].astype(np.float64) - xyzi[:, :3], axis=1)
     assert moved.max() > 0.5
+
+
+def test_batch_frame_index_fuzz(torch_mod, ctx):
+    """Randomised offsets -- empty frames, runs of empties, 1-point frames, tile-aligned and chunk-aligned frames, frames
+    far larger than a 16384-point chunk -- through the coarse table / split / search / LDS-walk logic: the per-point frame
+    index must equal numpy.searchsorted on the offsets, bit for bit, and a zero twist must hand every point back."""
+    torch = torch_mod
+    rng = np.random.default_rng(20240928)
+    ident = capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    pool = torch.empty((400_000, 4), dtype=torch.float32, device="cuda")
+    ctx.synth_points(pool, pool.shape[0], 31337)
+    for case in range(120):
+        n_frames = int(rng.integers(1, 400))
+        kind = rng.integers(0, 6, size=n_frames)
+        sizes = np.where(kind == 0, 0,
+                 np.where(kind == 1, rng.integers(1, 6, size=n_frames),
+                 np.where(kind == 2, 64 * rng.integers(1, 40, size=n_frames),
+                 np.where(kind == 3, 16384 * rng.integers(1, 3, size=n_frames),
+                 np.where(kind == 4, rng.integers(1, 3000, size=n_frames), rng.integers(10_000, 60_000, size=n_frames))))))
+        while sizes.sum() > pool.shape[0]:
+            sizes[np.argmax(sizes)] //= 2
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        n = int(offsets[-1])
+        if n == 0:
+            continue
+        d_out = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")
+        d_idx = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
+        ctx.set_launch_config(int(rng.integers(0, 3)), int(rng.choice([1, 2, 4])))
+        ctx.deskew_batch_f32(pool[:n], d_out, offsets, [ident] * n_frames, d_idx)
+        torch.cuda.synchronize()
+        want = (np.searchsorted(offsets, np.arange(n, dtype=np.uint64), side="right") - 1).astype(np.int32)
+        got = d_idx[:n].cpu().numpy()
+        assert np.array_equal(got, want), (case, n_frames, int(np.flatnonzero(got != want)[0]))
+        assert torch.equal(d_out[:n], pool[:n]), case
+        assert bool((d_out[n:] == 7.0).all()) and bool((d_idx[n:] == -1).all()), case
+    ctx.set_launch_config(0, 0)
