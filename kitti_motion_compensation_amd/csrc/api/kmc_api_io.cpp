@@ -12,6 +12,11 @@
 //     slip of writing the FIRST frame's points under the LAST frame's id (handlers.cpp:36-38); set
 //     KMC_FIX_LAST_FRAME_COPY=1 to write the last frame's own points instead.
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -204,62 +209,156 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
   std::vector<Oxts> oxts(n_frames);
   for (std::size_t i = 0; i < n_frames; ++i) oxts[i] = LoadOxtsWithStamp(run_folder, i, t_oxts[i]);
 
-  // Batches of <= 64 frames; the .bin payloads are read STRAIGHT into page-locked memory (the on-disk layout is the
-  // kernel's layout, so there is no conversion and no extra copy) and the results are written from page-locked memory.
-  constexpr std::size_t kMaxBatchFrames = 64;
+  // Batches of <= 64 frames through a three-stage pipeline on two page-locked buffer sets:
+  //   reader thread : .bin payloads read STRAIGHT into pinned memory (the on-disk layout is the kernel's layout: no
+  //                   conversion, no extra copy) + the per-frame poses (MakeFrame, data_io.cpp:253-269)
+  //   this thread   : one batched GPU call per buffer set (H2D, kernel, D2H)
+  //   writer thread : results written from pinned memory
+  // so reading batch k+1, deskewing batch k and writing batch k-1 overlap.  KMC_RUN_TIMING=1 prints the busy time per stage.
+  std::size_t const kMaxBatchFrames = [] {  // page-locking costs ~0.3 ms/MiB, so modest batches win for one-off runs
+    char const* e = std::getenv("KMC_RUN_BATCH_FRAMES");
+    long const v = e ? std::atol(e) : 0;
+    return static_cast<std::size_t>(v > 0 ? std::min(v, 4096L) : 16L);
+  }();
   struct Pinned {
     kmc_ctx* ctx = nullptr;
     float* p = nullptr;
-    std::size_t floats = 0;
     ~Pinned() { if (p) kmc_hip_host_free(ctx, p); }
-    void reserve(kmc_ctx* c, std::size_t n_floats) {
-      if (n_floats <= floats) return;
-      if (p) kmc_hip_host_free(ctx, p);
-      ctx = c; p = nullptr; floats = 0;
+    void alloc(kmc_ctx* c, std::size_t n_floats) {
       void* q = nullptr;
       int const rc = kmc_hip_host_alloc(c, n_floats * sizeof(float), &q);
       if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_host_alloc", c);
+      ctx = c;
       p = static_cast<float*>(q);
-      floats = n_floats;
     }
-  } in, out;
-  kmc_ctx* ctx = detail::thread_context();
-  for (std::size_t b0 = 1; b0 + 1 < n_frames; b0 += kMaxBatchFrames) {
-    std::size_t const b1 = std::min(b0 + kMaxBatchFrames, n_frames - 1);
-    std::vector<std::uint64_t> offsets{0};
-    std::vector<hip::FramePoses> frames;
+  };
+  struct BatchPlan {
+    std::size_t first = 0, last = 0;  // frames [first, last)
+    std::vector<std::uint64_t> offsets;
     std::vector<Path> files;
-    for (std::size_t i = b0; i < b1; ++i) {
-      files.push_back(velodyne / Path("data/" + IdToZeroPaddedString(i) + ".bin"));
+  };
+  enum class State { kFree, kReady, kDone };
+  struct BufferSet {
+    Pinned in, out;
+    State state = State::kFree;
+    std::vector<hip::FramePoses> frames;
+  };
+
+  bool const timing = [] { char const* e = std::getenv("KMC_RUN_TIMING"); return e && e[0] == '1'; }();
+  using clk = std::chrono::steady_clock;
+  auto const secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+
+  // plan: file sizes decide the batch boundaries and the buffer size
+  std::vector<BatchPlan> plans;
+  std::size_t max_points = 0;
+  for (std::size_t b0 = 1; b0 + 1 < n_frames; b0 += kMaxBatchFrames) {
+    BatchPlan plan;
+    plan.first = b0;
+    plan.last = std::min(b0 + kMaxBatchFrames, n_frames - 1);
+    plan.offsets.push_back(0);
+    for (std::size_t i = plan.first; i < plan.last; ++i) {
+      plan.files.push_back(velodyne / Path("data/" + IdToZeroPaddedString(i) + ".bin"));
       std::error_code ec;
-      auto const bytes = fs::file_size(files.back(), ec);
-      if (ec) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + files.back().string());
-      if (bytes % 4 != 0) throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + files.back().string());
-      offsets.push_back(offsets.back() + bytes / 16);
-      // MakeFrame (data_io.cpp:253-269) + requested_time = stamp_middle (handlers.cpp:59)
-      hip::FramePoses fp;
-      fp.T_start = trajectory_interpolation::InterpolateTrajectory(oxts[i - 1], oxts[i], t_start[i]);
-      fp.T_end = trajectory_interpolation::InterpolateTrajectory(oxts[i], oxts[i + 1], t_end[i]);
-      fp.stamp_start = t_start[i];
-      fp.stamp_end = t_end[i];
-      fp.requested_time = t_mid[i];
-      frames.push_back(fp);
+      auto const bytes = fs::file_size(plan.files.back(), ec);
+      if (ec) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + plan.files.back().string());
+      if (bytes % 4 != 0) throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + plan.files.back().string());
+      plan.offsets.push_back(plan.offsets.back() + bytes / 16);
     }
-    std::size_t const total = static_cast<std::size_t>(offsets.back());
-    in.reserve(ctx, 4 * total + 16);
-    out.reserve(ctx, 4 * total + 16);
-    for (std::size_t k = 0; k < files.size(); ++k) {
-      std::ifstream is{files[k], std::ios::in | std::ios::binary};
-      if (!is.is_open()) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + files[k].string());
-      is.read(reinterpret_cast<char*>(in.p + 4 * offsets[k]), static_cast<std::streamsize>((offsets[k + 1] - offsets[k]) * 16));
-    }
-    hip::MotionCompensateKittiClouds(in.p, offsets, frames, out.p);
-    for (std::size_t i = b0; i < b1; ++i) {
-      std::size_t const k = i - b0;
-      WriteRaw(out_dir, i, out.p + 4 * offsets[k], static_cast<std::size_t>(offsets[k + 1] - offsets[k]));
-      std::cout << "Motion compensated pointcloud number: " << i << std::endl;  // handlers.cpp:63
-    }
+    max_points = std::max<std::size_t>(max_points, static_cast<std::size_t>(plan.offsets.back()));
+    plans.push_back(std::move(plan));
   }
+
+  auto const t_ctx0 = clk::now();
+  kmc_ctx* ctx = detail::thread_context();
+  BufferSet sets[2];
+  for (auto& set : sets) {
+    set.in.alloc(ctx, 4 * max_points + 16);
+    set.out.alloc(ctx, 4 * max_points + 16);
+  }
+  double const t_ctx = secs(t_ctx0, clk::now());
+
+  std::mutex mu;
+  std::condition_variable cv;
+  std::exception_ptr failure;
+  double t_read = 0, t_gpu = 0, t_write = 0;
+  auto const wait_for = [&](BufferSet& set, State wanted) {
+    std::unique_lock<std::mutex> lock(mu);
+    cv.wait(lock, [&] { return set.state == wanted || failure; });
+    return !failure;
+  };
+  auto const publish = [&](BufferSet& set, State next) {
+    { std::lock_guard<std::mutex> lock(mu); set.state = next; }
+    cv.notify_all();
+  };
+  auto const fail = [&](std::exception_ptr e) {
+    { std::lock_guard<std::mutex> lock(mu); if (!failure) failure = e; }
+    cv.notify_all();
+  };
+
+  std::thread reader([&] {
+    try {
+      for (std::size_t k = 0; k < plans.size(); ++k) {
+        BufferSet& set = sets[k % 2];
+        BatchPlan const& plan = plans[k];
+        if (!wait_for(set, State::kFree)) return;
+        auto const t0 = clk::now();
+        set.frames.clear();
+        for (std::size_t j = 0; j < plan.files.size(); ++j) {
+          std::size_t const i = plan.first + j;
+          std::ifstream is{plan.files[j], std::ios::in | std::ios::binary};
+          if (!is.is_open()) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + plan.files[j].string());
+          is.read(reinterpret_cast<char*>(set.in.p + 4 * plan.offsets[j]), static_cast<std::streamsize>((plan.offsets[j + 1] - plan.offsets[j]) * 16));
+          hip::FramePoses fp;  // MakeFrame (data_io.cpp:253-269) + requested_time = stamp_middle (handlers.cpp:59)
+          fp.T_start = trajectory_interpolation::InterpolateTrajectory(oxts[i - 1], oxts[i], t_start[i]);
+          fp.T_end = trajectory_interpolation::InterpolateTrajectory(oxts[i], oxts[i + 1], t_end[i]);
+          fp.stamp_start = t_start[i];
+          fp.stamp_end = t_end[i];
+          fp.requested_time = t_mid[i];
+          set.frames.push_back(fp);
+        }
+        t_read += secs(t0, clk::now());
+        publish(set, State::kReady);
+      }
+    } catch (...) {
+      fail(std::current_exception());
+    }
+  });
+  std::thread writer([&] {
+    try {
+      for (std::size_t k = 0; k < plans.size(); ++k) {
+        BufferSet& set = sets[k % 2];
+        BatchPlan const& plan = plans[k];
+        if (!wait_for(set, State::kDone)) return;
+        auto const t0 = clk::now();
+        for (std::size_t j = 0; j < plan.files.size(); ++j) {
+          WriteRaw(out_dir, plan.first + j, set.out.p + 4 * plan.offsets[j], static_cast<std::size_t>(plan.offsets[j + 1] - plan.offsets[j]));
+          std::cout << "Motion compensated pointcloud number: " << plan.first + j << std::endl;  // handlers.cpp:63
+        }
+        t_write += secs(t0, clk::now());
+        publish(set, State::kFree);
+      }
+    } catch (...) {
+      fail(std::current_exception());
+    }
+  });
+  try {
+    for (std::size_t k = 0; k < plans.size(); ++k) {
+      BufferSet& set = sets[k % 2];
+      if (!wait_for(set, State::kReady)) break;
+      auto const t0 = clk::now();
+      hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.frames, set.out.p);
+      t_gpu += secs(t0, clk::now());
+      publish(set, State::kDone);
+    }
+  } catch (...) {
+    fail(std::current_exception());
+  }
+  reader.join();
+  writer.join();
+  if (failure) std::rethrow_exception(failure);
+  if (timing)
+    std::cerr << "kmc run timing, busy seconds per stage: context+pinned " << t_ctx << "  read " << t_read << "  gpu round trip " << t_gpu
+              << "  write " << t_write << "\n";
 }
 
 }  // namespace kmc
