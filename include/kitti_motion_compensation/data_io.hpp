@@ -1,8 +1,10 @@
 // data_io.hpp -- the producers and consumers either side of the hot path (reference include/.../data_io.hpp), minus the
-// image / calibration loaders (OpenCV, visualization only).  Host code; see SURVEY.md section 8(f) rows N1 and N2.
+// image loaders (OpenCV).  Host code; see SURVEY.md section 8(f) rows N1 and N2.
 #pragma once
 
+#include <string>
 #include <tuple>
+#include <vector>
 
 #include "kitti_motion_compensation/data_types.hpp"
 
@@ -32,4 +34,17 @@ void WritePointcloud(Path const data_folder, std::size_t const frame_id, Pointcl
                      VectorXd const& intensities);                        // :287-313
 void WriteRaw(Path const data_folder, std::size_t const frame_id, float const* xyzi, std::size_t num_points);
 
+// calib_velo_to_cam.txt (to_cam) or calib_imu_to_velo.txt: [R|T] as an Affine3d.  data_io.cpp:168-210
+Affine3d LoadLidarExtrinsics(Path const data_folder, bool const to_cam = true);
+
 }  // namespace kmc
+
+namespace kmc::viz {
+
+// The eight lines S_xx, K_xx, D_xx, R_xx, T_xx, S_rect_xx, R_rect_xx, P_rect_xx of one camera.  data_io.cpp:321-373
+CameraCalibration CalibrationLinesToCalibration(std::vector<std::string> const calibration_lines);
+// calib_cam_to_cam.txt: two header lines, then four blocks of eight.  data_io.cpp:375-406.  An unreadable file throws
+// (the reference prints and calls exit(0)).
+CameraCalibrations LoadCameraCalibrations(Path const data_folder);
+
+}  // namespace kmc::viz

@@ -207,5 +207,36 @@ struct Frame {  // data_types.hpp:76-91 (without the optional camera images)
 
 }  // namespace kmc
 
+// ---- camera calibration (data_types.hpp:96-116 of the reference), for the projection row N4 -------------------------
+namespace kmc::viz {
+
+struct Vector2d {
+  double v[2]{0, 0};
+  double& operator()(Index i) { return v[i]; }
+  double operator()(Index i) const { return v[i]; }
+};
+struct Matrix34d {  // Eigen::Matrix<double, 3, 4>
+  double m[3][4]{{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  double& operator()(Index i, Index j) { return m[i][j]; }
+  double operator()(Index i, Index j) const { return m[i][j]; }
+};
+using P = Matrix34d;  // pinhole projection matrix
+
+struct CameraCalibration {  // one S_xx .. P_rect_xx block of calib_cam_to_cam.txt
+  Vector2d S;
+  Matrix3d K;
+  double D[5]{0, 0, 0, 0, 0};
+  Matrix3d R;
+  Vector3d T;
+  Vector2d S_rect;
+  Matrix3d R_rect;
+  P P_rect;
+};
+struct CameraCalibrations {
+  CameraCalibration camera_00, camera_01, camera_02, camera_03;
+};
+
+}  // namespace kmc::viz
+
 // BASELINE.json's north_star names the namespace in full; the reference code uses `kmc`.
 namespace kitti_motion_compensation = kmc;

@@ -204,6 +204,36 @@ int kmc_hip_pseudo_timestamps_f64(kmc_ctx* ctx, const double* x, const double* y
                                   double scan_end, double* stamps_out, int mem_kind);
 
 /* ------------------------------------------------------------------------------------------------
+ * next row N4: LiDAR -> image projection   (replaces the arithmetic of camera_model.cpp:5-95; the cv::circle
+ * drawing itself stays with the caller)
+ * ---------------------------------------------------------------------------------------------- */
+/* The calibration the reference passes around as (CameraCalibrations, Affine3d tf_c00_lo) -- camera_model.hpp:10-11. */
+typedef struct kmc_camera_rig {
+  double tf_c00_lo[12]; /* row-major 3x4 velodyne -> camera 00 (LoadLidarExtrinsics, data_io.cpp:168-210)          */
+  double R_rect_00[9];  /* row-major, CameraCalibration::R_rect of camera 00 (camera_model.cpp:78-79)              */
+  double P_rect[4][12]; /* row-major 3x4, CameraCalibration::P_rect of cameras 00..03 (camera_model.cpp:9)         */
+  double max_range;     /* camera_model.hpp:8 (default 15.0)                                                       */
+} kmc_camera_rig;
+
+/* Per point i of the cloud and camera c (f64 on the device, operation for operation like the reference, so the integers
+ * are bit-exact against the CPU oracle):
+ *   uv[(c*n + i)*2 + {0,1}]  the integer pixel cv::circle is centred on (camera_model.cpp:12, :31), or INT32_MIN twice
+ *                            when the point is skipped by camera_model.cpp:21-24 (z_rect outside [0.01, max_range] or
+ *                            y_rect > 1.25)
+ *   bgrv[4*i + {0,1,2,3}]    the 8-bit colour {255-cs, cs, 255-cs} the reference draws it with (camera_model.cpp:28-32)
+ *                            and 1, or four zeros when skipped
+ * deskew == NULL: the cloud is projected as it is.  deskew != NULL: every point is motion-compensated first exactly like
+ * kmc_hip_deskew_f32 does (fused: the cloud is read once) and, when xyzi_out != NULL, the compensated cloud is written
+ * there -- GenerateProjectionVisualizationOfRun's "project raw, compensate, project again" (handlers.cpp:77-88) in two
+ * launches.  Algorithmic bytes per point: 16 read + 36 written (+16 with xyzi_out). */
+int kmc_hip_project_f32(kmc_ctx* ctx, const float* xyzi_in, uint64_t n, const kmc_camera_rig* rig,
+                        const kmc_frame_params* deskew, float* xyzi_out, int32_t* uv, uint8_t* bgrv, int mem_kind,
+                        kmc_stats* out_stats);
+/* The same for an Eigen-layout cloud (three f64 columns): ProjectPointcloudOnFrame(frame, ...) on frame.scan.cloud. */
+int kmc_hip_project_f64cols(kmc_ctx* ctx, const double* x, const double* y, const double* z, uint64_t n,
+                            const kmc_camera_rig* rig, int32_t* uv, uint8_t* bgrv, int mem_kind, kmc_stats* out_stats);
+
+/* ------------------------------------------------------------------------------------------------
  * synthetic workload (measurement infrastructure; BASELINE.json configs 2-5 have no shippable data)
  * ---------------------------------------------------------------------------------------------- */
 /* Fills xyzi_out (DEVICE memory) with n synthetic Velodyne-like points generated on the GPU from a

@@ -72,6 +72,22 @@ class DeviceInfo(C.Structure):
     ]
 
 
+class CameraRig(C.Structure):
+    """kmc_camera_rig: the calibration of camera_model.hpp:10-11 as plain row-major doubles."""
+    _fields_ = [("tf_c00_lo", C.c_double * 12), ("R_rect_00", C.c_double * 9), ("P_rect", (C.c_double * 12) * 4),
+                ("max_range", C.c_double)]
+
+    @staticmethod
+    def make(tf_c00_lo_3x4, R_rect_00, P_rects, max_range=15.0) -> "CameraRig":
+        g = CameraRig()
+        g.tf_c00_lo[:] = [float(v) for v in np.asarray(tf_c00_lo_3x4, dtype=np.float64).reshape(12)]
+        g.R_rect_00[:] = [float(v) for v in np.asarray(R_rect_00, dtype=np.float64).reshape(9)]
+        for c in range(4):
+            g.P_rect[c][:] = [float(v) for v in np.asarray(P_rects[c], dtype=np.float64).reshape(12)]
+        g.max_range = float(max_range)
+        return g
+
+
 class KmcError(RuntimeError):
     def __init__(self, status: int, where: str, detail: str = ""):
         self.status = status
@@ -127,6 +143,11 @@ SIGNATURES = {
          C.POINTER(Stats)],
     ),
     "kmc_hip_pseudo_timestamps_f64": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, _vp, C.c_int]),
+    "kmc_hip_project_f32": (
+        C.c_int,
+        [_vp, _vp, C.c_uint64, C.POINTER(CameraRig), C.POINTER(FrameParams), _vp, _vp, _vp, C.c_int, C.POINTER(Stats)],
+    ),
+    "kmc_hip_project_f64cols": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64, C.POINTER(CameraRig), _vp, _vp, C.c_int, C.POINTER(Stats)]),
     "kmc_hip_synth_points": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "kmc_synth_points_host": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
 }
@@ -403,6 +424,26 @@ class Context:
         kind = _mem_kind(x)
         rc = lib().kmc_hip_pseudo_timestamps_f64(self._h, _ptr(x), _ptr(y), int(x.shape[0]), scan_start, scan_end, _ptr(out), kind)
         self._check(rc, "kmc_hip_pseudo_timestamps_f64")
+
+    # -- N4: projection ------------------------------------------------------------------------------
+    def project_f32(self, xyzi_in, rig: CameraRig, uv_out, bgrv_out, deskew: FrameParams = None, xyzi_out=None, n=None) -> Stats:
+        """uv_out: (4, n, 2) int32; bgrv_out: (n, 4) uint8; deskew: fuse the motion compensation in front (optional)."""
+        kind = _mem_kind(xyzi_in)
+        if n is None:
+            n = int(xyzi_in.shape[0])
+        st = Stats()
+        rc = lib().kmc_hip_project_f32(self._h, _ptr(xyzi_in, np.float32), n, C.byref(rig), C.byref(deskew) if deskew is not None else None,
+                                       _ptr(xyzi_out, np.float32), _ptr(uv_out, np.int32), _ptr(bgrv_out, np.uint8), kind, C.byref(st))
+        self._check(rc, "kmc_hip_project_f32")
+        return st
+
+    def project_f64cols(self, x, y, z, rig: CameraRig, uv_out, bgrv_out) -> Stats:
+        kind = _mem_kind(x)
+        st = Stats()
+        rc = lib().kmc_hip_project_f64cols(self._h, _ptr(x, np.float64), _ptr(y, np.float64), _ptr(z, np.float64), int(x.shape[0]),
+                                           C.byref(rig), _ptr(uv_out, np.int32), _ptr(bgrv_out, np.uint8), kind, C.byref(st))
+        self._check(rc, "kmc_hip_project_f64cols")
+        return st
 
     def synth_points(self, out_device, n, seed):
         self._check(lib().kmc_hip_synth_points(self._h, _ptr(out_device), n, seed), "kmc_hip_synth_points")

@@ -248,4 +248,109 @@ __device__ __forceinline__ void deskew_point_f64(double x, double y, double z, d
   oz = z + al * q1z + be * q2z + tz * w;
 }
 
+// ------------------------------------------------------------------------------------------------
+// next row N4: LiDAR -> image projection (camera_model.cpp:5-95 without the OpenCV drawing).
+// f64, every product and sum individually rounded in the reference's order (it builds with plain -O3: no FMA), IEEE
+// division: the integer pixel coordinates and colour bytes are BIT-EXACT against the CPU restatement the tests use.
+// ------------------------------------------------------------------------------------------------
+struct CameraRigRec {
+  double T[12];      // tf_c00_lo, row-major 3x4
+  double R[9];       // R_rect_00, row-major
+  double P[4][12];   // P_rect_0c, row-major 3x4
+  double max_range;  // camera_model.hpp:8
+  double range_den;  // max_range - 0.01, camera_model.cpp:28
+};
+using v2i = int __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int trunc_i32(double v) {  // cv::Point(double, double): cvttsd2si semantics
+  return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000;
+}
+__device__ __forceinline__ uint32_t sat_u8(double v) {  // cv::saturate_cast<uchar>(double): cvRound (half to even) + clamp
+  const double r = __builtin_rint(v);
+  return (r == r) ? (uint32_t)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r)) : 0u;
+}
+
+// (trunc(a / d), trunc(b / d)) with the IEEE quotients' values, without two IEEE divisions on the common path: the
+// quotients are first approximated through ONE refined reciprocal (relative error < 2^-45); their truncations equal the
+// exact ones unless an integer lies within that error of the approximation, i.e. unless the approximation sits within
+// 2^-36 * max(1, |q|) of an integer (or is not a finite value inside the int range, whose ends are integers too).
+// Returns whether both truncations are certain; the caller redoes the point with real divisions otherwise (about once
+// in 1e8 coordinates).
+__device__ __forceinline__ bool trunc_quotients_fast(double a, double b, double d, int& ta, int& tb) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double qa = a * r, qb = b * r;
+  constexpr double kEps = 0x1p-36;
+  const bool sure_a = __builtin_fabs(qa - __builtin_rint(qa)) > kEps * __builtin_fmax(1.0, __builtin_fabs(qa)) && __builtin_fabs(qa) < 2147483000.0;
+  const bool sure_b = __builtin_fabs(qb - __builtin_rint(qb)) > kEps * __builtin_fmax(1.0, __builtin_fabs(qb)) && __builtin_fabs(qb) < 2147483000.0;
+  ta = (int)qa;
+  tb = (int)qb;
+  return sure_a && sure_b;
+}
+
+// P_rect_c * r for one camera, :9.  STRUCTURED: the products with the literal 0s and 1 of a pinhole matrix are skipped.
+template <bool STRUCTURED>
+__device__ __forceinline__ void camera_rows(const double* P, const double r[3], double h[3]) {
+#pragma clang fp contract(off)
+  if constexpr (STRUCTURED) {
+    h[0] = (P[0] * r[0] + P[2] * r[2]) + P[3];
+    h[1] = (P[5] * r[1] + P[6] * r[2]) + P[7];
+    h[2] = r[2] + P[11];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) h[k] = ((P[4 * k] * r[0] + P[4 * k + 1] * r[1]) + P[4 * k + 2] * r[2]) + P[4 * k + 3];
+  }
+}
+
+// -> validity; uv[c] = pixel cv::circle would be centred on; bgrv = {255-cs, cs, 255-cs, 1} packed little-endian.
+// STRUCTURED: every P_rect has the pinhole shape [fx 0 cx tx; 0 fy cy ty; 0 0 1 tz] (all KITTI calibrations do); skipping
+// its zeros changes no result for finite coordinates (x + (+-0) = x, 1 * x = x).  A point whose rectified coordinates
+// are not finite (0 * inf = NaN matters there) or whose quotients are not certain takes the plain sequence below.
+// Most of a scan is behind the cameras or beyond max_range, and neighbouring points share that fate: a wave in which no
+// lane passes the test of :21-24 skips the four cameras altogether (wave-uniform branch).
+template <bool STRUCTURED>
+__device__ __forceinline__ bool project_point(double x, double y, double z, const CameraRigRec& g, v2i uv[4], uint32_t& bgrv) {
+#pragma clang fp contract(off)
+  double c[3], r[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c[k] = ((g.T[4 * k] * x + g.T[4 * k + 1] * y) + g.T[4 * k + 2] * z) + g.T[4 * k + 3];  // :75
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r[k] = ((g.R[3 * k] * c[0] + g.R[3 * k + 1] * c[1]) + g.R[3 * k + 2] * c[2]) + 0.0;  // :81
+  const bool valid = !((r[2] < 0.01) || (r[2] > g.max_range) || (r[1] > 1.25));                                  // :21-24
+  if (__builtin_amdgcn_ballot_w64(valid) == 0) {
+#pragma unroll
+    for (int cam = 0; cam < 4; ++cam) uv[cam].x = uv[cam].y = (int)0x80000000;
+    bgrv = 0u;
+    return false;
+  }
+  bool sure = __builtin_fabs(r[0]) < __builtin_inf() && __builtin_fabs(r[1]) < __builtin_inf() && __builtin_fabs(r[2]) < __builtin_inf();
+#pragma unroll
+  for (int cam = 0; cam < 4; ++cam) {
+    double h[3];
+    camera_rows<STRUCTURED>(g.P[cam], r, h);
+    int tu, tv;
+    sure &= trunc_quotients_fast(h[0], h[1], h[2], tu, tv);
+    uv[cam].x = tu;
+    uv[cam].y = tv;
+  }
+  if (__builtin_expect(valid && !sure, 0)) {  // the reference's own sequence: general rows, two IEEE divisions (:9, :12, :31)
+#pragma unroll 1
+    for (int cam = 0; cam < 4; ++cam) {
+      double h[3];
+      camera_rows<false>(g.P[cam], r, h);
+      uv[cam].x = trunc_i32(h[0] / h[2]);
+      uv[cam].y = trunc_i32(h[1] / h[2]);
+    }
+  }
+  if (!valid) {
+#pragma unroll
+    for (int cam = 0; cam < 4; ++cam) uv[cam].x = uv[cam].y = (int)0x80000000;
+  }
+  const double cs = 255.0 * (r[2] / g.range_den);  // :28-29
+  const uint32_t a = sat_u8(255.0 - cs), b = sat_u8(cs);
+  bgrv = valid ? (a | (b << 8) | (a << 16) | (1u << 24)) : 0u;  // :32
+  return valid;
+}
+
 }  // namespace kmc_dev

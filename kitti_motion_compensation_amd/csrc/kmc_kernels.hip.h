@@ -446,4 +446,44 @@ __global__ __launch_bounds__(kBlock) void copy_points(const v4f* __restrict__ in
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N4: projection kernels.  One point per lane, one wave per workgroup like the deskew kernels.  Per point: 16 B read,
+// 4 x 8 B pixel pairs + 4 B colour/validity written (52 B), or 68 B when the fused deskew also writes its cloud.
+// TIER < 0: project the cloud as it is; TIER >= 0: deskew first (same arithmetic as deskew_frame_f32), then project.
+// ------------------------------------------------------------------------------------------------
+template <int TIER, bool STRUCTURED>
+__global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, uint64_t n, CameraRigRec g, FrameRec f,
+                                                  v4f* __restrict__ cloud_out, v2i* __restrict__ uv,
+                                                  uint32_t* __restrict__ bgrv) {
+  const uint64_t stride = (uint64_t)gridDim.x * 64;
+  for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
+    v4f p = __builtin_nontemporal_load(in + i);
+    if constexpr (TIER >= 0) {
+      p = deskew_point<TIER, false>(p, f);
+      if (cloud_out) __builtin_nontemporal_store(p, cloud_out + i);
+    }
+    v2i px[4];
+    uint32_t col;
+    project_point<STRUCTURED>((double)p.x, (double)p.y, (double)p.z, g, px, col);
+#pragma unroll
+    for (int cam = 0; cam < 4; ++cam) __builtin_nontemporal_store(px[cam], uv + (uint64_t)cam * n + i);
+    __builtin_nontemporal_store(col, bgrv + i);
+  }
+}
+
+template <bool STRUCTURED>
+__global__ __launch_bounds__(64) void project_f64cols(const double* __restrict__ x, const double* __restrict__ y,
+                                                      const double* __restrict__ z, uint64_t n, CameraRigRec g,
+                                                      v2i* __restrict__ uv, uint32_t* __restrict__ bgrv) {
+  const uint64_t stride = (uint64_t)gridDim.x * 64;
+  for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
+    v2i px[4];
+    uint32_t col;
+    project_point<STRUCTURED>(__builtin_nontemporal_load(x + i), __builtin_nontemporal_load(y + i), __builtin_nontemporal_load(z + i), g, px, col);
+#pragma unroll
+    for (int cam = 0; cam < 4; ++cam) __builtin_nontemporal_store(px[cam], uv + (uint64_t)cam * n + i);
+    __builtin_nontemporal_store(col, bgrv + i);
+  }
+}
+
 }  // namespace kmc_dev

@@ -719,3 +719,46 @@ void kmo_bracket_indices_f32(const float* xyzi, size_t n, const double* times, s
     out[i] = k;
   }
 }
+
+/* ---- N4: projection (camera_model.cpp:5-95 without the drawing; see kmc_oracle.h) ---- */
+static int32_t trunc_i32(double v) { /* cvttsd2si */
+  if (!(v > -2147483649.0 && v < 2147483648.0)) return INT32_MIN;
+  return (int32_t)v;
+}
+static uint8_t sat_u8(double v) { /* cv::saturate_cast<uchar>(double) */
+  double r = nearbyint(v);        /* default rounding mode: half to even, = cvRound */
+  return (uint8_t)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
+}
+static void project_one(double x, double y, double z, const kmo_camera_rig* g, size_t i, size_t n, int32_t* uv, uint8_t* bgrv) {
+  const double* T = g->tf_c00_lo;
+  const double* R = g->R_rect_00;
+  double c[3], r[3];
+  for (int k = 0; k < 3; ++k) c[k] = ((T[4 * k] * x + T[4 * k + 1] * y) + T[4 * k + 2] * z) + T[4 * k + 3] * 1.0; /* :75 */
+  for (int k = 0; k < 3; ++k) r[k] = ((R[3 * k] * c[0] + R[3 * k + 1] * c[1]) + R[3 * k + 2] * c[2]) + 0.0 * 1.0;  /* :81 */
+  int valid = !((r[2] < 0.01) || (r[2] > g->max_range) || (r[1] > 1.25));                                          /* :21-24 */
+  for (int cam = 0; cam < 4; ++cam) {
+    const double* P = g->P_rect[cam];
+    double h[3];
+    for (int k = 0; k < 3; ++k) h[k] = ((P[4 * k] * r[0] + P[4 * k + 1] * r[1]) + P[4 * k + 2] * r[2]) + P[4 * k + 3] * 1.0; /* :9 */
+    int32_t* o = uv + ((size_t)cam * n + i) * 2;
+    o[0] = valid ? trunc_i32(h[0] / h[2]) : INT32_MIN; /* :12, :31 */
+    o[1] = valid ? trunc_i32(h[1] / h[2]) : INT32_MIN;
+  }
+  uint8_t* q = bgrv + 4 * i;
+  if (valid) {
+    double cs = 255.0 * (r[2] / (g->max_range - 0.01)); /* :28-29 */
+    q[0] = sat_u8(255.0 - cs);                          /* :32 */
+    q[1] = sat_u8(cs);
+    q[2] = sat_u8(255.0 - cs);
+    q[3] = 1;
+  } else {
+    q[0] = q[1] = q[2] = q[3] = 0;
+  }
+}
+void kmo_project_points(const double* x, const double* y, const double* z, size_t n, const kmo_camera_rig* rig, int32_t* uv,
+                        uint8_t* bgrv) {
+  for (size_t i = 0; i < n; ++i) project_one(x[i], y[i], z[i], rig, i, n, uv, bgrv);
+}
+void kmo_project_xyzi_f32(const float* xyzi, size_t n, const kmo_camera_rig* rig, int32_t* uv, uint8_t* bgrv) {
+  for (size_t i = 0; i < n; ++i) project_one((double)xyzi[4 * i], (double)xyzi[4 * i + 1], (double)xyzi[4 * i + 2], rig, i, n, uv, bgrv);
+}

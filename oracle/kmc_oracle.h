@@ -137,6 +137,34 @@ int kmo_motion_compensate_frame_traj(const double* cloud_colmajor, const double*
 void kmo_bracket_indices_f32(const float* xyzi, size_t n, const double* times, size_t n_knots, double stamp_start,
                              double stamp_end, uint32_t* out);
 
+/* ---- next row N4: LiDAR -> image projection (camera_model.cpp), WITHOUT the OpenCV drawing --------------------------
+ * PARITY UNPINNED for this block: the reference has no test of camera_model.cpp, and OpenCV/Eigen are absent here; the
+ * arithmetic below is a restatement only.  What it states, per point p = (x, y, z) of the lidar cloud:
+ *   camera_model.cpp:62-75   p_c00  = tf_c00_lo * [x y z 1]'       Eigen Affine3d * 4xN: top 3 rows, k = 0..3 left to right
+ *   camera_model.cpp:78-81   p_rect = [R_rect_00 0; 0 1] * p_c00   (the 4th product of every row is exactly 0 or 1*1)
+ *   camera_model.cpp:9       pix_c  = P_rect_c * p_rect            3x4 * 4xN, k = 0..3 left to right
+ *   camera_model.cpp:12      pix_c  = pix_c / pix_c(2)             IEEE division
+ *   camera_model.cpp:21-24   skipped unless 0.01 <= z_rect <= max_range and y_rect <= 1.25
+ *   camera_model.cpp:28-29   color_scale = 255 * (z_rect / (max_range - 0.01))
+ *   camera_model.cpp:31      cv::Point(u, v): double -> int, truncation toward zero (x86 cvttsd2si: INT32_MIN when the
+ *                            value does not fit)
+ *   camera_model.cpp:32      cv::Scalar(255 - cs, cs, 255 - cs) -> 8-bit channels the way OpenCV (un-vendored apt
+ *                            libopencv-dev 4.5.4 of ubuntu:22.04, Dockerfile:3) writes a Scalar into a CV_8U image:
+ *                            saturate_cast<uchar>(double) = clamp(cvRound(v)), cvRound = round-half-to-even.
+ * All products and sums are individually rounded (the reference builds with plain -O3, CMakeLists.txt:8: no FMA).
+ * Outputs: uv[c][i][2] int32 for the 4 cameras (INT32_MIN, INT32_MIN when the point is skipped) and
+ * bgrv[i][4] = {255-cs, cs, 255-cs, 1} as uint8 (all 0 when skipped). */
+typedef struct kmo_camera_rig {
+  double tf_c00_lo[12]; /* row-major 3x4, LoadLidarExtrinsics data_io.cpp:168-210 */
+  double R_rect_00[9];  /* row-major, calib_cam_to_cam.txt R_rect_00 */
+  double P_rect[4][12]; /* row-major 3x4 per camera */
+  double max_range;     /* camera_model.hpp:8 default 15.0 */
+} kmo_camera_rig;
+void kmo_project_points(const double* x, const double* y, const double* z, size_t n, const kmo_camera_rig* rig,
+                        int32_t* uv, uint8_t* bgrv);
+/* the same on the KITTI f32 layout: every coordinate is widened to double first, like the loader does (data_io.cpp:118-131) */
+void kmo_project_xyzi_f32(const float* xyzi, size_t n, const kmo_camera_rig* rig, int32_t* uv, uint8_t* bgrv);
+
 int kmo_num_threads(void); /* omp_get_max_threads() or 1 */
 
 #ifdef __cplusplus

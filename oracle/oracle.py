@@ -401,3 +401,45 @@ def bracket_indices_f32(xyzi, times, stamp_start, stamp_end):
     lib().kmo_bracket_indices_f32(a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0], tp, len(t_), stamp_start, stamp_end,
                                   out.ctypes.data_as(C.POINTER(C.c_uint32)))
     return out
+
+
+# ---- N4: projection (camera_model.cpp without the drawing; parity unpinned, see kmc_oracle.h) ------------
+class CameraRig(C.Structure):
+    _fields_ = [("tf_c00_lo", C.c_double * 12), ("R_rect_00", C.c_double * 9), ("P_rect", (C.c_double * 12) * 4),
+                ("max_range", C.c_double)]
+
+
+def camera_rig(tf_c00_lo_3x4, R_rect_00, P_rects, max_range=15.0) -> CameraRig:
+    g = CameraRig()
+    g.tf_c00_lo[:] = [float(v) for v in np.asarray(tf_c00_lo_3x4, dtype=np.float64).reshape(12)]
+    g.R_rect_00[:] = [float(v) for v in np.asarray(R_rect_00, dtype=np.float64).reshape(9)]
+    for c in range(4):
+        g.P_rect[c][:] = [float(v) for v in np.asarray(P_rects[c], dtype=np.float64).reshape(12)]
+    g.max_range = float(max_range)
+    return g
+
+
+def project_points(xyz, rig):
+    """xyz (N,3) f64 -> (uv (4,N,2) int32, bgrv (N,4) uint8)"""
+    a = np.asarray(xyz, dtype=np.float64)
+    n = a.shape[0]
+    cols = [np.ascontiguousarray(a[:, k]) for k in range(3)]
+    uv = np.empty((4, n, 2), dtype=np.int32)
+    bgrv = np.empty((n, 4), dtype=np.uint8)
+    f = lib().kmo_project_points
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3 + [C.c_size_t, C.POINTER(CameraRig), C.c_void_p, C.c_void_p]
+    f(cols[0].ctypes.data, cols[1].ctypes.data, cols[2].ctypes.data, n, C.byref(rig), uv.ctypes.data, bgrv.ctypes.data)
+    return uv, bgrv
+
+
+def project_xyzi_f32(xyzi, rig):
+    a = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    n = a.shape[0]
+    uv = np.empty((4, n, 2), dtype=np.int32)
+    bgrv = np.empty((n, 4), dtype=np.uint8)
+    f = lib().kmo_project_xyzi_f32
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(CameraRig), C.c_void_p, C.c_void_p]
+    f(a.ctypes.data, n, C.byref(rig), uv.ctypes.data, bgrv.ctypes.data)
+    return uv, bgrv

@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 
+#include "kitti_motion_compensation/camera_model.hpp"
 #include "kitti_motion_compensation/data_io.hpp"
 #include "kitti_motion_compensation/data_types.hpp"
 #include "kitti_motion_compensation/handlers.hpp"
@@ -190,6 +191,61 @@ static void host_cases(std::string const& golden) {
     auto const tok = TokenizeString("2011-09-26 13:04:32.283701593");
     ASSERT_EQ(tok.size(), 2u);
   }
+  CASE("calibration loaders");  // data_io.cpp:168-210, :321-406 on the shipped calib_*.txt (values read off the files)
+  {
+    Affine3d const tf_c00_lo{LoadLidarExtrinsics(Path{golden})};
+    ASSERT_EQ(tf_c00_lo.linear()(0, 0), 7.533745e-03);
+    ASSERT_EQ(tf_c00_lo.linear()(0, 1), -9.999714e-01);
+    ASSERT_EQ(tf_c00_lo.linear()(2, 0), 9.998621e-01);
+    ASSERT_EQ(tf_c00_lo.translation()(0), -4.069766e-03);
+    ASSERT_EQ(tf_c00_lo.translation()(2), -2.717806e-01);
+    Affine3d const tf_lo_imu{LoadLidarExtrinsics(Path{golden}, false)};
+    ASSERT_EQ(tf_lo_imu.translation()(0), -8.086759e-01);
+    viz::CameraCalibrations const cc{viz::LoadCameraCalibrations(Path{golden})};
+    ASSERT_EQ(cc.camera_00.S(0), 1.392000e+03);
+    ASSERT_EQ(cc.camera_00.K(0, 0), 9.842439e+02);
+    ASSERT_EQ(cc.camera_00.D[0], -3.728755e-01);
+    ASSERT_EQ(cc.camera_00.S_rect(1), 3.750000e+02);
+    ASSERT_EQ(cc.camera_00.R_rect(0, 0), 9.999239e-01);
+    ASSERT_EQ(cc.camera_00.P_rect(0, 0), 7.215377e+02);
+    ASSERT_EQ(cc.camera_00.P_rect(1, 2), 1.728540e+02);
+    ASSERT_EQ(cc.camera_01.P_rect(0, 3), -3.875744e+02);
+    ASSERT_EQ(cc.camera_02.P_rect(0, 3), 4.485728e+01);
+    ASSERT_EQ(cc.camera_03.P_rect(0, 3), -3.395242e+02);
+    ASSERT_EQ(cc.camera_03.P_rect(2, 3), 2.729905e-03);
+    ASSERT_EQ(cc.camera_03.K(1, 1), 9.019653e+02);
+    bool threw = false;
+    try {
+      (void)viz::LoadCameraCalibrations(Path{golden + "/does_not_exist"});
+    } catch (std::runtime_error const&) {
+      threw = true;
+    }
+    ASSERT_TRUE(threw);
+  }
+}
+
+// camera_model.cpp:5-95 without the drawing, written out the long way for the harness (x86-64 baseline: no FMA contraction)
+static void ProjectOnHost(double x, double y, double z, Affine3d const& tf, viz::CameraCalibrations const& cc, double max_range,
+                          std::int32_t uv[4][2], std::uint8_t bgrv[4]) {
+  Vector4d const p_c00{tf * Vector4d{x, y, z, 1.0}};
+  Matrix3d const& R{cc.camera_00.R_rect};
+  double r[3];
+  for (int k = 0; k < 3; ++k) r[k] = ((R(k, 0) * p_c00(0) + R(k, 1) * p_c00(1)) + R(k, 2) * p_c00(2)) + 0.0;
+  bool const drawn{!((r[2] < 0.01) || (r[2] > max_range) || (r[1] > 1.25))};
+  viz::CameraCalibration const* cams[4] = {&cc.camera_00, &cc.camera_01, &cc.camera_02, &cc.camera_03};
+  for (int c = 0; c < 4; ++c) {
+    viz::P const& P{cams[c]->P_rect};
+    double h[3];
+    for (int k = 0; k < 3; ++k) h[k] = ((P(k, 0) * r[0] + P(k, 1) * r[1]) + P(k, 2) * r[2]) + P(k, 3) * 1.0;
+    uv[c][0] = drawn ? static_cast<std::int32_t>(h[0] / h[2]) : INT32_MIN;
+    uv[c][1] = drawn ? static_cast<std::int32_t>(h[1] / h[2]) : INT32_MIN;
+  }
+  double const cs{255.0 * (r[2] / (max_range - 0.01))};
+  auto const sat = [](double v) { double const q = std::nearbyint(v); return static_cast<std::uint8_t>(q < 0 ? 0 : (q > 255 ? 255 : q)); };
+  bgrv[0] = drawn ? sat(255.0 - cs) : 0;
+  bgrv[1] = drawn ? sat(cs) : 0;
+  bgrv[2] = bgrv[0];
+  bgrv[3] = drawn ? 1 : 0;
 }
 
 // ---- gpu cases ---------------------------------------------------------------------------------------------------------
@@ -410,6 +466,58 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
       std::printf("  run frame %zu: %td points, max rel err vs f64 API %.3e\n", i, ref.rows(), worst);
       ASSERT_TRUE(worst <= 1e-5);
     }
+  }
+  CASE("viz::ProjectPointcloud (camera_model.cpp:5-95 minus the drawing) on the shipped frame and calibration");
+  {
+    // the shipped frame 0 with a synthetic pair of scan poses (only its own OXTS packet ships): 1.3 m forward, slight yaw
+    LidarScan const scan{LoadLidarScan(data_folder, 0)};
+    Affine3d T_end;
+    T_end.rotate(AngleAxisd{0.03, Vector3d{0, 0, 1}});
+    T_end.translation() = Vector3d{1.3, 0.05, -0.02};
+    Frame const frame{Affine3d::Identity(), T_end, scan};
+    viz::CameraCalibrations const cc{viz::LoadCameraCalibrations(Path{golden})};
+    Affine3d const tf_c00_lo{LoadLidarExtrinsics(Path{golden})};
+    viz::Projection const proj{viz::ProjectPointcloud(frame, cc, tf_c00_lo)};
+    ASSERT_EQ(proj.num_points, static_cast<std::size_t>(frame.scan.cloud.rows()));
+    std::size_t mismatches = 0, drawn = 0, in_image = 0;
+    for (std::size_t i = 0; i < proj.num_points; ++i) {
+      std::int32_t uv[4][2];
+      std::uint8_t bgrv[4];
+      Index const k{static_cast<Index>(i)};
+      ProjectOnHost(frame.scan.cloud(k, 0), frame.scan.cloud(k, 1), frame.scan.cloud(k, 2), tf_c00_lo, cc, 15.0, uv, bgrv);
+      for (int c = 0; c < 4; ++c) mismatches += (proj.u(c, i) != uv[c][0]) + (proj.v(c, i) != uv[c][1]);
+      mismatches += std::memcmp(proj.color(i), bgrv, 4) != 0;
+      drawn += proj.drawn(i);
+      in_image += proj.drawn(i) && proj.u(0, i) >= 0 && proj.u(0, i) < 1242 && proj.v(0, i) >= 0 && proj.v(0, i) < 375;
+    }
+    std::printf("  projection: %zu points, %zu drawn, %zu inside image_00, %zu mismatching integers\n", proj.num_points, drawn, in_image, mismatches);
+    ASSERT_EQ(mismatches, 0u);
+    ASSERT_TRUE(drawn > 5000 && in_image > drawn / 5);
+
+    // KITTI-layout entry, raw and with the motion compensation fused in front (handlers.cpp:77-88 in two launches)
+    std::vector<float> const raw = read_bin(data_folder / "velodyne_points/data/0000000000.bin");
+    viz::Projection const proj_raw{viz::ProjectKittiCloud(raw.data(), raw.size() / 4, cc, tf_c00_lo)};
+    ASSERT_TRUE(proj_raw.uv == proj.uv && proj_raw.bgrv == proj.bgrv);  // the loader's f32 -> f64 widening is exact
+    hip::FramePoses fp;
+    fp.T_start = frame.T_start;
+    fp.T_end = frame.T_end;
+    fp.stamp_start = frame.scan.stamp_start;
+    fp.stamp_end = frame.scan.stamp_end;
+    fp.requested_time = frame.scan.stamp_middle;
+    std::vector<float> cloud(raw.size());
+    viz::Projection const proj_mc{viz::ProjectKittiCloud(raw.data(), raw.size() / 4, cc, tf_c00_lo, 15.0, &fp, cloud.data())};
+    std::vector<float> plain(raw.size());
+    hip::MotionCompensateKittiCloud(raw.data(), raw.size() / 4, fp.T_start, fp.T_end, fp.stamp_start, fp.stamp_end, fp.requested_time, plain.data());
+    ASSERT_TRUE(std::memcmp(cloud.data(), plain.data(), raw.size() * sizeof(float)) == 0);
+    std::size_t mm = 0;
+    for (std::size_t i = 0; i < proj_mc.num_points; ++i) {
+      std::int32_t uv[4][2];
+      std::uint8_t bgrv[4];
+      ProjectOnHost(cloud[4 * i], cloud[4 * i + 1], cloud[4 * i + 2], tf_c00_lo, cc, 15.0, uv, bgrv);
+      for (int c = 0; c < 4; ++c) mm += (proj_mc.u(c, i) != uv[c][0]) + (proj_mc.v(c, i) != uv[c][1]);
+      mm += std::memcmp(proj_mc.color(i), bgrv, 4) != 0;
+    }
+    ASSERT_EQ(mm, 0u);
   }
 }
 

@@ -91,3 +91,52 @@ def real_cadence_drive(run_dir, n_frames=108, speed=13.0, yaw_rate=0.3):
         oxts.append(dict(stamp=t_oxts[i], lat=360.0 / np.pi * np.arctan(np.exp(north / R_E)) - 90.0, lon=east * 180.0 / (np.pi * R_E),
                          alt=f0["alt"] + 0.02 * dt, roll=f0["roll"] + 0.01 * dt, pitch=f0["pitch"] - 0.008 * dt, yaw=yaw))
     return t_start, t_mid, t_end, oxts
+
+
+def load_kitti_calibration(date_dir):
+    """calib_velo_to_cam.txt + calib_cam_to_cam.txt restated (data_io.cpp:168-210, :321-406) ->
+    (tf_c00_lo 3x4, R_rect_00 3x3, [P_rect_00..03] 3x4 each)."""
+    def values(line):
+        return [float(t) for t in line.strip().split(" ")[1:]]
+
+    with open(os.path.join(date_dir, "calib_velo_to_cam.txt")) as f:
+        lines = f.read().splitlines()
+    R = np.array(values(lines[1])).reshape(3, 3)
+    T = np.array(values(lines[2])).reshape(3, 1)
+    tf = np.hstack([R, T])
+    with open(os.path.join(date_dir, "calib_cam_to_cam.txt")) as f:
+        lines = f.read().splitlines()[2:]
+    R_rect_00 = np.array(values(lines[6])).reshape(3, 3)
+    P = [np.array(values(lines[8 * c + 7])).reshape(3, 4) for c in range(4)]
+    return tf, R_rect_00, P
+
+
+def project_numpy(xyz, tf, R_rect, P_rects, max_range=15.0):
+    """camera_model.cpp:5-95 (without the drawing) in numpy f64, one rounded operation at a time in the reference's order;
+    an independent twin of oracle kmo_project_points.  -> (uv (4,N,2) int32, bgrv (N,4) uint8)"""
+    p = np.asarray(xyz, dtype=np.float64)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    with np.errstate(all="ignore"):
+        c = [((tf[k, 0] * x + tf[k, 1] * y) + tf[k, 2] * z) + tf[k, 3] * 1.0 for k in range(3)]
+        r = [((R_rect[k, 0] * c[0] + R_rect[k, 1] * c[1]) + R_rect[k, 2] * c[2]) + 0.0 for k in range(3)]
+        drawn = ~((r[2] < 0.01) | (r[2] > max_range) | (r[1] > 1.25))
+        n = p.shape[0]
+        uv = np.full((4, n, 2), np.iinfo(np.int32).min, dtype=np.int32)
+        for cam in range(4):
+            P = P_rects[cam]
+            h = [((P[k, 0] * r[0] + P[k, 1] * r[1]) + P[k, 2] * r[2]) + P[k, 3] * 1.0 for k in range(3)]
+            for j in range(2):
+                q = h[j] / h[2]
+                fits = (q > -2147483649.0) & (q < 2147483648.0)
+                t = np.where(fits, np.trunc(np.where(fits, q, 0.0)), -2147483648.0).astype(np.int64).astype(np.int32)
+                uv[cam, :, j] = np.where(drawn, t, np.iinfo(np.int32).min)
+        cs = 255.0 * (r[2] / (max_range - 0.01))
+
+        def sat(v):
+            rr = np.rint(v)
+            rr = np.where(rr != rr, 0.0, np.clip(rr, 0.0, 255.0))
+            return rr.astype(np.uint8)
+
+        bgrv = np.stack([sat(255.0 - cs), sat(cs), sat(255.0 - cs), np.ones(n, dtype=np.uint8)], axis=1)
+        bgrv[~drawn] = 0
+    return uv, bgrv
