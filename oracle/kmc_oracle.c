@@ -503,6 +503,13 @@ int kmo_num_threads(void) {
   return 1;
 #endif
 }
+void kmo_set_num_threads(int threads) {
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+}
 
 int kmo_deskew_xyzi_f32(const float* xyzi, size_t n, double stamp_start, const kmo_affine* T_start,
                         double stamp_end, const kmo_affine* T_end, double requested_time, int mode,
@@ -757,8 +764,10 @@ static void project_one(double x, double y, double z, const kmo_camera_rig* g, s
 }
 void kmo_project_points(const double* x, const double* y, const double* z, size_t n, const kmo_camera_rig* rig, int32_t* uv,
                         uint8_t* bgrv) {
+#pragma omp parallel for schedule(static) if (n >= 65536)
   for (size_t i = 0; i < n; ++i) project_one(x[i], y[i], z[i], rig, i, n, uv, bgrv);
 }
 void kmo_project_xyzi_f32(const float* xyzi, size_t n, const kmo_camera_rig* rig, int32_t* uv, uint8_t* bgrv) {
+#pragma omp parallel for schedule(static) if (n >= 65536)
   for (size_t i = 0; i < n; ++i) project_one((double)xyzi[4 * i], (double)xyzi[4 * i + 1], (double)xyzi[4 * i + 2], rig, i, n, uv, bgrv);
 }

@@ -166,6 +166,7 @@ void kmo_project_points(const double* x, const double* y, const double* z, size_
 void kmo_project_xyzi_f32(const float* xyzi, size_t n, const kmo_camera_rig* rig, int32_t* uv, uint8_t* bgrv);
 
 int kmo_num_threads(void); /* omp_get_max_threads() or 1 */
+void kmo_set_num_threads(int threads); /* default team size of the loops that take no explicit thread count */
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,9 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    L.kmo_set_num_threads.restype = None
+    L.kmo_set_num_threads.argtypes = [C.c_int]
+    L.kmo_set_num_threads(default_threads())
     _lib = L
     return L
 

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Randomised differential soak: HIP path vs CPU oracle, for a wall-clock budget, over random sizes / twists / batch
+layouts / camera rigs.  Test infrastructure (it drives the oracle); prints one JSON summary.
+  python tools/soak_parity.py [seconds=300] [seed=1] > gpurun_out/soak.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kitti_motion_compensation_amd import capi  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from tests import util  # noqa: E402
+
+T0, T1 = 47072.283701593, 47072.386973931
+
+
+def random_twist(rng):
+    kind = rng.integers(0, 5)
+    rho = rng.normal(0, [1.5, 0.2, 0.05])
+    phi = rng.normal(0, [0.002, 0.004, 0.03])
+    if kind == 0:
+        phi[:] = 0
+    elif kind == 3:
+        phi *= 10           # series5 tier
+    elif kind == 4:
+        phi *= 60           # trig tier
+        th = np.linalg.norm(phi)
+        if th > 2.8:        # stay inside the principal branch of Log: beyond pi the reference itself takes the short way round
+            phi *= 2.8 / th
+    return np.concatenate([rho, phi])
+
+
+IDENT = np.hstack([np.eye(3), np.zeros((3, 1))])
+
+
+def params_from_twist(twist, x_req):
+    """What a caller does: poses in, kmc_frame_params_from_poses (host f64 Log) out."""
+    T = orc.se3_exp(list(twist))
+    M = np.hstack([np.array(list(T.R)).reshape(3, 3), np.array(list(T.t)).reshape(3, 1)])
+    return capi.frame_params_from_poses(IDENT, M, T0, T1, T0 + x_req * (T1 - T0))
+
+
+def random_points(rng, n):
+    pts = capi.synth_points_host(n, int(rng.integers(1, 2**62)))
+    if rng.random() < 0.3:   # sprinkle axis points, origin, signed zeros
+        k = min(n, 16)
+        idx = rng.choice(n, k, replace=False)
+        pts[idx, 0] = rng.choice([0.0, -0.0, 1.0, -1.0, 5.0], k)
+        pts[idx, 1] = rng.choice([0.0, -0.0, 1.0, -1.0, 5.0], k)
+    return pts
+
+
+def check_cloud(acc, key, pts, out, ref, context):
+    """The parity gate: |p - ref| / max(|ref|, 1e-3) <= 1e-5.  A synthetic point can be carried to
+    within centimetres of the sensor origin, where |ref| is a hundred times smaller than the f32 input it came from and
+    the gate measures input quantisation, not the kernel; those points (|ref| < 0.1 |p_in|) are counted, and every point is
+    additionally gated on |p - ref| / max(|p_in|, |ref|) <= 2e-6 (reported as *_max_err_over_scale)."""
+    d = np.linalg.norm(out[:, :3] - ref, axis=1)
+    nref = np.linalg.norm(ref, axis=1)
+    nin = np.linalg.norm(pts[:, :3].astype(np.float64), axis=1)
+    cancel = nref < 0.1 * nin
+    rel = d / np.maximum(nref, 1e-3)
+    lit = float(rel.max())
+    if lit > acc[key + "_max_rel_err_literal"]:
+        k = int(np.argmax(rel))
+        acc[key + "_max_rel_err_literal"] = lit
+        acc[key + "_worst_case"] = dict(context, point=[float(v) for v in pts[k, :3]], ref=[float(v) for v in ref[k]],
+                                        got=[float(v) for v in out[k, :3]])
+    if (~cancel).any():
+        acc[key + "_max_rel_err"] = max(acc[key + "_max_rel_err"], float(rel[~cancel].max()))
+    ein = d / np.maximum(np.maximum(nin, nref), 1e-3)
+    if float(ein.max()) > acc[key + "_max_err_over_scale"]:
+        k = int(np.argmax(ein))
+        acc[key + "_max_err_over_scale"] = float(ein.max())
+        acc[key + "_worst_case_scale"] = dict(context, point=[float(v) for v in pts[k, :3]], ref=[float(v) for v in ref[k]],
+                                                   got=[float(v) for v in out[k, :3]])
+    acc[key + "_near_origin_points"] += int(cancel.sum())
+
+
+def deskew_round(ctx, rng, acc):
+    n = int(rng.choice([1, 63, 64, 65, 1000, 123397, 1 << 20, 3_000_017]))
+    pts = random_points(rng, n)
+    twist = random_twist(rng)
+    x_req = float(rng.choice([0.0, 0.5, 1.0, rng.random()]))
+    out = np.empty_like(pts)
+    ctx.deskew_f32(pts, out, params_from_twist(twist, x_req))
+    ref = orc.deskew_xyzi_f32(pts, T0, orc.se3_exp([0] * 6), T1, orc.se3_exp(list(twist)), T0 + x_req * (T1 - T0), mode=orc.HOISTED)
+    check_cloud(acc, "deskew", pts, out, ref["xyz_f64"], dict(twist=[float(v) for v in twist], x_req=x_req))
+    acc["deskew_points"] += n
+    acc["deskew_intensity_mismatch"] += int(np.count_nonzero(out[:, 3].view(np.uint32) != pts[:, 3].view(np.uint32)))
+
+
+def batch_round(ctx, rng, acc):
+    nf = int(rng.integers(1, 200))
+    sizes = rng.choice([0, 1, 63, 64, 65, 777, 16384, 16385, 120000], nf, p=[.05, .05, .05, .1, .05, .2, .1, .1, .3])
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(offsets[-1])
+    if n == 0:
+        return
+    pts = random_points(rng, n)
+    twists = [random_twist(rng) * (0.2 if rng.random() < 0.8 else 1.0) for _ in range(nf)]
+    xr = [float(rng.random()) for _ in range(nf)]
+    out = np.empty_like(pts)
+    idx = np.empty(n, dtype=np.uint32)
+    ctx.deskew_batch_f32(pts, out, offsets, [params_from_twist(t, x) for t, x in zip(twists, xr)], idx)
+    expect_idx = np.repeat(np.arange(nf, dtype=np.uint32), sizes)
+    acc["batch_index_mismatch"] += int(np.count_nonzero(idx != expect_idx))
+    for f in rng.choice(nf, min(nf, 6), replace=False):   # oracle on a sample of the frames
+        a, b = int(offsets[f]), int(offsets[f + 1])
+        if a == b:
+            continue
+        ref = orc.deskew_xyzi_f32(pts[a:b], T0, orc.se3_exp([0] * 6), T1, orc.se3_exp(list(twists[f])), T0 + xr[f] * (T1 - T0), mode=orc.HOISTED)
+        check_cloud(acc, "batch", pts[a:b], out[a:b], ref["xyz_f64"], dict(twist=[float(v) for v in twists[f]], x_req=xr[f]))
+    acc["batch_points"] += n
+
+
+def projection_round(ctx, rng, acc, calib):
+    n = int(rng.choice([1000, 123397, 1 << 20, 4_000_003]))
+    pts = random_points(rng, n)
+    if rng.random() < 0.5:   # everything in front of the cameras: every lane takes the per-camera arithmetic
+        pts[:, 0] = np.abs(pts[:, 0]) * 0.2 + 0.3
+        pts[:, 2] = pts[:, 2] * 0.05
+    tf, R_rect, P = calib
+    if rng.random() < 0.5:
+        tf = tf + 0.01 * rng.standard_normal(tf.shape)
+        R_rect = R_rect + 0.005 * rng.standard_normal((3, 3))
+    if rng.random() < 0.3:   # dense P: the general kernel variant
+        P = [p + 0.01 * rng.standard_normal((3, 4)) for p in P]
+    max_range = float(rng.choice([15.0, 40.0, 80.0, 1e9]))
+    rig, orig = capi.CameraRig.make(tf, R_rect, P, max_range), orc.camera_rig(tf, R_rect, P, max_range)
+    uv = np.empty((4, n, 2), dtype=np.int32)
+    bgrv = np.empty((n, 4), dtype=np.uint8)
+    ctx.project_f32(pts, rig, uv, bgrv)
+    uv_ref, bgrv_ref = orc.project_xyzi_f32(pts, orig)
+    acc["projection_points"] += n
+    acc["projection_drawn"] += int(bgrv_ref[:, 3].sum())
+    acc["projection_int_mismatch"] += int(np.count_nonzero(uv != uv_ref) + np.count_nonzero(bgrv != bgrv_ref))
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    ctx = capi.Context(0)
+    calib = util.load_kitti_calibration(os.path.join(ROOT, "tests", "golden"))
+    acc = dict(seed=seed, seconds=budget, rounds=0, deskew_points=0, deskew_intensity_mismatch=0, batch_points=0, batch_index_mismatch=0, projection_points=0, projection_drawn=0,
+               projection_int_mismatch=0, oracle_threads=orc.num_threads())
+    for key in ("deskew", "batch"):
+        acc.update({key + "_max_rel_err": 0.0, key + "_max_rel_err_literal": 0.0, key + "_max_err_over_scale": 0.0,
+                    key + "_near_origin_points": 0})
+    t_end = time.time() + budget
+    while time.time() < t_end:
+        r = acc["rounds"] % 3
+        if r == 0:
+            deskew_round(ctx, rng, acc)
+        elif r == 1:
+            batch_round(ctx, rng, acc)
+        else:
+            projection_round(ctx, rng, acc, calib)
+        acc["rounds"] += 1
+    acc["ok"] = bool(acc["deskew_max_rel_err"] <= 1e-5 and acc["batch_max_rel_err"] <= 1e-5 and acc["deskew_intensity_mismatch"] == 0
+                     and acc["deskew_max_err_over_scale"] <= 2e-6 and acc["batch_max_err_over_scale"] <= 2e-6
+                     and acc["deskew_max_rel_err_literal"] <= 1e-5 and acc["batch_max_rel_err_literal"] <= 1e-5
+                     and acc["batch_index_mismatch"] == 0 and acc["projection_int_mismatch"] == 0)
+    print(json.dumps(acc))
+    sys.exit(0 if acc["ok"] else 1)
+
+
+if __name__ == "__main__":
+    main()
