@@ -68,5 +68,14 @@ void MotionCompensateKittiClouds(float const* xyzi_in, std::vector<std::uint64_t
                                  std::vector<FramePoses> const& frames, float* xyzi_out,
                                  std::uint32_t* frame_index_out = nullptr);
 
+// Many frames in one launch, every frame with its OWN trajectory (e.g. the three OXTS poses around it, used as they are).
+struct FrameTrajectory {
+  Trajectory trajectory;  // must cover [stamp_start, stamp_end]
+  Time stamp_start, stamp_end, requested_time;
+};
+void MotionCompensateKittiClouds(float const* xyzi_in, std::vector<std::uint64_t> const& offsets,
+                                 std::vector<FrameTrajectory> const& frames, float* xyzi_out,
+                                 std::uint32_t* frame_index_out = nullptr, std::uint32_t* bracket_index_out = nullptr);
+
 }  // namespace hip
 }  // namespace kmc

@@ -199,6 +199,21 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* ctx, const double* x, const double* y, 
                                 uint32_t n_knots, double requested_time, double* ox, double* oy, double* oz, double* ow,
                                 uint32_t* bracket_idx_out, int mem_kind, kmc_stats* out_stats);
 
+/* Batched N-knot form: n_frames frames concatenated like in kmc_hip_deskew_batch_f32, every frame with its OWN trajectory
+ * (e.g. its three bracketing OXTS poses), one launch for the whole batch.  frames[f] must satisfy what
+ * kmc_hip_deskew_traj_f32 asks of a single frame.  frame_idx_out / bracket_idx_out (optional, NULL to skip; same mem_kind as
+ * the points): per-point frame index and segment index, both bit-exact integers. */
+typedef struct kmc_traj_frame {
+  const double* knot_times; /* n_knots, strictly increasing (HOST)          */
+  const double* knot_poses; /* 12 * n_knots, row-major 3x4 [R|t] (HOST)    */
+  uint32_t n_knots;         /* 2 .. 17                                      */
+  uint32_t reserved;        /* 0                                            */
+  double stamp_start, stamp_end, requested_time;
+} kmc_traj_frame;
+int kmc_hip_deskew_traj_batch_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets,
+                                  uint32_t n_frames, const kmc_traj_frame* frames, uint32_t* frame_idx_out,
+                                  uint32_t* bracket_idx_out, int mem_kind, kmc_stats* out_stats);
+
 /* GetPseudoTimeStamps (timestamp_mocking.cpp:56-63) on the device, f64: stamps[i] = start + frac_i*(end-start). */
 int kmc_hip_pseudo_timestamps_f64(kmc_ctx* ctx, const double* x, const double* y, uint64_t n, double scan_start,
                                   double scan_end, double* stamps_out, int mem_kind);

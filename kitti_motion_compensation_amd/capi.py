@@ -88,6 +88,12 @@ class CameraRig(C.Structure):
         return g
 
 
+class TrajFrame(C.Structure):
+    """kmc_traj_frame: one frame's trajectory for the batched N-knot entry point (pointers into HOST arrays)."""
+    _fields_ = [("knot_times", C.POINTER(C.c_double)), ("knot_poses", C.POINTER(C.c_double)), ("n_knots", C.c_uint32),
+                ("reserved", C.c_uint32), ("stamp_start", C.c_double), ("stamp_end", C.c_double), ("requested_time", C.c_double)]
+
+
 class KmcError(RuntimeError):
     def __init__(self, status: int, where: str, detail: str = ""):
         self.status = status
@@ -136,6 +142,10 @@ SIGNATURES = {
     "kmc_hip_deskew_traj_f32": (
         C.c_int,
         [_vp, _vp, _vp, C.c_uint64, _dp, _dp, C.c_uint32, C.c_double, C.c_double, C.c_double, _vp, C.c_int, C.POINTER(Stats)],
+    ),
+    "kmc_hip_deskew_traj_batch_f32": (
+        C.c_int,
+        [_vp, _vp, _vp, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(TrajFrame), _vp, _vp, C.c_int, C.POINTER(Stats)],
     ),
     "kmc_hip_deskew_traj_f64cols": (
         C.c_int,
@@ -404,6 +414,29 @@ class Context:
         rc = lib().kmc_hip_deskew_traj_f32(self._h, _ptr(xyzi_in, np.float32), _ptr(xyzi_out, np.float32), n, t.ctypes.data_as(_dp), P.ctypes.data_as(_dp),
                                            len(t), stamp_start, stamp_end, requested_time, _ptr(bracket_idx_out), kind, C.byref(st))
         self._check(rc, "kmc_hip_deskew_traj_f32")
+        return st
+
+    def deskew_traj_batch_f32(self, xyzi_in, xyzi_out, offsets, frames, frame_idx_out=None, bracket_idx_out=None) -> Stats:
+        """frames: list of dicts(times, poses (K,3,4)|(K,12), stamp_start, stamp_end, requested_time), one per frame."""
+        kind = _mem_kind(xyzi_in)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        keep = []
+        arr = (TrajFrame * max(len(frames), 1))()
+        for i, fr in enumerate(frames):
+            t = np.ascontiguousarray(fr["times"], dtype=np.float64)
+            P = np.ascontiguousarray(np.asarray(fr["poses"], dtype=np.float64).reshape(len(t), 12))
+            keep.append((t, P))
+            arr[i].knot_times = t.ctypes.data_as(_dp)
+            arr[i].knot_poses = P.ctypes.data_as(_dp)
+            arr[i].n_knots = len(t)
+            arr[i].stamp_start = float(fr["stamp_start"])
+            arr[i].stamp_end = float(fr["stamp_end"])
+            arr[i].requested_time = float(fr["requested_time"])
+        st = Stats()
+        rc = lib().kmc_hip_deskew_traj_batch_f32(self._h, _ptr(xyzi_in, np.float32), _ptr(xyzi_out, np.float32),
+                                                 offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(offs) - 1, arr,
+                                                 _ptr(frame_idx_out), _ptr(bracket_idx_out), kind, C.byref(st))
+        self._check(rc, "kmc_hip_deskew_traj_batch_f32")
         return st
 
     def deskew_traj_f64cols(self, x, y, z, w, stamps, knot_times, knot_poses, requested_time, ox, oy, oz, ow=None,

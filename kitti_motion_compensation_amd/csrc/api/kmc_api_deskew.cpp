@@ -99,6 +99,32 @@ void MotionCompensateKittiClouds(float const* xyzi_in, std::vector<std::uint64_t
   if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_batch_f32", c);
 }
 
+void MotionCompensateKittiClouds(float const* xyzi_in, std::vector<std::uint64_t> const& offsets,
+                                 std::vector<FrameTrajectory> const& frames, float* xyzi_out, std::uint32_t* frame_index_out,
+                                 std::uint32_t* bracket_index_out) {
+  if (offsets.size() != frames.size() + 1) throw std::invalid_argument("kmc::hip::MotionCompensateKittiClouds: offsets.size() != frames.size() + 1");
+  std::vector<std::vector<double>> poses(frames.size());
+  std::vector<kmc_traj_frame> c_frames(frames.size());
+  for (std::size_t f = 0; f < frames.size(); ++f) {
+    Trajectory const& tr = frames[f].trajectory;
+    if (tr.times.size() != tr.poses.size()) throw std::invalid_argument("kmc::Trajectory: times.size() != poses.size()");
+    poses[f].resize(12 * tr.poses.size());
+    for (std::size_t k = 0; k < tr.poses.size(); ++k) tr.poses[k].to_rt12(poses[f].data() + 12 * k);
+    c_frames[f].knot_times = tr.times.data();
+    c_frames[f].knot_poses = poses[f].data();
+    c_frames[f].n_knots = static_cast<std::uint32_t>(tr.times.size());
+    c_frames[f].reserved = 0;
+    c_frames[f].stamp_start = frames[f].stamp_start;
+    c_frames[f].stamp_end = frames[f].stamp_end;
+    c_frames[f].requested_time = frames[f].requested_time;
+  }
+  kmc_ctx* c = detail::thread_context();
+  int const rc = kmc_hip_deskew_traj_batch_f32(c, xyzi_in, xyzi_out, offsets.data(), static_cast<std::uint32_t>(frames.size()),
+                                               c_frames.data(), frame_index_out, bracket_index_out, KMC_MEM_HOST, nullptr);
+  if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::hip::MotionCompensateKittiClouds");
+  if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_traj_batch_f32", c);
+}
+
 }  // namespace hip
 
 // motion_compensation.cpp:16-28

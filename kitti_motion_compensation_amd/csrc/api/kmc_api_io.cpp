@@ -242,9 +242,13 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
     Pinned in, out;
     State state = State::kFree;
     std::vector<hip::FramePoses> frames;
+    std::vector<hip::FrameTrajectory> trajectories;  // KMC_RUN_KNOTS=3
   };
 
   bool const timing = [] { char const* e = std::getenv("KMC_RUN_TIMING"); return e && e[0] == '1'; }();
+  // KMC_RUN_KNOTS=3: interpolate along the piecewise geodesic through the three OXTS poses around the frame, used as they
+  // are, instead of first reducing them to the two scan-end poses like MakeFrame does (data_io.cpp:253-269).
+  bool const three_knots = [] { char const* e = std::getenv("KMC_RUN_KNOTS"); return e && e[0] == '3'; }();
   using clk = std::chrono::steady_clock;
   auto const secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
@@ -303,11 +307,22 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
         if (!wait_for(set, State::kFree)) return;
         auto const t0 = clk::now();
         set.frames.clear();
+        set.trajectories.clear();
         for (std::size_t j = 0; j < plan.files.size(); ++j) {
           std::size_t const i = plan.first + j;
           std::ifstream is{plan.files[j], std::ios::in | std::ios::binary};
           if (!is.is_open()) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + plan.files[j].string());
           is.read(reinterpret_cast<char*>(set.in.p + 4 * plan.offsets[j]), static_cast<std::streamsize>((plan.offsets[j + 1] - plan.offsets[j]) * 16));
+          if (three_knots) {
+            hip::FrameTrajectory ft;
+            ft.trajectory.times = {oxts[i - 1].stamp, oxts[i].stamp, oxts[i + 1].stamp};
+            ft.trajectory.poses = {OxtsToPose(oxts[i - 1]), OxtsToPose(oxts[i]), OxtsToPose(oxts[i + 1])};
+            ft.stamp_start = t_start[i];
+            ft.stamp_end = t_end[i];
+            ft.requested_time = t_mid[i];
+            set.trajectories.push_back(std::move(ft));
+            continue;
+          }
           hip::FramePoses fp;  // MakeFrame (data_io.cpp:253-269) + requested_time = stamp_middle (handlers.cpp:59)
           fp.T_start = trajectory_interpolation::InterpolateTrajectory(oxts[i - 1], oxts[i], t_start[i]);
           fp.T_end = trajectory_interpolation::InterpolateTrajectory(oxts[i], oxts[i + 1], t_end[i]);
@@ -346,7 +361,8 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
       BufferSet& set = sets[k % 2];
       if (!wait_for(set, State::kReady)) break;
       auto const t0 = clk::now();
-      hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.frames, set.out.p);
+      if (three_knots) hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.trajectories, set.out.p);
+      else hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.frames, set.out.p);
       t_gpu += secs(t0, clk::now());
       publish(set, State::kDone);
     }

@@ -345,6 +345,52 @@ void knot_direction(double c, float* ck, float* sk) {
   *sk = (float)std::sin(alpha);
 }
 
+// device records of one frame's trajectory (f32): one TrajSeg32 per segment
+void fill_traj_segs(const TrajHost& th, double stamp_start, double stamp_end, TrajSeg32* segs) {
+  const double scan = stamp_end - stamp_start;
+  for (uint32_t k = 0; k < th.n_seg; ++k) {
+    TrajSeg32& r = segs[k];
+    kmc_frame_params fp;
+    fp.twist[0] = th.f[k].rho.x; fp.twist[1] = th.f[k].rho.y; fp.twist[2] = th.f[k].rho.z;
+    fp.twist[3] = th.f[k].phi.x; fp.twist[4] = th.f[k].phi.y; fp.twist[5] = th.f[k].phi.z;
+    fp.x_req = 0.0;
+    fill_rec(fp, &r);  // phi, |phi|^2, rho, c1, c2 (s0 overwritten below)
+    const double ck = (th.t0[k] - stamp_start) / scan;   // scan fraction of the segment's start knot
+    const double g = scan / th.dur[k];
+    const double a = (k == th.r) ? th.x_r : 0.0;
+    r.g = (float)g;
+    r.s0 = (float)((0.5 - ck) * g - a);                  // 2 knots on the scan: (0.5 - 0) * 1 - x_req, as kmc_hip_deskew_f32
+    r.knot_c = (float)ck;
+    r.m00 = (float)th.M[k].L.m[0][0]; r.m01 = (float)th.M[k].L.m[0][1]; r.m02 = (float)th.M[k].L.m[0][2]; r.tx = (float)th.M[k].t.x;
+    r.m10 = (float)th.M[k].L.m[1][0]; r.m11 = (float)th.M[k].L.m[1][1]; r.m12 = (float)th.M[k].L.m[1][2]; r.ty = (float)th.M[k].t.y;
+    r.m20 = (float)th.M[k].L.m[2][0]; r.m21 = (float)th.M[k].L.m[2][1]; r.m22 = (float)th.M[k].L.m[2][2]; r.tz = (float)th.M[k].t.z;
+    knot_direction(ck, &r.knot_cos, &r.knot_sin);
+    r.flags = (k == th.r ? kSegIdentity : 0u) | (ck <= 0.0 ? kKnotAlwaysGe : 0u) | (ck > 1.0 ? kKnotNeverGe : 0u);
+  }
+}
+
+// coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point
+void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n, uint2* h_coarse) {
+  const uint64_t chunk = 1ull << kChunkShift;
+  const uint64_t n_chunks = (n + chunk - 1) / chunk;
+  uint32_t f = 0;
+  for (uint64_t ci = 0; ci < n_chunks; ++ci) {
+    const uint64_t first = ci * chunk;
+    const uint64_t chunk_end = std::min<uint64_t>(first + chunk, n);
+    while (f + 1 < n_frames && offsets[f + 1] <= first) ++f;
+    uint32_t split = kSplitNone;
+    const uint64_t e = offsets[f + 1];
+    if (e < chunk_end) {  // frame f ends inside this chunk
+      // a second boundary inside the chunk (frame f+1 ends here too, e.g. it is tiny or empty) -> search on the device
+      const bool second = (f + 1 < n_frames) && offsets[f + 2] < chunk_end;
+      split = second ? kSplitSearch : (uint32_t)(e - first);
+    }
+    h_coarse[ci] = make_uint2(f, split);
+  }
+  while (f + 1 < n_frames && offsets[f + 1] <= n - 1) ++f;
+  h_coarse[n_chunks] = make_uint2(f, kSplitNone);
+}
+
 constexpr size_t kTrajBytes = kMaxSegments * (sizeof(TrajSeg32) + sizeof(TrajSeg64));
 
 int ensure_traj(kmc_ctx* c) {
@@ -693,25 +739,7 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
     r->end_lo = (uint32_t)(offsets[f + 1] & 0xFFFFFFFFull);
     r->end_hi = (uint32_t)(offsets[f + 1] >> 32);
   }
-  {
-    // coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point
-    uint32_t f = 0;
-    for (uint64_t ci = 0; ci < n_chunks; ++ci) {
-      const uint64_t first = ci * chunk;
-      const uint64_t chunk_end = std::min<uint64_t>(first + chunk, n);
-      while (f + 1 < n_frames && offsets[f + 1] <= first) ++f;
-      uint32_t split = kSplitNone;
-      const uint64_t e = offsets[f + 1];
-      if (e < chunk_end) {  // frame f ends inside this chunk
-        // a second boundary inside the chunk (frame f+1 ends here too, e.g. it is tiny or empty) -> search on the device
-        const bool second = (f + 2 <= n_frames) && (f + 1 < n_frames) && offsets[f + 2] < chunk_end;
-        split = second ? kSplitSearch : (uint32_t)(e - first);
-      }
-      h_coarse[ci] = make_uint2(f, split);
-    }
-    while (f + 1 < n_frames && offsets[f + 1] <= n - 1) ++f;
-    h_coarse[n_chunks] = make_uint2(f, kSplitNone);
-  }
+  build_coarse(offsets, n_frames, n, h_coarse);
   // one table upload on the side stream (overlaps whatever the compute stream is still running), awaited on the host
   {
     const int rc_up = slot_upload(c, slot_id, need);
@@ -873,28 +901,9 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
 
-  const double scan = stamp_end - stamp_start;
   TrajSeg32 segs[kMaxSegments];
   std::memset(segs, 0, sizeof(segs));
-  for (uint32_t k = 0; k < th.n_seg; ++k) {
-    TrajSeg32& r = segs[k];
-    kmc_frame_params fp;
-    fp.twist[0] = th.f[k].rho.x; fp.twist[1] = th.f[k].rho.y; fp.twist[2] = th.f[k].rho.z;
-    fp.twist[3] = th.f[k].phi.x; fp.twist[4] = th.f[k].phi.y; fp.twist[5] = th.f[k].phi.z;
-    fp.x_req = 0.0;
-    fill_rec(fp, &r);  // phi, |phi|^2, rho, c1, c2 (s0 overwritten below)
-    const double ck = (th.t0[k] - stamp_start) / scan;   // scan fraction of the segment's start knot
-    const double g = scan / th.dur[k];
-    const double a = (k == th.r) ? th.x_r : 0.0;
-    r.g = (float)g;
-    r.s0 = (float)((0.5 - ck) * g - a);                  // 2 knots on the scan: (0.5 - 0) * 1 - x_req, as kmc_hip_deskew_f32
-    r.knot_c = (float)ck;
-    r.m00 = (float)th.M[k].L.m[0][0]; r.m01 = (float)th.M[k].L.m[0][1]; r.m02 = (float)th.M[k].L.m[0][2]; r.tx = (float)th.M[k].t.x;
-    r.m10 = (float)th.M[k].L.m[1][0]; r.m11 = (float)th.M[k].L.m[1][1]; r.m12 = (float)th.M[k].L.m[1][2]; r.ty = (float)th.M[k].t.y;
-    r.m20 = (float)th.M[k].L.m[2][0]; r.m21 = (float)th.M[k].L.m[2][1]; r.m22 = (float)th.M[k].L.m[2][2]; r.tz = (float)th.M[k].t.z;
-    knot_direction(ck, &r.knot_cos, &r.knot_sin);
-    r.flags = (k == th.r ? kSegIdentity : 0u) | (ck <= 0.0 ? kKnotAlwaysGe : 0u) | (ck > 1.0 ? kKnotNeverGe : 0u);
-  }
+  fill_traj_segs(th, stamp_start, stamp_end, segs);
   int slot_id = 0;
   rc = slot_begin(c, sizeof(segs), &slot_id);
   if (rc != KMC_OK) return rc;
@@ -938,6 +947,112 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (mem_kind == KMC_MEM_HOST) {
     KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out, d_out, n * sizeof(v4f), hipMemcpyDeviceToHost, c->stream));
     if (bracket_idx_out) KMC_HIP_TRY(c, hipMemcpyAsync(bracket_idx_out, d_idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (st) st->n_launches = 1;
+  return tm.end_call(st);
+}
+
+// ---- batched N-knot trajectories ---------------------------------------------------------------------
+int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets, uint32_t n_frames,
+                                  const kmc_traj_frame* frames, uint32_t* frame_idx_out, uint32_t* bracket_idx_out, int mem_kind,
+                                  kmc_stats* st) {
+  if (!c || !offsets || (n_frames && !frames)) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (st) std::memset(st, 0, sizeof(*st));
+  if (offsets[0] != 0) return KMC_ERR_INVALID_ARG;
+  for (uint32_t f = 0; f < n_frames; ++f)
+    if (offsets[f + 1] < offsets[f]) return KMC_ERR_INVALID_ARG;
+  const uint64_t n = n_frames ? offsets[n_frames] : 0;
+  if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+
+  // host pre-step per frame (f64): segments, anchors, M_k
+  std::vector<TrajHost> th(n_frames);
+  size_t total_seg = 0;
+  int tier = kSeries3;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const kmc_traj_frame& fr = frames[f];
+    if (!(fr.stamp_start < fr.stamp_end)) return KMC_ERR_DEGENERATE;
+    int rc = build_trajectory(fr.knot_times, fr.knot_poses, fr.n_knots, fr.requested_time, &th[f]);
+    if (rc != KMC_OK) return rc;
+    if (!(fr.knot_times[0] <= fr.stamp_start && fr.stamp_end <= fr.knot_times[fr.n_knots - 1])) return KMC_ERR_TIME_OUT_OF_RANGE;
+    if (!(fr.requested_time >= fr.stamp_start && fr.requested_time <= fr.stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
+    total_seg += th[f].n_seg;
+    tier = std::max(tier, traj_tier(c, th[f], fr.stamp_start, fr.stamp_end));
+  }
+  if (c->force_tier >= 0 && c->force_tier <= 2) tier = c->force_tier;
+  if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
+  if (n == 0) return KMC_OK;
+
+  const uint64_t chunk = 1ull << kChunkShift;
+  const uint64_t n_coarse = (n + chunk - 1) / chunk + 1;
+  const size_t frecs_bytes = ((size_t)n_frames * sizeof(TrajFrameRec) + 255) & ~(size_t)255;
+  const size_t segs_bytes = ((size_t)total_seg * sizeof(TrajSeg32) + 255) & ~(size_t)255;
+  const size_t need = frecs_bytes + segs_bytes + (size_t)n_coarse * sizeof(uint2);
+  int slot_id = 0;
+  int rc = slot_begin(c, need, &slot_id);
+  if (rc != KMC_OK) return rc;
+  kmc_ctx::TableSlot& sl = c->slots[slot_id];
+  TrajFrameRec* h_frecs = reinterpret_cast<TrajFrameRec*>(sl.h_buf);
+  TrajSeg32* h_segs = reinterpret_cast<TrajSeg32*>(sl.h_buf + frecs_bytes);
+  uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + frecs_bytes + segs_bytes);
+  std::memset(h_segs, 0, segs_bytes);
+  uint32_t seg_at = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    h_frecs[f].end_lo = (uint32_t)(offsets[f + 1] & 0xFFFFFFFFull);
+    h_frecs[f].end_hi = (uint32_t)(offsets[f + 1] >> 32);
+    h_frecs[f].seg_begin = seg_at;
+    h_frecs[f].n_seg = th[f].n_seg;
+    fill_traj_segs(th[f], frames[f].stamp_start, frames[f].stamp_end, h_segs + seg_at);
+    seg_at += th[f].n_seg;
+  }
+  build_coarse(offsets, n_frames, n, h_coarse);
+  rc = slot_upload(c, slot_id, need);
+  if (rc != KMC_OK) return rc;
+  const TrajFrameRec* d_frecs = reinterpret_cast<const TrajFrameRec*>(sl.d_buf);
+  const TrajSeg32* d_segs = reinterpret_cast<const TrajSeg32*>(sl.d_buf + frecs_bytes);
+  const uint2* d_coarse = reinterpret_cast<const uint2*>(sl.d_buf + frecs_bytes + segs_bytes);
+
+  CallTimer tm(c);
+  const v4f* d_in = (const v4f*)xyzi_in;
+  v4f* d_out = (v4f*)xyzi_out;
+  uint32_t* d_fidx = frame_idx_out;
+  uint32_t* d_bidx = bracket_idx_out;
+  const size_t pts = n * sizeof(v4f), idx_bytes = n * sizeof(uint32_t);
+  if (mem_kind == KMC_MEM_HOST) {
+    rc = ensure_tmp(c, 2 * pts + 2 * idx_bytes);
+    if (rc != KMC_OK) return rc;
+    d_in = (const v4f*)c->d_tmp;
+    d_out = (v4f*)((char*)c->d_tmp + pts);
+    d_fidx = frame_idx_out ? (uint32_t*)((char*)c->d_tmp + 2 * pts) : nullptr;
+    d_bidx = bracket_idx_out ? (uint32_t*)((char*)c->d_tmp + 2 * pts + idx_bytes) : nullptr;
+  }
+  if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (mem_kind == KMC_MEM_HOST) KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, pts, hipMemcpyHostToDevice, c->stream));
+  if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  const int grid = grid_for(c, (n + 63) / 64);
+  const bool idx = d_fidx || d_bidx;
+#define KMC_LAUNCH_TRAJ_BATCH(T)                                                                                                   \
+  do {                                                                                                                             \
+    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_frecs, d_segs, d_coarse, n_frames, d_fidx, d_bidx); \
+    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_frecs, d_segs, d_coarse, n_frames, d_fidx, d_bidx);     \
+  } while (0)
+  switch (tier) {
+    case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;
+    case kSeries5: KMC_LAUNCH_TRAJ_BATCH(kSeries5); break;
+    default: KMC_LAUNCH_TRAJ_BATCH(kTrig); break;
+  }
+#undef KMC_LAUNCH_TRAJ_BATCH
+  KMC_HIP_TRY(c, hipGetLastError());
+  rc = slot_end(c, slot_id);
+  if (rc != KMC_OK) return rc;
+  if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (mem_kind == KMC_MEM_HOST) {
+    KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out, d_out, pts, hipMemcpyDeviceToHost, c->stream));
+    if (frame_idx_out) KMC_HIP_TRY(c, hipMemcpyAsync(frame_idx_out, d_fidx, idx_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (bracket_idx_out) KMC_HIP_TRY(c, hipMemcpyAsync(bracket_idx_out, d_bidx, idx_bytes, hipMemcpyDeviceToHost, c->stream));
     KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   if (st) st->n_launches = 1;

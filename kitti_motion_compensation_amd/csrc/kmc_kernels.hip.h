@@ -377,6 +377,110 @@ __global__ __launch_bounds__(64) void deskew_traj_f32(const v4f* __restrict__ in
   }
 }
 
+// Batched N-knot kernel: many frames in one launch, every frame with its own trajectory (its own segment records).
+// Per frame a 16-byte header {end offset, first segment, segment count}; the frame of a tile is found exactly like in
+// deskew_batch_f32 (coarse table, scalar loads), then the tile's frame stages ITS segments into LDS and runs the body of
+// deskew_traj_f32.  A tile that straddles frame boundaries walks the frames it touches one after the other (wave-uniform
+// loop): stage, let the lanes of that frame compute, next.  Outputs the per-point frame index and bracket index on demand.
+struct alignas(16) TrajFrameRec {
+  uint32_t end_lo, end_hi;  // offsets[f+1]
+  uint32_t seg_begin;       // first TrajSeg32 of the frame in the segment table
+  uint32_t n_seg;
+};
+__device__ __forceinline__ uint64_t rec_end(const TrajFrameRec& r) { return ((uint64_t)r.end_hi << 32) | r.end_lo; }
+
+template <int TIER>
+__device__ __forceinline__ v4f traj_lane(const v4f p, const TrajSeg32* lds, uint32_t n_seg, uint32_t& k_out) {
+  uint32_t k = 0;
+  for (uint32_t j = 1; j < n_seg; ++j) {  // interior knots
+    const v4f kn = reinterpret_cast<const v4f*>(&lds[j])[7];  // {knot_cos, knot_sin, flags, knot_c}
+    k += knot_ge(p.x, p.y, kn.w, kn.x, kn.y, __float_as_uint(kn.z)) ? 1u : 0u;
+  }
+  const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
+  const uint32_t ks = __all(k == k0) ? k0 : k;
+  k_out = k;
+  return traj_point<TIER>(p, lds[ks]);
+}
+
+template <int TIER, int NT, bool WRITE_IDX>
+__global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+                                                           const TrajFrameRec* __restrict__ frecs,
+                                                           const TrajSeg32* __restrict__ segs,
+                                                           const uint2* __restrict__ coarse, uint32_t n_frames,
+                                                           uint32_t* __restrict__ frame_idx_out,
+                                                           uint32_t* __restrict__ bracket_out) {
+  constexpr int BLOCK = 64;
+  __shared__ TrajSeg32 lds[kMaxSegments];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t base = t * BLOCK;
+    const uint64_t i = base + tid;
+    const uint64_t tile_end = base + BLOCK <= n ? base + BLOCK : n;
+    const v4f p = load_point<NT>(in + (i < n ? i : n - 1));  // dead lanes of a ragged tile re-read the last point
+    // frame of the tile's first point (wave-uniform)
+    const uint64_t c = base >> kChunkShift;
+    const uint2 entry = coarse[c];
+    uint32_t f0;
+    if (entry.y != kSplitSearch) {
+      f0 = entry.x + ((uint32_t)(base - (c << kChunkShift)) >= entry.y ? 1u : 0u);
+    } else {
+      uint32_t lo = entry.x, hi = coarse[c + 1].x;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rec_end(frecs[mid]) > base) hi = mid;
+        else lo = mid + 1;
+      }
+      f0 = lo;
+    }
+    TrajFrameRec r = frecs[f0];
+    __syncthreads();  // the previous tile's LDS readers are done (one-wave workgroup: a wait, not a barrier)
+    if (rec_end(r) >= tile_end) {
+      for (uint32_t w = tid; w < r.n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + r.seg_begin)[w];
+      __syncthreads();
+      uint32_t k;
+      const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k);
+      if constexpr (NT & kStoreSc1) {
+        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
+        tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
+      } else {
+        if (i < n) store_point<NT>(out + i, q);
+      }
+      if constexpr (WRITE_IDX) {
+        if (i < n) {
+          if (frame_idx_out) __builtin_nontemporal_store(f0, frame_idx_out + i);
+          if (bracket_out) __builtin_nontemporal_store(k, bracket_out + i);
+        }
+      }
+    } else {
+      uint32_t fi = f0;
+      uint64_t begin = base;
+      while (true) {
+        const uint64_t e = rec_end(r);
+        const bool mine = i >= begin && i < e && i < n;
+        if (e > begin) {  // frame fi owns at least one point of the tile (empty frames are skipped)
+          for (uint32_t w = tid; w < r.n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + r.seg_begin)[w];
+          __syncthreads();
+          uint32_t k;
+          const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k);
+          if (mine) {
+            store_point<NT>(out + i, q);
+            if constexpr (WRITE_IDX) {
+              if (frame_idx_out) frame_idx_out[i] = fi;
+              if (bracket_out) bracket_out[i] = k;
+            }
+          }
+          __syncthreads();
+          begin = e;
+        }
+        if (e >= tile_end || fi + 1 >= n_frames) break;
+        ++fi;
+        r = frecs[fi];
+      }
+    }
+  }
+}
+
 // f64 Eigen-layout variant: honours the caller's per-point stamps; the bracket is found by f64 time compares.
 __global__ __launch_bounds__(kBlock) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                              const double* __restrict__ z, const double* __restrict__ w,

@@ -467,6 +467,77 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
       ASSERT_TRUE(worst <= 1e-5);
     }
   }
+  CASE("MotionCompensateRun with KMC_RUN_KNOTS=3: the three OXTS poses around each frame, used as they are");
+  {
+    // re-run the same synthetic run through the batched N-knot kernel; interior frames must equal the 3-argument
+    // MotionCompensateFrame(Frame, Trajectory, Time) of the f64 API frame by frame
+    Path const run{tmp + "/run_0005_sync"};
+    Path const out_dir{run / "velodyne_points/data_motion_compensated"};
+    std::filesystem::remove_all(out_dir);
+    setenv("KMC_RUN_KNOTS", "3", 1);
+    MotionCompensateRun(run);
+    unsetenv("KMC_RUN_KNOTS");
+    ASSERT_EQ(NumberOfFilesInDirectory(out_dir), 5u);
+    for (std::size_t i = 1; i + 1 < 5; ++i) {
+      Frame const frame{LoadSingleFrame(run, i)};
+      Oxts const o0{LoadOxts(run, i - 1)}, o1{LoadOxts(run, i)}, o2{LoadOxts(run, i + 1)};
+      Trajectory tr;
+      tr.times = {o0.stamp, o1.stamp, o2.stamp};
+      tr.poses = {OxtsToPose(o0), OxtsToPose(o1), OxtsToPose(o2)};
+      Pointcloud const ref{MotionCompensateFrame(frame, tr, frame.scan.stamp_middle)};
+      std::vector<float> const got = read_bin(out_dir / (IdToZeroPaddedString(i) + ".bin"));
+      ASSERT_EQ(static_cast<Index>(got.size() / 4), ref.rows());
+      double worst = 0;
+      for (Index k = 0; k < ref.rows(); ++k) {
+        double d2 = 0, n2 = 0;
+        for (int j = 0; j < 3; ++j) {
+          double const d = got[4 * k + j] - ref(k, j);
+          d2 += d * d;
+          n2 += ref(k, j) * ref(k, j);
+        }
+        worst = std::fmax(worst, std::sqrt(d2) / std::fmax(std::sqrt(n2), 1e-3));
+      }
+      std::printf("  3-knot run frame %zu: max rel err vs f64 trajectory API %.3e\n", i, worst);
+      ASSERT_TRUE(worst <= 1e-5);
+    }
+  }
+  CASE("hip::MotionCompensateKittiClouds with per-frame trajectories vs the single-frame trajectory call");
+  {
+    std::vector<float> const raw = read_bin(data_folder / "velodyne_points/data/0000000000.bin");
+    std::vector<std::uint64_t> const offsets{0, 40000, 40000, 40063, 100000};
+    std::vector<hip::FrameTrajectory> frames(4);
+    for (std::size_t f = 0; f < frames.size(); ++f) {
+      double const t0 = 47072.283701593, t1 = 47072.386973931;
+      Affine3d a, b, c3;
+      b.rotate(AngleAxisd{0.02 * static_cast<double>(f + 1), Vector3d{0, 0, 1}});
+      b.translation() = Vector3d{1.3, 0.05 * static_cast<double>(f), -0.02};
+      c3 = b;
+      c3.rotate(AngleAxisd{-0.015, Vector3d{0, 1, 0}});
+      c3.translation() = Vector3d{2.7, 0.1, -0.03};
+      frames[f].trajectory.times = {t0 - 0.05, 0.5 * (t0 + t1) + 0.004, t1 + 0.05};
+      frames[f].trajectory.poses = {a, b, c3};
+      frames[f].stamp_start = t0;
+      frames[f].stamp_end = t1;
+      frames[f].requested_time = 0.5 * (t0 + t1);
+    }
+    std::vector<float> batched(4 * offsets.back()), single(4 * offsets.back());
+    std::vector<std::uint32_t> fidx(offsets.back()), bidx(offsets.back()), bsingle(offsets.back());
+    hip::MotionCompensateKittiClouds(raw.data(), offsets, frames, batched.data(), fidx.data(), bidx.data());
+    std::size_t bad_index = 0;
+    for (std::size_t f = 0; f < frames.size(); ++f) {
+      std::size_t const a = offsets[f], b = offsets[f + 1];
+      if (a == b) continue;
+      // 16-byte alignment of the sub-range: a * 16 bytes from a 16-byte aligned base
+      std::vector<float> in(raw.begin() + 4 * a, raw.begin() + 4 * b), out(4 * (b - a));
+      hip::MotionCompensateKittiCloud(in.data(), b - a, frames[f].trajectory, frames[f].stamp_start, frames[f].stamp_end,
+                                      frames[f].requested_time, out.data(), bsingle.data() + a);
+      std::memcpy(single.data() + 4 * a, out.data(), out.size() * sizeof(float));
+      for (std::size_t i = a; i < b; ++i) bad_index += fidx[i] != f;
+    }
+    ASSERT_EQ(bad_index, 0u);
+    ASSERT_TRUE(std::memcmp(batched.data(), single.data(), batched.size() * sizeof(float)) == 0);
+    ASSERT_TRUE(bidx == bsingle);
+  }
   CASE("viz::ProjectPointcloud (camera_model.cpp:5-95 minus the drawing) on the shipped frame and calibration");
   {
     // the shipped frame 0 with a synthetic pair of scan poses (only its own OXTS packet ships): 1.3 m forward, slight yaw

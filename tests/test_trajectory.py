@@ -222,3 +222,138 @@ def test_trajectory_argument_checks(ctx, kitti):
     with pytest.raises(capi.KmcError) as e:  # too many knots
         ctx.deskew_traj_f32(pts, out, np.linspace(T0 - 1, T1 + 1, 19), _rt(poses * 7)[:19], T0, T1, TREQ)
     assert e.value.status == capi.ERR_INVALID_ARG
+
+
+# ---- batched N-knot form: every frame with its own trajectory, one launch ----------------------------------------------
+def _random_frames(rng, P1, sizes):
+    frames = []
+    for _ in sizes:
+        k = int(rng.integers(2, 7))  # 2..6 knots
+        t0 = T0 + float(rng.uniform(-1e-3, 1e-3))
+        t1 = t0 + float(rng.uniform(0.09, 0.11))
+        inner = np.sort(rng.uniform(t0 + 0.005, t1 - 0.005, k - 2)) if k > 2 else np.array([])
+        if k > 2 and rng.random() < 0.3:
+            inner[0] = t0 + 0.25 * (t1 - t0)  # a knot exactly on a quarter turn
+            inner = np.sort(inner)
+        times = np.concatenate([[t0 - float(rng.uniform(0, 0.05))], inner, [t1 + float(rng.uniform(0, 0.05))]])
+        steps = [list(rng.normal(0, [0.5, 0.05, 0.02, 0.002, 0.003, 0.02])) for _ in range(k - 1)]
+        start = orc.affine_mul(P1, orc.se3_exp(list(rng.normal(0, [3, 3, 0.1, 0.01, 0.01, 0.3]))))
+        poses = _chain(start, steps)
+        frames.append(dict(times=times, poses=_rt(poses), oracle_poses=poses, stamp_start=t0, stamp_end=t1,
+                           requested_time=t0 + float(rng.random()) * (t1 - t0)))
+    return frames
+
+
+def _check_traj_batch(ctx, xyzi, sizes, frames, mem="host"):
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(offsets[-1])
+    pts = np.ascontiguousarray(xyzi[:n])
+    out = np.full_like(pts, 7.0)
+    fidx = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+    bidx = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+    if mem == "host":
+        ctx.deskew_traj_batch_f32(pts, out, offsets, frames, fidx, bidx)
+    else:
+        import torch
+
+        d_in = torch.from_numpy(pts).cuda()
+        d_out = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")
+        d_f = torch.zeros(n, dtype=torch.int32, device="cuda")
+        d_b = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.deskew_traj_batch_f32(d_in, d_out, offsets, frames, d_f, d_b)
+        torch.cuda.synchronize()
+        ctx.set_stream(None)
+        assert bool((d_out[n:] == 7.0).all()), "wrote past the end"
+        out = d_out[:n].cpu().numpy()
+        fidx = d_f.cpu().numpy().view(np.uint32)
+        bidx = d_b.cpu().numpy().view(np.uint32)
+    assert np.array_equal(fidx, np.repeat(np.arange(len(sizes), dtype=np.uint32), sizes)), "frame indices must be bit-exact"
+    assert np.array_equal(out[:, 3].view(np.uint32), pts[:, 3].view(np.uint32))
+    for f, fr in enumerate(frames):
+        a, b = int(offsets[f]), int(offsets[f + 1])
+        if a == b:
+            continue
+        # the single-frame entry point on the same frame: same arithmetic, so the same bits
+        one = np.empty_like(pts[a:b])
+        br1 = np.empty(b - a, dtype=np.uint32)
+        ctx.deskew_traj_f32(np.ascontiguousarray(pts[a:b]), one, fr["times"], fr["poses"], fr["stamp_start"], fr["stamp_end"],
+                            fr["requested_time"], br1)
+        assert np.array_equal(out[a:b].view(np.uint32), one.view(np.uint32)), f"frame {f}"
+        assert np.array_equal(bidx[a:b], br1), f"frame {f}"
+        assert np.array_equal(bidx[a:b], orc.bracket_indices_f32(pts[a:b], fr["times"], fr["stamp_start"], fr["stamp_end"]))
+        if f % 7 == 0 or b - a < 2000:
+            ref = orc.deskew_xyzi_f32_traj(pts[a:b], fr["stamp_start"], fr["stamp_end"], fr["times"], fr["oracle_poses"], fr["requested_time"])
+            assert ref["rc"] == orc.OK
+            assert util.rel_point_error(out[a:b, :3], ref["xyz_f64"]).max() <= REL_TOL
+    return out, fidx, bidx
+
+
+@pytest.mark.gpu
+def test_batched_trajectories_vs_single_frame_kernel_and_oracle(ctx, kitti):
+    xyzi, P1 = kitti
+    rng = np.random.default_rng(5)
+    big = np.tile(xyzi, (4, 1))
+    sizes = [20000, 1, 63, 0, 64, 65, 30000, 0, 0, 5, 16384, 16385, 100, 40000, 127, 129]  # ragged, empty, tiny, chunk-aligned
+    frames = _random_frames(rng, P1, sizes)
+    host = _check_traj_batch(ctx, big, sizes, frames, "host")
+    dev = _check_traj_batch(ctx, big, sizes, frames, "device")
+    for h, d in zip(host, dev):
+        assert np.array_equal(h.view(np.uint32), d.view(np.uint32))
+    # a capped grid (several tiles per wave, LDS restaged per tile): same bits
+    ctx.set_launch_config(1, 0)
+    capped = _check_traj_batch(ctx, big, sizes, frames, "host")
+    ctx.set_launch_config(0, 0)
+    for h, d in zip(host, capped):
+        assert np.array_equal(h.view(np.uint32), d.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_batched_trajectories_many_tiny_frames(ctx, kitti):
+    """More frames than points per tile: a 64-point tile walks through dozens of frames."""
+    xyzi, P1 = kitti
+    rng = np.random.default_rng(6)
+    sizes = [int(v) for v in rng.integers(0, 9, 300)] + [5000] + [int(v) for v in rng.integers(0, 4, 100)]
+    frames = _random_frames(rng, P1, sizes)
+    _check_traj_batch(ctx, xyzi, sizes, frames, "host")
+
+
+@pytest.mark.gpu
+def test_batched_trajectories_two_knots_equal_the_batched_two_pose_kernel(ctx, kitti):
+    xyzi, P1 = kitti
+    sizes = [30000, 12345, 50000]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(offsets[-1])
+    pts = np.ascontiguousarray(xyzi[:n])
+    steps = [[1.3, 0.05, -0.02, 0.001, -0.002, 0.03], [0.9, 0.0, 0.0, 0.0, 0.0, -0.04], [2.9, -0.3, 0.1, 0.02, 0.01, -0.1]]
+    frames, params = [], []
+    for s in steps:
+        P2 = orc.affine_mul(P1, orc.se3_exp(s))
+        frames.append(dict(times=[T0, T1], poses=_rt([P1, P2]), stamp_start=T0, stamp_end=T1, requested_time=TREQ))
+        params.append(capi.frame_params_from_poses(P1.rt12().reshape(3, 4), P2.rt12().reshape(3, 4), T0, T1, TREQ))
+    a = np.empty_like(pts)
+    b = np.empty_like(pts)
+    ctx.deskew_traj_batch_f32(pts, a, offsets, frames)
+    ctx.deskew_batch_f32(pts, b, offsets, params)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_batched_trajectories_argument_checks(ctx, kitti):
+    xyzi, P1 = kitti
+    pts = np.ascontiguousarray(xyzi[:1000])
+    out = np.empty_like(pts)
+    good = dict(times=[T0, T1], poses=_rt([P1, P1]), stamp_start=T0, stamp_end=T1, requested_time=TREQ)
+    short = dict(good, times=[T0 + 0.01, T1])          # does not cover the scan
+    with pytest.raises(capi.KmcError) as e:
+        ctx.deskew_traj_batch_f32(pts, out, [0, 500, 1000], [good, short])
+    assert e.value.status == capi.ERR_TIME_OUT_OF_RANGE
+    late = dict(good, requested_time=T1 + 1.0)
+    with pytest.raises(capi.KmcError) as e:
+        ctx.deskew_traj_batch_f32(pts, out, [0, 500, 1000], [late, good])
+    assert e.value.status == capi.ERR_TIME_OUT_OF_RANGE
+    with pytest.raises(capi.KmcError) as e:
+        ctx.deskew_traj_batch_f32(pts, out, [0, 600, 500], [good, good])
+    assert e.value.status == capi.ERR_INVALID_ARG
+    st = ctx.deskew_traj_batch_f32(pts, out, [0], [])   # no frames: nothing to do
+    assert st.n_points == 0
