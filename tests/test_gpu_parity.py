@@ -653,3 +653,38 @@ def test_batch_frame_index_fuzz(torch_mod, ctx):
         assert torch.equal(d_out[:n], pool[:n]), case
         assert bool((d_out[n:] == 7.0).all()) and bool((d_idx[n:] == -1).all()), case
     ctx.set_launch_config(0, 0)
+
+
+def test_single_frame_entry_point_is_graph_capturable(ctx, torch_mod):
+    """KMC_MEM_DEVICE calls only enqueue work on the caller's stream, so a sequence of them can be captured once into a HIP
+    graph (torch.cuda.CUDAGraph on ROCm) and replayed; the replay writes the same bits (tools/measure_graph.py times it)."""
+    torch = torch_mod
+    nf, per = 16, 10_000
+    pts = capi.synth_points_host(nf * per, 321)
+    d_in = torch.from_numpy(pts).cuda()
+    d_out = torch.zeros_like(d_in)
+    params = [capi.FrameParams.make([1.0 + 0.01 * f, 0.02, 0.0, 0.001, 0.0, 0.03], 0.25) for f in range(nf)]
+
+    def launches():
+        for f in range(nf):
+            ctx.deskew_f32(d_in[f * per:(f + 1) * per], d_out[f * per:(f + 1) * per], params[f], n=per)
+
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    launches()
+    torch.cuda.synchronize()
+    ref = d_out.clone()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.stream(side):
+            ctx.set_stream(side.cuda_stream)
+            launches()
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                launches()
+        d_out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d_out.view(torch.int32), ref.view(torch.int32))
+    finally:
+        ctx.set_stream(None)
