@@ -970,7 +970,7 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
 
   // host pre-step per frame (f64): segments, anchors, M_k
   std::vector<TrajHost> th(n_frames);
-  size_t total_seg = 0;
+  uint32_t seg_stride = 1;  // slots per frame in the segment table = the longest trajectory of the batch
   int tier = kSeries3;
   for (uint32_t f = 0; f < n_frames; ++f) {
     const kmc_traj_frame& fr = frames[f];
@@ -979,7 +979,7 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
     if (rc != KMC_OK) return rc;
     if (!(fr.knot_times[0] <= fr.stamp_start && fr.stamp_end <= fr.knot_times[fr.n_knots - 1])) return KMC_ERR_TIME_OUT_OF_RANGE;
     if (!(fr.requested_time >= fr.stamp_start && fr.requested_time <= fr.stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
-    total_seg += th[f].n_seg;
+    seg_stride = std::max(seg_stride, th[f].n_seg);
     tier = std::max(tier, traj_tier(c, th[f], fr.stamp_start, fr.stamp_end));
   }
   if (c->force_tier >= 0 && c->force_tier <= 2) tier = c->force_tier;
@@ -989,7 +989,7 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   const uint64_t chunk = 1ull << kChunkShift;
   const uint64_t n_coarse = (n + chunk - 1) / chunk + 1;
   const size_t frecs_bytes = ((size_t)n_frames * sizeof(TrajFrameRec) + 255) & ~(size_t)255;
-  const size_t segs_bytes = ((size_t)total_seg * sizeof(TrajSeg32) + 255) & ~(size_t)255;
+  const size_t segs_bytes = ((size_t)n_frames * seg_stride * sizeof(TrajSeg32) + 255) & ~(size_t)255;
   const size_t need = frecs_bytes + segs_bytes + (size_t)n_coarse * sizeof(uint2);
   int slot_id = 0;
   int rc = slot_begin(c, need, &slot_id);
@@ -999,14 +999,12 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   TrajSeg32* h_segs = reinterpret_cast<TrajSeg32*>(sl.h_buf + frecs_bytes);
   uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + frecs_bytes + segs_bytes);
   std::memset(h_segs, 0, segs_bytes);
-  uint32_t seg_at = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
     h_frecs[f].end_lo = (uint32_t)(offsets[f + 1] & 0xFFFFFFFFull);
     h_frecs[f].end_hi = (uint32_t)(offsets[f + 1] >> 32);
-    h_frecs[f].seg_begin = seg_at;
     h_frecs[f].n_seg = th[f].n_seg;
-    fill_traj_segs(th[f], frames[f].stamp_start, frames[f].stamp_end, h_segs + seg_at);
-    seg_at += th[f].n_seg;
+    h_frecs[f].pad = 0;
+    fill_traj_segs(th[f], frames[f].stamp_start, frames[f].stamp_end, h_segs + (size_t)f * seg_stride);
   }
   build_coarse(offsets, n_frames, n, h_coarse);
   rc = slot_upload(c, slot_id, need);
@@ -1036,8 +1034,8 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   const bool idx = d_fidx || d_bidx;
 #define KMC_LAUNCH_TRAJ_BATCH(T)                                                                                                   \
   do {                                                                                                                             \
-    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_frecs, d_segs, d_coarse, n_frames, d_fidx, d_bidx); \
-    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_frecs, d_segs, d_coarse, n_frames, d_fidx, d_bidx);     \
+    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_frecs, d_segs, seg_stride, d_coarse, n_frames, d_fidx, d_bidx); \
+    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_frecs, d_segs, seg_stride, d_coarse, n_frames, d_fidx, d_bidx);     \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;

@@ -378,14 +378,15 @@ __global__ __launch_bounds__(64) void deskew_traj_f32(const v4f* __restrict__ in
 }
 
 // Batched N-knot kernel: many frames in one launch, every frame with its own trajectory (its own segment records).
-// Per frame a 16-byte header {end offset, first segment, segment count}; the frame of a tile is found exactly like in
+// Per frame a 16-byte header {end offset, segment count} and `seg_stride` slots in the segment table (frame f's records start
+// at f * seg_stride, so their address does not wait for the header load); the frame of a tile is found exactly like in
 // deskew_batch_f32 (coarse table, scalar loads), then the tile's frame stages ITS segments into LDS and runs the body of
 // deskew_traj_f32.  A tile that straddles frame boundaries walks the frames it touches one after the other (wave-uniform
 // loop): stage, let the lanes of that frame compute, next.  Outputs the per-point frame index and bracket index on demand.
 struct alignas(16) TrajFrameRec {
   uint32_t end_lo, end_hi;  // offsets[f+1]
-  uint32_t seg_begin;       // first TrajSeg32 of the frame in the segment table
   uint32_t n_seg;
+  uint32_t pad;
 };
 __device__ __forceinline__ uint64_t rec_end(const TrajFrameRec& r) { return ((uint64_t)r.end_hi << 32) | r.end_lo; }
 
@@ -406,8 +407,8 @@ template <int TIER, int NT, bool WRITE_IDX>
 __global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                            const TrajFrameRec* __restrict__ frecs,
                                                            const TrajSeg32* __restrict__ segs,
-                                                           const uint2* __restrict__ coarse, uint32_t n_frames,
-                                                           uint32_t* __restrict__ frame_idx_out,
+                                                           uint32_t seg_stride, const uint2* __restrict__ coarse,
+                                                           uint32_t n_frames, uint32_t* __restrict__ frame_idx_out,
                                                            uint32_t* __restrict__ bracket_out) {
   constexpr int BLOCK = 64;
   __shared__ TrajSeg32 lds[kMaxSegments];
@@ -435,8 +436,9 @@ __global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restric
     }
     TrajFrameRec r = frecs[f0];
     __syncthreads();  // the previous tile's LDS readers are done (one-wave workgroup: a wait, not a barrier)
+    // stage frame f0's slots (all seg_stride of them: the copy does not depend on the header) while the header arrives
+    for (uint32_t w = tid; w < seg_stride * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + (uint64_t)f0 * seg_stride)[w];
     if (rec_end(r) >= tile_end) {
-      for (uint32_t w = tid; w < r.n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + r.seg_begin)[w];
       __syncthreads();
       uint32_t k;
       const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k);
@@ -459,7 +461,9 @@ __global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restric
         const uint64_t e = rec_end(r);
         const bool mine = i >= begin && i < e && i < n;
         if (e > begin) {  // frame fi owns at least one point of the tile (empty frames are skipped)
-          for (uint32_t w = tid; w < r.n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + r.seg_begin)[w];
+          if (fi != f0) {
+            for (uint32_t w = tid; w < r.n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + (uint64_t)fi * seg_stride)[w];
+          }
           __syncthreads();
           uint32_t k;
           const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k);
