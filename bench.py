@@ -32,15 +32,17 @@ SEED = 0x4B4D43
 SPIN_UP_STEPS = 12  # untimed, before the W warm-up steps (see main)
 
 
-def make_workload(capi, n_frames, rank):
-    """configs[1] trajectory: yaw = roll = pitch = 0, 10 m/s east; OXTS at T0 + {.05,.15,.25}, scan T0 + {.10,.15,.20}."""
+def make_workload(capi, n_frames, rank, yaw_per_frame=0.0):
+    """configs[1] trajectory: yaw = roll = pitch = 0, 10 m/s east; OXTS at T0 + {.05,.15,.25}, scan T0 + {.10,.15,.20}.
+    yaw_per_frame != 0 turns it into configs[3]'s constant-twist track (|phi| ~ 0.03 per frame)."""
     v = 10.0
     dlon = v * 0.1 * 180.0 / (np.pi * 6378137.0)
     params = []
     for f in range(n_frames):
         Tz = 47072.0 + 0.1 * (f + rank * n_frames)
         k0 = f + rank * n_frames
-        ox = [capi.Oxts(stamp=Tz + 0.05 + 0.1 * i, lat=0.0, lon=dlon * (k0 + i), alt=0, roll=0, pitch=0, yaw=0) for i in range(3)]
+        ox = [capi.Oxts(stamp=Tz + 0.05 + 0.1 * i, lat=0.0, lon=dlon * (k0 + i), alt=0, roll=0, pitch=0,
+                        yaw=((yaw_per_frame * (k0 + i) + np.pi) % (2 * np.pi)) - np.pi if yaw_per_frame else 0) for i in range(3)]
         t0, tm, t1 = Tz + 0.10, Tz + 0.15, Tz + 0.20
         T_start, T_end = capi.make_frame_poses(ox[0], ox[1], ox[2], t0, t1)
         params.append((capi.frame_params_from_poses(T_start, T_end, t0, t1, tm), (t0, tm, t1), (ox[0], ox[1], ox[2])))
@@ -96,7 +98,7 @@ def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample, gpu_out_frame0):
     b3 = run(orc.HOISTED, cores, n_frames_sample)         # B3: hoisted closed form, all cores
     return {
         "value": round(b1, 3), "unit": "Mpts/s", "cores": 1, "kind": "port",
-        "sample": f"{n_frames_sample} of the step's 1M-point frames ({n_frames_sample * per} points), oracle FAITHFUL mode "
+        "sample": f"{n_frames_sample} of the step's {per}-point frames ({n_frames_sample * per} points), oracle FAITHFUL mode "
                   "(reference op sequence incl. per-point Log/Exp), f64, 1 thread like the reference",
         "all_cores": {"cores": cores, "logical_cpus_visible": os.cpu_count(), "faithful_Mpts_s": round(b2, 3),
                       "hoisted_closed_form_Mpts_s": round(b3, 3)},
@@ -104,15 +106,22 @@ def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample, gpu_out_frame0):
 
 
 def main():
+    global POINTS_PER_FRAME
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames-per-step", type=int, default=256)
+    ap.add_argument("--points-per-frame", type=int, default=POINTS_PER_FRAME,
+                    help="1000000 = BASELINE.json configs[1] (the default, the headline); 10000000 with --frames-per-step 24 "
+                         "--yaw-per-frame 0.03 = the per-GPU share of configs[3]'s 10 M-point-per-frame stream")
+    ap.add_argument("--yaw-per-frame", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
     ap.add_argument("--rotate", type=int, default=1, help="number of in/out buffer pairs cycled through by the steps")
     args = ap.parse_args()
+    headline = args.points_per_frame == POINTS_PER_FRAME and args.yaw_per_frame == 0.0
+    POINTS_PER_FRAME = args.points_per_frame
 
     import torch
 
@@ -154,7 +163,7 @@ def main():
         d_ins[r].copy_(d_ins[0])
     d_in, d_out = d_ins[0], d_outs[0]
     state = {"k": 0}
-    work = make_workload(capi, F, rank)
+    work = make_workload(capi, F, rank, args.yaw_per_frame)
     params = capi.params_array([w[0] for w in work])
     offsets = np.arange(F + 1, dtype=np.uint64) * POINTS_PER_FRAME
     torch.cuda.synchronize()
@@ -216,8 +225,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[1]: synthetic 1M-point frames, straight-line constant-velocity trajectory; "
-                            f"{F} distinct frames per step in one batched launch (per GPU), device-resident",
+                "workload": (f"configs[1]: synthetic 1M-point frames, straight-line constant-velocity trajectory; " if headline else
+                             f"NOT the headline -- configs[3]-shaped stream: synthetic {POINTS_PER_FRAME}-point frames, yaw {args.yaw_per_frame} rad per frame; ")
+                            + f"{F} distinct frames per step in one batched launch (per GPU), device-resident",
                 "points_per_frame": POINTS_PER_FRAME, "frames_per_step_per_gpu": F, "points_per_step_per_gpu": n,
                 "parallelism": f"frame-sharded x{world} (no data-path collective)",
                 "kernel": "kmc_dev::deskew_batch_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64>, one 64-point tile (one wave) per workgroup", "device": info["name"], "arch": info["arch"],
@@ -229,7 +239,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            k = min(args.cpu_sample_frames, F)
+            k = min(args.cpu_sample_frames, F, max(1, 32_000_000 // POINTS_PER_FRAME))  # ~10-30 s of single-thread oracle work
             sample = d_in[:k * POINTS_PER_FRAME].cpu().numpy()
             gpu_frame0 = d_outs[(state["k"] - 1) % R][:POINTS_PER_FRAME].cpu().numpy()
             out["cpu_baseline"], out["parity_spot_check"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k, gpu_frame0)
