@@ -156,7 +156,10 @@ int kmc_make_frame_poses(const kmc_oxts* o_nm1, const kmc_oxts* o_n, const kmc_o
  *   s    = frac - x_req                                trajectory_interpolation.cpp:49-51
  *   p'   = Exp(s * twist) * p                          motion_compensation.cpp:9-14 (closed form)
  * and intensity is passed through bit-identically.  32 algorithmic bytes per point (16 read + 16 written).
- * xyzi_in and xyzi_out must be 16-byte aligned and must not partially overlap (in == out is allowed). */
+ * xyzi_in and xyzi_out must be 16-byte aligned and must not partially overlap (in == out is allowed).  Device-resident
+ * pointers may be any 16-byte-aligned addresses (sub-ranges of a larger buffer): the kernels cut their tiles on the 1 KiB lines
+ * of the output; full speed needs the input to sit at the same offset within its 1 KiB line (e.g. the same index range of
+ * two allocator-aligned buffers), otherwise ~6 % is lost to split loads. */
 int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint64_t n,
                        const kmc_frame_params* params, int mem_kind, kmc_stats* out_stats);
 

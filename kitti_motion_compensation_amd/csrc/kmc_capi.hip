@@ -117,6 +117,13 @@ void fill_rec(const kmc_frame_params& p, REC* r) {
   r->c2_x = (float)c2.x; r->c2_y = (float)c2.y; r->c2_z = (float)c2.z;
 }
 
+// Device-resident buffers: distance (in points, < 64) from the last 1 KiB boundary to the start of the OUTPUT.  The kernels are
+// launched on pointers moved back by that much with the first `head` indices dead, so that every tile stores whole aligned
+// lines whatever 16-byte-aligned address the caller passes ("alignment").
+uint32_t head_of(const void* out, int mem_kind) {
+  return mem_kind == KMC_MEM_DEVICE ? (uint32_t)(((uintptr_t)out >> 4) & 63u) : 0u;
+}
+
 bool params_ok(const kmc_frame_params* p) {
   for (int i = 0; i < 6; ++i)
     if (!std::isfinite(p->twist[i])) return false;
@@ -137,45 +144,49 @@ int ppt_of(const kmc_ctx* c) {
 
 // ---- template dispatch ---------------------------------------------------------------------------
 template <int TIER, int PPT>
-void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
-  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f);
+void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head) {
+  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head);
 }
 template <int TIER>
-void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
+void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head) {
   switch (ppt) {
-    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f); break;
-    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f); break;
-    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f); break;
-    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f); break;
+    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head); break;
+    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head); break;
+    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head); break;
+    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head); break;
   }
 }
-void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f) {
+// in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of()
+void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head = 0) {
   const int ppt = ppt_of(c);
+  in -= head;
+  out -= head;
+  n += head;
   const uint64_t n_tiles = (n + (uint64_t)kLaunchBlock * ppt - 1) / ((uint64_t)kLaunchBlock * ppt);
   const int grid = grid_for(c, n_tiles);
   switch (tier) {
-    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f); break;
-    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f); break;
-    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f); break;
+    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head); break;
+    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head); break;
+    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head); break;
   }
 }
 
 template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
-                     uint32_t nf, uint64_t n, uint32_t* idx) {
+                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head) {
   if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head);
   else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head);
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
-                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx) {
+                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head) {
   switch (ppt) {
-    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx); break;
-    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx); break;
-    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx); break;
-    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx); break;
+    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
+    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
+    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
+    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
   }
 }
 
@@ -369,25 +380,27 @@ void fill_traj_segs(const TrajHost& th, double stamp_start, double stamp_end, Tr
   }
 }
 
-// coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point
-void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n, uint2* h_coarse) {
+// coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point.
+// All positions are VIRTUAL: `head` dead points precede the batch (frame 0 owns them), n_virtual = n + head.
+void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n_virtual, uint32_t head, uint2* h_coarse) {
   const uint64_t chunk = 1ull << kChunkShift;
-  const uint64_t n_chunks = (n + chunk - 1) / chunk;
+  const uint64_t n_chunks = (n_virtual + chunk - 1) / chunk;
+  auto end_of = [&](uint32_t f) { return offsets[f + 1] + head; };  // virtual end offset of frame f
   uint32_t f = 0;
   for (uint64_t ci = 0; ci < n_chunks; ++ci) {
     const uint64_t first = ci * chunk;
-    const uint64_t chunk_end = std::min<uint64_t>(first + chunk, n);
-    while (f + 1 < n_frames && offsets[f + 1] <= first) ++f;
+    const uint64_t chunk_end = std::min<uint64_t>(first + chunk, n_virtual);
+    while (f + 1 < n_frames && end_of(f) <= first) ++f;
     uint32_t split = kSplitNone;
-    const uint64_t e = offsets[f + 1];
+    const uint64_t e = end_of(f);
     if (e < chunk_end) {  // frame f ends inside this chunk
       // a second boundary inside the chunk (frame f+1 ends here too, e.g. it is tiny or empty) -> search on the device
-      const bool second = (f + 1 < n_frames) && offsets[f + 2] < chunk_end;
+      const bool second = (f + 1 < n_frames) && end_of(f + 1) < chunk_end;
       split = second ? kSplitSearch : (uint32_t)(e - first);
     }
     h_coarse[ci] = make_uint2(f, split);
   }
-  while (f + 1 < n_frames && offsets[f + 1] <= n - 1) ++f;
+  while (f + 1 < n_frames && end_of(f) <= n_virtual - 1) ++f;
   h_coarse[n_chunks] = make_uint2(f, kSplitNone);
 }
 
@@ -656,7 +669,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   CallTimer tm(c);
   if (mem_kind == KMC_MEM_DEVICE) {
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    launch_frame(c, c->stream, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f);
+    launch_frame(c, c->stream, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, head_of(xyzi_out, mem_kind));
     KMC_HIP_TRY(c, hipGetLastError());
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     if (st) st->n_launches = 1;
@@ -715,10 +728,12 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (n == 0) return KMC_OK;
 
   const int ppt = ppt_of(c);
+  const uint32_t head = head_of(xyzi_out, mem_kind);  // dead points in front: tiles are cut on 1 KiB lines of the output
+  const uint64_t nv = n + head;                       // virtual size; every offset below is shifted by `head` too
   const uint64_t tile = (uint64_t)kLaunchBlock * ppt;
-  const uint64_t n_tiles = (n + tile - 1) / tile;
+  const uint64_t n_tiles = (nv + tile - 1) / tile;
   const uint64_t chunk = 1ull << kChunkShift;
-  const uint64_t n_chunks = (n + chunk - 1) / chunk;
+  const uint64_t n_chunks = (nv + chunk - 1) / chunk;
   const uint64_t n_coarse = n_chunks + 1;
 
   const size_t recs_bytes = ((size_t)n_frames * sizeof(BatchRec) + 255) & ~(size_t)255;
@@ -736,10 +751,10 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   for (uint32_t f = 0; f < n_frames; ++f) {
     BatchRec* r = &h_recs[f];
     fill_rec(params[f], r);
-    r->end_lo = (uint32_t)(offsets[f + 1] & 0xFFFFFFFFull);
-    r->end_hi = (uint32_t)(offsets[f + 1] >> 32);
+    r->end_lo = (uint32_t)((offsets[f + 1] + head) & 0xFFFFFFFFull);
+    r->end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
   }
-  build_coarse(offsets, n_frames, n, h_coarse);
+  build_coarse(offsets, n_frames, nv, head, h_coarse);
   // one table upload on the side stream (overlaps whatever the compute stream is still running), awaited on the host
   {
     const int rc_up = slot_upload(c, slot_id, need);
@@ -764,10 +779,11 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
     KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, n * sizeof(v4f), hipMemcpyHostToDevice, c->stream));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, n_tiles);
+  uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
   switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in, d_out, d_recs, d_coarse, n_frames, n, d_idx); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in, d_out, d_recs, d_coarse, n_frames, n, d_idx); break;
-    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in, d_out, d_recs, d_coarse, n_frames, n, d_idx); break;
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
   {
@@ -927,12 +943,15 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
-  const int grid = grid_for(c, (n + 63) / 64);
+  const uint32_t head = head_of(xyzi_out, mem_kind);
+  const uint64_t nv = n + head;
+  const int grid = grid_for(c, (nv + 63) / 64);
   const TrajSeg32* d_segs = (const TrajSeg32*)c->slots[slot_id].d_buf;
+  uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
 #define KMC_LAUNCH_TRAJ(T)                                                                                                          \
   do {                                                                                                                              \
-    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx); \
-    else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_segs, th.n_seg, d_idx);      \
+    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_segs, th.n_seg, v_idx, head); \
+    else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_segs, th.n_seg, v_idx, head);      \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ(kSeries3); break;
@@ -986,8 +1005,10 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
 
+  const uint32_t head = head_of(xyzi_out, mem_kind);
+  const uint64_t nv = n + head;
   const uint64_t chunk = 1ull << kChunkShift;
-  const uint64_t n_coarse = (n + chunk - 1) / chunk + 1;
+  const uint64_t n_coarse = (nv + chunk - 1) / chunk + 1;
   const size_t frecs_bytes = ((size_t)n_frames * sizeof(TrajFrameRec) + 255) & ~(size_t)255;
   const size_t segs_bytes = ((size_t)n_frames * seg_stride * sizeof(TrajSeg32) + 255) & ~(size_t)255;
   const size_t need = frecs_bytes + segs_bytes + (size_t)n_coarse * sizeof(uint2);
@@ -1000,13 +1021,13 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + frecs_bytes + segs_bytes);
   std::memset(h_segs, 0, segs_bytes);
   for (uint32_t f = 0; f < n_frames; ++f) {
-    h_frecs[f].end_lo = (uint32_t)(offsets[f + 1] & 0xFFFFFFFFull);
-    h_frecs[f].end_hi = (uint32_t)(offsets[f + 1] >> 32);
+    h_frecs[f].end_lo = (uint32_t)((offsets[f + 1] + head) & 0xFFFFFFFFull);
+    h_frecs[f].end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
     h_frecs[f].n_seg = th[f].n_seg;
     h_frecs[f].pad = 0;
     fill_traj_segs(th[f], frames[f].stamp_start, frames[f].stamp_end, h_segs + (size_t)f * seg_stride);
   }
-  build_coarse(offsets, n_frames, n, h_coarse);
+  build_coarse(offsets, n_frames, nv, head, h_coarse);
   rc = slot_upload(c, slot_id, need);
   if (rc != KMC_OK) return rc;
   const TrajFrameRec* d_frecs = reinterpret_cast<const TrajFrameRec*>(sl.d_buf);
@@ -1030,12 +1051,14 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, pts, hipMemcpyHostToDevice, c->stream));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (n + 63) / 64);
+  const int grid = grid_for(c, (nv + 63) / 64);
   const bool idx = d_fidx || d_bidx;
+  uint32_t* v_fidx = d_fidx ? d_fidx - head : nullptr;
+  uint32_t* v_bidx = d_bidx ? d_bidx - head : nullptr;
 #define KMC_LAUNCH_TRAJ_BATCH(T)                                                                                                   \
   do {                                                                                                                             \
-    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_frecs, d_segs, seg_stride, d_coarse, n_frames, d_fidx, d_bidx); \
-    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in, d_out, n, d_frecs, d_segs, seg_stride, d_coarse, n_frames, d_fidx, d_bidx);     \
+    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head); \
+    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head);     \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;

@@ -688,3 +688,71 @@ def test_single_frame_entry_point_is_graph_capturable(ctx, torch_mod):
         assert torch.equal(d_out.view(torch.int32), ref.view(torch.int32))
     finally:
         ctx.set_stream(None)
+
+
+@pytest.mark.parametrize("shift_in,shift_out", [(1, 1), (7, 3), (37, 37), (63, 0), (0, 63), (5, 64 + 9)])
+def test_device_buffers_at_any_16_byte_offset(ctx, torch_mod, kitti, shift_in, shift_out):
+    """The kernels cut their tiles on 1 KiB lines of the OUTPUT whatever 16-byte-aligned pointers the caller passes (sub-ranges
+    of a resident buffer): same bits as an aligned call, nothing written in front of or behind the range -- for the
+    single-frame, batched, trajectory and batched-trajectory entry points and their index outputs."""
+    torch = torch_mod
+    xyzi, P1 = kitti
+    n = 100_000 + 11
+    pts = np.ascontiguousarray(xyzi[:n])
+    guard = 128
+    d_in_big = torch.zeros((n + 2 * guard, 4), dtype=torch.float32, device="cuda")
+    d_in = d_in_big[shift_in:shift_in + n]
+    d_in.copy_(torch.from_numpy(pts))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def fresh():
+        big = torch.full((n + 2 * guard, 4), 7.0, dtype=torch.float32, device="cuda")
+        idx = torch.full((n + 2 * guard,), 77, dtype=torch.int32, device="cuda")
+        idx2 = torch.full((n + 2 * guard,), 77, dtype=torch.int32, device="cuda")
+        return big, idx, idx2
+
+    def check(big, ref_out, idxs=()):
+        torch.cuda.synchronize()
+        got = big[shift_out:shift_out + n].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), ref_out.view(np.uint32))
+        assert bool((big[:shift_out] == 7.0).all()) and bool((big[shift_out + n:] == 7.0).all()), "wrote outside the range"
+        for idx, ref_idx, s in idxs:
+            assert np.array_equal(idx[s:s + n].cpu().numpy().view(np.uint32), ref_idx)
+            assert bool((idx[:s] == 77).all()) and bool((idx[s + n:] == 77).all()), "index written outside the range"
+
+    try:
+        # single frame
+        params = capi.frame_params_from_poses(P1.rt12().reshape(3, 4), _poses(P1, TRAJECTORIES["gentle_turn"])[1].rt12().reshape(3, 4), T0, T1, TREQ)
+        ref = np.empty_like(pts)
+        ctx.deskew_f32(pts, ref, params)
+        big, idx, idx2 = fresh()
+        ctx.deskew_f32(d_in, big[shift_out:shift_out + n], params, n=n)
+        check(big, ref)
+        # batched, ragged frames, with frame indices at their own odd offset
+        sizes = [1, 0, 63, 20000, 64, 30000, 0, n - 50128]
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        plist = [capi.FrameParams.make(np.array(TRAJECTORIES["gentle_turn"]) * (0.5 + 0.1 * f), 0.1 * f) for f in range(len(sizes))]
+        ref_idx = np.empty(n, dtype=np.uint32)
+        ctx.deskew_batch_f32(pts, ref, offsets, plist, ref_idx)
+        big, idx, idx2 = fresh()
+        ctx.deskew_batch_f32(d_in, big[shift_out:shift_out + n], offsets, plist, idx[3:3 + n])
+        check(big, ref, [(idx, ref_idx, 3)])
+        # trajectory, three knots
+        times = [T0 - 0.05, 0.5 * (T0 + T1) + 0.003, T1 + 0.05]
+        poses = [P1, orc.affine_mul(P1, orc.se3_exp([1.3, 0.04, -0.01, 0.002, -0.004, 0.035]))]
+        poses.append(orc.affine_mul(poses[1], orc.se3_exp([1.4, -0.02, 0.01, -0.003, 0.002, 0.05])))
+        rt = np.stack([p.rt12().reshape(3, 4) for p in poses])
+        ref_br = np.empty(n, dtype=np.uint32)
+        ctx.deskew_traj_f32(pts, ref, times, rt, T0, T1, TREQ, ref_br)
+        big, idx, idx2 = fresh()
+        ctx.deskew_traj_f32(d_in, big[shift_out:shift_out + n], times, rt, T0, T1, TREQ, idx[5:5 + n], n=n)
+        check(big, ref, [(idx, ref_br, 5)])
+        # batched trajectories
+        frames = [dict(times=times, poses=rt, stamp_start=T0, stamp_end=T1, requested_time=T0 + (0.1 + 0.1 * f) * (T1 - T0)) for f in range(len(sizes))]
+        ref_f = np.empty(n, dtype=np.uint32)
+        ctx.deskew_traj_batch_f32(pts, ref, offsets, frames, ref_f, ref_br)
+        big, idx, idx2 = fresh()
+        ctx.deskew_traj_batch_f32(d_in, big[shift_out:shift_out + n], offsets, frames, idx[1:1 + n], idx2[9:9 + n])
+        check(big, ref, [(idx, ref_f, 1), (idx2, ref_br, 9)])
+    finally:
+        ctx.set_stream(None)

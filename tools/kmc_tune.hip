@@ -176,7 +176,7 @@ static Variant occ_variant(const char* label) {
   v.ppt = 1;
   v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
     static const FrameRec f = make_rec();
-    hipLaunchKernelGGL((deskew_frame_f32<kSeries3, 1, kPolicyDefault, false, 64>), dim3((unsigned)((n + 63) / 64)), dim3(64), LDS_BYTES, s, in, out, n, f);
+    hipLaunchKernelGGL((deskew_frame_f32<kSeries3, 1, kPolicyDefault, false, 64>), dim3((unsigned)((n + 63) / 64)), dim3(64), LDS_BYTES, s, in, out, n, f, 0u);
   };
   return v;
 }
@@ -280,7 +280,7 @@ static Variant traj_lib_variant(const char* label) {
   v.ppt = 1;
   v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
     hipLaunchKernelGGL((deskew_traj_f32<kSeries3, kPolicyDefault, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in, out, n,
-                       g_traj_segs, 2u, (uint32_t*)nullptr);
+                       g_traj_segs, 2u, (uint32_t*)nullptr, 0u);
   };
   return v;
 }
@@ -294,7 +294,7 @@ static Variant frame_variant(const char* label) {
     static const FrameRec f = make_rec();
     const uint64_t tiles = (n + (uint64_t)BLOCK * PPT - 1) / ((uint64_t)BLOCK * PPT);
     const uint64_t cap = bpc <= 0 ? tiles : (uint64_t)g_cus * bpc * (kBlock / (BLOCK < kBlock ? BLOCK : kBlock));
-    hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, NT, OCML, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s, in, out, n, f);
+    hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, NT, OCML, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s, in, out, n, f, 0u);
   };
   return v;
 }
@@ -361,7 +361,7 @@ static Variant batch_variant(const char* label) {
     const uint64_t tiles = (n + (uint64_t)BLOCK * PPT - 1) / ((uint64_t)BLOCK * PPT);
     const uint64_t cap = bpc <= 0 ? tiles : (uint64_t)g_cus * bpc * (kBlock / (BLOCK < kBlock ? BLOCK : kBlock));
     hipLaunchKernelGGL((deskew_batch_f32<kSeries3, PPT, NT, false, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s,
-                       in, out, bt.d_recs, bt.d_coarse, bt.n_frames, n, (uint32_t*)nullptr);
+                       in, out, bt.d_recs, bt.d_coarse, bt.n_frames, n, (uint32_t*)nullptr, 0u);
   };
   return v;
 }
