@@ -16,12 +16,12 @@ namespace kmc::viz {
 
 struct Projection {
   std::size_t num_points{0};
-  std::vector<std::int32_t> uv;    // [camera 0..3][point][u, v]; INT32_MIN twice for a skipped point
+  std::vector<std::int32_t> uv;    // [point][camera 0..3][u, v]; INT32_MIN twice for a skipped point
   std::vector<std::uint8_t> bgrv;  // [point][255-cs, cs, 255-cs, drawn?]: the cv::Scalar of camera_model.cpp:32 as 8-bit channels
 
   bool drawn(std::size_t i) const { return bgrv[4 * i + 3] != 0; }  // passes camera_model.cpp:21-24
-  std::int32_t u(int camera, std::size_t i) const { return uv[(static_cast<std::size_t>(camera) * num_points + i) * 2]; }
-  std::int32_t v(int camera, std::size_t i) const { return uv[(static_cast<std::size_t>(camera) * num_points + i) * 2 + 1]; }
+  std::int32_t u(int camera, std::size_t i) const { return uv[(i * 4 + static_cast<std::size_t>(camera)) * 2]; }
+  std::int32_t v(int camera, std::size_t i) const { return uv[(i * 4 + static_cast<std::size_t>(camera)) * 2 + 1]; }
   std::uint8_t const* color(std::size_t i) const { return &bgrv[4 * i]; }
 };
 

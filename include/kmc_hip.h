@@ -235,7 +235,7 @@ typedef struct kmc_camera_rig {
 
 /* Per point i of the cloud and camera c (f64 on the device, operation for operation like the reference, so the integers
  * are bit-exact against the CPU oracle):
- *   uv[(c*n + i)*2 + {0,1}]  the integer pixel cv::circle is centred on (camera_model.cpp:12, :31), or INT32_MIN twice
+ *   uv[(i*4 + c)*2 + {0,1}]  the integer pixel cv::circle is centred on (camera_model.cpp:12, :31), or INT32_MIN twice
  *                            when the point is skipped by camera_model.cpp:21-24 (z_rect outside [0.01, max_range] or
  *                            y_rect > 1.25)
  *   bgrv[4*i + {0,1,2,3}]    the 8-bit colour {255-cs, cs, 255-cs} the reference draws it with (camera_model.cpp:28-32)
@@ -243,7 +243,8 @@ typedef struct kmc_camera_rig {
  * deskew == NULL: the cloud is projected as it is.  deskew != NULL: every point is motion-compensated first exactly like
  * kmc_hip_deskew_f32 does (fused: the cloud is read once) and, when xyzi_out != NULL, the compensated cloud is written
  * there -- GenerateProjectionVisualizationOfRun's "project raw, compensate, project again" (handlers.cpp:77-88) in two
- * launches.  Algorithmic bytes per point: 16 read + 36 written (+16 with xyzi_out). */
+ * launches.  The eight pixel integers of a point are contiguous (32 bytes: one coalesced 2 KiB store per wave whatever n is).
+ * Algorithmic bytes per point: 16 read + 36 written (+16 with xyzi_out). */
 int kmc_hip_project_f32(kmc_ctx* ctx, const float* xyzi_in, uint64_t n, const kmc_camera_rig* rig,
                         const kmc_frame_params* deskew, float* xyzi_out, int32_t* uv, uint8_t* bgrv, int mem_kind,
                         kmc_stats* out_stats);

@@ -460,7 +460,7 @@ class Context:
 
     # -- N4: projection ------------------------------------------------------------------------------
     def project_f32(self, xyzi_in, rig: CameraRig, uv_out, bgrv_out, deskew: FrameParams = None, xyzi_out=None, n=None) -> Stats:
-        """uv_out: (4, n, 2) int32; bgrv_out: (n, 4) uint8; deskew: fuse the motion compensation in front (optional)."""
+        """uv_out: (n, 4, 2) int32 -- per point, per camera, (u, v); bgrv_out: (n, 4) uint8; deskew: fuse the motion compensation in front (optional)."""
         kind = _mem_kind(xyzi_in)
         if n is None:
             n = int(xyzi_in.shape[0])

@@ -1188,7 +1188,7 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
   if (xyzi_out && !deskew) return KMC_ERR_INVALID_ARG;
   if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)uv & 7u) || ((uintptr_t)bgrv & 3u)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)uv & 15u) || ((uintptr_t)bgrv & 3u)) return KMC_ERR_INVALID_ARG;
   if (!rig_ok(rig)) return KMC_ERR_INVALID_ARG;
   if (deskew) {
     if (!params_ok(deskew)) return KMC_ERR_INVALID_ARG;
@@ -1251,7 +1251,7 @@ int kmc_hip_project_f64cols(kmc_ctx* c, const double* x, const double* y, const 
                             int32_t* uv, uint8_t* bgrv, int mem_kind, kmc_stats* st) {
   if (!c || !rig || (n && (!x || !y || !z || !uv || !bgrv))) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)uv & 7u) || ((uintptr_t)bgrv & 3u)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)uv & 15u) || ((uintptr_t)bgrv & 3u)) return KMC_ERR_INVALID_ARG;
   if (!rig_ok(rig)) return KMC_ERR_INVALID_ARG;
   if (st) std::memset(st, 0, sizeof(*st));
   if (st) { st->n_points = n; st->variant = 4; }
@@ -1263,15 +1263,16 @@ int kmc_hip_project_f64cols(kmc_ctx* c, const double* x, const double* y, const 
   uint32_t* d_col = (uint32_t*)bgrv;
   const size_t col = n * sizeof(double), uv_bytes = n * 4 * sizeof(v2i), col_bytes = n * sizeof(uint32_t);
   if (mem_kind == KMC_MEM_HOST) {
-    int rc = ensure_tmp(c, 3 * col + uv_bytes + col_bytes);
+    const size_t cols_bytes = (3 * col + 15) & ~(size_t)15;  // the pixel records behind the columns stay 16-byte aligned
+    int rc = ensure_tmp(c, cols_bytes + uv_bytes + col_bytes);
     if (rc != KMC_OK) return rc;
     double* base = (double*)c->d_tmp;
     KMC_HIP_TRY(c, hipMemcpyAsync(base, x, col, hipMemcpyHostToDevice, c->stream));
     KMC_HIP_TRY(c, hipMemcpyAsync(base + n, y, col, hipMemcpyHostToDevice, c->stream));
     KMC_HIP_TRY(c, hipMemcpyAsync(base + 2 * n, z, col, hipMemcpyHostToDevice, c->stream));
     dx = base; dy = base + n; dz = base + 2 * n;
-    d_uv = (v2i*)(base + 3 * n);
-    d_col = (uint32_t*)((char*)(base + 3 * n) + uv_bytes);
+    d_uv = (v2i*)((char*)base + cols_bytes);
+    d_col = (uint32_t*)((char*)base + cols_bytes + uv_bytes);
   }
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");

@@ -261,6 +261,7 @@ struct CameraRigRec {
   double range_den;  // max_range - 0.01, camera_model.cpp:28
 };
 using v2i = int __attribute__((ext_vector_type(2)));
+using v4i = int __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int trunc_i32(double v) {  // cv::Point(double, double): cvttsd2si semantics
   return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000;

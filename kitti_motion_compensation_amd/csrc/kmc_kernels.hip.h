@@ -573,26 +573,52 @@ __global__ __launch_bounds__(kBlock) void copy_points(const v4f* __restrict__ in
 
 // ------------------------------------------------------------------------------------------------
 // N4: projection kernels.  One point per lane, one wave per workgroup like the deskew kernels.  Per point: 16 B read,
-// 4 x 8 B pixel pairs + 4 B colour/validity written (52 B), or 68 B when the fused deskew also writes its cloud.
+// 32 B of pixel pairs (uv[point][camera][2]) + 4 B colour/validity written (52 B), or 68 B when the fused deskew also writes its cloud.
 // TIER < 0: project the cloud as it is; TIER >= 0: deskew first (same arithmetic as deskew_frame_f32), then project.
 // ------------------------------------------------------------------------------------------------
+// The eight pixel integers of a point are one 32-byte record of uv[point][camera][2].  A lane holds its point's record, but
+// a store instruction in which every lane writes half a record leaves every line half written twice (measured: +10 % HBM
+// write traffic); the records therefore take a trip through LDS so that each of the two store instructions of a wave
+// writes 1 KiB of CONSECUTIVE bytes.  Waves without an in-view point store the constant record directly.
+__device__ __forceinline__ void store_uv_tile(v2i* __restrict__ uv, uint64_t tile_base, uint64_t n, uint32_t tid, const v2i px[4],
+                                              bool any_drawn, v4i* xpose) {
+  v4i lo, hi;  // 16-byte chunks tid and 64 + tid of the tile's 2 KiB
+  if (any_drawn) {
+    xpose[2 * tid] = (v4i){px[0].x, px[0].y, px[1].x, px[1].y};
+    xpose[2 * tid + 1] = (v4i){px[2].x, px[2].y, px[3].x, px[3].y};
+    __syncthreads();  // one-wave workgroup: orders the wave's own LDS writes before its reads
+    lo = xpose[tid];
+    hi = xpose[64 + tid];
+    __syncthreads();
+  } else {
+    lo = hi = (v4i){(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  }
+  v4i* o = reinterpret_cast<v4i*>(uv + 4 * tile_base);
+  if (tile_base + (tid >> 1) < n) __builtin_nontemporal_store(lo, o + tid);
+  if (tile_base + 32 + (tid >> 1) < n) __builtin_nontemporal_store(hi, o + 64 + tid);
+}
+
 template <int TIER, bool STRUCTURED>
 __global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, uint64_t n, CameraRigRec g, FrameRec f,
                                                   v4f* __restrict__ cloud_out, v2i* __restrict__ uv,
                                                   uint32_t* __restrict__ bgrv) {
-  const uint64_t stride = (uint64_t)gridDim.x * 64;
-  for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
-    v4f p = __builtin_nontemporal_load(in + i);
+  __shared__ v4i xpose[128];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_tiles = (n + 63) / 64;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t base = t * 64;
+    const uint64_t i = base + tid;
+    const bool live = i < n;
+    v4f p = __builtin_nontemporal_load(in + (live ? i : n - 1));  // dead lanes of the ragged tile re-read the last point
     if constexpr (TIER >= 0) {
       p = deskew_point<TIER, false>(p, f);
-      if (cloud_out) __builtin_nontemporal_store(p, cloud_out + i);
+      if (cloud_out && live) __builtin_nontemporal_store(p, cloud_out + i);
     }
     v2i px[4];
     uint32_t col;
-    project_point<STRUCTURED>((double)p.x, (double)p.y, (double)p.z, g, px, col);
-#pragma unroll
-    for (int cam = 0; cam < 4; ++cam) __builtin_nontemporal_store(px[cam], uv + (uint64_t)cam * n + i);
-    __builtin_nontemporal_store(col, bgrv + i);
+    const bool drawn = project_point<STRUCTURED>((double)p.x, (double)p.y, (double)p.z, g, px, col);
+    store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
+    if (live) __builtin_nontemporal_store(col, bgrv + i);
   }
 }
 
@@ -600,14 +626,20 @@ template <bool STRUCTURED>
 __global__ __launch_bounds__(64) void project_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                       const double* __restrict__ z, uint64_t n, CameraRigRec g,
                                                       v2i* __restrict__ uv, uint32_t* __restrict__ bgrv) {
-  const uint64_t stride = (uint64_t)gridDim.x * 64;
-  for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += stride) {
+  __shared__ v4i xpose[128];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_tiles = (n + 63) / 64;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t base = t * 64;
+    const uint64_t i = base + tid;
+    const bool live = i < n;
+    const uint64_t j = live ? i : n - 1;
     v2i px[4];
     uint32_t col;
-    project_point<STRUCTURED>(__builtin_nontemporal_load(x + i), __builtin_nontemporal_load(y + i), __builtin_nontemporal_load(z + i), g, px, col);
-#pragma unroll
-    for (int cam = 0; cam < 4; ++cam) __builtin_nontemporal_store(px[cam], uv + (uint64_t)cam * n + i);
-    __builtin_nontemporal_store(col, bgrv + i);
+    const bool drawn = project_point<STRUCTURED>(__builtin_nontemporal_load(x + j), __builtin_nontemporal_load(y + j),
+                                                 __builtin_nontemporal_load(z + j), g, px, col);
+    store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
+    if (live) __builtin_nontemporal_store(col, bgrv + i);
   }
 }
 

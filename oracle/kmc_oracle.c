@@ -736,7 +736,7 @@ static uint8_t sat_u8(double v) { /* cv::saturate_cast<uchar>(double) */
   double r = nearbyint(v);        /* default rounding mode: half to even, = cvRound */
   return (uint8_t)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r));
 }
-static void project_one(double x, double y, double z, const kmo_camera_rig* g, size_t i, size_t n, int32_t* uv, uint8_t* bgrv) {
+static void project_one(double x, double y, double z, const kmo_camera_rig* g, size_t i, int32_t* uv, uint8_t* bgrv) {
   const double* T = g->tf_c00_lo;
   const double* R = g->R_rect_00;
   double c[3], r[3];
@@ -747,7 +747,7 @@ static void project_one(double x, double y, double z, const kmo_camera_rig* g, s
     const double* P = g->P_rect[cam];
     double h[3];
     for (int k = 0; k < 3; ++k) h[k] = ((P[4 * k] * r[0] + P[4 * k + 1] * r[1]) + P[4 * k + 2] * r[2]) + P[4 * k + 3] * 1.0; /* :9 */
-    int32_t* o = uv + ((size_t)cam * n + i) * 2;
+    int32_t* o = uv + (i * 4 + (size_t)cam) * 2;
     o[0] = valid ? trunc_i32(h[0] / h[2]) : INT32_MIN; /* :12, :31 */
     o[1] = valid ? trunc_i32(h[1] / h[2]) : INT32_MIN;
   }
@@ -765,9 +765,9 @@ static void project_one(double x, double y, double z, const kmo_camera_rig* g, s
 void kmo_project_points(const double* x, const double* y, const double* z, size_t n, const kmo_camera_rig* rig, int32_t* uv,
                         uint8_t* bgrv) {
 #pragma omp parallel for schedule(static) if (n >= 65536)
-  for (size_t i = 0; i < n; ++i) project_one(x[i], y[i], z[i], rig, i, n, uv, bgrv);
+  for (size_t i = 0; i < n; ++i) project_one(x[i], y[i], z[i], rig, i, uv, bgrv);
 }
 void kmo_project_xyzi_f32(const float* xyzi, size_t n, const kmo_camera_rig* rig, int32_t* uv, uint8_t* bgrv) {
 #pragma omp parallel for schedule(static) if (n >= 65536)
-  for (size_t i = 0; i < n; ++i) project_one((double)xyzi[4 * i], (double)xyzi[4 * i + 1], (double)xyzi[4 * i + 2], rig, i, n, uv, bgrv);
+  for (size_t i = 0; i < n; ++i) project_one((double)xyzi[4 * i], (double)xyzi[4 * i + 1], (double)xyzi[4 * i + 2], rig, i, uv, bgrv);
 }

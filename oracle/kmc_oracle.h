@@ -152,7 +152,7 @@ void kmo_bracket_indices_f32(const float* xyzi, size_t n, const double* times, s
  *                            libopencv-dev 4.5.4 of ubuntu:22.04, Dockerfile:3) writes a Scalar into a CV_8U image:
  *                            saturate_cast<uchar>(double) = clamp(cvRound(v)), cvRound = round-half-to-even.
  * All products and sums are individually rounded (the reference builds with plain -O3, CMakeLists.txt:8: no FMA).
- * Outputs: uv[c][i][2] int32 for the 4 cameras (INT32_MIN, INT32_MIN when the point is skipped) and
+ * Outputs: uv[i][c][2] int32 for the 4 cameras c (INT32_MIN, INT32_MIN when the point is skipped) and
  * bgrv[i][4] = {255-cs, cs, 255-cs, 1} as uint8 (all 0 when skipped). */
 typedef struct kmo_camera_rig {
   double tf_c00_lo[12]; /* row-major 3x4, LoadLidarExtrinsics data_io.cpp:168-210 */

@@ -423,11 +423,11 @@ def camera_rig(tf_c00_lo_3x4, R_rect_00, P_rects, max_range=15.0) -> CameraRig:
 
 
 def project_points(xyz, rig):
-    """xyz (N,3) f64 -> (uv (4,N,2) int32, bgrv (N,4) uint8)"""
+    """xyz (N,3) f64 -> (uv (N,4,2) int32: per point, per camera, (u, v); bgrv (N,4) uint8)"""
     a = np.asarray(xyz, dtype=np.float64)
     n = a.shape[0]
     cols = [np.ascontiguousarray(a[:, k]) for k in range(3)]
-    uv = np.empty((4, n, 2), dtype=np.int32)
+    uv = np.empty((n, 4, 2), dtype=np.int32)
     bgrv = np.empty((n, 4), dtype=np.uint8)
     f = lib().kmo_project_points
     f.restype = None
@@ -439,7 +439,7 @@ def project_points(xyz, rig):
 def project_xyzi_f32(xyzi, rig):
     a = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
     n = a.shape[0]
-    uv = np.empty((4, n, 2), dtype=np.int32)
+    uv = np.empty((n, 4, 2), dtype=np.int32)
     bgrv = np.empty((n, 4), dtype=np.uint8)
     f = lib().kmo_project_xyzi_f32
     f.restype = None

@@ -57,16 +57,16 @@ def test_oracle_hand_cases():
     ])
     uv, bgrv = orc.project_points(pts, rig)
     assert uv[0, 0].tolist() == [600, 180]
-    assert uv[0, 1].tolist() == [670, 110]
-    assert uv[0, 2].tolist() == [-100, 180]
-    assert uv[0, 3, 0] == int((700.0 * -8.6 + 600.0 * 10.0) / 10.0)
-    assert uv[0, 4, 0] == 0
+    assert uv[1, 0].tolist() == [670, 110]
+    assert uv[2, 0].tolist() == [-100, 180]
+    assert uv[3, 0, 0] == int((700.0 * -8.6 + 600.0 * 10.0) / 10.0)
+    assert uv[4, 0, 0] == 0
     assert bgrv[5].tolist() == [255, 0, 255, 1]     # cs = 0.17
     assert bgrv[6].tolist() == [0, 255, 0, 1]       # cs = 255.17 -> saturates
     for i in (7, 8, 9, 11):
-        assert bgrv[i].tolist() == [0, 0, 0, 0] and np.all(uv[:, i] == I32_MIN)
+        assert bgrv[i].tolist() == [0, 0, 0, 0] and np.all(uv[i] == I32_MIN)
     assert bgrv[10, 3] == 1
-    assert np.all(uv[1:] == uv[:1])                 # four identical cameras
+    assert np.all(uv[:, 1:] == uv[:, :1])           # four identical cameras
 
 
 def test_oracle_half_to_even_colour():
@@ -92,7 +92,7 @@ def test_oracle_matches_numpy_twin_on_kitti(calib, kitti_xyzi):
     drawn = bgrv[:, 3] == 1
     assert 5000 < drawn.sum() < 40000               # the slice of the scan in front of the cameras, within 15 m
     # camera 00 sees them around its 1242 x 375 image
-    inside = (uv[0, drawn, 0] >= 0) & (uv[0, drawn, 0] < 1242) & (uv[0, drawn, 1] >= 0) & (uv[0, drawn, 1] < 375)
+    inside = (uv[drawn, 0, 0] >= 0) & (uv[drawn, 0, 0] < 1242) & (uv[drawn, 0, 1] >= 0) & (uv[drawn, 0, 1] < 375)
     assert inside.mean() > 0.2
     # the f64-column entry agrees with the f32 entry (widening is exact)
     uv3, bgrv3 = orc.project_points(kitti_xyzi[:, :3].astype(np.float64), rig)
@@ -107,7 +107,7 @@ def test_oracle_special_values():
     uv2, bgrv2 = util.project_numpy(pts, tf, R, P, 15.0)
     assert np.array_equal(uv, uv2) and np.array_equal(bgrv, bgrv2)
     assert uv[0, 0, 0] == I32_MIN and bgrv[0, 3] == 1      # NaN x: every comparison of :21-24 is false -> "drawn" at INT_MIN
-    assert uv[0, 2, 0] == I32_MIN                            # does not fit an int: cvttsd2si's indefinite value
+    assert uv[2, 0, 0] == I32_MIN                            # does not fit an int: cvttsd2si's indefinite value
 
 
 # ---------------------------------------------------------------- GPU: HIP kernels vs the oracle
@@ -135,7 +135,7 @@ def _rigs(calib, max_range=15.0):
 def test_gpu_project_f32_host_bit_exact(ctx, calib, kitti_xyzi, n):
     rig, orig = _rigs(calib)
     pts = np.ascontiguousarray(kitti_xyzi[:n])
-    uv = np.full((4, n, 2), 7, dtype=np.int32)
+    uv = np.full((n, 4, 2), 7, dtype=np.int32)
     bgrv = np.full((n, 4), 7, dtype=np.uint8)
     st = ctx.project_f32(pts, rig, uv, bgrv)
     assert st.n_points == n
@@ -150,7 +150,7 @@ def test_gpu_project_f32_device_and_f64cols(ctx, calib, kitti_xyzi):
     rig, orig = _rigs(calib, 40.0)
     n = kitti_xyzi.shape[0]
     d_in = torch.from_numpy(kitti_xyzi).cuda()
-    d_uv = torch.zeros((4, n, 2), dtype=torch.int32, device="cuda")
+    d_uv = torch.zeros((n, 4, 2), dtype=torch.int32, device="cuda")
     d_col = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.project_f32(d_in, rig, d_uv, d_col)
@@ -159,7 +159,7 @@ def test_gpu_project_f32_device_and_f64cols(ctx, calib, kitti_xyzi):
     assert np.array_equal(d_uv.cpu().numpy(), uv_ref) and np.array_equal(d_col.cpu().numpy(), bgrv_ref)
     # Eigen-layout entry: three f64 columns
     cols = [np.ascontiguousarray(kitti_xyzi[:, k].astype(np.float64)) for k in range(3)]
-    uv = np.zeros((4, n, 2), dtype=np.int32)
+    uv = np.zeros((n, 4, 2), dtype=np.int32)
     bgrv = np.zeros((n, 4), dtype=np.uint8)
     ctx.project_f64cols(cols[0], cols[1], cols[2], rig, uv, bgrv)
     assert np.array_equal(uv, uv_ref) and np.array_equal(bgrv, bgrv_ref)
@@ -186,7 +186,7 @@ def test_gpu_fused_deskew_then_project(ctx, calib, kitti_xyzi, twist):
     plain = np.empty_like(kitti_xyzi)
     ctx.deskew_f32(kitti_xyzi, plain, params)
     cloud = np.empty_like(kitti_xyzi)
-    uv = np.zeros((4, n, 2), dtype=np.int32)
+    uv = np.zeros((n, 4, 2), dtype=np.int32)
     bgrv = np.zeros((n, 4), dtype=np.uint8)
     ctx.project_f32(kitti_xyzi, rig, uv, bgrv, deskew=params, xyzi_out=cloud)
     assert np.array_equal(cloud.view(np.uint32), plain.view(np.uint32))
@@ -202,8 +202,8 @@ def test_gpu_fused_deskew_then_project(ctx, calib, kitti_xyzi, twist):
     res = orc.deskew_xyzi_f32(kitti_xyzi, T0, ident, T1, orc.se3_exp(twist), T0 + 0.5 * (T1 - T0), mode=orc.FAITHFUL)
     uv64, bgrv64 = orc.project_points(res["xyz_f64"], orig)
     both = (bgrv[:, 3] == 1) & (bgrv64[:, 3] == 1)
-    d = np.abs(uv[:, both].astype(np.int64) - uv64[:, both].astype(np.int64))
-    mag = np.abs(uv64[:, both].astype(np.int64))
+    d = np.abs(uv[both].astype(np.int64) - uv64[both].astype(np.int64))
+    mag = np.abs(uv64[both].astype(np.int64))
     assert np.all(d <= 1 + mag // 4096)          # 1 px; points centimetres from the camera plane land at |u| ~ 1e4..1e6 px
     assert (d > 0).mean() < 5e-3
     assert (bgrv[:, 3] != bgrv64[:, 3]).mean() < 1e-3
@@ -225,7 +225,7 @@ def test_gpu_project_synthetic_1m_and_special_values(ctx, kitti_xyzi):
     R_rect = np.eye(3) + np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
     P = [np.array([[721.5 + c, 0, 609.5, -387.0 * c], [0, 721.5 + c, 172.8, 0.3 * c], [0, 0, 1, 0.002 * c]]) for c in range(4)]
     rig, orig = capi.CameraRig.make(tf, R_rect, P, 80.0), orc.camera_rig(tf, R_rect, P, 80.0)
-    uv = np.zeros((4, n, 2), dtype=np.int32)
+    uv = np.zeros((n, 4, 2), dtype=np.int32)
     bgrv = np.zeros((n, 4), dtype=np.uint8)
     ctx.project_f32(pts, rig, uv, bgrv)
     uv_ref, bgrv_ref = orc.project_xyzi_f32(pts, orig)
@@ -253,13 +253,13 @@ def test_gpu_project_exact_integer_pixels(ctx, dense):
     pts = np.ascontiguousarray(np.vstack([pts, extra]))
     n = pts.shape[0]
     rig, orig = capi.CameraRig.make(tf, R, P, 15.0), orc.camera_rig(tf, R, P, 15.0)
-    uv = np.zeros((4, n, 2), dtype=np.int32)
+    uv = np.zeros((n, 4, 2), dtype=np.int32)
     bgrv = np.zeros((n, 4), dtype=np.uint8)
     ctx.project_f32(pts, rig, uv, bgrv)
     uv_ref, bgrv_ref = orc.project_xyzi_f32(pts, orig)
     assert np.array_equal(uv, uv_ref) and np.array_equal(bgrv, bgrv_ref)
     if not dense:
-        assert np.array_equal(uv[0, :600, 0], np.arange(300, 900))   # z = 0.5 row: exact integers
+        assert np.array_equal(uv[:600, 0, 0], np.arange(300, 900))   # z = 0.5 row: exact integers
 
 
 @pytest.mark.gpu
@@ -274,7 +274,7 @@ def test_gpu_project_dense_rig_1m(ctx):
     R_rect = np.eye(3) + 0.02 * rng.standard_normal((3, 3))
     P = [np.array([[700.0, 0, 600, 40], [0, 700, 180, 0], [0, 0, 1, 0]]) + 0.01 * rng.standard_normal((3, 4)) for _ in range(4)]
     rig, orig = capi.CameraRig.make(tf, R_rect, P, 60.0), orc.camera_rig(tf, R_rect, P, 60.0)
-    uv = np.zeros((4, n, 2), dtype=np.int32)
+    uv = np.zeros((n, 4, 2), dtype=np.int32)
     bgrv = np.zeros((n, 4), dtype=np.uint8)
     ctx.project_f32(pts, rig, uv, bgrv)
     uv_ref, bgrv_ref = orc.project_xyzi_f32(pts, orig)
@@ -288,7 +288,7 @@ def test_gpu_project_argument_checks(ctx, calib, kitti_xyzi):
     rig, _ = _rigs(calib)
     n = 128
     pts = np.ascontiguousarray(kitti_xyzi[:n])
-    uv = np.zeros((4, n, 2), dtype=np.int32)
+    uv = np.zeros((n, 4, 2), dtype=np.int32)
     bgrv = np.zeros((n, 4), dtype=np.uint8)
     with pytest.raises(capi.KmcError) as e:   # a cloud output needs a deskew
         ctx.project_f32(pts, rig, uv, bgrv, xyzi_out=np.empty_like(pts))

@@ -113,7 +113,7 @@ def load_kitti_calibration(date_dir):
 
 def project_numpy(xyz, tf, R_rect, P_rects, max_range=15.0):
     """camera_model.cpp:5-95 (without the drawing) in numpy f64, one rounded operation at a time in the reference's order;
-    an independent twin of oracle kmo_project_points.  -> (uv (4,N,2) int32, bgrv (N,4) uint8)"""
+    an independent twin of oracle kmo_project_points.  -> (uv (N,4,2) int32, bgrv (N,4) uint8)"""
     p = np.asarray(xyz, dtype=np.float64)
     x, y, z = p[:, 0], p[:, 1], p[:, 2]
     with np.errstate(all="ignore"):
@@ -121,7 +121,7 @@ def project_numpy(xyz, tf, R_rect, P_rects, max_range=15.0):
         r = [((R_rect[k, 0] * c[0] + R_rect[k, 1] * c[1]) + R_rect[k, 2] * c[2]) + 0.0 for k in range(3)]
         drawn = ~((r[2] < 0.01) | (r[2] > max_range) | (r[1] > 1.25))
         n = p.shape[0]
-        uv = np.full((4, n, 2), np.iinfo(np.int32).min, dtype=np.int32)
+        uv = np.full((n, 4, 2), np.iinfo(np.int32).min, dtype=np.int32)
         for cam in range(4):
             P = P_rects[cam]
             h = [((P[k, 0] * r[0] + P[k, 1] * r[1]) + P[k, 2] * r[2]) + P[k, 3] * 1.0 for k in range(3)]
@@ -129,7 +129,7 @@ def project_numpy(xyz, tf, R_rect, P_rects, max_range=15.0):
                 q = h[j] / h[2]
                 fits = (q > -2147483649.0) & (q < 2147483648.0)
                 t = np.where(fits, np.trunc(np.where(fits, q, 0.0)), -2147483648.0).astype(np.int64).astype(np.int32)
-                uv[cam, :, j] = np.where(drawn, t, np.iinfo(np.int32).min)
+                uv[:, cam, j] = np.where(drawn, t, np.iinfo(np.int32).min)
         cs = 255.0 * (r[2] / (max_range - 0.01))
 
         def sat(v):

@@ -36,7 +36,7 @@ def main():
         ctx.synth_points(d_in, n, 0x4B4D43)
     print("data:", data)
     d_out = torch.empty_like(d_in)
-    d_uv = torch.empty((4, n, 2), dtype=torch.int32, device="cuda")
+    d_uv = torch.empty((n, 4, 2), dtype=torch.int32, device="cuda")
     d_col = torch.empty((n, 4), dtype=torch.uint8, device="cuda")
     params = capi.FrameParams.make([1.3, 0.05, -0.02, 0.001, -0.002, 0.03], 0.5)
     cases = {

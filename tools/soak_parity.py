@@ -132,7 +132,7 @@ def projection_round(ctx, rng, acc, calib):
         P = [p + 0.01 * rng.standard_normal((3, 4)) for p in P]
     max_range = float(rng.choice([15.0, 40.0, 80.0, 1e9]))
     rig, orig = capi.CameraRig.make(tf, R_rect, P, max_range), orc.camera_rig(tf, R_rect, P, max_range)
-    uv = np.empty((4, n, 2), dtype=np.int32)
+    uv = np.empty((n, 4, 2), dtype=np.int32)
     bgrv = np.empty((n, 4), dtype=np.uint8)
     ctx.project_f32(pts, rig, uv, bgrv)
     uv_ref, bgrv_ref = orc.project_xyzi_f32(pts, orig)
