@@ -300,3 +300,26 @@ def test_gpu_project_argument_checks(ctx, calib, kitti_xyzi):
     with pytest.raises(capi.KmcError) as e:   # requested time outside the scan
         ctx.project_f32(pts, rig, uv, bgrv, deskew=capi.FrameParams.make([1, 0, 0, 0, 0, 0.1], 1.5))
     assert e.value.status == capi.ERR_TIME_OUT_OF_RANGE
+
+
+def test_pixels_do_not_depend_on_the_summation_order_on_real_data(calib, kitti_xyzi):
+    """The oracle sums every dot product left to right without FMA, which is how Eigen evaluates these small products in a
+    plain -O3 build; the reference has no test that would pin that choice.  How much could it matter?  The same projection
+    through BLAS matrix products (blocked / FMA order) must give the same integers on the shipped scan -- a pixel only changes
+    if a quotient sits within ~1e-13 of an integer."""
+    tf, R_rect, P = calib
+    rig = orc.camera_rig(tf, R_rect, P, 15.0)
+    uv, bgrv = orc.project_xyzi_f32(kitti_xyzi, rig)
+    ph = np.hstack([kitti_xyzi[:, :3].astype(np.float64), np.ones((kitti_xyzi.shape[0], 1))])
+    T4 = np.vstack([tf, [0, 0, 0, 1]])
+    R4 = np.eye(4)
+    R4[:3, :3] = R_rect
+    rect = (R4 @ (T4 @ ph.T)).T
+    drawn = ~((rect[:, 2] < 0.01) | (rect[:, 2] > 15.0) | (rect[:, 1] > 1.25))
+    assert np.array_equal(drawn, bgrv[:, 3] == 1)
+    mismatches = 0
+    for cam in range(4):
+        pix = (P[cam] @ rect.T).T
+        q = pix[:, :2] / pix[:, 2:3]
+        mismatches += int(np.count_nonzero(np.trunc(q[drawn]).astype(np.int64) != uv[drawn, cam]))
+    assert mismatches == 0
