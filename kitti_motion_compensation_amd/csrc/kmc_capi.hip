@@ -851,8 +851,8 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(deskew_f64cols, dim3(grid), dim3(kBlock), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter);
+  const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
+  hipLaunchKernelGGL(deskew_f64cols, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter);
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   unsigned long long bad = 0;
@@ -1133,8 +1133,8 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   if (rc != KMC_OK) return rc;
   KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(deskew_traj_f64cols, dim3(grid), dim3(kBlock), 0, c->stream, dx, dy, dz, dw, ds, n, (const TrajSeg64*)d_segs, th.n_seg,
+  const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
+  hipLaunchKernelGGL(deskew_traj_f64cols, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, (const TrajSeg64*)d_segs, th.n_seg,
                      knot_times[0], knot_times[n_knots - 1], dox, doy, doz, dow, d_idx, c->d_counter);
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");

@@ -278,31 +278,72 @@ __global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict_
 // ------------------------------------------------------------------------------------------------
 // f64 Eigen-layout kernel (compatibility path of MotionCompensateFrame(Frame const&, Time))
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
-                                                        const double* __restrict__ z, const double* __restrict__ w,
-                                                        const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
-                                                        double* __restrict__ ox, double* __restrict__ oy,
-                                                        double* __restrict__ oz, double* __restrict__ ow,
-                                                        unsigned long long* __restrict__ n_bad) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const double t = __builtin_nontemporal_load(stamps + i);
-    const double px = __builtin_nontemporal_load(x + i), py = __builtin_nontemporal_load(y + i), pz = __builtin_nontemporal_load(z + i);
-    const double pw = w ? __builtin_nontemporal_load(w + i) : 1.0;
-    const bool in_range = (t >= f.t_start) && (t <= f.t_end);  // TimeIsInRange, trajectory_interpolation.cpp:47
-    double rx, ry, rz;
-    if (in_range) {
-      const double xi = (t - f.t_start) / f.dur;  // FractionOfTrajectory, :49-51 (a true divide, like the reference)
-      deskew_point_f64(px, py, pz, pw, xi - f.x_req, f, rx, ry, rz);
+// One wave per workgroup, TWO consecutive points per lane: every column access is a 16-byte load / store per lane, i.e. 1 KiB
+// of consecutive bytes per wave instruction like the f32 kernels (8-byte accesses move half lines).  Eigen columns are only
+// 8-byte aligned in general (column j starts at j * n doubles), hence the under-aligned vector type; gfx950 global memory
+// instructions take any 4-byte-aligned address.
+typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
+
+__device__ __forceinline__ void deskew_one_f64(double px, double py, double pz, double pw, double t, const FrameRec64& f, double& rx,
+                                               double& ry, double& rz, bool& in_range) {
+  in_range = (t >= f.t_start) && (t <= f.t_end);  // TimeIsInRange, trajectory_interpolation.cpp:47
+  if (in_range) {
+    const double xi = (t - f.t_start) / f.dur;  // FractionOfTrajectory, :49-51 (a true divide, like the reference)
+    deskew_point_f64(px, py, pz, pw, xi - f.x_req, f, rx, ry, rz);
+  } else {
+    rx = ry = rz = __builtin_nan("");
+  }
+}
+
+__global__ __launch_bounds__(64) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
+                                                     const double* __restrict__ z, const double* __restrict__ w,
+                                                     const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
+                                                     double* __restrict__ ox, double* __restrict__ oy,
+                                                     double* __restrict__ oz, double* __restrict__ ow,
+                                                     unsigned long long* __restrict__ n_bad) {
+  constexpr uint64_t kTile = 128;  // points per wave
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_tiles = (n + kTile - 1) / kTile;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t i = t * kTile + 2 * (uint64_t)tid;
+    unsigned long long bad_lanes;
+    uint32_t bad_count;
+    if (i + 1 < n) {
+      const v2d_u ts = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(stamps + i));
+      const v2d_u vx = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(x + i));
+      const v2d_u vy = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(y + i));
+      const v2d_u vz = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(z + i));
+      v2d_u vw = {1.0, 1.0};
+      if (w) vw = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(w + i));
+      v2d_u rx, ry, rz;
+      bool ok0, ok1;
+      double a, b, c;
+      deskew_one_f64(vx.x, vy.x, vz.x, vw.x, ts.x, f, a, b, c, ok0);
+      rx.x = a; ry.x = b; rz.x = c;
+      deskew_one_f64(vx.y, vy.y, vz.y, vw.y, ts.y, f, a, b, c, ok1);
+      rx.y = a; ry.y = b; rz.y = c;
+      __builtin_nontemporal_store(rx, reinterpret_cast<v2d_u*>(ox + i));
+      __builtin_nontemporal_store(ry, reinterpret_cast<v2d_u*>(oy + i));
+      __builtin_nontemporal_store(rz, reinterpret_cast<v2d_u*>(oz + i));
+      if (ow) __builtin_nontemporal_store(vw, reinterpret_cast<v2d_u*>(ow + i));
+      bad_count = (ok0 ? 0u : 1u) + (ok1 ? 0u : 1u);
+    } else if (i < n) {  // the odd last point
+      const double pw = w ? w[i] : 1.0;
+      double a, b, c;
+      bool ok;
+      deskew_one_f64(x[i], y[i], z[i], pw, stamps[i], f, a, b, c, ok);
+      ox[i] = a; oy[i] = b; oz[i] = c;
+      if (ow) ow[i] = pw;
+      bad_count = ok ? 0u : 1u;
     } else {
-      rx = ry = rz = __builtin_nan("");
+      bad_count = 0;
     }
-    __builtin_nontemporal_store(rx, ox + i);
-    __builtin_nontemporal_store(ry, oy + i);
-    __builtin_nontemporal_store(rz, oz + i);
-    if (ow) __builtin_nontemporal_store(pw, ow + i);
-    const unsigned long long bad = __ballot(!in_range);
-    if (bad && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(bad)) atomicAdd(n_bad, (unsigned long long)__builtin_popcountll(bad));
+    bad_lanes = __ballot(bad_count != 0);
+    if (bad_lanes) {  // rare: count through a wave reduction, one atomic per wave
+      uint32_t total = bad_count;
+      for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+      if (tid == 0) atomicAdd(n_bad, (unsigned long long)total);
+    }
   }
 }
 
@@ -503,44 +544,85 @@ __global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restric
 }
 
 // f64 Eigen-layout variant: honours the caller's per-point stamps; the bracket is found by f64 time compares.
-__global__ __launch_bounds__(kBlock) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
-                                                             const double* __restrict__ z, const double* __restrict__ w,
-                                                             const double* __restrict__ stamps, uint64_t n,
-                                                             const TrajSeg64* __restrict__ segs, uint32_t n_seg,
-                                                             double t_first, double t_last, double* __restrict__ ox,
-                                                             double* __restrict__ oy, double* __restrict__ oz,
-                                                             double* __restrict__ ow, uint32_t* __restrict__ bracket_out,
-                                                             unsigned long long* __restrict__ n_bad) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const double t = stamps[i];
-    const double px = x[i], py = y[i], pz = z[i], pw = w ? w[i] : 1.0;
-    const bool in_range = (t >= t_first) && (t <= t_last);
-    double rx, ry, rz;
-    uint32_t k = 0;
-    if (in_range) {
-      while (k + 1 < n_seg && t >= segs[k + 1].f.t_start) ++k;  // t_k <= t < t_{k+1}; the last knot belongs to the last segment
-      const TrajSeg64& sg = segs[k];
-      const double xi = (t - sg.f.t_start) / sg.f.dur;
-      double qx, qy, qz;
-      deskew_point_f64(px, py, pz, pw, xi - sg.f.x_req, sg.f, qx, qy, qz);
-      if (sg.identity) {
-        rx = qx; ry = qy; rz = qz;
-      } else {  // M_k * (q, w): rotation on the point, translation scaled by the homogeneous coordinate
-        rx = sg.M[0] * qx + sg.M[1] * qy + sg.M[2] * qz + sg.M[3] * pw;
-        ry = sg.M[4] * qx + sg.M[5] * qy + sg.M[6] * qz + sg.M[7] * pw;
-        rz = sg.M[8] * qx + sg.M[9] * qy + sg.M[10] * qz + sg.M[11] * pw;
-      }
-    } else {
-      rx = ry = rz = __builtin_nan("");
+__device__ __forceinline__ void traj_one_f64(double px, double py, double pz, double pw, double t, const TrajSeg64* __restrict__ segs,
+                                             uint32_t n_seg, double t_first, double t_last, double& rx, double& ry, double& rz,
+                                             uint32_t& k_out, bool& in_range) {
+  in_range = (t >= t_first) && (t <= t_last);
+  uint32_t k = 0;
+  if (in_range) {
+    while (k + 1 < n_seg && t >= segs[k + 1].f.t_start) ++k;  // t_k <= t < t_{k+1}; the last knot belongs to the last segment
+    const TrajSeg64& sg = segs[k];
+    const double xi = (t - sg.f.t_start) / sg.f.dur;
+    double qx, qy, qz;
+    deskew_point_f64(px, py, pz, pw, xi - sg.f.x_req, sg.f, qx, qy, qz);
+    if (sg.identity) {
+      rx = qx; ry = qy; rz = qz;
+    } else {  // M_k * (q, w): rotation on the point, translation scaled by the homogeneous coordinate
+      rx = sg.M[0] * qx + sg.M[1] * qy + sg.M[2] * qz + sg.M[3] * pw;
+      ry = sg.M[4] * qx + sg.M[5] * qy + sg.M[6] * qz + sg.M[7] * pw;
+      rz = sg.M[8] * qx + sg.M[9] * qy + sg.M[10] * qz + sg.M[11] * pw;
     }
-    ox[i] = rx;
-    oy[i] = ry;
-    oz[i] = rz;
-    if (ow) ow[i] = pw;
-    if (bracket_out) bracket_out[i] = k;
-    const unsigned long long bad = __ballot(!in_range);
-    if (bad && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(bad)) atomicAdd(n_bad, (unsigned long long)__builtin_popcountll(bad));
+  } else {
+    rx = ry = rz = __builtin_nan("");
+  }
+  k_out = k;
+}
+
+// same geometry as deskew_f64cols: one wave per workgroup, two consecutive points per lane, 16-byte column accesses
+__global__ __launch_bounds__(64) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
+                                                          const double* __restrict__ z, const double* __restrict__ w,
+                                                          const double* __restrict__ stamps, uint64_t n,
+                                                          const TrajSeg64* __restrict__ segs, uint32_t n_seg,
+                                                          double t_first, double t_last, double* __restrict__ ox,
+                                                          double* __restrict__ oy, double* __restrict__ oz,
+                                                          double* __restrict__ ow, uint32_t* __restrict__ bracket_out,
+                                                          unsigned long long* __restrict__ n_bad) {
+  constexpr uint64_t kTile = 128;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t n_tiles = (n + kTile - 1) / kTile;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t i = t * kTile + 2 * (uint64_t)tid;
+    uint32_t bad_count = 0;
+    if (i + 1 < n) {
+      const v2d_u ts = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(stamps + i));
+      const v2d_u vx = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(x + i));
+      const v2d_u vy = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(y + i));
+      const v2d_u vz = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(z + i));
+      v2d_u vw = {1.0, 1.0};
+      if (w) vw = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(w + i));
+      v2d_u rx, ry, rz;
+      double a, b, c;
+      uint32_t k0, k1;
+      bool ok0, ok1;
+      traj_one_f64(vx.x, vy.x, vz.x, vw.x, ts.x, segs, n_seg, t_first, t_last, a, b, c, k0, ok0);
+      rx.x = a; ry.x = b; rz.x = c;
+      traj_one_f64(vx.y, vy.y, vz.y, vw.y, ts.y, segs, n_seg, t_first, t_last, a, b, c, k1, ok1);
+      rx.y = a; ry.y = b; rz.y = c;
+      __builtin_nontemporal_store(rx, reinterpret_cast<v2d_u*>(ox + i));
+      __builtin_nontemporal_store(ry, reinterpret_cast<v2d_u*>(oy + i));
+      __builtin_nontemporal_store(rz, reinterpret_cast<v2d_u*>(oz + i));
+      if (ow) __builtin_nontemporal_store(vw, reinterpret_cast<v2d_u*>(ow + i));
+      if (bracket_out) {
+        bracket_out[i] = k0;
+        bracket_out[i + 1] = k1;
+      }
+      bad_count = (ok0 ? 0u : 1u) + (ok1 ? 0u : 1u);
+    } else if (i < n) {  // the odd last point
+      const double pw = w ? w[i] : 1.0;
+      double a, b, c;
+      uint32_t k;
+      bool ok;
+      traj_one_f64(x[i], y[i], z[i], pw, stamps[i], segs, n_seg, t_first, t_last, a, b, c, k, ok);
+      ox[i] = a; oy[i] = b; oz[i] = c;
+      if (ow) ow[i] = pw;
+      if (bracket_out) bracket_out[i] = k;
+      bad_count = ok ? 0u : 1u;
+    }
+    if (__ballot(bad_count != 0)) {
+      uint32_t total = bad_count;
+      for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+      if (tid == 0) atomicAdd(n_bad, (unsigned long long)total);
+    }
   }
 }
 
