@@ -141,6 +141,58 @@ def projection_round(ctx, rng, acc, calib):
     acc["projection_int_mismatch"] += int(np.count_nonzero(uv != uv_ref) + np.count_nonzero(bgrv != bgrv_ref))
 
 
+def subrange_round(ctx, rng, acc, torch):
+    """Device-resident sub-ranges at random 16-byte offsets: same bits as the aligned host-buffer call, nothing outside."""
+    n = int(rng.choice([1, 63, 64, 65, 127, 4097, 100_003, 1_000_001]))
+    sh_in, sh_out = int(rng.integers(0, 130)), int(rng.integers(0, 130))
+    pts = random_points(rng, n)
+    nf = int(rng.integers(1, 12))
+    cuts = np.sort(rng.integers(0, n + 1, nf - 1)) if nf > 1 else np.array([], dtype=np.int64)
+    offsets = np.concatenate([[0], cuts, [n]]).astype(np.uint64)
+    plist = [params_from_twist(random_twist(rng) * 0.3, float(rng.random())) for _ in range(nf)]
+    ref = np.empty_like(pts)
+    ref_idx = np.empty(n, dtype=np.uint32)
+    ctx.deskew_batch_f32(pts, ref, offsets, plist, ref_idx)
+    d_in = torch.zeros((n + 260, 4), dtype=torch.float32, device="cuda")
+    d_in[sh_in:sh_in + n].copy_(torch.from_numpy(pts))
+    big = torch.full((n + 260, 4), 7.0, dtype=torch.float32, device="cuda")
+    idx = torch.full((n + 260,), 77, dtype=torch.int32, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.deskew_batch_f32(d_in[sh_in:sh_in + n], big[sh_out:sh_out + n], offsets, plist, idx[5:5 + n])
+    torch.cuda.synchronize()
+    ctx.set_stream(None)
+    ok = bool(torch.equal(big[sh_out:sh_out + n].view(torch.int32), torch.from_numpy(ref).cuda().view(torch.int32)))
+    ok = ok and bool((big[:sh_out] == 7.0).all()) and bool((big[sh_out + n:] == 7.0).all())
+    ok = ok and bool((idx[:5] == 77).all()) and bool((idx[5 + n:] == 77).all())
+    ok = ok and np.array_equal(idx[5:5 + n].cpu().numpy().view(np.uint32), ref_idx)
+    acc["subrange_points"] += n
+    acc["subrange_failures"] += 0 if ok else 1
+
+
+def f64_round(ctx, rng, acc):
+    """The Eigen-layout kernel (the reference API's device side) against the oracle's faithful per-point sequence."""
+    n = int(rng.choice([1, 2, 3, 127, 128, 129, 50_001, 400_000]))
+    pts = random_points(rng, n).astype(np.float64)
+    twist = random_twist(rng)
+    T_end = orc.se3_exp(list(twist))
+    stamps = np.ascontiguousarray(T0 + rng.random(n) * (T1 - T0))
+    treq = T0 + float(rng.random()) * (T1 - T0)
+    M = np.hstack([np.array(list(T_end.R)).reshape(3, 3), np.array(list(T_end.t)).reshape(3, 1)])
+    params = capi.frame_params_from_poses(IDENT, M, T0, T1, treq)
+    cols = [np.ascontiguousarray(pts[:, k]) for k in range(3)]
+    w = np.ones(n)
+    outs = [np.empty(n) for _ in range(4)]
+    ctx.deskew_f64cols(cols[0], cols[1], cols[2], w, stamps, T0, T1, params, *outs)
+    cloud = np.stack([cols[0], cols[1], cols[2], w], axis=1)
+    res = orc.motion_compensate_frame(cloud, stamps, T0, orc.se3_exp([0] * 6), T1, T_end, treq)
+    ref = res[-1] if isinstance(res, tuple) else res
+    ref = np.asarray(ref)[:, :3]
+    got = np.stack(outs[:3], axis=1)
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-3)
+    acc["f64_points"] += n
+    acc["f64_max_rel_err"] = max(acc["f64_max_rel_err"], float(err.max()))
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -153,18 +205,26 @@ def main():
         acc.update({key + "_max_rel_err": 0.0, key + "_max_rel_err_literal": 0.0, key + "_max_err_over_scale": 0.0,
                     key + "_near_origin_points": 0})
     t_end = time.time() + budget
+    import torch
+
+    acc.update(subrange_points=0, subrange_failures=0, f64_points=0, f64_max_rel_err=0.0)
     while time.time() < t_end:
-        r = acc["rounds"] % 3
+        r = acc["rounds"] % 5
         if r == 0:
             deskew_round(ctx, rng, acc)
         elif r == 1:
             batch_round(ctx, rng, acc)
-        else:
+        elif r == 2:
             projection_round(ctx, rng, acc, calib)
+        elif r == 3:
+            subrange_round(ctx, rng, acc, torch)
+        else:
+            f64_round(ctx, rng, acc)
         acc["rounds"] += 1
     acc["ok"] = bool(acc["deskew_max_rel_err"] <= 1e-5 and acc["batch_max_rel_err"] <= 1e-5 and acc["deskew_intensity_mismatch"] == 0
                      and acc["deskew_max_err_over_scale"] <= 2e-6 and acc["batch_max_err_over_scale"] <= 2e-6
                      and acc["deskew_max_rel_err_literal"] <= 1e-5 and acc["batch_max_rel_err_literal"] <= 1e-5
+                     and acc["subrange_failures"] == 0 and acc["f64_max_rel_err"] <= 1e-9
                      and acc["batch_index_mismatch"] == 0 and acc["projection_int_mismatch"] == 0)
     print(json.dumps(acc))
     sys.exit(0 if acc["ok"] else 1)
