@@ -21,6 +21,10 @@
 #include <cstddef>
 #include <filesystem>
 #include <initializer_list>
+#include <memory>
+#include <new>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace kmc {
@@ -131,10 +135,36 @@ Affine3d operator*(Affine3d const& a, Affine3d const& b);
 Vector4d operator*(Affine3d const& a, Vector4d const& p);  // homogeneous product, w passed through (motion_compensation.cpp:13)
 Affine3d operator*(Matrix3d const& r, Affine3d const& a);  // "pose = R * pose" (data_io.cpp:84)
 
+namespace detail {
+// std::allocator that default-initialises (i.e. leaves doubles untouched) on vector(n) / resize(n): lets the library hand out
+// a result buffer without first writing 4 n zeros into it (Eigen's MatrixX4d(n, 4) does not initialise either).
+template <typename T>
+struct DefaultInitAllocator : std::allocator<T> {
+  template <typename U>
+  struct rebind {
+    using other = DefaultInitAllocator<U>;
+  };
+  template <typename U>
+  void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+    ::new (static_cast<void*>(p)) U;
+  }
+  template <typename U, typename... Args>
+  void construct(U* p, Args&&... args) {
+    ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+  }
+};
+using Storage = std::vector<double, DefaultInitAllocator<double>>;
+}  // namespace detail
+
 class VectorXd {
  public:
   VectorXd() = default;
   explicit VectorXd(Index n) : d_(static_cast<std::size_t>(n), 0.0) {}
+  static VectorXd Uninitialized(Index n) {  // contents indeterminate until written
+    VectorXd v;
+    v.d_ = detail::Storage(static_cast<std::size_t>(n));
+    return v;
+  }
   Index size() const { return static_cast<Index>(d_.size()); }
   Index rows() const { return size(); }
   double& operator()(Index i) { return d_[static_cast<std::size_t>(i)]; }
@@ -143,7 +173,7 @@ class VectorXd {
   double const* data() const { return d_.data(); }
 
  private:
-  std::vector<double> d_;
+  detail::Storage d_;
 };
 
 // N x 4, column-major (Eigen::MatrixX4d).  Homogeneous points: the last column is 1 (data_types.hpp:13-14).
@@ -166,6 +196,12 @@ class MatrixX4d {
   };
   MatrixX4d() = default;
   MatrixX4d(Index rows, Index /*cols == 4*/) : n_(rows), d_(static_cast<std::size_t>(rows) * 4, 0.0) {}
+  static MatrixX4d Uninitialized(Index rows) {  // contents indeterminate until written (what Eigen's MatrixX4d(rows, 4) gives)
+    MatrixX4d m;
+    m.n_ = rows;
+    m.d_ = detail::Storage(static_cast<std::size_t>(rows) * 4);
+    return m;
+  }
   Index rows() const { return n_; }
   Index cols() const { return 4; }
   double& operator()(Index i, Index j) { return d_[static_cast<std::size_t>(j * n_ + i)]; }
@@ -179,7 +215,7 @@ class MatrixX4d {
 
  private:
   Index n_ = 0;
-  std::vector<double> d_;
+  detail::Storage d_;
 };
 using Pointcloud = MatrixX4d;
 

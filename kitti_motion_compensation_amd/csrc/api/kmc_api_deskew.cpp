@@ -133,7 +133,7 @@ Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time) 
   if (frame.scan.timestamps.size() != n) throw std::invalid_argument("kmc::MotionCompensateFrame: timestamps.size() != cloud.rows()");
   kmc_frame_params const p = detail::frame_params(frame.T_start, frame.T_end, frame.scan.stamp_start, frame.scan.stamp_end, requested_time,
                                                   "kmc::MotionCompensateFrame");
-  Pointcloud out{MatrixX4d(n, 4)};
+  Pointcloud out{MatrixX4d::Uninitialized(n)};  // every element is written by the download below
   if (n == 0) return out;
   kmc_ctx* c = detail::thread_context();
   kmc_stats st;
@@ -153,7 +153,7 @@ Pointcloud MotionCompensateFrame(Frame const& frame, Trajectory const& tr, Time 
   if (tr.times.size() != tr.poses.size()) throw std::invalid_argument("kmc::Trajectory: times.size() != poses.size()");
   std::vector<double> poses(12 * tr.poses.size());
   for (std::size_t k = 0; k < tr.poses.size(); ++k) tr.poses[k].to_rt12(poses.data() + 12 * k);
-  Pointcloud out{MatrixX4d(n, 4)};
+  Pointcloud out{MatrixX4d::Uninitialized(n)};  // every element is written by the download below
   kmc_ctx* c = detail::thread_context();
   Pointcloud const& in = frame.scan.cloud;
   int const rc = kmc_hip_deskew_traj_f64cols(c, in.col(0), in.col(1), in.col(2), in.col(3), frame.scan.timestamps.data(),
@@ -181,7 +181,7 @@ Vector4d MotionCompensatePoint(TrajectoryInterpolator const& ti, Time const poin
 
 // timestamp_mocking.cpp:56-63
 VectorXd GetPseudoTimeStamps(Pointcloud const& cloud, Time const start_time, Time const end_time) {
-  VectorXd stamps(cloud.rows());
+  VectorXd stamps{VectorXd::Uninitialized(cloud.rows())};
   if (cloud.rows() == 0) return stamps;
   kmc_ctx* c = detail::thread_context();
   int const rc = kmc_hip_pseudo_timestamps_f64(c, cloud.col(0), cloud.col(1), static_cast<std::uint64_t>(cloud.rows()), start_time, end_time,

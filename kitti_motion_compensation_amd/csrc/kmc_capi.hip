@@ -839,10 +839,16 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
     double* base = (double*)c->d_tmp;
     double* cols[9];
     for (int i = 0; i < 9; ++i) cols[i] = base + (size_t)i * n;
-    KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, col, hipMemcpyHostToDevice, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(cols[1], y, col, hipMemcpyHostToDevice, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(cols[2], z, col, hipMemcpyHostToDevice, c->stream));
-    if (w) KMC_HIP_TRY(c, hipMemcpyAsync(cols[3], w, col, hipMemcpyHostToDevice, c->stream));
+    // an Eigen::MatrixX4d is ONE column-major block: x, y, z, w follow each other -> one copy instead of four (each
+    // pageable copy has a fixed cost of tens of microseconds, which is what a 123 k-point frame is made of)
+    if (y == x + n && z == y + n && (!w || w == z + n)) {
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, (w ? 4 : 3) * col, hipMemcpyHostToDevice, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[1], y, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[2], z, col, hipMemcpyHostToDevice, c->stream));
+      if (w) KMC_HIP_TRY(c, hipMemcpyAsync(cols[3], w, col, hipMemcpyHostToDevice, c->stream));
+    }
     KMC_HIP_TRY(c, hipMemcpyAsync(cols[4], stamps, col, hipMemcpyHostToDevice, c->stream));
     dx = cols[0]; dy = cols[1]; dz = cols[2]; dw = w ? cols[3] : nullptr; ds = cols[4];
     dox = cols[5]; doy = cols[6]; doz = cols[7]; dow = ow ? cols[8] : nullptr;
@@ -858,10 +864,14 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   unsigned long long bad = 0;
   KMC_HIP_TRY(c, hipMemcpyAsync(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
   if (mem_kind == KMC_MEM_HOST) {
-    KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, col, hipMemcpyDeviceToHost, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(oy, doy, col, hipMemcpyDeviceToHost, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(oz, doz, col, hipMemcpyDeviceToHost, c->stream));
-    if (ow) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
+    if (oy == ox + n && oz == oy + n && (!ow || ow == oz + n)) {  // one column-major block again
+      KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, (ow ? 4 : 3) * col, hipMemcpyDeviceToHost, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, col, hipMemcpyDeviceToHost, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(oy, doy, col, hipMemcpyDeviceToHost, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(oz, doz, col, hipMemcpyDeviceToHost, c->stream));
+      if (ow) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
+    }
   }
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the out-of-range verdict is part of the call's result
   if (st) { st->n_launches = 1; st->n_out_of_range = bad; }
@@ -1118,10 +1128,16 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
     double* base = (double*)c->d_tmp;
     double* cols[9];
     for (int i = 0; i < 9; ++i) cols[i] = base + (size_t)i * n;
-    KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, col, hipMemcpyHostToDevice, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(cols[1], y, col, hipMemcpyHostToDevice, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(cols[2], z, col, hipMemcpyHostToDevice, c->stream));
-    if (w) KMC_HIP_TRY(c, hipMemcpyAsync(cols[3], w, col, hipMemcpyHostToDevice, c->stream));
+    // an Eigen::MatrixX4d is ONE column-major block: x, y, z, w follow each other -> one copy instead of four (each
+    // pageable copy has a fixed cost of tens of microseconds, which is what a 123 k-point frame is made of)
+    if (y == x + n && z == y + n && (!w || w == z + n)) {
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, (w ? 4 : 3) * col, hipMemcpyHostToDevice, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[1], y, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[2], z, col, hipMemcpyHostToDevice, c->stream));
+      if (w) KMC_HIP_TRY(c, hipMemcpyAsync(cols[3], w, col, hipMemcpyHostToDevice, c->stream));
+    }
     KMC_HIP_TRY(c, hipMemcpyAsync(cols[4], stamps, col, hipMemcpyHostToDevice, c->stream));
     dx = cols[0]; dy = cols[1]; dz = cols[2]; dw = w ? cols[3] : nullptr; ds = cols[4];
     dox = cols[5]; doy = cols[6]; doz = cols[7]; dow = ow ? cols[8] : nullptr;
@@ -1141,10 +1157,14 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   unsigned long long bad = 0;
   KMC_HIP_TRY(c, hipMemcpyAsync(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
   if (mem_kind == KMC_MEM_HOST) {
-    KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, col, hipMemcpyDeviceToHost, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(oy, doy, col, hipMemcpyDeviceToHost, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(oz, doz, col, hipMemcpyDeviceToHost, c->stream));
-    if (ow) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
+    if (oy == ox + n && oz == oy + n && (!ow || ow == oz + n)) {  // one column-major block again
+      KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, (ow ? 4 : 3) * col, hipMemcpyDeviceToHost, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, col, hipMemcpyDeviceToHost, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(oy, doy, col, hipMemcpyDeviceToHost, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(oz, doz, col, hipMemcpyDeviceToHost, c->stream));
+      if (ow) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
+    }
     if (bracket_idx_out) KMC_HIP_TRY(c, hipMemcpyAsync(bracket_idx_out, d_idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   }
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
