@@ -893,12 +893,16 @@ int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, 
     int rc = ensure_tmp(c, 3 * col);
     if (rc != KMC_OK) return rc;
     double* base = (double*)c->d_tmp;
-    KMC_HIP_TRY(c, hipMemcpyAsync(base, x, col, hipMemcpyHostToDevice, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(base + n, y, col, hipMemcpyHostToDevice, c->stream));
+    if (y == x + n) {  // two adjacent columns of one Eigen matrix: one copy
+      KMC_HIP_TRY(c, hipMemcpyAsync(base, x, 2 * col, hipMemcpyHostToDevice, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(base, x, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(base + n, y, col, hipMemcpyHostToDevice, c->stream));
+    }
     dx = base; dy = base + n; dout = base + 2 * n;
   }
-  const int grid = grid_for(c, (n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(pseudo_timestamps_f64, dim3(grid), dim3(kBlock), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
+  const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
+  hipLaunchKernelGGL(pseudo_timestamps_f64, dim3(grid), dim3(64), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
   KMC_HIP_TRY(c, hipGetLastError());
   if (mem_kind == KMC_MEM_HOST) {
     KMC_HIP_TRY(c, hipMemcpyAsync(stamps_out, dout, col, hipMemcpyDeviceToHost, c->stream));
@@ -1287,9 +1291,13 @@ int kmc_hip_project_f64cols(kmc_ctx* c, const double* x, const double* y, const 
     int rc = ensure_tmp(c, cols_bytes + uv_bytes + col_bytes);
     if (rc != KMC_OK) return rc;
     double* base = (double*)c->d_tmp;
-    KMC_HIP_TRY(c, hipMemcpyAsync(base, x, col, hipMemcpyHostToDevice, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(base + n, y, col, hipMemcpyHostToDevice, c->stream));
-    KMC_HIP_TRY(c, hipMemcpyAsync(base + 2 * n, z, col, hipMemcpyHostToDevice, c->stream));
+    if (y == x + n && z == y + n) {  // three adjacent columns of one Eigen matrix: one copy
+      KMC_HIP_TRY(c, hipMemcpyAsync(base, x, 3 * col, hipMemcpyHostToDevice, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(base, x, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(base + n, y, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(base + 2 * n, z, col, hipMemcpyHostToDevice, c->stream));
+    }
     dx = base; dy = base + n; dz = base + 2 * n;
     d_uv = (v2i*)((char*)base + cols_bytes);
     d_col = (uint32_t*)((char*)base + cols_bytes + uv_bytes);

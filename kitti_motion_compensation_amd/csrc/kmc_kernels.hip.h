@@ -348,14 +348,26 @@ __global__ __launch_bounds__(64) void deskew_f64cols(const double* __restrict__ 
 }
 
 // GetPseudoTimeStamps (timestamp_mocking.cpp:46-63) in f64
-__global__ __launch_bounds__(kBlock) void pseudo_timestamps_f64(const double* __restrict__ x, const double* __restrict__ y,
-                                                               uint64_t n, double start, double end,
-                                                               double* __restrict__ stamps) {
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+// (one wave per workgroup, two consecutive points per lane, 16-byte column accesses -- see deskew_f64cols below)
+typedef double v2d_col __attribute__((ext_vector_type(2), aligned(8)));
+__global__ __launch_bounds__(64) void pseudo_timestamps_f64(const double* __restrict__ x, const double* __restrict__ y,
+                                                            uint64_t n, double start, double end,
+                                                            double* __restrict__ stamps) {
+  constexpr double kPi = 3.14159265358979323846;
   const double dur = end - start;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const double frac = (3.14159265358979323846 - atan2(y[i], x[i])) / (2.0 * 3.14159265358979323846);
-    stamps[i] = start + (frac * dur);
+  const uint64_t n_tiles = (n + 127) / 128;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t i = t * 128 + 2 * (uint64_t)threadIdx.x;
+    if (i + 1 < n) {
+      const v2d_col vx = __builtin_nontemporal_load(reinterpret_cast<const v2d_col*>(x + i));
+      const v2d_col vy = __builtin_nontemporal_load(reinterpret_cast<const v2d_col*>(y + i));
+      v2d_col o;
+      o.x = start + (((kPi - atan2(vy.x, vx.x)) / (2.0 * kPi)) * dur);
+      o.y = start + (((kPi - atan2(vy.y, vx.y)) / (2.0 * kPi)) * dur);
+      __builtin_nontemporal_store(o, reinterpret_cast<v2d_col*>(stamps + i));
+    } else if (i < n) {
+      stamps[i] = start + (((kPi - atan2(y[i], x[i])) / (2.0 * kPi)) * dur);
+    }
   }
 }
 
