@@ -1,0 +1,324 @@
+// kmc_capi_core.hip -- context life cycle, streams, timers, pinned allocations, the f64 host pre-step entry points and the
+// definitions of the helpers every other translation unit of libkmc_hip.so shares (kmc_internal.hip.h).
+#include "kmc_internal.hip.h"
+
+namespace kmc_impl {
+
+int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n) {
+  if (c->force_tier >= 0 && c->force_tier <= 2) return c->force_tier;
+  double theta_max = 0.0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const double* f = p[i].twist;
+    const double phi = std::sqrt(f[3] * f[3] + f[4] * f[4] + f[5] * f[5]);
+    const double smax = std::fmax(std::fabs(p[i].x_req), std::fabs(1.0 - p[i].x_req));  // frac in [0,1]
+    theta_max = std::fmax(theta_max, phi * smax);
+  }
+  if (!(theta_max <= 1.0)) return kTrig;  // also catches NaN
+  return theta_max <= 0.25 ? kSeries3 : kSeries5;
+}
+int ensure_tmp(kmc_ctx* c, size_t bytes) {
+  if (bytes <= c->tmp_cap) return KMC_OK;
+  if (c->d_tmp) {
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    KMC_HIP_TRY(c, hipFree(c->d_tmp));
+    c->d_tmp = nullptr;
+    c->tmp_cap = 0;
+  }
+  KMC_HIP_TRY(c, hipMalloc(&c->d_tmp, bytes));
+  c->tmp_cap = bytes;
+  return KMC_OK;
+}
+
+int ensure_pipeline(kmc_ctx* c) {
+  if (c->stage_cap) return KMC_OK;
+  const size_t bytes = kHostChunkPoints * sizeof(v4f);
+  for (int b = 0; b < 3; ++b) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe[b], hipStreamNonBlocking));
+  for (int b = 0; b < kmc_ctx::kPipeSlots; ++b) {
+    KMC_HIP_TRY(c, hipMalloc(&c->d_stage_in[b], bytes));
+    KMC_HIP_TRY(c, hipMalloc(&c->d_stage_out[b], bytes));
+    KMC_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming));
+    KMC_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_kernel[b], hipEventDisableTiming));
+    KMC_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_d2h[b], hipEventDisableTiming));
+  }
+  c->stage_cap = bytes;
+  return KMC_OK;
+}
+int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
+  const int slot_id = c->next_slot;
+  const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
+  c->next_slot = (c->next_slot + 1) % kmc_ctx::kTableSlots;
+  if (slot_id % kmc_ctx::kSlotsPerGroup == 0 && c->group_busy[group_id]) {
+    KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
+    c->group_busy[group_id] = false;
+  }
+  if (need > c->slots[slot_id].cap) {
+    // grow EVERY slot at once (so that steady state never allocates again); slots may still be referenced by kernels in
+    // flight: drain first
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    const size_t cap = std::max<size_t>(64 * 1024, need * 2);
+    for (auto& each : c->slots) {
+      if (each.cap >= cap) continue;
+      if (each.d_buf) (void)hipFree(each.d_buf);
+      if (each.h_buf) (void)hipHostFree(each.h_buf);
+      each.d_buf = nullptr; each.h_buf = nullptr; each.cap = 0;
+      KMC_HIP_TRY(c, hipMalloc((void**)&each.d_buf, cap));
+      KMC_HIP_TRY(c, hipHostMalloc((void**)&each.h_buf, cap, hipHostMallocDefault));
+      each.cap = cap;
+    }
+    for (auto& busy : c->group_busy) busy = false;
+  }
+  *slot_id_out = slot_id;
+  return KMC_OK;
+}
+
+int slot_upload(kmc_ctx* c, int slot_id, size_t bytes) {
+  kmc_ctx::TableSlot& sl = c->slots[slot_id];
+  KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  KMC_HIP_TRY(c, hipEventRecord(sl.uploaded, c->copy_stream));
+  KMC_HIP_TRY(c, hipEventSynchronize(sl.uploaded));
+  return KMC_OK;
+}
+
+int slot_end(kmc_ctx* c, int slot_id) {
+  if (slot_id % kmc_ctx::kSlotsPerGroup == kmc_ctx::kSlotsPerGroup - 1) {
+    const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
+    KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
+    c->group_busy[group_id] = true;
+  }
+  return KMC_OK;
+}
+// coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point.
+// All positions are VIRTUAL: `head` dead points precede the batch (frame 0 owns them), n_virtual = n + head.
+void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n_virtual, uint32_t head, uint2* h_coarse) {
+  const uint64_t chunk = 1ull << kChunkShift;
+  const uint64_t n_chunks = (n_virtual + chunk - 1) / chunk;
+  auto end_of = [&](uint32_t f) { return offsets[f + 1] + head; };  // virtual end offset of frame f
+  uint32_t f = 0;
+  for (uint64_t ci = 0; ci < n_chunks; ++ci) {
+    const uint64_t first = ci * chunk;
+    const uint64_t chunk_end = std::min<uint64_t>(first + chunk, n_virtual);
+    while (f + 1 < n_frames && end_of(f) <= first) ++f;
+    uint32_t split = kSplitNone;
+    const uint64_t e = end_of(f);
+    if (e < chunk_end) {  // frame f ends inside this chunk
+      // a second boundary inside the chunk (frame f+1 ends here too, e.g. it is tiny or empty) -> search on the device
+      const bool second = (f + 1 < n_frames) && end_of(f + 1) < chunk_end;
+      split = second ? kSplitSearch : (uint32_t)(e - first);
+    }
+    h_coarse[ci] = make_uint2(f, split);
+  }
+  while (f + 1 < n_frames && end_of(f) <= n_virtual - 1) ++f;
+  h_coarse[n_chunks] = make_uint2(f, kSplitNone);
+}
+}  // namespace kmc_impl
+
+extern "C" {
+
+int kmc_abi_version(void) { return KMC_ABI_VERSION; }
+
+const char* kmc_status_string(int status) {
+  switch (status) {
+    case KMC_OK: return "KMC_OK";
+    case KMC_ERR_INVALID_ARG: return "KMC_ERR_INVALID_ARG";
+    case KMC_ERR_HIP: return "KMC_ERR_HIP";
+    case KMC_ERR_NO_DEVICE: return "KMC_ERR_NO_DEVICE: no usable HIP device (the deskew path has no CPU fallback)";
+    case KMC_ERR_TIME_OUT_OF_RANGE: return "KMC_ERR_TIME_OUT_OF_RANGE: a time outside [stamp_start, stamp_end] (the reference asserts)";
+    case KMC_ERR_ALLOC: return "KMC_ERR_ALLOC";
+    case KMC_ERR_DEGENERATE: return "KMC_ERR_DEGENERATE";
+    default: return "KMC_ERR_UNKNOWN";
+  }
+}
+
+int kmc_hip_create(kmc_ctx** out, int device_id) {
+  if (!out) return KMC_ERR_INVALID_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    return KMC_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= count) return KMC_ERR_INVALID_ARG;
+  kmc_ctx* c = new (std::nothrow) kmc_ctx();
+  if (!c) return KMC_ERR_ALLOC;
+  c->device = device_id;
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  hipEvent_t* evs[] = {&c->ev_k0, &c->ev_k1, &c->ev_c0, &c->ev_c1, &c->ev_t0, &c->ev_t1};
+  for (hipEvent_t* ev : evs)
+    if (e == hipSuccess) e = hipEventCreate(ev);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  for (auto& sl : c->slots)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming);
+  for (auto& ev : c->group_consumed)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    kmc_hip_destroy(c);
+    return KMC_ERR_NO_DEVICE;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return KMC_OK;
+}
+
+void kmc_hip_destroy(kmc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (int b = 0; b < 3; ++b)
+    if (c->pipe[b]) { (void)hipStreamSynchronize(c->pipe[b]); (void)hipStreamDestroy(c->pipe[b]); }
+  for (int b = 0; b < kmc_ctx::kPipeSlots; ++b) {
+    if (c->d_stage_in[b]) (void)hipFree(c->d_stage_in[b]);
+    if (c->d_stage_out[b]) (void)hipFree(c->d_stage_out[b]);
+    if (c->ev_h2d[b]) (void)hipEventDestroy(c->ev_h2d[b]);
+    if (c->ev_kernel[b]) (void)hipEventDestroy(c->ev_kernel[b]);
+    if (c->ev_d2h[b]) (void)hipEventDestroy(c->ev_d2h[b]);
+  }
+  if (c->d_tmp) (void)hipFree(c->d_tmp);
+  if (c->d_traj) (void)hipFree(c->d_traj);
+  if (c->h_traj) (void)hipHostFree(c->h_traj);
+  if (c->ev_traj) (void)hipEventDestroy(c->ev_traj);
+  for (auto& sl : c->slots) {
+    if (sl.d_buf) (void)hipFree(sl.d_buf);
+    if (sl.h_buf) (void)hipHostFree(sl.h_buf);
+    if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+  }
+  for (auto& ev : c->group_consumed)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->d_counter) (void)hipFree(c->d_counter);
+  hipEvent_t evs[] = {c->ev_k0, c->ev_k1, c->ev_c0, c->ev_c1, c->ev_t0, c->ev_t1};
+  for (hipEvent_t ev : evs)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int kmc_hip_set_stream(kmc_ctx* c, void* hip_stream) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  c->stream = (hipStream_t)hip_stream;  // literally: NULL is HIP's legacy default stream
+  return KMC_OK;
+}
+
+int kmc_hip_use_own_stream(kmc_ctx* c) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  c->stream = c->own_stream;
+  return KMC_OK;
+}
+
+int kmc_hip_synchronize(kmc_ctx* c) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return KMC_OK;
+}
+
+int kmc_hip_enable_timing(kmc_ctx* c, int enabled) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  c->timing = enabled != 0;
+  return KMC_OK;
+}
+
+const char* kmc_hip_last_error(kmc_ctx* c) { return c ? c->last_error.c_str() : "null ctx"; }
+
+int kmc_hip_device_info(kmc_ctx* c, kmc_device_info* out) {
+  if (!c || !out) return KMC_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  std::snprintf(out->name, sizeof(out->name), "%s", c->prop.name);
+  std::snprintf(out->arch, sizeof(out->arch), "%s", c->prop.gcnArchName);
+  out->device_id = c->device;
+  out->compute_units = c->prop.multiProcessorCount;
+  out->wavefront_size = c->prop.warpSize;
+  out->hbm_bytes = c->prop.totalGlobalMem;
+  out->clock_khz = c->prop.clockRate;
+  return KMC_OK;
+}
+
+int kmc_hip_set_launch_config(kmc_ctx* c, int blocks_per_cu, int points_per_thread) {
+  if (!c || blocks_per_cu < 0 || blocks_per_cu > 64) return KMC_ERR_INVALID_ARG;
+  if (!(points_per_thread == 0 || points_per_thread == 1 || points_per_thread == 2 || points_per_thread == 4 ||
+        points_per_thread == 8))
+    return KMC_ERR_INVALID_ARG;
+  c->blocks_per_cu = blocks_per_cu;
+  c->ppt = points_per_thread;
+  return KMC_OK;
+}
+
+int kmc_hip_force_tier(kmc_ctx* c, int tier) {
+  if (!c || tier < -1 || tier > 2) return KMC_ERR_INVALID_ARG;
+  c->force_tier = tier;
+  return KMC_OK;
+}
+
+int kmc_hip_timer_begin(kmc_ctx* c) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipEventRecord(c->ev_t0, c->stream));
+  return KMC_OK;
+}
+
+int kmc_hip_timer_end(kmc_ctx* c, float* elapsed_ms) {
+  if (!c || !elapsed_ms) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipEventRecord(c->ev_t1, c->stream));
+  KMC_HIP_TRY(c, hipEventSynchronize(c->ev_t1));
+  KMC_HIP_TRY(c, hipEventElapsedTime(elapsed_ms, c->ev_t0, c->ev_t1));
+  return KMC_OK;
+}
+
+int kmc_hip_host_alloc(kmc_ctx* c, size_t bytes, void** out) {
+  if (!c || !out) return KMC_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (bytes == 0) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_HIP_TRY(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return KMC_OK;
+}
+
+int kmc_hip_host_free(kmc_ctx* c, void* ptr) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  if (ptr) KMC_HIP_TRY(c, hipHostFree(ptr));
+  return KMC_OK;
+}
+
+// ---- host pre-step -------------------------------------------------------------------------------
+int kmc_frame_params_from_poses(const double T_start[12], const double T_end[12], double stamp_start, double stamp_end,
+                                double requested_time, kmc_frame_params* out) {
+  if (!T_start || !T_end || !out) return KMC_ERR_INVALID_ARG;
+  if (!(stamp_start < stamp_end)) return KMC_ERR_DEGENERATE;
+  // TimeIsInRange(requested_time): the reference asserts on it for every point (trajectory_interpolation.cpp:32)
+  if (!(requested_time >= stamp_start && requested_time <= stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  kmc_host::Twist f;
+  if (!kmc_host::relative_twist(kmc_host::Pose::from_rt12(T_start), kmc_host::Pose::from_rt12(T_end), &f)) return KMC_ERR_DEGENERATE;
+  out->twist[0] = f.rho.x; out->twist[1] = f.rho.y; out->twist[2] = f.rho.z;
+  out->twist[3] = f.phi.x; out->twist[4] = f.phi.y; out->twist[5] = f.phi.z;
+  out->x_req = (requested_time - stamp_start) / (stamp_end - stamp_start);
+  return params_ok(out) ? KMC_OK : KMC_ERR_DEGENERATE;
+}
+
+int kmc_oxts_to_pose(const kmc_oxts* o, double scale, double T_out[12]) {
+  if (!o || !T_out) return KMC_ERR_INVALID_ARG;
+  kmc_host::oxts_to_pose(o->lat, o->lon, o->alt, o->roll, o->pitch, o->yaw, scale).to_rt12(T_out);
+  return KMC_OK;
+}
+
+int kmc_interpolate_trajectory(const kmc_oxts* o1, const kmc_oxts* o2, double time, double T_out[12]) {
+  if (!o1 || !o2 || !T_out) return KMC_ERR_INVALID_ARG;
+  const kmc_host::Pose P1 = kmc_host::oxts_to_pose(o1->lat, o1->lon, o1->alt, o1->roll, o1->pitch, o1->yaw, 1.0);
+  const kmc_host::Pose P2 = kmc_host::oxts_to_pose(o2->lat, o2->lon, o2->alt, o2->roll, o2->pitch, o2->yaw, 1.0);
+  kmc_host::Pose P;
+  const int rc = kmc_host::pose_at_time(o1->stamp, P1, o2->stamp, P2, time, &P);
+  if (rc == -1) return KMC_ERR_TIME_OUT_OF_RANGE;
+  if (rc != 0) return KMC_ERR_DEGENERATE;
+  P.to_rt12(T_out);
+  return KMC_OK;
+}
+
+int kmc_make_frame_poses(const kmc_oxts* o_nm1, const kmc_oxts* o_n, const kmc_oxts* o_np1, double stamp_start,
+                         double stamp_end, double T_start_out[12], double T_end_out[12]) {
+  int rc = kmc_interpolate_trajectory(o_nm1, o_n, stamp_start, T_start_out);
+  if (rc != KMC_OK) return rc;
+  return kmc_interpolate_trajectory(o_n, o_np1, stamp_end, T_end_out);
+}
+}  // extern "C"

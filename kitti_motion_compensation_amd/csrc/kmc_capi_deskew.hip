@@ -1,0 +1,319 @@
+// kmc_capi_deskew.hip -- the hot path's entry points: single frame and batch of frames in the KITTI f32 layout, the f64
+// Eigen-layout route of MotionCompensateFrame(Frame const&, Time), GetPseudoTimeStamps.  Thin on purpose: argument checks,
+// f64 -> device-precision frame records, launch geometry, optional host staging; all per-point work is in kmc_kernels.hip.h.
+#include "kmc_internal.hip.h"
+
+namespace {
+
+// ---- template dispatch ---------------------------------------------------------------------------
+template <int TIER, int PPT>
+void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head) {
+  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head);
+}
+template <int TIER>
+void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head) {
+  switch (ppt) {
+    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head); break;
+    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head); break;
+    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head); break;
+    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head); break;
+  }
+}
+// in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of()
+void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head = 0) {
+  const int ppt = ppt_of(c);
+  in -= head;
+  out -= head;
+  n += head;
+  const uint64_t n_tiles = (n + (uint64_t)kLaunchBlock * ppt - 1) / ((uint64_t)kLaunchBlock * ppt);
+  const int grid = grid_for(c, n_tiles);
+  switch (tier) {
+    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head); break;
+    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head); break;
+    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head); break;
+  }
+}
+
+template <int TIER, int PPT>
+void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
+                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head) {
+  if (idx)
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head);
+  else
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head);
+}
+template <int TIER>
+void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
+                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head) {
+  switch (ppt) {
+    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
+    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
+    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
+    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+// ---- hot path: single frame, f32 -----------------------------------------------------------------
+int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params,
+                       int mem_kind, kmc_stats* st) {
+  if (!c || !params || (n && (!xyzi_in || !xyzi_out))) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
+  if (!params_ok(params)) return KMC_ERR_INVALID_ARG;
+  if (!(params->x_req >= 0.0 && params->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  if (st) std::memset(st, 0, sizeof(*st));
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const int tier = pick_tier(c, params, 1);
+  FrameRec f;
+  std::memset(&f, 0, sizeof(f));
+  fill_rec(*params, &f);
+  if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
+  if (n == 0) return KMC_OK;
+  CallTimer tm(c);
+  if (mem_kind == KMC_MEM_DEVICE) {
+    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    launch_frame(c, c->stream, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, head_of(xyzi_out, mem_kind));
+    KMC_HIP_TRY(c, hipGetLastError());
+    if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    if (st) st->n_launches = 1;
+    return tm.end_call(st);
+  }
+  // KMC_MEM_HOST: upload / compute / download on three streams over a ring of device slots, so that the H2D of chunk
+  // k+1, the kernel of chunk k and the D2H of chunk k-1 run concurrently (PCIe is full duplex; DESIGN.md "host buffers")
+  int rc = ensure_pipeline(c);
+  if (rc != KMC_OK) return rc;
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  uint32_t launches = 0;
+  for (uint64_t off = 0, k = 0; off < n; off += kHostChunkPoints, ++k) {
+    const int b = (int)(k % kmc_ctx::kPipeSlots);
+    const bool reused = k >= (uint64_t)kmc_ctx::kPipeSlots;
+    const uint64_t m = std::min<uint64_t>(kHostChunkPoints, n - off);
+    if (reused) KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[0], c->ev_kernel[b], 0));  // the slot's input was consumed
+    KMC_HIP_TRY(c, hipMemcpyAsync(c->d_stage_in[b], xyzi_in + 4 * off, m * sizeof(v4f), hipMemcpyHostToDevice, c->pipe[0]));
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_h2d[b], c->pipe[0]));
+    KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[1], c->ev_h2d[b], 0));
+    if (reused) KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[1], c->ev_d2h[b], 0));     // the slot's output was downloaded
+    launch_frame(c, c->pipe[1], tier, (const v4f*)c->d_stage_in[b], (v4f*)c->d_stage_out[b], m, f);
+    KMC_HIP_TRY(c, hipGetLastError());
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_kernel[b], c->pipe[1]));
+    KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[2], c->ev_kernel[b], 0));
+    KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out + 4 * off, c->d_stage_out[b], m * sizeof(v4f), hipMemcpyDeviceToHost, c->pipe[2]));
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_d2h[b], c->pipe[2]));
+    ++launches;
+  }
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[2]));
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[1]));
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->pipe[0]));
+  if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (st) st->n_launches = launches;
+  return tm.end_call(st);
+}
+
+// ---- hot path: batch of frames, f32 ---------------------------------------------------------------
+int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets, uint32_t n_frames,
+                             const kmc_frame_params* params, uint32_t* frame_idx_out, int mem_kind, kmc_stats* st) {
+  if (!c || !offsets || (n_frames && !params)) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (st) std::memset(st, 0, sizeof(*st));
+  if (offsets[0] != 0) return KMC_ERR_INVALID_ARG;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (offsets[f + 1] < offsets[f]) return KMC_ERR_INVALID_ARG;
+    if (!params_ok(&params[f])) return KMC_ERR_INVALID_ARG;
+    if (!(params[f].x_req >= 0.0 && params[f].x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  }
+  const uint64_t n = n_frames ? offsets[n_frames] : 0;
+  if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const int tier = pick_tier(c, params, n_frames);
+  if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
+  if (n == 0) return KMC_OK;
+
+  const int ppt = ppt_of(c);
+  const uint32_t head = head_of(xyzi_out, mem_kind);  // dead points in front: tiles are cut on 1 KiB lines of the output
+  const uint64_t nv = n + head;                       // virtual size; every offset below is shifted by `head` too
+  const uint64_t tile = (uint64_t)kLaunchBlock * ppt;
+  const uint64_t n_tiles = (nv + tile - 1) / tile;
+  const uint64_t chunk = 1ull << kChunkShift;
+  const uint64_t n_chunks = (nv + chunk - 1) / chunk;
+  const uint64_t n_coarse = n_chunks + 1;
+
+  const size_t recs_bytes = ((size_t)n_frames * sizeof(BatchRec) + 255) & ~(size_t)255;
+  const size_t need = recs_bytes + (size_t)n_coarse * sizeof(uint2);
+  int slot_id = 0;
+  {
+    const int rc_slot = slot_begin(c, need, &slot_id);
+    if (rc_slot != KMC_OK) return rc_slot;
+  }
+  kmc_ctx::TableSlot& sl = c->slots[slot_id];
+  BatchRec* h_recs = reinterpret_cast<BatchRec*>(sl.h_buf);
+  uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + recs_bytes);
+  const BatchRec* d_recs = reinterpret_cast<const BatchRec*>(sl.d_buf);
+  const uint2* d_coarse = reinterpret_cast<const uint2*>(sl.d_buf + recs_bytes);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    BatchRec* r = &h_recs[f];
+    fill_rec(params[f], r);
+    r->end_lo = (uint32_t)((offsets[f + 1] + head) & 0xFFFFFFFFull);
+    r->end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
+  }
+  build_coarse(offsets, n_frames, nv, head, h_coarse);
+  // one table upload on the side stream (overlaps whatever the compute stream is still running), awaited on the host
+  {
+    const int rc_up = slot_upload(c, slot_id, need);
+    if (rc_up != KMC_OK) return rc_up;
+  }
+
+  CallTimer tm(c);
+  const v4f* d_in = (const v4f*)xyzi_in;
+  v4f* d_out = (v4f*)xyzi_out;
+  uint32_t* d_idx = frame_idx_out;
+  if (mem_kind == KMC_MEM_HOST) {
+    const size_t pts = n * sizeof(v4f);
+    const size_t idx_bytes = frame_idx_out ? n * sizeof(uint32_t) : 0;
+    int rc = ensure_tmp(c, 2 * pts + idx_bytes);
+    if (rc != KMC_OK) return rc;
+    d_in = (const v4f*)c->d_tmp;
+    d_out = (v4f*)((char*)c->d_tmp + pts);
+    d_idx = frame_idx_out ? (uint32_t*)((char*)c->d_tmp + 2 * pts) : nullptr;
+  }
+  if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (mem_kind == KMC_MEM_HOST)
+    KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, n * sizeof(v4f), hipMemcpyHostToDevice, c->stream));
+  if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  const int grid = grid_for(c, n_tiles);
+  uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
+  switch (tier) {
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
+  }
+  KMC_HIP_TRY(c, hipGetLastError());
+  {
+    const int rc_end = slot_end(c, slot_id);
+    if (rc_end != KMC_OK) return rc_end;
+  }
+  if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (mem_kind == KMC_MEM_HOST) {
+    KMC_HIP_TRY(c, hipMemcpyAsync(xyzi_out, d_out, n * sizeof(v4f), hipMemcpyDeviceToHost, c->stream));
+    if (frame_idx_out) KMC_HIP_TRY(c, hipMemcpyAsync(frame_idx_out, d_idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (st) st->n_launches = 1;
+  return tm.end_call(st);
+}
+
+// ---- f64 Eigen-layout path ------------------------------------------------------------------------
+int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
+                           uint64_t n, double stamp_start, double stamp_end, const kmc_frame_params* params, double* ox,
+                           double* oy, double* oz, double* ow, int mem_kind, kmc_stats* st) {
+  if (!c || !params) return KMC_ERR_INVALID_ARG;
+  if (n && (!x || !y || !z || !stamps || !ox || !oy || !oz)) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (!(stamp_start < stamp_end)) return KMC_ERR_DEGENERATE;
+  if (!params_ok(params)) return KMC_ERR_INVALID_ARG;
+  if (!(params->x_req >= 0.0 && params->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  if (st) std::memset(st, 0, sizeof(*st));
+  if (st) { st->n_points = n; st->variant = 3; }
+  if (n == 0) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+
+  FrameRec64 f;
+  const kmc_host::Vec3 rho = {params->twist[0], params->twist[1], params->twist[2]};
+  const kmc_host::Vec3 phi = {params->twist[3], params->twist[4], params->twist[5]};
+  const kmc_host::Vec3 c1 = kmc_host::cross(phi, rho);
+  const kmc_host::Vec3 c2 = kmc_host::cross(phi, c1);
+  f.phi[0] = phi.x; f.phi[1] = phi.y; f.phi[2] = phi.z;
+  f.rho[0] = rho.x; f.rho[1] = rho.y; f.rho[2] = rho.z;
+  f.c1[0] = c1.x; f.c1[1] = c1.y; f.c1[2] = c1.z;
+  f.c2[0] = c2.x; f.c2[1] = c2.y; f.c2[2] = c2.z;
+  f.phi2 = kmc_host::dot(phi, phi);
+  f.x_req = params->x_req;
+  f.t_start = stamp_start;
+  f.t_end = stamp_end;
+  f.dur = stamp_end - stamp_start;
+
+  const double *dx = x, *dy = y, *dz = z, *dw = w, *ds = stamps;
+  double *dox = ox, *doy = oy, *doz = oz, *dow = ow;
+  const size_t col = n * sizeof(double);
+  if (mem_kind == KMC_MEM_HOST) {
+    int rc = ensure_tmp(c, 9 * col);
+    if (rc != KMC_OK) return rc;
+    double* base = (double*)c->d_tmp;
+    double* cols[9];
+    for (int i = 0; i < 9; ++i) cols[i] = base + (size_t)i * n;
+    // an Eigen::MatrixX4d is ONE column-major block: x, y, z, w follow each other -> one copy instead of four (each
+    // pageable copy has a fixed cost of tens of microseconds, which is what a 123 k-point frame is made of)
+    if (y == x + n && z == y + n && (!w || w == z + n)) {
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, (w ? 4 : 3) * col, hipMemcpyHostToDevice, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[1], y, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[2], z, col, hipMemcpyHostToDevice, c->stream));
+      if (w) KMC_HIP_TRY(c, hipMemcpyAsync(cols[3], w, col, hipMemcpyHostToDevice, c->stream));
+    }
+    KMC_HIP_TRY(c, hipMemcpyAsync(cols[4], stamps, col, hipMemcpyHostToDevice, c->stream));
+    dx = cols[0]; dy = cols[1]; dz = cols[2]; dw = w ? cols[3] : nullptr; ds = cols[4];
+    dox = cols[5]; doy = cols[6]; doz = cols[7]; dow = ow ? cols[8] : nullptr;
+  }
+  CallTimer tm(c);
+  if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+  if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
+  hipLaunchKernelGGL(deskew_f64cols<0>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter);
+  KMC_HIP_TRY(c, hipGetLastError());
+  if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  unsigned long long bad = 0;
+  KMC_HIP_TRY(c, hipMemcpyAsync(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+  if (mem_kind == KMC_MEM_HOST) {
+    if (oy == ox + n && oz == oy + n && (!ow || ow == oz + n)) {  // one column-major block again
+      KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, (ow ? 4 : 3) * col, hipMemcpyDeviceToHost, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, col, hipMemcpyDeviceToHost, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(oy, doy, col, hipMemcpyDeviceToHost, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(oz, doz, col, hipMemcpyDeviceToHost, c->stream));
+      if (ow) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the out-of-range verdict is part of the call's result
+  if (st) { st->n_launches = 1; st->n_out_of_range = bad; }
+  int rc = tm.end_call(st);
+  if (rc != KMC_OK) return rc;
+  return bad ? KMC_ERR_TIME_OUT_OF_RANGE : KMC_OK;
+}
+
+int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, uint64_t n, double scan_start, double scan_end,
+                                  double* stamps_out, int mem_kind) {
+  if (!c || (n && (!x || !y || !stamps_out))) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (n == 0) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const size_t col = n * sizeof(double);
+  const double *dx = x, *dy = y;
+  double* dout = stamps_out;
+  if (mem_kind == KMC_MEM_HOST) {
+    int rc = ensure_tmp(c, 3 * col);
+    if (rc != KMC_OK) return rc;
+    double* base = (double*)c->d_tmp;
+    if (y == x + n) {  // two adjacent columns of one Eigen matrix: one copy
+      KMC_HIP_TRY(c, hipMemcpyAsync(base, x, 2 * col, hipMemcpyHostToDevice, c->stream));
+    } else {
+      KMC_HIP_TRY(c, hipMemcpyAsync(base, x, col, hipMemcpyHostToDevice, c->stream));
+      KMC_HIP_TRY(c, hipMemcpyAsync(base + n, y, col, hipMemcpyHostToDevice, c->stream));
+    }
+    dx = base; dy = base + n; dout = base + 2 * n;
+  }
+  const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
+  hipLaunchKernelGGL(pseudo_timestamps_f64<0>, dim3(grid), dim3(64), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
+  KMC_HIP_TRY(c, hipGetLastError());
+  if (mem_kind == KMC_MEM_HOST) {
+    KMC_HIP_TRY(c, hipMemcpyAsync(stamps_out, dout, col, hipMemcpyDeviceToHost, c->stream));
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return KMC_OK;
+}
+}  // extern "C"

@@ -1,0 +1,177 @@
+// kmc_internal.hip.h -- shared by the translation units that implement the C-ABI of include/kmc_hip.h (library-internal):
+// the context, error plumbing, launch geometry, the table-slot ring and the call timer.
+//   kmc_capi_core.hip     context life cycle, streams, timers, host pre-step entry points, the shared helpers' definitions
+//   kmc_capi_deskew.hip   single-frame, batched and f64 Eigen-layout deskew, pseudo time stamps
+//   kmc_capi_traj.hip     N-knot trajectory entry points and their f64 host pre-step
+//   kmc_capi_project.hip  LiDAR -> image projection (row N4)
+//   kmc_capi_synth.hip    synthetic workload generator
+// There is no CPU fallback anywhere: every hot-path entry point needs a live kmc_ctx, and kmc_hip_create() fails without a
+// HIP device.
+#pragma once
+
+#include "../../include/kmc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kmc_host_math.hpp"
+#include "kmc_kernels.hip.h"
+
+using namespace kmc_dev;
+
+struct kmc_ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  bool timing = false;
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  std::string last_error;
+  hipDeviceProp_t prop;
+  int blocks_per_cu = 0;  // 0 = default
+  int ppt = 0;            // 0 = default
+  int force_tier = -1;
+  // out-of-range counter (f64 path)
+  unsigned long long* d_counter = nullptr;
+  // batch tables: a ring of slots, each one device buffer + one pinned staging buffer holding
+  // [BatchRec x n_frames | coarse x (n_chunks + 1)], uploaded with ONE copy on a side stream so that the per-step host
+  // preparation and the table H2D overlap the previous step's kernel.  The compute stream sees no event between two
+  // launches except one "consumed" marker per group of kSlotsPerGroup launches (a marker between kernels costs ~3 us).
+  struct TableSlot {
+    char* d_buf = nullptr;
+    char* h_buf = nullptr;
+    size_t cap = 0;
+    hipEvent_t uploaded = nullptr;  // tables are on the device (copy stream)
+  };
+  static constexpr int kSlotsPerGroup = 4;
+  static constexpr int kSlotGroups = 4;
+  static constexpr int kTableSlots = kSlotsPerGroup * kSlotGroups;
+  TableSlot slots[kTableSlots];
+  hipEvent_t group_consumed[kSlotGroups] = {nullptr, nullptr, nullptr, nullptr};  // kernels of the group finished
+  bool group_busy[kSlotGroups] = {false, false, false, false};
+  int next_slot = 0;
+  hipStream_t copy_stream = nullptr;
+  // host-staging buffers
+  // host-buffer pipeline: dedicated upload / compute / download streams over a ring of device slots
+  static constexpr int kPipeSlots = 4;
+  hipStream_t pipe[3] = {nullptr, nullptr, nullptr};  // [0] H2D, [1] kernels, [2] D2H
+  void* d_stage_in[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  void* d_stage_out[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_h2d[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_kernel[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_d2h[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stage_cap = 0;  // bytes per buffer
+  void* d_traj = nullptr; // segment tables of the N-knot trajectory kernels (16 x TrajSeg32 + 16 x TrajSeg64)
+  void* h_traj = nullptr; // pinned staging of the same size
+  hipEvent_t ev_traj = nullptr;  // last upload from h_traj has completed
+  bool traj_in_flight = false;
+  void* d_tmp = nullptr; // grow-only scratch for the f64 / batch host paths
+  size_t tmp_cap = 0;
+};
+
+namespace kmc_impl {
+
+// measured best on MI355X (profiles/r01_tune.csv): one wave per workgroup, one point per lane, one tile per workgroup
+constexpr int kLaunchBlock = 64;
+constexpr int kDefaultPpt = 1;
+constexpr uint64_t kHostChunkPoints = 1ull << 21;  // 32 MiB per direction per pipeline slot
+
+inline int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
+  if (c) {
+    c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+  }
+  (void)hipGetLastError();
+  return KMC_ERR_HIP;
+}
+
+#define KMC_HIP_TRY(ctx, expr)                        \
+  do {                                                \
+    hipError_t _e = (expr);                           \
+    if (_e != hipSuccess) return fail_hip(ctx, _e, #expr); \
+  } while (0)
+
+int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n);
+
+template <typename REC>
+void fill_rec(const kmc_frame_params& p, REC* r) {
+  const kmc_host::Vec3 rho = {p.twist[0], p.twist[1], p.twist[2]};
+  const kmc_host::Vec3 phi = {p.twist[3], p.twist[4], p.twist[5]};
+  const kmc_host::Vec3 c1 = kmc_host::cross(phi, rho);
+  const kmc_host::Vec3 c2 = kmc_host::cross(phi, c1);
+  r->phi_x = (float)phi.x; r->phi_y = (float)phi.y; r->phi_z = (float)phi.z;
+  r->phi2 = (float)kmc_host::dot(phi, phi);
+  r->rho_x = (float)rho.x; r->rho_y = (float)rho.y; r->rho_z = (float)rho.z;
+  r->s0 = (float)(0.5 - p.x_req);
+  r->c1_x = (float)c1.x; r->c1_y = (float)c1.y; r->c1_z = (float)c1.z;
+  r->c2_x = (float)c2.x; r->c2_y = (float)c2.y; r->c2_z = (float)c2.z;
+}
+
+// Device-resident buffers: distance (in points, < 64) from the last 1 KiB boundary to the start of the OUTPUT.  The kernels are
+// launched on pointers moved back by that much with the first `head` indices dead, so that every tile stores whole aligned
+// lines whatever 16-byte-aligned address the caller passes ("alignment").
+inline uint32_t head_of(const void* out, int mem_kind) {
+  return mem_kind == KMC_MEM_DEVICE ? (uint32_t)(((uintptr_t)out >> 4) & 63u) : 0u;
+}
+
+inline bool params_ok(const kmc_frame_params* p) {
+  for (int i = 0; i < 6; ++i)
+    if (!std::isfinite(p->twist[i])) return false;
+  return std::isfinite(p->x_req);
+}
+
+inline int grid_for(const kmc_ctx* c, uint64_t n_tiles) {
+  // default: one tile per workgroup -- the hardware dispatcher streaming 64-point tiles beats a persistent grid-stride loop
+  // (6.8 vs 5.2-5.8 TB/s, profiles/r01_tune.csv); blocks_per_cu > 0 caps the grid instead (in units of 256 threads per CU).
+  const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu * (kBlock / kLaunchBlock) : 0x7fffffffull;
+  return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, cap));
+}
+
+inline int ppt_of(const kmc_ctx* c) {
+  const int p = c->ppt > 0 ? c->ppt : kDefaultPpt;
+  return (p == 1 || p == 2 || p == 4 || p == 8) ? p : kDefaultPpt;
+}
+
+int ensure_tmp(kmc_ctx* c, size_t bytes);  // grow-only device scratch of the host-buffer paths
+int ensure_pipeline(kmc_ctx* c);           // streams, events and device slots of the three-stage host pipeline
+
+// ---- ring of table slots (batch tables and trajectory segment tables) ---------------------------------------------------
+// slot_begin : picks the next slot, waits (host) until the kernels of its group from the previous lap are done, grows every
+//              slot if `need` bytes do not fit;
+// slot_upload: one H2D copy of the slot's pinned staging on the side stream, then a HOST wait for that tiny copy -- the
+//              launch that follows has no cross-stream dependency, so back-to-back launches keep the ~2 us same-stream boundary;
+// slot_end   : after the launch; records one "consumed" marker per group of launches on the compute stream.
+int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out);
+int slot_upload(kmc_ctx* c, int slot_id, size_t bytes);
+int slot_end(kmc_ctx* c, int slot_id);
+
+struct CallTimer {
+  kmc_ctx* c;
+  explicit CallTimer(kmc_ctx* ctx) : c(ctx) {}
+  int begin_call() { return c->timing ? (hipEventRecord(c->ev_c0, c->stream) == hipSuccess ? KMC_OK : KMC_ERR_HIP) : KMC_OK; }
+  int begin_kernel() { return c->timing ? (hipEventRecord(c->ev_k0, c->stream) == hipSuccess ? KMC_OK : KMC_ERR_HIP) : KMC_OK; }
+  int end_kernel() { return c->timing ? (hipEventRecord(c->ev_k1, c->stream) == hipSuccess ? KMC_OK : KMC_ERR_HIP) : KMC_OK; }
+  int end_call(kmc_stats* st) {
+    if (!c->timing) return KMC_OK;
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_c1, c->stream));
+    KMC_HIP_TRY(c, hipEventSynchronize(c->ev_c1));
+    if (st) {
+      KMC_HIP_TRY(c, hipEventElapsedTime(&st->kernel_ms, c->ev_k0, c->ev_k1));
+      KMC_HIP_TRY(c, hipEventElapsedTime(&st->total_ms, c->ev_c0, c->ev_c1));
+    }
+    return KMC_OK;
+  }
+};
+
+// coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point.
+// All positions are VIRTUAL: `head` dead points precede the batch (frame 0 owns them), n_virtual = n + head.
+void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n_virtual, uint32_t head, uint2* h_coarse);
+
+}  // namespace kmc_impl
+
+using namespace kmc_impl;

@@ -295,6 +295,7 @@ __device__ __forceinline__ void deskew_one_f64(double px, double py, double pz, 
   }
 }
 
+template <int kInstance = 0>  // a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(64) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                      const double* __restrict__ z, const double* __restrict__ w,
                                                      const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(64) void deskew_f64cols(const double* __restrict__ 
 // GetPseudoTimeStamps (timestamp_mocking.cpp:46-63) in f64
 // (one wave per workgroup, two consecutive points per lane, 16-byte column accesses -- see deskew_f64cols below)
 typedef double v2d_col __attribute__((ext_vector_type(2), aligned(8)));
+template <int kInstance = 0>  // a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(64) void pseudo_timestamps_f64(const double* __restrict__ x, const double* __restrict__ y,
                                                             uint64_t n, double start, double end,
                                                             double* __restrict__ stamps) {
@@ -581,6 +583,7 @@ __device__ __forceinline__ void traj_one_f64(double px, double py, double pz, do
 }
 
 // same geometry as deskew_f64cols: one wave per workgroup, two consecutive points per lane, 16-byte column accesses
+template <int kInstance = 0>  // a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(64) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, const double* __restrict__ w,
                                                           const double* __restrict__ stamps, uint64_t n,
@@ -641,6 +644,7 @@ __global__ __launch_bounds__(64) void deskew_traj_f64cols(const double* __restri
 // ------------------------------------------------------------------------------------------------
 // synthetic generator + a plain copy kernel (the measured same-hardware ceiling for the roofline table)
 // ------------------------------------------------------------------------------------------------
+template <int kInstance = 0>  // a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(kBlock) void synth_points(v4f* __restrict__ out, uint64_t n, uint64_t seed) {
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {

@@ -385,7 +385,7 @@ int main(int argc, char** argv) {
   for (int b = 0; b < kBufs; ++b) {
     CK(hipMalloc((void**)&in[b], n * sizeof(v4f)));
     CK(hipMalloc((void**)&out[b], n * sizeof(v4f)));
-    hipLaunchKernelGGL(synth_points, dim3(g_cus * 8), dim3(kBlock), 0, s, in[b], n, 0x4B4D43ull + b);
+    hipLaunchKernelGGL(synth_points<0>, dim3(g_cus * 8), dim3(kBlock), 0, s, in[b], n, 0x4B4D43ull + b);
     CK(hipMemsetAsync(out[b], 0, n * sizeof(v4f), s));
   }
   CK(hipStreamSynchronize(s));
