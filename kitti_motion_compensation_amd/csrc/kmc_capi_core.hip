@@ -16,6 +16,7 @@ int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n) {
   if (!(theta_max <= 1.0)) return kTrig;  // also catches NaN
   return theta_max <= 0.25 ? kSeries3 : kSeries5;
 }
+
 int ensure_tmp(kmc_ctx* c, size_t bytes) {
   if (bytes <= c->tmp_cap) return KMC_OK;
   if (c->d_tmp) {
@@ -43,6 +44,7 @@ int ensure_pipeline(kmc_ctx* c) {
   c->stage_cap = bytes;
   return KMC_OK;
 }
+
 int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
   const int slot_id = c->next_slot;
   const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;

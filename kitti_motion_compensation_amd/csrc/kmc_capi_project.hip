@@ -1,10 +1,8 @@
 // kmc_capi_project.hip -- row N4: the arithmetic of camera_model.cpp (LiDAR -> four rectified cameras) on the GPU.
 #include "kmc_internal.hip.h"
 
-extern "C" {
-
-// ---- N4: projection ----------------------------------------------------------------------------------
 namespace {
+
 bool rig_ok(const kmc_camera_rig* g) {
   const double* v = g->tf_c00_lo;  // the struct is 70 contiguous doubles
   for (size_t i = 0; i < sizeof(kmc_camera_rig) / sizeof(double); ++i)
@@ -29,6 +27,8 @@ CameraRigRec rig_rec(const kmc_camera_rig* g) {
   return r;
 }
 }  // namespace
+
+extern "C" {
 
 int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_camera_rig* rig, const kmc_frame_params* deskew,
                         float* xyzi_out, int32_t* uv, uint8_t* bgrv, int mem_kind, kmc_stats* st) {
