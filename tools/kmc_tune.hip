@@ -299,6 +299,67 @@ static Variant frame_variant(const char* label) {
   return v;
 }
 
+// one-directional ceilings, one wave per workgroup like the shipped kernels: 16 B per lane read (the sum keeps the loads alive; the
+// store never happens) or written.  Throughput is reported against the table's 32 B/point, so double it for bytes actually moved.
+__global__ __launch_bounds__(64) void read_only_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const v4f p = __builtin_nontemporal_load(in + i);
+  if (p.x + p.y + p.z + p.w == 1.2345e30f) out[i] = p;
+}
+__global__ __launch_bounds__(64) void write_only_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const v4f p = {1.0f, 2.0f, 3.0f, (float)threadIdx.x};
+  const __amdgpu_buffer_rsrc_t r = tile_rsrc(out + (uint64_t)blockIdx.x * 64, (n - (uint64_t)blockIdx.x * 64) * sizeof(v4f));
+  tile_store<kPolicyDefault>(r, (uint32_t)(threadIdx.x * sizeof(v4f)), p);
+}
+// four loads (stores) in flight per lane: the one-wave, one-access kernels above are bounded by occupancy x latency, these by bandwidth
+__global__ __launch_bounds__(64) void read_only_points4(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  const uint64_t base = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (base + 192 >= n) return;
+  const v4f a = __builtin_nontemporal_load(in + base), b = __builtin_nontemporal_load(in + base + 64);
+  const v4f c = __builtin_nontemporal_load(in + base + 128), d = __builtin_nontemporal_load(in + base + 192);
+  if (a.x + b.y + c.z + d.w == 1.2345e30f) out[base] = a;
+}
+__global__ __launch_bounds__(64) void write_only_points4(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  const uint64_t base = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (base + 192 >= n) return;
+  const v4f p = {1.0f, 2.0f, 3.0f, (float)threadIdx.x};
+  __builtin_nontemporal_store(p, out + base);
+  __builtin_nontemporal_store(p, out + base + 64);
+  __builtin_nontemporal_store(p, out + base + 128);
+  __builtin_nontemporal_store(p, out + base + 192);
+}
+static Variant oneway4_variant(const char* label, bool read) {
+  Variant v;
+  v.name = label;
+  v.ppt = 1;
+  if (read)
+    v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+      hipLaunchKernelGGL(read_only_points4, dim3((unsigned)((n + 255) / 256)), dim3(64), 0, s, in, out, n);
+    };
+  else
+    v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+      hipLaunchKernelGGL(write_only_points4, dim3((unsigned)((n + 255) / 256)), dim3(64), 0, s, in, out, n);
+    };
+  return v;
+}
+static Variant oneway_variant(const char* label, bool read) {
+  Variant v;
+  v.name = label;
+  v.ppt = 1;
+  if (read)
+    v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+      hipLaunchKernelGGL(read_only_points, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in, out, n);
+    };
+  else
+    v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
+      hipLaunchKernelGGL(write_only_points, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in, out, n);
+    };
+  return v;
+}
+
 template <int PPT, int NT>
 static Variant copy_variant(const char* label) {
   Variant v;
@@ -401,6 +462,10 @@ int main(int argc, char** argv) {
   es.push_back({copy_variant<1, kNtStore>("copy_ppt1_ntstore"), kZero});
   es.push_back({copy_variant<1, 0>("copy_ppt1_plain"), kZero});
   es.push_back({copy_variant<4, kNtBoth>("copy_ppt4_nt"), kAll});
+  es.push_back({oneway_variant("x_read_only_16B_per_point", true), kZero});
+  es.push_back({oneway_variant("x_write_only_16B_per_point", false), kZero});
+  es.push_back({oneway4_variant("x_read_only_4_loads_per_lane", true), kZero});
+  es.push_back({oneway4_variant("x_write_only_4_stores_per_lane", false), kZero});
   es.push_back({frame_variant<kSeries3, 1, kNtBoth, false>("s3_ppt1_nt"), kAll});
   es.push_back({frame_variant<kSeries3, 1, kNtLoad, false>("s3_ppt1_ntload"), kZero});
   es.push_back({frame_variant<kSeries3, 1, kNtStore, false>("s3_ppt1_ntstore"), kZero});
