@@ -140,11 +140,21 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
+        # Test knobs (tests/test_bench_contract.py runs the whole N = 2 flow on a one-GPU box): KMC_BENCH_BACKEND=gloo reduces the
+        # counters over gloo on CPU tensors, KMC_BENCH_DEVICE=<id> puts every rank on that device.  Unset = the contract: RCCL, one
+        # rank per GPU.
+        backend = os.environ.get("KMC_BENCH_BACKEND", "nccl")
+        if "KMC_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["KMC_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the deskew path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    reduce_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     F = args.frames_per_step
     n = F * POINTS_PER_FRAME
@@ -197,7 +207,7 @@ def main():
     wall = time.perf_counter() - t_begin
 
     # the job's ONLY collective: SUM of points, MAX of times (RCCL all-reduce when N > 1)
-    pts_total, t_max, ev_max_s = sharding.reduce_throughput(dist, dev, float(n * args.steps), wall, ev_ms * 1e-3)
+    pts_total, t_max, ev_max_s = sharding.reduce_throughput(dist, reduce_dev, float(n * args.steps), wall, ev_ms * 1e-3)
 
     if rank == 0:
         kernel_ms = ev_ms / args.steps  # average launch duration of the dominant kernel, HIP events, this rank

@@ -45,3 +45,25 @@ def test_bench_rccl_path_initialises_and_reduces_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["value"] > 10_000
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_end_to_end_on_one_gpu():
+    """The driver's N > 1 launch line (torch.distributed.run, one process per rank) with both ranks placed on the only GPU of
+    the test box and the counters reduced over gloo (KMC_BENCH_DEVICE / KMC_BENCH_BACKEND are test knobs): rank-specific
+    workloads, barrier + max-over-ranks timing, ONE JSON line from rank 0 with the whole-job aggregate."""
+    env = dict(os.environ, KMC_BENCH_BACKEND="gloo", KMC_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+           "--frames-per-step", "32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["config"]["frames_per_step_per_gpu"] == 32 and "x2" in d["config"]["parallelism"]
+    # two ranks share one GPU here: the aggregate is about one GPU's rate (each rank gets half), never two GPUs' worth
+    assert 50_000 < d["value"] < 260_000
+    # whole-job aggregate = all ranks' points / max-rank time
+    assert abs(d["value"] - 2 * 32 * 1_000_000 * 8 / (d["ms_per_step"] * 8 * 1e-3) / 1e6) / d["value"] < 0.02
