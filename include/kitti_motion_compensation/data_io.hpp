@@ -28,7 +28,9 @@ LidarScan LoadLidarScan(Path const folder, std::size_t const frame_id);  // :142
 Frame MakeFrame(Oxts const& odometry_n_m_1, Oxts const& odometry_n, Oxts const& odometry_n_p_1,
                 LidarScan const& lidar_scan);                            // :253-269
 
-Frame LoadSingleFrame(Path const data_folder, std::size_t const frame_id);  // :271-285
+// The reference's third parameter asks for the four camera images as well (cv::Mat, data_io.cpp:279-282); this build has no
+// OpenCV, so load_images == true throws std::runtime_error instead of silently returning a frame without images.
+Frame LoadSingleFrame(Path const data_folder, std::size_t const frame_id, bool const load_images = false);  // :271-285
 
 void WritePointcloud(Path const data_folder, std::size_t const frame_id, Pointcloud const& pointcloud,
                      VectorXd const& intensities);                        // :287-313

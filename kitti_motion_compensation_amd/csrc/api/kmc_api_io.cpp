@@ -144,7 +144,8 @@ Frame MakeFrame(Oxts const& o_nm1, Oxts const& o_n, Oxts const& o_np1, LidarScan
   return Frame(start_pose, end_pose, scan);
 }
 
-Frame LoadSingleFrame(Path const data_folder, std::size_t const frame_id) {  // :271-285
+Frame LoadSingleFrame(Path const data_folder, std::size_t const frame_id, bool const load_images) {  // :271-285
+  if (load_images) throw std::runtime_error("LoadSingleFrame: loading the camera images needs OpenCV, which this build does not use");
   if (frame_id == 0) throw std::invalid_argument("LoadSingleFrame: frame 0 has no previous OXTS packet");  // reference: size_t underflow
   Oxts const a{LoadOxts(data_folder, frame_id - 1)}, b{LoadOxts(data_folder, frame_id)}, c{LoadOxts(data_folder, frame_id + 1)};
   return MakeFrame(a, b, c, LoadLidarScan(data_folder, frame_id));

@@ -214,6 +214,13 @@ static void host_cases(std::string const& golden) {
     ASSERT_EQ(cc.camera_03.P_rect(0, 3), -3.395242e+02);
     ASSERT_EQ(cc.camera_03.P_rect(2, 3), 2.729905e-03);
     ASSERT_EQ(cc.camera_03.K(1, 1), 9.019653e+02);
+    bool refused_images = false;
+    try {
+      (void)LoadSingleFrame(Path{golden + "/kitti_2011_09_26_drive_0005"}, 1, true);  // data_io.cpp:279-282 needs cv::imread
+    } catch (std::runtime_error const&) {
+      refused_images = true;
+    }
+    ASSERT_TRUE(refused_images);
     bool threw = false;
     try {
       (void)viz::LoadCameraCalibrations(Path{golden + "/does_not_exist"});
