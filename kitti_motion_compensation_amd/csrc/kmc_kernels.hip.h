@@ -691,9 +691,10 @@ __device__ __forceinline__ void store_uv_tile(v2i* __restrict__ uv, uint64_t til
   } else {
     lo = hi = (v4i){(int)0x80000000, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   }
-  v4i* o = reinterpret_cast<v4i*>(uv + 4 * tile_base);
-  if (tile_base + (tid >> 1) < n) __builtin_nontemporal_store(lo, o + tid);
-  if (tile_base + 32 + (tid >> 1) < n) __builtin_nontemporal_store(hi, o + 64 + tid);
+  // nt + sc1 stores through a descriptor that ends with the array: the ragged last tile is clipped by the hardware
+  const __amdgpu_buffer_rsrc_t r = tile_rsrc(uv + 4 * tile_base, (n - tile_base) * 4 * sizeof(v2i));
+  tile_store<kPolicyDefault>(r, tid * 16u, __builtin_bit_cast(v4f, lo));
+  tile_store<kPolicyDefault>(r, 1024u + tid * 16u, __builtin_bit_cast(v4f, hi));
 }
 
 template <int TIER, bool STRUCTURED>
