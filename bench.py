@@ -105,6 +105,42 @@ def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample, gpu_out_frame0):
     }, parity
 
 
+def live_traffic(frames_per_step, points_per_frame, yaw_per_frame, calibration):
+    """HBM bytes per launch of the bench kernel, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, no trace domain), corrected with the factors profiles/pmc_traffic.json derived from the copy
+    kernel of known size (gfx950: FETCH_SIZE counts half of a wide coalesced stream).  Returns bytes per launch or None."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    total = 0.0
+    for counter, factor in (("FETCH_SIZE", calibration["fetch_correction_factor"]), ("WRITE_SIZE", calibration["write_correction_factor"])):
+        out = tempfile.mkdtemp(prefix="kmc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--frames-per-step", str(frames_per_step),
+               "--points-per-frame", str(points_per_frame), "--yaw-per-frame", str(yaw_per_frame)]
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "KMC_BENCH_FORCE_DIST"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=os.environ.get("TMPDIR", "/tmp"))
+        vals = []
+        for dp, _, fns in os.walk(out):
+            for fn in fns:
+                if fn.endswith("counter_collection.csv"):
+                    with open(os.path.join(dp, fn)) as fh:
+                        vals += [float(row["Counter_Value"]) for row in csv.DictReader(fh)
+                                 if row["Counter_Name"] == counter and "deskew_batch_f32" in row["Kernel_Name"]]
+        shutil.rmtree(out, ignore_errors=True)
+        if r.returncode != 0 or not vals:
+            return None
+        total += sum(vals) / len(vals) * 1024.0 * factor  # counters are in KiB
+    return total
+
+
 def main():
     global POINTS_PER_FRAME
     ap = argparse.ArgumentParser()
@@ -116,6 +152,9 @@ def main():
                     help="1000000 = BASELINE.json configs[1] (the default, the headline); 10000000 with --frames-per-step 24 "
                          "--yaw-per-frame 0.03 = the per-GPU share of configs[3]'s 10 M-point-per-frame stream")
     ap.add_argument("--yaw-per-frame", type=float, default=0.0)
+    ap.add_argument("--live-traffic", action="store_true",
+                    help="measure roofline.traffic now (two extra rocprofv3 --pmc child runs, ~1 minute) instead of scaling the "
+                         "per-point figure of the committed PMC passes (profiles/pmc_traffic.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
     ap.add_argument("--rotate", type=int, default=1, help="number of in/out buffer pairs cycled through by the steps")
@@ -221,6 +260,9 @@ def main():
             with open(tpath) as fjson:
                 tj = json.load(fjson)
             traffic = round(tj["hbm_bytes_per_point"] * n)
+            if args.live_traffic and world == 1:
+                live = live_traffic(F, POINTS_PER_FRAME, args.yaw_per_frame, tj)
+                traffic = round(live) if live else traffic
         out = {
             "metric": "M points/sec deskewed",
             "value": round(pts_total / t_max / 1e6, 1),
@@ -245,6 +287,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": "rocprofv3 --pmc child runs of this invocation" if (args.live_traffic and world == 1 and traffic) else
+                                  "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command), per point x points per launch",
                 "bytes_per_point": BYTES_PER_POINT, "points_per_launch": n, "kernel_ms_avg": round(kernel_ms, 4),
             },
         }

@@ -67,3 +67,21 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert 50_000 < d["value"] < 260_000
     # whole-job aggregate = all ranks' points / max-rank time
     assert abs(d["value"] - 2 * 32 * 1_000_000 * 8 / (d["ms_per_step"] * 8 * 1e-3) / 1e6) / d["value"] < 0.02
+
+
+@pytest.mark.gpu
+def test_bench_live_traffic_matches_the_algorithmic_bytes():
+    """--live-traffic: HBM bytes per launch from rocprofv3 --pmc child runs of the same invocation (FETCH_SIZE and WRITE_SIZE in
+    separate passes) -- within 1 % of 32 B x points per launch, i.e. nothing is re-read."""
+    import shutil
+
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames-per-step", "64",
+                        "--no-cpu-baseline", "--live-traffic"], capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    rf = d["roofline"]
+    assert "child runs" in rf["traffic_source"], rf
+    assert abs(rf["traffic"] / (32.0 * rf["points_per_launch"]) - 1.0) < 0.01
