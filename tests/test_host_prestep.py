@@ -133,3 +133,23 @@ def test_make_frame_and_twist_on_a_real_cadence_drive(golden_dir):
         # the scan lasts ~0.1033 s on a 13 m/s, 0.3 rad/s arc
         assert 1.2 < np.linalg.norm(p.twist_np()[:3]) < 1.5 and 0.028 < np.linalg.norm(p.twist_np()[3:]) < 0.034
         assert 0.45 < p.x_req < 0.55
+
+
+def test_bench_workload_is_configs1_straight_line_and_configs3_turn():
+    """bench.py's workload builder (host logic, no GPU): BASELINE.json configs[1] is 10 m/s due east with no rotation, scan
+    T0 + {.10, .15, .20} -> every frame's twist is 1 m of pure x translation, requested at the middle; --yaw-per-frame turns it
+    into configs[3]'s constant-twist track."""
+    import bench
+
+    work = bench.make_workload(capi, 4, rank=1)
+    for params, (t0, tm, t1), oxts in work:
+        tw = params.twist_np()
+        assert abs(tw[0] - 1.0) < 1e-6 and np.all(np.abs(tw[1:]) < 1e-6), tw     # 10 m/s x 0.1 s along the heading
+        assert abs(params.x_req - 0.5) < 1e-9 and abs((t1 - t0) - 0.1) < 1e-9 and abs(tm - 0.5 * (t0 + t1)) < 1e-9
+        assert oxts[0].stamp < t0 and oxts[2].stamp > t1                       # the three packets bracket the scan
+    # ranks get different frames (rank 1 starts after rank 0's four)
+    w0 = bench.make_workload(capi, 4, rank=0)
+    assert abs(work[0][1][0] - (w0[3][1][0] + 0.1)) < 1e-9
+    turn = bench.make_workload(capi, 2, rank=0, yaw_per_frame=0.03)
+    tw = turn[1][0].twist_np()
+    assert abs(tw[5] - 0.03) < 1e-6 and abs(np.linalg.norm(tw[:3]) - 1.0) < 1e-3  # 0.03 rad of yaw per scan, ~1 m of arc
