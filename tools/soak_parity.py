@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential soak: HIP path vs CPU oracle, for a wall-clock budget, over random sizes / twists / batch
 layouts / camera rigs.  Test infrastructure (it drives the oracle); prints one JSON summary.
-  python tools/soak_parity.py [seconds=300] [seed=1] > gpurun_out/soak.json"""
+  python tools/soak_parity.py [seconds=300] [seed=1] [checkpoint.json] > gpurun_out/soak.json
+With a checkpoint path the running totals are rewritten there once a minute, so a run that is cut short (gpurun caps a call at
+3600 s) still leaves its evidence."""
 import json
 import os
 import sys
@@ -198,6 +200,8 @@ def f64_round(ctx, rng, acc):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    checkpoint = sys.argv[3] if len(sys.argv) > 3 else None
+    last_checkpoint = time.time()
     rng = np.random.default_rng(seed)
     ctx = capi.Context(0)
     calib = util.load_kitti_calibration(os.path.join(ROOT, "tests", "golden"))
@@ -223,6 +227,11 @@ def main():
         else:
             f64_round(ctx, rng, acc)
         acc["rounds"] += 1
+        if checkpoint and time.time() - last_checkpoint > 60.0:
+            last_checkpoint = time.time()
+            with open(checkpoint + ".tmp", "w") as fh:
+                json.dump(dict(acc, partial=True, elapsed=round(budget - (t_end - time.time()), 1)), fh)
+            os.replace(checkpoint + ".tmp", checkpoint)
     acc["ok"] = bool(acc["deskew_max_rel_err"] <= 1e-5 and acc["batch_max_rel_err"] <= 1e-5 and acc["deskew_intensity_mismatch"] == 0
                      and acc["deskew_max_err_over_scale"] <= 2e-6 and acc["batch_max_err_over_scale"] <= 2e-6
                      and acc["subrange_failures"] == 0 and acc["f64_max_rel_err"] <= 1e-9
