@@ -179,7 +179,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        # Test knobs (tests/test_bench_contract.py runs the whole N = 2 flow on a one-GPU box): KMC_BENCH_BACKEND=gloo reduces the
+        # Test knobs (tests/test_z_bench_contract.py runs the whole N = 2 flow on a one-GPU box): KMC_BENCH_BACKEND=gloo reduces the
         # counters over gloo on CPU tensors, KMC_BENCH_DEVICE=<id> puts every rank on that device.  Unset = the contract: RCCL, one
         # rank per GPU.
         backend = os.environ.get("KMC_BENCH_BACKEND", "nccl")
