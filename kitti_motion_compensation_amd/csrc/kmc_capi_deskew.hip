@@ -7,20 +7,20 @@ namespace {
 
 // ---- template dispatch ---------------------------------------------------------------------------
 template <int TIER, int PPT>
-void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head) {
-  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head);
+void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d) {
+  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head, d);
 }
 template <int TIER>
-void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head) {
+void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d) {
   switch (ppt) {
-    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head); break;
-    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head); break;
-    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head); break;
-    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head); break;
+    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head, d); break;
+    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head, d); break;
+    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head, d); break;
+    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head, d); break;
   }
 }
 // in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of()
-void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head = 0) {
+void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0) {
   const int ppt = ppt_of(c);
   in -= head;
   out -= head;
@@ -28,28 +28,28 @@ void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f*
   const uint64_t n_tiles = (n + (uint64_t)kLaunchBlock * ppt - 1) / ((uint64_t)kLaunchBlock * ppt);
   const int grid = grid_for(c, n_tiles);
   switch (tier) {
-    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head); break;
-    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head); break;
-    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head); break;
+    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head, d); break;
+    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head, d); break;
+    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head, d); break;
   }
 }
 
 template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
-                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head) {
+                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64) {
   if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64);
   else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64);
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
-                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head) {
+                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64) {
   switch (ppt) {
-    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
-    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
-    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
-    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head); break;
+    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
+    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
+    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
+    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
   }
 }
 }  // namespace
@@ -70,12 +70,14 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   FrameRec f;
   std::memset(&f, 0, sizeof(f));
   fill_rec(*params, &f);
+  FrameRecD d;
+  fill_recd(*params, &d);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
   CallTimer tm(c);
   if (mem_kind == KMC_MEM_DEVICE) {
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    launch_frame(c, c->stream, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, head_of(xyzi_out, mem_kind));
+    launch_frame(c, c->stream, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, mem_kind));
     KMC_HIP_TRY(c, hipGetLastError());
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     if (st) st->n_launches = 1;
@@ -97,7 +99,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     KMC_HIP_TRY(c, hipEventRecord(c->ev_h2d[b], c->pipe[0]));
     KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[1], c->ev_h2d[b], 0));
     if (reused) KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[1], c->ev_d2h[b], 0));     // the slot's output was downloaded
-    launch_frame(c, c->pipe[1], tier, (const v4f*)c->d_stage_in[b], (v4f*)c->d_stage_out[b], m, f);
+    launch_frame(c, c->pipe[1], tier, (const v4f*)c->d_stage_in[b], (v4f*)c->d_stage_out[b], m, f, d);
     KMC_HIP_TRY(c, hipGetLastError());
     KMC_HIP_TRY(c, hipEventRecord(c->ev_kernel[b], c->pipe[1]));
     KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[2], c->ev_kernel[b], 0));
@@ -142,8 +144,10 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const uint64_t n_chunks = (nv + chunk - 1) / chunk;
   const uint64_t n_coarse = n_chunks + 1;
 
+  // slot layout: [BatchRec x F | FrameRecD x F (f64 twins for the near-origin guard) | coarse x (n_chunks + 1)]
   const size_t recs_bytes = ((size_t)n_frames * sizeof(BatchRec) + 255) & ~(size_t)255;
-  const size_t need = recs_bytes + (size_t)n_coarse * sizeof(uint2);
+  const size_t recd_bytes = ((size_t)n_frames * sizeof(FrameRecD) + 255) & ~(size_t)255;
+  const size_t need = recs_bytes + recd_bytes + (size_t)n_coarse * sizeof(uint2);
   int slot_id = 0;
   {
     const int rc_slot = slot_begin(c, need, &slot_id);
@@ -151,12 +155,15 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   }
   kmc_ctx::TableSlot& sl = c->slots[slot_id];
   BatchRec* h_recs = reinterpret_cast<BatchRec*>(sl.h_buf);
-  uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + recs_bytes);
+  FrameRecD* h_recd = reinterpret_cast<FrameRecD*>(sl.h_buf + recs_bytes);
+  uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + recs_bytes + recd_bytes);
   const BatchRec* d_recs = reinterpret_cast<const BatchRec*>(sl.d_buf);
-  const uint2* d_coarse = reinterpret_cast<const uint2*>(sl.d_buf + recs_bytes);
+  const FrameRecD* d_recd = reinterpret_cast<const FrameRecD*>(sl.d_buf + recs_bytes);
+  const uint2* d_coarse = reinterpret_cast<const uint2*>(sl.d_buf + recs_bytes + recd_bytes);
   for (uint32_t f = 0; f < n_frames; ++f) {
     BatchRec* r = &h_recs[f];
     fill_rec(params[f], r);
+    fill_recd(params[f], &h_recd[f]);
     r->end_lo = (uint32_t)((offsets[f + 1] + head) & 0xFFFFFFFFull);
     r->end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
   }
@@ -187,9 +194,9 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const int grid = grid_for(c, n_tiles);
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
   switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
-    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head); break;
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
   {

@@ -47,7 +47,9 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   const int tier = deskew ? pick_tier(c, deskew, 1) : -1;
   FrameRec f;
   std::memset(&f, 0, sizeof(f));
-  if (deskew) fill_rec(*deskew, &f);
+  FrameRecD fd;
+  std::memset(&fd, 0, sizeof(fd));
+  if (deskew) { fill_rec(*deskew, &f); fill_recd(*deskew, &fd); }
   if (st) { st->n_points = n; st->variant = (uint32_t)(tier < 0 ? 4 : tier); }
   if (n == 0) return KMC_OK;
   const CameraRigRec g = rig_rec(rig);
@@ -73,8 +75,8 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   const bool pinhole = rig_is_pinhole(rig);
 #define KMC_LAUNCH_PROJECT(T)                                                                                                     \
   do {                                                                                                                            \
-    if (pinhole) hipLaunchKernelGGL((project_f32<T, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col); \
-    else hipLaunchKernelGGL((project_f32<T, false>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col);       \
+    if (pinhole) hipLaunchKernelGGL((project_f32<T, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
+    else hipLaunchKernelGGL((project_f32<T, false>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd);       \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_PROJECT(kSeries3); break;

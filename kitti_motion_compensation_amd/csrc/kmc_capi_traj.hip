@@ -72,8 +72,8 @@ void knot_direction(double c, float* ck, float* sk) {
   *sk = (float)std::sin(alpha);
 }
 
-// device records of one frame's trajectory (f32): one TrajSeg32 per segment
-void fill_traj_segs(const TrajHost& th, double stamp_start, double stamp_end, TrajSeg32* segs) {
+// device records of one frame's trajectory: one TrajSeg32 per segment and its f64 twin for the near-origin guard's redo
+void fill_traj_segs(const TrajHost& th, double stamp_start, double stamp_end, TrajSeg32* segs, TrajSegD* segs64) {
   const double scan = stamp_end - stamp_start;
   for (uint32_t k = 0; k < th.n_seg; ++k) {
     TrajSeg32& r = segs[k];
@@ -93,6 +93,20 @@ void fill_traj_segs(const TrajHost& th, double stamp_start, double stamp_end, Tr
     r.m20 = (float)th.M[k].L.m[2][0]; r.m21 = (float)th.M[k].L.m[2][1]; r.m22 = (float)th.M[k].L.m[2][2]; r.tz = (float)th.M[k].t.z;
     knot_direction(ck, &r.knot_cos, &r.knot_sin);
     r.flags = (k == th.r ? kSegIdentity : 0u) | (ck <= 0.0 ? kKnotAlwaysGe : 0u) | (ck > 1.0 ? kKnotNeverGe : 0u);
+    r.guard2 = (k == th.r) ? 0.0f : (float)kmc_host::dot(th.M[k].t, th.M[k].t);
+    TrajSegD& d = segs64[k];
+    {
+      kmc_frame_params fd = fp;
+      FrameRecD w;
+      fill_recd(fd, &w);
+      for (int j = 0; j < 3; ++j) { d.phi[j] = w.phi[j]; d.rho[j] = w.rho[j]; d.c1[j] = w.c1[j]; d.c2[j] = w.c2[j]; }
+      d.phi2 = w.phi2;
+    }
+    d.c = ck;
+    d.g = g;
+    d.a = a;
+    th.M[k].to_rt12(d.M);
+    d.identity = (k == th.r) ? 1u : 0u;
   }
 }
 constexpr size_t kTrajBytes = kMaxSegments * (sizeof(TrajSeg32) + sizeof(TrajSeg64));
@@ -153,14 +167,15 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
 
-  TrajSeg32 segs[kMaxSegments];
-  std::memset(segs, 0, sizeof(segs));
-  fill_traj_segs(th, stamp_start, stamp_end, segs);
+  // slot layout: [TrajSeg32 x kMaxSegments | TrajSegD x kMaxSegments]
   int slot_id = 0;
-  rc = slot_begin(c, sizeof(segs), &slot_id);
+  rc = slot_begin(c, kMaxSegments * (sizeof(TrajSeg32) + sizeof(TrajSegD)), &slot_id);
   if (rc != KMC_OK) return rc;
-  std::memcpy(c->slots[slot_id].h_buf, segs, th.n_seg * sizeof(TrajSeg32));
-  rc = slot_upload(c, slot_id, th.n_seg * sizeof(TrajSeg32));
+  TrajSeg32* segs = reinterpret_cast<TrajSeg32*>(c->slots[slot_id].h_buf);
+  TrajSegD* segs64 = reinterpret_cast<TrajSegD*>(c->slots[slot_id].h_buf + kMaxSegments * sizeof(TrajSeg32));
+  std::memset(segs, 0, kMaxSegments * (sizeof(TrajSeg32) + sizeof(TrajSegD)));
+  fill_traj_segs(th, stamp_start, stamp_end, segs, segs64);
+  rc = slot_upload(c, slot_id, kMaxSegments * sizeof(TrajSeg32) + th.n_seg * sizeof(TrajSegD));
   if (rc != KMC_OK) return rc;
 
   const v4f* d_in = (const v4f*)xyzi_in;
@@ -183,11 +198,12 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   const uint64_t nv = n + head;
   const int grid = grid_for(c, (nv + 63) / 64);
   const TrajSeg32* d_segs = (const TrajSeg32*)c->slots[slot_id].d_buf;
+  const TrajSegD* d_segs64 = (const TrajSegD*)(c->slots[slot_id].d_buf + kMaxSegments * sizeof(TrajSeg32));
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
 #define KMC_LAUNCH_TRAJ(T)                                                                                                          \
   do {                                                                                                                              \
-    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_segs, th.n_seg, v_idx, head); \
-    else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_segs, th.n_seg, v_idx, head);      \
+    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_segs, th.n_seg, v_idx, head, d_segs64); \
+    else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_segs, th.n_seg, v_idx, head, d_segs64);      \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ(kSeries3); break;
@@ -247,28 +263,31 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   const uint64_t n_coarse = (nv + chunk - 1) / chunk + 1;
   const size_t frecs_bytes = ((size_t)n_frames * sizeof(TrajFrameRec) + 255) & ~(size_t)255;
   const size_t segs_bytes = ((size_t)n_frames * seg_stride * sizeof(TrajSeg32) + 255) & ~(size_t)255;
-  const size_t need = frecs_bytes + segs_bytes + (size_t)n_coarse * sizeof(uint2);
+  const size_t segd_bytes = ((size_t)n_frames * seg_stride * sizeof(TrajSegD) + 255) & ~(size_t)255;  // f64 twins (guard redo)
+  const size_t need = frecs_bytes + segs_bytes + segd_bytes + (size_t)n_coarse * sizeof(uint2);
   int slot_id = 0;
   int rc = slot_begin(c, need, &slot_id);
   if (rc != KMC_OK) return rc;
   kmc_ctx::TableSlot& sl = c->slots[slot_id];
   TrajFrameRec* h_frecs = reinterpret_cast<TrajFrameRec*>(sl.h_buf);
   TrajSeg32* h_segs = reinterpret_cast<TrajSeg32*>(sl.h_buf + frecs_bytes);
-  uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + frecs_bytes + segs_bytes);
-  std::memset(h_segs, 0, segs_bytes);
+  TrajSegD* h_segd = reinterpret_cast<TrajSegD*>(sl.h_buf + frecs_bytes + segs_bytes);
+  uint2* h_coarse = reinterpret_cast<uint2*>(sl.h_buf + frecs_bytes + segs_bytes + segd_bytes);
+  std::memset(h_segs, 0, segs_bytes + segd_bytes);
   for (uint32_t f = 0; f < n_frames; ++f) {
     h_frecs[f].end_lo = (uint32_t)((offsets[f + 1] + head) & 0xFFFFFFFFull);
     h_frecs[f].end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
     h_frecs[f].n_seg = th[f].n_seg;
     h_frecs[f].pad = 0;
-    fill_traj_segs(th[f], frames[f].stamp_start, frames[f].stamp_end, h_segs + (size_t)f * seg_stride);
+    fill_traj_segs(th[f], frames[f].stamp_start, frames[f].stamp_end, h_segs + (size_t)f * seg_stride, h_segd + (size_t)f * seg_stride);
   }
   build_coarse(offsets, n_frames, nv, head, h_coarse);
   rc = slot_upload(c, slot_id, need);
   if (rc != KMC_OK) return rc;
   const TrajFrameRec* d_frecs = reinterpret_cast<const TrajFrameRec*>(sl.d_buf);
   const TrajSeg32* d_segs = reinterpret_cast<const TrajSeg32*>(sl.d_buf + frecs_bytes);
-  const uint2* d_coarse = reinterpret_cast<const uint2*>(sl.d_buf + frecs_bytes + segs_bytes);
+  const TrajSegD* d_segd = reinterpret_cast<const TrajSegD*>(sl.d_buf + frecs_bytes + segs_bytes);
+  const uint2* d_coarse = reinterpret_cast<const uint2*>(sl.d_buf + frecs_bytes + segs_bytes + segd_bytes);
 
   CallTimer tm(c);
   const v4f* d_in = (const v4f*)xyzi_in;
@@ -293,8 +312,8 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   uint32_t* v_bidx = d_bidx ? d_bidx - head : nullptr;
 #define KMC_LAUNCH_TRAJ_BATCH(T)                                                                                                   \
   do {                                                                                                                             \
-    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head); \
-    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head);     \
+    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
+    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);     \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;

@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace kmc_dev {
@@ -29,6 +30,20 @@ struct alignas(16) FrameRec {
   float c1_x, c1_y, c1_z, pad0;     // c1 = phi x rho
   float c2_x, c2_y, c2_z, pad1;     // c2 = phi x (phi x rho)
 };
+
+// The same frame in f64 -- what the guarded redo below needs (128 B; kernarg of the single-frame kernels, a second
+// table next to the BatchRec table for the batched kernel; only ever read -- through scalar loads -- by waves that contain a
+// guarded lane).  c1, c2 and |phi|^2 come from the host so that the redo needs no wave-uniform f64 VALU work.
+struct alignas(16) FrameRecD {
+  double phi[3];
+  double rho[3];
+  double c1[3];   // phi x rho
+  double c2[3];   // phi x (phi x rho)
+  double phi2;
+  double x_req;
+  double pad[2];
+};
+static_assert(sizeof(FrameRecD) == 128, "FrameRecD must stay one 128-byte record");
 static_assert(sizeof(FrameRec) == 64, "FrameRec must stay one 64-byte record");
 
 enum Tier : int { kSeries3 = 0, kSeries5 = 1, kTrig = 2 };
@@ -147,6 +162,29 @@ __device__ __forceinline__ v4f deskew_point(const v4f p, const FrameRec& f) {
   return deskew_point_s<TIER>(p, f.s0 - a, f);  // s = frac - x_req
 }
 
+// ---- near-origin guard ------------------------------------------------------------------------------------------------
+// The reference computes in f64 and casts to f32 only when the cloud is written (motion_compensation.cpp:13,
+// data_io.cpp:300-310).  The f32 closed form above carries an ABSOLUTE error of a few f32 ulps of its largest operand,
+// ~3 eps (|p| + |rho|): harmless relative to |p'| for every ordinary return, but a point that the ego-motion carries
+// towards the sensor origin (p ~ -s rho) keeps that absolute error while |p'| shrinks, and the literal parity bar
+// |p' - p'_ref| <= 1e-5 max(|p'_ref|, 1e-3) breaks below |p'| ~ |p| / 50 (round-1 soak: 2.0e-5 at 8.8 mm).
+// Guard: a lane whose result lost more than a factor 4 against its operands,
+//     16 |p'|^2 < |p|^2 + scale2,     scale2 = |rho|^2  (+ |t_k|^2 of the anchor transform for trajectory segments),
+// is redone the reference's way -- f64 atan2, f64 exponential, one cast at the end.  Outside the guard
+// |p'| >= (|p| + |rho|) / (4 sqrt 2), so the f32 error stays below ~6 x 3 eps = 1.1e-6 relative.  The branch is wave-uniform
+// (ballot) and is never taken on real scans (nothing returns from within a metre of the sensor head): the kernels stay
+// on the HBM roofline, with ~10 more VALU instructions per point for the two norms.
+__device__ __forceinline__ bool lost_significance(const v4f p, const v4f o, float scale2) {
+  const float n_in = __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z));
+  const float n_out = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, o.z * o.z));
+  return 16.0f * n_out < n_in + scale2;  // false for NaN: non-finite points keep the f32 result
+}
+// |rho|^2 of the record in device precision; ONE definition, so that a two-knot trajectory takes exactly the decisions of
+// the two-pose kernels (their results are bit-identical, tests/test_trajectory.py)
+__device__ __forceinline__ float rho_norm2(float rx, float ry, float rz) {
+  return __builtin_fmaf(rx, rx, __builtin_fmaf(ry, ry, rz * rz));
+}
+
 // ---- N-knot trajectories (piecewise SE(3) geodesic through time-stamped poses) ------------------------------------
 // One record per trajectory segment k = [knot k, knot k+1]; 128 B, staged into LDS by the workgroup.
 //   p' = M_k * ( Exp((x_i - a_k) f_k) * p ),   x_i = position of the point's stamp inside the segment
@@ -156,7 +194,7 @@ struct alignas(16) TrajSeg32 {
   float phi_x, phi_y, phi_z, phi2;
   float rho_x, rho_y, rho_z, s0;     // s = s0 - turns * g
   float c1_x, c1_y, c1_z, g;         // g = scan duration / segment duration
-  float c2_x, c2_y, c2_z, pad;
+  float c2_x, c2_y, c2_z, guard2;    // |t|^2 of the anchor transform (0 for the anchor's own segment): near-origin guard
   float m00, m01, m02, tx;           // M_k rows with the translation in the 4th column
   float m10, m11, m12, ty;
   float m20, m21, m22, tz;
@@ -246,6 +284,219 @@ __device__ __forceinline__ void deskew_point_f64(double x, double y, double z, d
   ox = x + al * q1x + be * q2x + tx * w;
   oy = y + al * q1y + be * q2y + ty * w;
   oz = z + al * q1z + be * q2z + tz * w;
+}
+
+// ---- the guarded redo (see lost_significance above): one point the reference's way, f64 throughout ---------------------
+// frac = (pi - atan2(y, x)) / 2 pi in f64 (timestamp_mocking.cpp:46); s = frac - x_req (trajectory_interpolation.cpp:49-51);
+// p' = Exp(s f) p in f64 (lie_algebra.cpp:83-92 in closed form); ONE cast to f32 at the end (data_io.cpp:300-310).
+// Written for a SMALL register footprint, not for speed: the redo is compiled into every f32 kernel, and those must keep
+// their 8 waves per SIMD (<= 64 VGPRs).  ocml's f64 atan2 alone takes 60 VGPRs and its sincos drags in the large-argument
+// reduction; the two routines below are straight Horner chains (constants through SGPRs) and fit next to the f32 path.
+
+// Their coefficient tables live in constant memory and are read through an address the optimiser cannot see through
+// (opaque_table): as literals the compiler hoists all ~40 of them out of the kernels' tile loops into VGPR pairs --
+// measured: 102-170 VGPRs instead of 34-60, or 140-300 bytes of scratch per lane under an occupancy attribute.
+__constant__ double kRedoTable[42] = {
+    // [0..11]  atan(r) / r in r^2, highest degree first (degree-11 fit on r^2 <= tan^2(pi/8), tools/gen_atan_coeffs.py --f64)
+    -1.78108398111324964e-02, 3.79703151591785637e-02, -5.03530597010270892e-02, 5.84692471107266312e-02,
+    -6.66295840125903926e-02, 7.69204593125487474e-02, -9.09089684393908082e-02, 1.11111107461531272e-01,
+    -1.42857142792741643e-01, 1.99999999999410899e-01, -3.33333333333331205e-01, 1.0,
+    // [12..19] sin t / t in t^2:        (-1)^k / (2k+1)!, k = 7..0
+    -1.0 / 1307674368000.0, 1.0 / 6227020800.0, -1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0, 1.0,
+    // [20..27] (1 - cos t) / t^2:       (-1)^k / (2k+2)!
+    -1.0 / 20922789888000.0, 1.0 / 87178291200.0, -1.0 / 479001600.0, 1.0 / 3628800.0, -1.0 / 40320.0, 1.0 / 720.0, -1.0 / 24.0, 0.5,
+    // [28..35] (t - sin t) / t^3:       (-1)^k / (2k+3)!
+    -1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0,
+    // [36..41] tan(pi/8), pi/4, pi/2, pi, 2 pi, spare -- even these: as literals they are hoisted into VGPR pairs like the rest
+    0.41421356237309503, 0.78539816339744831, 1.5707963267948966, 3.14159265358979323846, 6.28318530717958647692, 0.0};
+
+// All tables of the redo -- the coefficients above and the frame / segment records -- are read through constant-address-space
+// pointers (uniform address -> scalar loads into SGPRs, no VGPRs for constants) that pass through an empty volatile asm
+// tied to the previous phase's result (`after`).  That pins every group of table reads behind the arithmetic that precedes
+// it, so that at most 12-24 SGPRs of table are live at any time.  Left to itself the compiler loads the 36 coefficients and
+// the whole record up front (80+ SGPRs: spills, and a private segment for the kernel).
+using cdouble_p = const double __attribute__((address_space(4)))*;
+__device__ __forceinline__ cdouble_p after(cdouble_p t, double dep) {
+  asm volatile("" : "+s"(t) : "v"(dep));
+  return t;
+}
+__device__ __forceinline__ uint32_t opaque_uniform(uint32_t v) {  // a wave-uniform value the optimiser cannot trace back
+  asm volatile("" : "+s"(v));
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ cdouble_p as_constant(const T* rec) {  // records are written by the host before the launch: constant
+  return (cdouble_p)(uintptr_t)rec;
+}
+
+// atan2(y, x) in f64, |error| <= 5e-16 rad (2 M random points against long double, tools/gen_atan_coeffs.py --f64):
+// octant reduction, a second reduction at tan(pi/8) folded into the ONE division, degree-11 polynomial in r^2 on
+// |r| <= tan(pi/8).  Signed zeros like libm: (+-0, x >= +0) -> +-0, (+-0, x <= -0) -> +-pi; atan2(0, 0) = 0.
+__device__ __forceinline__ double atan2_f64_lean(double y, double x) {
+  const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+  const double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
+  cdouble_p t = after((cdouble_p)kRedoTable, mx);
+  const bool big = mn > t[36] * mx;  // atan q = pi/4 + atan((q - 1) / (q + 1))
+  const double num = big ? mn - mx : mn;
+  const double den = big ? mn + mx : mx;
+  double r = num / den;
+  r = (den == 0.0) ? 0.0 : r;
+  const double z = r * r;
+  t = after(t, z);
+  double p = t[0];
+#pragma unroll
+  for (int k = 1; k < 6; ++k) p = __builtin_fma(p, z, t[k]);
+  t = after(t, p);
+#pragma unroll
+  for (int k = 6; k < 12; ++k) p = __builtin_fma(p, z, t[k]);
+  double a = r * p;
+  t = after(t, a);
+  a = big ? t[37] + a : a;
+  a = (ay > ax) ? t[38] - a : a;
+  a = (__builtin_signbit(x)) ? t[39] - a : a;
+  return __builtin_copysign(a, y);
+}
+// (pi - atan2(y, x)) / (2 pi), timestamp_mocking.cpp:46 -- a true division like the reference's
+__device__ __forceinline__ double scan_fraction_f64_lean(double x, double y) {
+  const double a = atan2_f64_lean(y, x);
+  cdouble_p t = after((cdouble_p)kRedoTable, a);
+  return (t[39] - a) / t[40];
+}
+
+// alpha = A s, beta = B s^2, gamma = C s^3 with A = sin t / t, B = (1 - cos t) / t^2, C = (t - sin t) / t^3, t = |s phi|:
+// 8-term series at t / 8 (exact to 1e-19 for t <= 4), then three angle doublings
+//     A(2x) = A(x) cos x,  cos x = 1 - x^2 B(x);   B(2x) = A(x)^2 / 2;   C(2x) = (C(x) + A(x) B(x)) / 4
+// (no cancellation anywhere, no trig, no divide, no branch).  One series after the other: 16 SGPRs of coefficients at a time.
+__device__ __forceinline__ void se3_coefficients_f64_lean(double s, double phi2, double& alpha, double& beta, double& gamma) {
+  const double s2 = s * s;
+  double u = __builtin_ldexp(s2 * phi2, -6);  // (t / 8)^2
+  cdouble_p t = after((cdouble_p)kRedoTable, u);
+  double A = t[12];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) A = __builtin_fma(A, u, t[12 + k]);
+  t = after(t, A);
+  double B = t[20];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) B = __builtin_fma(B, u, t[20 + k]);
+  t = after(t, B);
+  double C = t[28];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) C = __builtin_fma(C, u, t[28 + k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double cosx = __builtin_fma(-u, B, 1.0);
+    C = __builtin_ldexp(__builtin_fma(A, B, C), -2);
+    B = 0.5 * A * A;
+    A = A * cosx;
+    u *= 4.0;
+  }
+  alpha = A * s;
+  beta = B * s2;
+  gamma = C * (s2 * s);
+}
+
+// Exp(s f) p in f64.  `rec`: the record's leading doubles, the layout FrameRecD and TrajSegD share:
+// phi[0..2], rho[3..5], c1[6..8], c2[9..11], phi2[12].
+constexpr int kRecPhi = 0, kRecRho = 3, kRecC1 = 6, kRecC2 = 9, kRecPhi2 = 12;
+__device__ __forceinline__ void exp_apply_f64_lean(cdouble_p rec, double s, double phi2, double x, double y, double z, double& ox,
+                                                   double& oy, double& oz) {
+  double al, be, ga;
+  se3_coefficients_f64_lean(s, phi2, al, be, ga);
+  rec = after(rec, ga);  // phi and c1
+  const double q1x = rec[kRecPhi + 1] * z - rec[kRecPhi + 2] * y;
+  const double q1y = rec[kRecPhi + 2] * x - rec[kRecPhi + 0] * z;
+  const double q1z = rec[kRecPhi + 0] * y - rec[kRecPhi + 1] * x;
+  const double q2x = rec[kRecPhi + 1] * q1z - rec[kRecPhi + 2] * q1y + rec[kRecC1 + 0];
+  const double q2y = rec[kRecPhi + 2] * q1x - rec[kRecPhi + 0] * q1z + rec[kRecC1 + 1];
+  const double q2z = rec[kRecPhi + 0] * q1y - rec[kRecPhi + 1] * q1x + rec[kRecC1 + 2];
+  const double hx = x + al * q1x + be * q2x;
+  const double hy = y + al * q1y + be * q2y;
+  const double hz = z + al * q1z + be * q2z;
+  rec = after(rec, hz);  // rho and c2
+  ox = hx + s * rec[kRecRho + 0] + ga * rec[kRecC2 + 0];
+  oy = hy + s * rec[kRecRho + 1] + ga * rec[kRecC2 + 1];
+  oz = hz + s * rec[kRecRho + 2] + ga * rec[kRecC2 + 2];
+}
+
+// one point of a two-pose frame; `rec` addresses a FrameRecD
+static_assert(offsetof(FrameRecD, phi) == 8 * kRecPhi && offsetof(FrameRecD, rho) == 8 * kRecRho && offsetof(FrameRecD, c1) == 8 * kRecC1 &&
+                  offsetof(FrameRecD, c2) == 8 * kRecC2 && offsetof(FrameRecD, phi2) == 8 * kRecPhi2 && offsetof(FrameRecD, x_req) == 8 * 13,
+              "exp_apply_f64_lean / deskew_point_redo_f64 index FrameRecD as an array of doubles");
+__device__ __forceinline__ v4f deskew_point_redo_f64(const v4f p, cdouble_p rec) {
+  const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+  const double frac = scan_fraction_f64_lean(x, y);
+  rec = after(rec, frac);  // phi2 and x_req
+  double ox, oy, oz;
+  exp_apply_f64_lean(rec, frac - rec[13], rec[kRecPhi2], x, y, z, ox, oy, oz);
+  return v4f{(float)ox, (float)oy, (float)oz, p.w};
+}
+
+// The guard is split in two so that the f64 work sits AFTER the wave's regular store, when the f32 result and the f32 frame
+// record are dead (register pressure: the f32 kernels must stay at <= 64 VGPRs):
+//   1. hot:  o = deskew_point(p, f);  redo = needs_redo(p, o, f);  lanes with !redo store o;
+//   2. cold: redo_lanes(redo, p, tbl, fi, store) -- the flagged lanes are recomputed in f64 and stored through `store`.
+// `tbl[fi]` is the lane's frame in f64.  The flagged lanes are redone frame by frame (a waterfall over the distinct `fi`
+// among them -- one turn unless the wave straddles a frame boundary) so that the record is always read at a wave-uniform
+// address.
+__device__ __forceinline__ bool needs_redo(const v4f p, const v4f o, const FrameRec& f) {
+  return lost_significance(p, o, rho_norm2(f.rho_x, f.rho_y, f.rho_z));
+}
+template <typename STORE>
+__device__ __forceinline__ void redo_lanes(bool redo, const v4f p, const FrameRecD* __restrict__ tbl, uint32_t fi, STORE&& store) {
+  uint64_t todo = __builtin_amdgcn_ballot_w64(redo);
+  while (__builtin_expect(todo != 0, 0)) {  // wave-uniform, cold
+    const uint32_t fu = (uint32_t)__builtin_amdgcn_readlane((int)fi, __builtin_ctzll(todo));
+    // the record index is a copy of fu made through `opaque_uniform`: inside `if (fi == fu)` the optimiser would otherwise
+    // replace the uniform fu by the per-lane fi, and the record would be gathered per lane (32 VGPRs) instead of scalar-loaded
+    const uint32_t fu_idx = opaque_uniform(fu);
+    const bool mine = redo && fi == fu;
+    if (mine) store(deskew_point_redo_f64(p, as_constant(tbl + fu_idx)));
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+  }
+}
+// the single-frame kernels: ONE record, at `rec` (in the kernel's own argument segment, see deskew_frame_f32)
+template <typename STORE>
+__device__ __forceinline__ void redo_lanes(bool redo, const v4f p, cdouble_p rec, STORE&& store) {
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo) != 0, 0)) {  // wave-uniform, cold
+    if (redo) store(deskew_point_redo_f64(p, rec));
+  }
+}
+
+// f64 twin of TrajSeg32 for the guarded redo of the N-knot kernels (240 B, global memory, read by guarded waves only)
+struct alignas(16) TrajSegD {
+  double phi[3];
+  double rho[3];
+  double c1[3];
+  double c2[3];
+  double phi2;
+  double c, g;         // scan fraction of the segment's start knot; scan duration / segment duration
+  double a;            // anchor: x_req inside the anchor's own segment, 0 elsewhere;  s = (frac - c) g - a
+  double M[12];        // row-major 3x4 anchor transform
+  uint64_t identity;   // M = I (the segment that contains requested_time)
+  double pad;
+};
+static_assert(sizeof(TrajSegD) == 240, "TrajSegD must stay 240 bytes");
+static_assert(offsetof(TrajSegD, phi) == 8 * kRecPhi && offsetof(TrajSegD, rho) == 8 * kRecRho && offsetof(TrajSegD, c1) == 8 * kRecC1 &&
+                  offsetof(TrajSegD, c2) == 8 * kRecC2 && offsetof(TrajSegD, phi2) == 8 * kRecPhi2 && offsetof(TrajSegD, c) == 8 * 13 &&
+                  offsetof(TrajSegD, g) == 8 * 14 && offsetof(TrajSegD, a) == 8 * 15 && offsetof(TrajSegD, M) == 8 * 16 &&
+                  offsetof(TrajSegD, identity) == 8 * 28,
+              "traj_point_redo_f64 indexes TrajSegD as an array of doubles");
+
+__device__ __forceinline__ v4f traj_point_redo_f64(const v4f p, cdouble_p rec) {
+  const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+  const double frac = scan_fraction_f64_lean(x, y);
+  rec = after(rec, frac);  // phi2, c, g, a
+  const double s = (frac - rec[13]) * rec[14] - rec[15];  // two knots on the scan: (frac - 0) * 1 - x_req, exactly deskew_point_redo_f64
+  double qx, qy, qz;
+  exp_apply_f64_lean(rec, s, rec[kRecPhi2], x, y, z, qx, qy, qz);
+  rec = after(rec, qz);  // identity flag and M
+  if (__builtin_bit_cast(uint64_t, rec[28]) == 0) {
+    const double rx = rec[16] * qx + rec[17] * qy + rec[18] * qz + rec[19];
+    const double ry = rec[20] * qx + rec[21] * qy + rec[22] * qz + rec[23];
+    const double rz = rec[24] * qx + rec[25] * qy + rec[26] * qz + rec[27];
+    qx = rx; qy = ry; qz = rz;
+  }
+  return v4f{(float)qx, (float)qy, (float)qz, p.w};
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -112,6 +112,21 @@ void fill_rec(const kmc_frame_params& p, REC* r) {
   r->c2_x = (float)c2.x; r->c2_y = (float)c2.y; r->c2_z = (float)c2.z;
 }
 
+// the same constants in f64, for the near-origin guard's redo (kmc_device_math.hip.h)
+inline void fill_recd(const kmc_frame_params& p, FrameRecD* d) {
+  const kmc_host::Vec3 rho = {p.twist[0], p.twist[1], p.twist[2]};
+  const kmc_host::Vec3 phi = {p.twist[3], p.twist[4], p.twist[5]};
+  const kmc_host::Vec3 c1 = kmc_host::cross(phi, rho);
+  const kmc_host::Vec3 c2 = kmc_host::cross(phi, c1);
+  d->phi[0] = phi.x; d->phi[1] = phi.y; d->phi[2] = phi.z;
+  d->rho[0] = rho.x; d->rho[1] = rho.y; d->rho[2] = rho.z;
+  d->c1[0] = c1.x; d->c1[1] = c1.y; d->c1[2] = c1.z;
+  d->c2[0] = c2.x; d->c2[1] = c2.y; d->c2[2] = c2.z;
+  d->phi2 = kmc_host::dot(phi, phi);
+  d->x_req = p.x_req;
+  d->pad[0] = d->pad[1] = 0.0;
+}
+
 // Device-resident buffers: distance (in points, < 64) from the last 1 KiB boundary to the start of the OUTPUT.  The kernels are
 // launched on pointers moved back by that much with the first `head` indices dead, so that every tile stores whole aligned
 // lines whatever 16-byte-aligned address the caller passes ("alignment").

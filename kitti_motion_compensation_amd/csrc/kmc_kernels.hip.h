@@ -68,19 +68,32 @@ __device__ __forceinline__ void tile_store(__amdgpu_buffer_rsrc_t r, uint32_t by
 // single-frame kernel: constants by value (kernarg segment -> s_load -> SGPRs)
 // ------------------------------------------------------------------------------------------------
 template <int TIER, int PPT, int NT, bool OCML_ATAN, int BLOCK = kBlock>
-__global__ __launch_bounds__(BLOCK) void deskew_frame_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
-                                                         uint64_t n, FrameRec f, uint32_t head) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 ? 8 : 4, 8))) void deskew_frame_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
+                                                         uint64_t n, FrameRec f, uint32_t head, FrameRecD d) {
+  // `d`: the frame's constants in f64, read only by a wave that contains a lane the near-origin guard redoes (kmc_device_math).
+  // It is addressed through the kernel-argument segment instead of by name: named, the compiler preloads its 32 SGPRs at
+  // kernel entry and keeps them alive for the whole kernel.
+  struct ArgLayout { const v4f* in; v4f* out; uint64_t n; FrameRec f; uint32_t head; FrameRecD d; };  // == the parameter list
+  const cdouble_p d_rec = (cdouble_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, d));
   // `head` (< 64): the first `head` indices are DEAD.  A caller whose output does not start on a 1 KiB boundary passes
   // pointers moved back to that boundary, n + head and head = the distance in points: every tile's store then covers whole
   // aligned lines (a 16-byte-aligned base measured 5.5 TB/s against 6.8 aligned).  Only tile 0 pays for it.
   constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
   const uint32_t tid = threadIdx.x;
   uint64_t t_begin = blockIdx.x;
+  // one point through plain loads / stores (head tile, ragged tail of the non-descriptor variants)
+  auto one_point = [&](uint64_t i) {
+    const v4f p = load_point<NT>(in + i);
+    const v4f o = deskew_point<TIER, OCML_ATAN>(p, f);
+    const bool redo = needs_redo(p, o, f);
+    if (!redo) store_point<NT>(out + i, o);
+    redo_lanes(redo, p, d_rec, [&](v4f v) { store_point<NT>(out + i, v); });
+  };
   if (head != 0 && t_begin == 0) {
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       const uint64_t i = (uint64_t)u * BLOCK + tid;
-      if (i >= head && i < n) store_point<NT>(out + i, deskew_point<TIER, OCML_ATAN>(load_point<NT>(in + i), f));
+      if (i >= head && i < n) one_point(i);
     }
     t_begin += gridDim.x;
   }
@@ -103,9 +116,19 @@ __global__ __launch_bounds__(BLOCK) void deskew_frame_f32(const v4f* __restrict_
           p[u] = load_point<NT>(in + (i < n ? i : n - 1));  // clamp: the store of a dead lane is clipped anyway
         }
       }
+      uint32_t redo_mask = 0;
 #pragma unroll
-      for (int u = 0; u < PPT; ++u)
-        tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), deskew_point<TIER, OCML_ATAN>(p[u], f));
+      for (int u = 0; u < PPT; ++u) {
+        const v4f o = deskew_point<TIER, OCML_ATAN>(p[u], f);
+        const bool redo = needs_redo(p[u], o, f);
+        redo_mask |= redo ? (1u << u) : 0u;
+        if (!redo) tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), o);
+      }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo_mask != 0) != 0, 0)) {  // near-origin guard, cold
+#pragma unroll
+        for (int u = 0; u < PPT; ++u)
+          redo_lanes(((redo_mask >> u) & 1u) != 0, p[u], d_rec, [&](v4f v) { tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), v); });
+      }
     }
     return;
   }
@@ -116,8 +139,19 @@ __global__ __launch_bounds__(BLOCK) void deskew_frame_f32(const v4f* __restrict_
     v4f p[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * BLOCK + tid);
+    uint32_t redo_mask = 0;
 #pragma unroll
-    for (int u = 0; u < PPT; ++u) store_point<NT>(tout + u * BLOCK + tid, deskew_point<TIER, OCML_ATAN>(p[u], f));
+    for (int u = 0; u < PPT; ++u) {
+      const v4f o = deskew_point<TIER, OCML_ATAN>(p[u], f);
+      const bool redo = needs_redo(p[u], o, f);
+      redo_mask |= redo ? (1u << u) : 0u;
+      if (!redo) store_point<NT>(tout + u * BLOCK + tid, o);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo_mask != 0) != 0, 0)) {  // near-origin guard, cold
+#pragma unroll
+      for (int u = 0; u < PPT; ++u)
+        redo_lanes(((redo_mask >> u) & 1u) != 0, p[u], d_rec, [&](v4f v) { store_point<NT>(tout + u * BLOCK + tid, v); });
+    }
   }
   // ragged tail (< kTile points): handled by the workgroup that would own tile n_full
   if (blockIdx.x == n_full % gridDim.x && !(head != 0 && n_full == 0)) {
@@ -125,7 +159,7 @@ __global__ __launch_bounds__(BLOCK) void deskew_frame_f32(const v4f* __restrict_
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       const uint64_t i = base + (uint64_t)u * BLOCK + tid;
-      if (i < n) store_point<NT>(out + i, deskew_point<TIER, OCML_ATAN>(load_point<NT>(in + i), f));
+      if (i < n) one_point(i);
     }
   }
 }
@@ -178,10 +212,12 @@ constexpr uint32_t kSplitSearch = 0xFFFFFFFFu;  // two or more boundaries (tiny 
 //      record from LDS; a wave whose lanes all landed in one frame broadcasts the index through readfirstlane and stays on
 //      the uniform path.
 template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock>
-__global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 ? 8 : 4, 8))) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
                                                          const BatchRec* __restrict__ recs,
                                                          const uint2* __restrict__ coarse, uint32_t n_frames,
-                                                         uint64_t n, uint32_t* __restrict__ frame_idx_out, uint32_t head) {
+                                                         uint64_t n, uint32_t* __restrict__ frame_idx_out, uint32_t head,
+                                                         const FrameRecD* __restrict__ recs64) {
+  // `recs64[f]`: frame f's constants in f64 for the near-origin guard's redo (kmc_device_math); cold
   // `head`: dead leading indices, see deskew_frame_f32 (the host has shifted the pointers and every offset by it)
   static_assert(BLOCK >= kLdsFrames * 4, "the LDS staging uses one lane per 16 bytes of the record table");
   constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
@@ -215,16 +251,23 @@ __global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict_
       f0 = lo;
     }
     const BatchRec r0 = recs[f0];
+    // near-origin guard (kmc_device_math): lanes whose f32 result lost significance are flagged here, skipped by the regular
+    // stores and redone in f64 at the end of the tile -- ONE cold site for both paths below
+    uint32_t redo_mask = 0;
+    uint32_t fi_of[PPT];
     if (full && rec_end(r0) >= tile_end) {
       const FrameRec f = to_frame(r0);
-      if constexpr (NT & kStoreSc1) {
-        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(tout, kTile * sizeof(v4f));
+      const __amdgpu_buffer_rsrc_t rout = tile_rsrc(tout, kTile * sizeof(v4f));
 #pragma unroll
-        for (int u = 0; u < PPT; ++u)
-          tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), deskew_point<TIER, false>(p[u], f));
-      } else {
-#pragma unroll
-        for (int u = 0; u < PPT; ++u) store_point<NT>(tout + u * BLOCK + tid, deskew_point<TIER, false>(p[u], f));
+      for (int u = 0; u < PPT; ++u) {
+        const v4f o = deskew_point<TIER, false>(p[u], f);
+        const bool redo = needs_redo(p[u], o, f);
+        redo_mask |= redo ? (1u << u) : 0u;
+        fi_of[u] = f0;
+        if (!redo) {
+          if constexpr (NT & kStoreSc1) tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), o);
+          else store_point<NT>(tout + u * BLOCK + tid, o);
+        }
       }
       if constexpr (WRITE_IDX) {
 #pragma unroll
@@ -253,6 +296,7 @@ __global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict_
             ++fi;
           }
         }
+        fi_of[u] = fi;
         // wave-level broadcast when the whole wave sits in one frame
         const uint32_t fi0 = __builtin_amdgcn_readfirstlane(fi);
         const bool wave_uniform = __all(fi == fi0);
@@ -266,11 +310,22 @@ __global__ __launch_bounds__(BLOCK) void deskew_batch_f32(const v4f* __restrict_
         }
         if (live) {
           const FrameRec f = to_frame(r);
-          const v4f pt = full ? p[u] : load_point<NT>(in + i);
-          store_point<NT>(out + i, deskew_point<TIER, false>(pt, f));
+          if (!full) p[u] = load_point<NT>(in + i);
+          const v4f o = deskew_point<TIER, false>(p[u], f);
+          const bool redo = needs_redo(p[u], o, f);
+          redo_mask |= redo ? (1u << u) : 0u;
+          if (!redo) store_point<NT>(out + i, o);
           if constexpr (WRITE_IDX) frame_idx_out[i] = fi;
         }
       }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo_mask != 0) != 0, 0)) {  // cold
+      // stores through a descriptor (one VGPR of address state instead of a 64-bit pointer per point); only live lanes are flagged
+      const __amdgpu_buffer_rsrc_t rfix = tile_rsrc(tout, (tile_end - base) * sizeof(v4f));
+#pragma unroll
+      for (int u = 0; u < PPT; ++u)
+        redo_lanes(((redo_mask >> u) & 1u) != 0, p[u], recs64, fi_of[u],
+                   [&](v4f v) { tile_store<NT>(rfix, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), v); });
     }
   }
 }
@@ -386,8 +441,10 @@ __global__ __launch_bounds__(64) void pseudo_timestamps_f64(const double* __rest
 //   4. a wave whose lanes share one bracket -- all but the few waves that contain a knot's azimuth -- broadcasts it through
 //      readfirstlane and reads its record at a uniform LDS address; a wave that straddles a knot gathers per lane;
 //   5. fused exp-map + rotate + translate per lane, then the 3x4 anchor transform unless the segment is the anchor's own.
+// `redo`: the near-origin guard's verdict (kmc_device_math); flagged lanes are not stored by the hot path but recomputed in f64
+// by traj_redo_lanes after it.
 template <int TIER>
-__device__ __forceinline__ v4f traj_point(const v4f p, const TrajSeg32& r) {
+__device__ __forceinline__ v4f traj_point(const v4f p, const TrajSeg32& r, bool& redo) {
   FrameRec f;
   f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
   f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
@@ -404,13 +461,28 @@ __device__ __forceinline__ v4f traj_point(const v4f p, const TrajSeg32& r) {
     o.w = q.w;
     q = o;
   }
+  redo = lost_significance(p, q, rho_norm2(r.rho_x, r.rho_y, r.rho_z) + r.guard2);
   return q;
+}
+// cold half: `segs64[k]` is the f64 twin of the lane's segment record; a waterfall over the brackets of the flagged lanes keeps
+// the record address wave-uniform (scalar loads), see redo_lanes
+template <typename STORE>
+__device__ __forceinline__ void traj_redo_lanes(bool redo, const v4f p, const TrajSegD* __restrict__ segs64, uint32_t k, STORE&& store) {
+  uint64_t todo = __builtin_amdgcn_ballot_w64(redo);
+  while (__builtin_expect(todo != 0, 0)) {  // wave-uniform, cold
+    const uint32_t ku = (uint32_t)__builtin_amdgcn_readlane((int)k, __builtin_ctzll(todo));
+    const uint32_t ku_idx = opaque_uniform(ku);
+    const bool mine = redo && k == ku;
+    if (mine) store(traj_point_redo_f64(p, as_constant(segs64 + ku_idx)));
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+  }
 }
 
 template <int TIER, int NT, bool WRITE_IDX>
-__global__ __launch_bounds__(64) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                      const TrajSeg32* __restrict__ segs, uint32_t n_seg,
-                                                     uint32_t* __restrict__ bracket_out, uint32_t head) {
+                                                     uint32_t* __restrict__ bracket_out, uint32_t head,
+                                                     const TrajSegD* __restrict__ segs64) {
   // `head`: dead leading indices, see deskew_frame_f32
   constexpr int BLOCK = 64;
   __shared__ TrajSeg32 lds[kMaxSegments];
@@ -434,16 +506,19 @@ __global__ __launch_bounds__(64) void deskew_traj_f32(const v4f* __restrict__ in
     }
     const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
     const uint32_t ks = __all(k == k0) ? k0 : k;  // uniform bracket -> uniform LDS address (broadcast), else per-lane gather
-    const v4f q = traj_point<TIER>(p, lds[ks]);
+    bool redo;
+    const v4f q = traj_point<TIER>(p, lds[ks], redo);
+    redo = redo && alive;
+    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
     if constexpr (NT & kStoreSc1) {
-      const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
-      if (i >= head) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
+      if (i >= head && !redo) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
     } else {
-      if (alive) store_point<NT>(out + i, q);
+      if (alive && !redo) store_point<NT>(out + i, q);
     }
     if constexpr (WRITE_IDX) {
       if (alive) __builtin_nontemporal_store(k, bracket_out + i);
     }
+    traj_redo_lanes(redo, p, segs64, k, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
   }
 }
 
@@ -461,7 +536,7 @@ struct alignas(16) TrajFrameRec {
 __device__ __forceinline__ uint64_t rec_end(const TrajFrameRec& r) { return ((uint64_t)r.end_hi << 32) | r.end_lo; }
 
 template <int TIER>
-__device__ __forceinline__ v4f traj_lane(const v4f p, const TrajSeg32* lds, uint32_t n_seg, uint32_t& k_out) {
+__device__ __forceinline__ v4f traj_lane(const v4f p, const TrajSeg32* lds, uint32_t n_seg, uint32_t& k_out, bool& redo) {
   uint32_t k = 0;
   for (uint32_t j = 1; j < n_seg; ++j) {  // interior knots
     const v4f kn = reinterpret_cast<const v4f*>(&lds[j])[7];  // {knot_cos, knot_sin, flags, knot_c}
@@ -470,16 +545,17 @@ __device__ __forceinline__ v4f traj_lane(const v4f p, const TrajSeg32* lds, uint
   const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
   const uint32_t ks = __all(k == k0) ? k0 : k;
   k_out = k;
-  return traj_point<TIER>(p, lds[ks]);
+  return traj_point<TIER>(p, lds[ks], redo);
 }
 
 template <int TIER, int NT, bool WRITE_IDX>
-__global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == kTrig || WRITE_IDX) ? 6 : 8, 8))) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                            const TrajFrameRec* __restrict__ frecs,
                                                            const TrajSeg32* __restrict__ segs,
                                                            uint32_t seg_stride, const uint2* __restrict__ coarse,
                                                            uint32_t n_frames, uint32_t* __restrict__ frame_idx_out,
-                                                           uint32_t* __restrict__ bracket_out, uint32_t head) {
+                                                           uint32_t* __restrict__ bracket_out, uint32_t head,
+                                                           const TrajSegD* __restrict__ segs64) {
   // `head`: dead leading indices, see deskew_frame_f32 (the host has shifted the pointers and every offset by it)
   constexpr int BLOCK = 64;
   __shared__ TrajSeg32 lds[kMaxSegments];
@@ -510,15 +586,23 @@ __global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restric
     __syncthreads();  // the previous tile's LDS readers are done (one-wave workgroup: a wait, not a barrier)
     // stage frame f0's slots (all seg_stride of them: the copy does not depend on the header) while the header arrives
     for (uint32_t w = tid; w < seg_stride * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + (uint64_t)f0 * seg_stride)[w];
+    // near-origin guard: flagged lanes remember their segment (frame * seg_stride + bracket) and are redone in f64 at the end
+    // of the tile -- ONE cold site for both paths below
+    bool redo_any = false;
+    uint32_t redo_seg = 0;
+    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
     if (rec_end(r) >= tile_end) {
       __syncthreads();
       uint32_t k;
-      const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k);
+      bool redo;
+      const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k, redo);
+      redo = redo && alive;
+      redo_any = redo;
+      redo_seg = f0 * seg_stride + k;
       if constexpr (NT & kStoreSc1) {
-        const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
-        if (i >= head) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
+        if (i >= head && !redo) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
       } else {
-        if (alive) store_point<NT>(out + i, q);
+        if (alive && !redo) store_point<NT>(out + i, q);
       }
       if constexpr (WRITE_IDX) {
         if (alive) {
@@ -538,9 +622,15 @@ __global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restric
           }
           __syncthreads();
           uint32_t k;
-          const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k);
+          bool redo;
+          const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k, redo);
+          redo = redo && mine;
+          if (redo) {
+            redo_any = true;
+            redo_seg = fi * seg_stride + k;
+          }
           if (mine) {
-            store_point<NT>(out + i, q);
+            if (!redo) store_point<NT>(out + i, q);
             if constexpr (WRITE_IDX) {
               if (frame_idx_out) frame_idx_out[i] = fi;
               if (bracket_out) bracket_out[i] = k;
@@ -554,6 +644,7 @@ __global__ __launch_bounds__(64) void deskew_traj_batch_f32(const v4f* __restric
         r = frecs[fi];
       }
     }
+    traj_redo_lanes(redo_any, p, segs64, redo_seg, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
   }
 }
 
@@ -700,7 +791,10 @@ __device__ __forceinline__ void store_uv_tile(v2i* __restrict__ uv, uint64_t til
 template <int TIER, bool STRUCTURED>
 __global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, uint64_t n, CameraRigRec g, FrameRec f,
                                                   v4f* __restrict__ cloud_out, v2i* __restrict__ uv,
-                                                  uint32_t* __restrict__ bgrv) {
+                                                  uint32_t* __restrict__ bgrv, FrameRecD d) {
+  // `d` is read through the kernel-argument segment only, see deskew_frame_f32
+  struct ArgLayout { const v4f* in; uint64_t n; CameraRigRec g; FrameRec f; v4f* cloud_out; v2i* uv; uint32_t* bgrv; FrameRecD d; };
+  const cdouble_p d_rec = (cdouble_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, d));
   __shared__ v4i xpose[128];
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + 63) / 64;
@@ -710,7 +804,13 @@ __global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, ui
     const bool live = i < n;
     v4f p = __builtin_nontemporal_load(in + (live ? i : n - 1));  // dead lanes of the ragged tile re-read the last point
     if constexpr (TIER >= 0) {
-      p = deskew_point<TIER, false>(p, f);
+      {  // the same cloud kmc_hip_deskew_f32 writes, bit for bit: f32 closed form + the near-origin guard's f64 redo
+        const v4f o = deskew_point<TIER, false>(p, f);
+        const bool redo = needs_redo(p, o, f);
+        v4f fixed = o;
+        redo_lanes(redo, p, d_rec, [&](v4f v) { fixed = v; });
+        p = fixed;
+      }
       if (cloud_out && live) __builtin_nontemporal_store(p, cloud_out + i);
     }
     v2i px[4];

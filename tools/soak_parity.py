@@ -57,12 +57,11 @@ def random_points(rng, n):
 
 
 def check_cloud(acc, key, pts, out, ref, context):
-    """The parity gate: |p - ref| / max(|ref|, 1e-3) <= 1e-5.  A synthetic point can be carried to
-    within centimetres of the sensor origin, where |ref| is a hundred times smaller than the f32 input it came from and
-    the gate measures input quantisation, not the kernel; those points (|ref| < 0.1 |p_in|) are counted and reported
-    (*_max_rel_err_literal covers them, *_max_rel_err does not), and every point is additionally gated on
-    |p - ref| / max(|p_in|, |ref|) <= 2e-6 (*_max_err_over_scale).  An f32 kernel cannot meet 1e-5 of a 1 cm norm: its
-    abscissa s alone carries 6e-8 of a 2 m translation."""
+    """The parity gate, LITERALLY and for every point: |p - ref| / max(|ref|, 1e-3) <= 1e-5
+    (*_max_rel_err_literal).  Points that the ego-motion carries towards the sensor origin (|ref| < 0.1 |p_in|) are the ones an
+    all-f32 kernel fails on; the kernels redo them in f64 (near-origin guard, kmc_device_math.hip.h) and they are counted
+    (*_near_origin_points).  *_max_rel_err is the same quantity away from the origin, *_max_err_over_scale the error relative
+    to the larger of input and output norm (<= 2e-6 everywhere)."""
     d = np.linalg.norm(out[:, :3] - ref, axis=1)
     nref = np.linalg.norm(ref, axis=1)
     nin = np.linalg.norm(pts[:, :3].astype(np.float64), axis=1)
@@ -120,6 +119,37 @@ def batch_round(ctx, rng, acc):
         ref = orc.deskew_xyzi_f32(pts[a:b], T0, orc.se3_exp([0] * 6), T1, orc.se3_exp(list(twists[f])), T0 + xr[f] * (T1 - T0), mode=orc.HOISTED)
         check_cloud(acc, "batch", pts[a:b], out[a:b], ref["xyz_f64"], dict(twist=[float(v) for v in twists[f]], x_req=xr[f]))
     acc["batch_points"] += n
+
+
+def near_origin_round(ctx, rng, acc):
+    """Points built ON the cancellation p ~ -s rho (tests/test_near_origin.py's construction), single-frame and batched."""
+    from tests import test_near_origin as tno
+
+    tier = int(rng.integers(0, 3))
+    nf = int(rng.integers(1, 40))
+    sizes = rng.choice([1, 63, 64, 65, 500, 4000], nf)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    n = int(offsets[-1])
+    pts = np.empty((n, 4), dtype=np.float32)
+    frames = []
+    for f in range(nf):
+        twist, x_req, p_star = tno._frame(rng, tier, jitter=0.3)
+        frames.append((twist, x_req))
+        pts[int(offsets[f]):int(offsets[f + 1])] = tno._scatter(rng, p_star, int(sizes[f]))
+    out = np.empty_like(pts)
+    ctx.deskew_batch_f32(pts, out, offsets, [params_from_twist(t, x) for t, x in frames], None)
+    for f in range(nf):
+        a, b = int(offsets[f]), int(offsets[f + 1])
+        twist, x_req = frames[f]
+        ref = orc.deskew_xyzi_f32(pts[a:b], T0, orc.se3_exp([0] * 6), T1, orc.se3_exp(list(twist)), T0 + x_req * (T1 - T0), mode=orc.HOISTED)
+        check_cloud(acc, "batch", pts[a:b], out[a:b], ref["xyz_f64"], dict(twist=[float(v) for v in twist], x_req=x_req, near_origin=True))
+    f = int(rng.integers(0, nf))
+    a, b = int(offsets[f]), int(offsets[f + 1])
+    one = np.empty_like(pts[a:b])
+    ctx.deskew_f32(np.ascontiguousarray(pts[a:b]), one, params_from_twist(*frames[f]))
+    acc["near_origin_single_vs_batch_mismatch"] += int(np.count_nonzero(one.view(np.uint32) != out[a:b].view(np.uint32)))
+    acc["batch_points"] += n
+    acc["near_origin_rounds"] += 1
 
 
 def projection_round(ctx, rng, acc, calib):
@@ -213,9 +243,10 @@ def main():
     t_end = time.time() + budget
     import torch
 
-    acc.update(subrange_points=0, subrange_failures=0, f64_points=0, f64_max_rel_err=0.0)
+    acc.update(subrange_points=0, subrange_failures=0, f64_points=0, f64_max_rel_err=0.0, near_origin_rounds=0,
+               near_origin_single_vs_batch_mismatch=0)
     while time.time() < t_end:
-        r = acc["rounds"] % 5
+        r = acc["rounds"] % 6
         if r == 0:
             deskew_round(ctx, rng, acc)
         elif r == 1:
@@ -224,6 +255,8 @@ def main():
             projection_round(ctx, rng, acc, calib)
         elif r == 3:
             subrange_round(ctx, rng, acc, torch)
+        elif r == 4:
+            near_origin_round(ctx, rng, acc)
         else:
             f64_round(ctx, rng, acc)
         acc["rounds"] += 1
@@ -232,10 +265,11 @@ def main():
             with open(checkpoint + ".tmp", "w") as fh:
                 json.dump(dict(acc, partial=True, elapsed=round(budget - (t_end - time.time()), 1)), fh)
             os.replace(checkpoint + ".tmp", checkpoint)
-    acc["ok"] = bool(acc["deskew_max_rel_err"] <= 1e-5 and acc["batch_max_rel_err"] <= 1e-5 and acc["deskew_intensity_mismatch"] == 0
+    acc["ok"] = bool(acc["deskew_max_rel_err_literal"] <= 1e-5 and acc["batch_max_rel_err_literal"] <= 1e-5 and acc["deskew_intensity_mismatch"] == 0
                      and acc["deskew_max_err_over_scale"] <= 2e-6 and acc["batch_max_err_over_scale"] <= 2e-6
                      and acc["subrange_failures"] == 0 and acc["f64_max_rel_err"] <= 1e-9
-                     and acc["batch_index_mismatch"] == 0 and acc["projection_int_mismatch"] == 0)
+                     and acc["batch_index_mismatch"] == 0 and acc["projection_int_mismatch"] == 0
+                     and acc["near_origin_single_vs_batch_mismatch"] == 0)
     print(json.dumps(acc))
     sys.exit(0 if acc["ok"] else 1)
 
