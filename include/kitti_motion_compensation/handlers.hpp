@@ -16,8 +16,11 @@ void CopyOverUncompensatedFirstAndLastFrame(Path const run_folder);
 // handlers.cpp:41-65: frames 1 .. n-2 are deskewed to the scan's middle stamp and written to
 // velodyne_points/data_motion_compensated/; first and last are copied through.  Frames are batched on the GPU
 // (kmc_hip_deskew_batch_f32) straight from / to the on-disk f32 layout, with reading, GPU work and writing overlapped.
+// Several GPUs: KMC_DEVICES=0,1,... or kmc::hip::SetRunDevices() -- the frames are cut into one contiguous, point-balanced
+// range per device (the frames of a run are independent), every range on its own device context; the files written are
+// the same whatever the device list.
 // Environment: KMC_RUN_BATCH_FRAMES (frames per GPU batch, default 16), KMC_RUN_KNOTS=3 (use the three OXTS poses around each
-// frame as they are), KMC_RUN_TIMING=1 (busy time per stage on stderr).
+// frame as they are), KMC_RUN_TIMING=1 (busy time per stage on stderr), KMC_DEVICES (device list).
 void MotionCompensateRun(Path const run_folder);
 
 }  // namespace kmc

@@ -49,6 +49,12 @@ namespace hip {
 void SetDevice(int device_id);
 int GetDevice();
 
+// Devices of kmc::MotionCompensateRun (handlers.hpp): one worker with its own device context per entry, each deskewing one
+// contiguous, point-balanced range of the run's frames.  An id may repeat (several contexts on one GPU).  Empty list =
+// back to the default: $KMC_DEVICES ("0,1,2,..."), else the calling thread's device.  Process-wide setting.
+void SetRunDevices(std::vector<int> const& devices);
+std::vector<int> GetRunDevices();
+
 // One frame in the on-disk KITTI layout (f32 AoS x,y,z,intensity): fuses GetPseudoTimeStamps (data_io.cpp:163),
 // MotionCompensateFrame (handlers.cpp:60) and WritePointcloud's f64->f32 cast (data_io.cpp:300-310) in one kernel.
 // xyzi_in / xyzi_out are HOST pointers here (16-byte aligned); use the C-ABI directly for device-resident buffers.

@@ -148,6 +148,15 @@ int kmc_interpolate_trajectory(const kmc_oxts* o1, const kmc_oxts* o2, double ti
 int kmc_make_frame_poses(const kmc_oxts* o_nm1, const kmc_oxts* o_n, const kmc_oxts* o_np1, double stamp_start,
                          double stamp_end, double T_start_out[12], double T_end_out[12]);
 
+/* Frame-range sharding (north_star: "one KITTI drive split into contiguous frame ranges per rank"; the frames of
+ * motion_compensation.cpp:22-25's callers are independent, handlers.cpp:55-64).  Splits n_frames frames of
+ * frame_points[f] points each into n_parts CONTIGUOUS ranges balanced on POINT counts: part r owns the frames whose
+ * point-prefix midpoint lies in [r, r+1) * total / n_parts (integer arithmetic, no rounding).  bounds_out has n_parts + 1
+ * entries, bounds_out[0] = 0, bounds_out[n_parts] = n_frames; part r = frames [bounds_out[r], bounds_out[r+1]).
+ * With all-zero sizes the split is by frame count.  Used by MotionCompensateRun's multi-device driver and, through
+ * ctypes, by the Python sharding helpers -- one definition for ranks and devices. */
+int kmc_frame_ranges_balanced(const uint64_t* frame_points, uint32_t n_frames, uint32_t n_parts, uint32_t* bounds_out);
+
 /* ------------------------------------------------------------------------------------------------
  * the hot path
  * ---------------------------------------------------------------------------------------------- */

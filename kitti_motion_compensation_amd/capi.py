@@ -129,6 +129,7 @@ SIGNATURES = {
     "kmc_oxts_to_pose": (C.c_int, [C.POINTER(Oxts), C.c_double, _dp]),
     "kmc_interpolate_trajectory": (C.c_int, [C.POINTER(Oxts), C.POINTER(Oxts), C.c_double, _dp]),
     "kmc_make_frame_poses": (C.c_int, [C.POINTER(Oxts), C.POINTER(Oxts), C.POINTER(Oxts), C.c_double, C.c_double, _dp, _dp]),
+    "kmc_frame_ranges_balanced": (C.c_int, [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "kmc_hip_deskew_f32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(FrameParams), C.c_int, C.POINTER(Stats)]),
     "kmc_hip_deskew_batch_f32": (
         C.c_int,
@@ -276,6 +277,17 @@ def make_frame_poses(o_nm1: Oxts, o_n: Oxts, o_np1: Oxts, stamp_start: float, st
     if rc != OK:
         raise KmcError(rc, "kmc_make_frame_poses")
     return a.reshape(3, 4), b.reshape(3, 4)
+
+
+def frame_ranges_balanced(frame_points, n_parts: int) -> np.ndarray:
+    """kmc_frame_ranges_balanced: bounds[0..n_parts] of the contiguous, point-balanced frame ranges (host code, no GPU)."""
+    sizes = np.ascontiguousarray(frame_points, dtype=np.uint64)
+    bounds = np.zeros(n_parts + 1, dtype=np.uint32)
+    rc = lib().kmc_frame_ranges_balanced(sizes.ctypes.data_as(C.POINTER(C.c_uint64)), len(sizes), n_parts,
+                                         bounds.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc != OK:
+        raise KmcError(rc, "kmc_frame_ranges_balanced")
+    return bounds
 
 
 def synth_points_host(n: int, seed: int) -> np.ndarray:

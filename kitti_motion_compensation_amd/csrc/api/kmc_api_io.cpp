@@ -191,36 +191,68 @@ void CopyOverUncompensatedFirstAndLastFrame(Path const run_folder) {  // :19-39
   }
 }
 
-void MotionCompensateRun(Path const run_folder) {  // :41-65
-  Path const velodyne{run_folder / Path{"velodyne_points"}};
-  std::size_t const n_frames{NumberOfFilesInDirectory(velodyne / Path("data"))};
-  Path const out_dir{velodyne / Path("data_motion_compensated")};
-  if (!fs::is_directory(out_dir) || !fs::exists(out_dir)) fs::create_directory(out_dir);
-  if (n_frames == 0) return;
-  CopyOverUncompensatedFirstAndLastFrame(run_folder);
-  if (n_frames < 3) return;
+// ---- devices of the run driver ------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_devices_mu;
+std::vector<int> g_run_devices;  // empty: $KMC_DEVICES, else the calling thread's device
 
-  // every text file is parsed once per run
-  auto const t_start = LoadAllTimeStamps(velodyne / Path("timestamps_start.txt"));
-  auto const t_mid = LoadAllTimeStamps(velodyne / Path("timestamps.txt"));
-  auto const t_end = LoadAllTimeStamps(velodyne / Path("timestamps_end.txt"));
-  auto const t_oxts = LoadAllTimeStamps(run_folder / Path("oxts/timestamps.txt"));
-  if (t_start.size() < n_frames || t_mid.size() < n_frames || t_end.size() < n_frames || t_oxts.size() < n_frames)
-    throw std::runtime_error("timestamp files are shorter than the number of velodyne frames in " + run_folder.string());
-  std::vector<Oxts> oxts(n_frames);
-  for (std::size_t i = 0; i < n_frames; ++i) oxts[i] = LoadOxtsWithStamp(run_folder, i, t_oxts[i]);
+std::vector<int> ParseDeviceList(char const* text) {
+  std::vector<int> out;
+  std::string token;
+  std::istringstream is{std::string(text)};
+  while (std::getline(is, token, ',')) {
+    if (token.empty()) continue;
+    std::size_t used = 0;
+    int const v = std::stoi(token, &used);
+    if (used != token.size() || v < 0) throw std::invalid_argument("KMC_DEVICES: not a device list: " + std::string(text));
+    out.push_back(v);
+  }
+  return out;
+}
+}  // namespace
 
-  // Batches of <= 64 frames through a three-stage pipeline on two page-locked buffer sets:
-  //   reader thread : .bin payloads read STRAIGHT into pinned memory (the on-disk layout is the kernel's layout: no
-  //                   conversion, no extra copy) + the per-frame poses (MakeFrame, data_io.cpp:253-269)
-  //   this thread   : one batched GPU call per buffer set (H2D, kernel, D2H)
-  //   writer thread : results written from pinned memory
-  // so reading batch k+1, deskewing batch k and writing batch k-1 overlap.  KMC_RUN_TIMING=1 prints the busy time per stage.
-  std::size_t const kMaxBatchFrames = [] {  // page-locking costs ~0.3 ms/MiB, so modest batches win for one-off runs
-    char const* e = std::getenv("KMC_RUN_BATCH_FRAMES");
-    long const v = e ? std::atol(e) : 0;
-    return static_cast<std::size_t>(v > 0 ? std::min(v, 4096L) : 16L);
-  }();
+namespace hip {
+void SetRunDevices(std::vector<int> const& devices) {
+  for (int d : devices)
+    if (d < 0) throw std::invalid_argument("kmc::hip::SetRunDevices: negative device id");
+  std::lock_guard<std::mutex> lock(g_devices_mu);
+  g_run_devices = devices;
+}
+std::vector<int> GetRunDevices() {
+  {
+    std::lock_guard<std::mutex> lock(g_devices_mu);
+    if (!g_run_devices.empty()) return g_run_devices;
+  }
+  if (char const* e = std::getenv("KMC_DEVICES")) {
+    auto list = ParseDeviceList(e);
+    if (!list.empty()) return list;
+  }
+  return {GetDevice()};
+}
+}  // namespace hip
+
+namespace {
+// One contiguous frame range [first, last) of a run on ONE device: batches of <= kMaxBatchFrames frames through a
+// three-stage pipeline on two page-locked buffer sets:
+//   reader thread : .bin payloads read STRAIGHT into pinned memory (the on-disk layout is the kernel's layout: no
+//                   conversion, no extra copy) + the per-frame poses (MakeFrame, data_io.cpp:253-269)
+//   this thread   : one batched GPU call per buffer set (H2D, kernel, D2H) on the thread's own device context
+//   writer thread : results written from pinned memory
+// so reading batch k+1, deskewing batch k and writing batch k-1 overlap.
+struct RunInputs {
+  Path velodyne, out_dir;
+  std::vector<Time> const* t_start;
+  std::vector<Time> const* t_mid;
+  std::vector<Time> const* t_end;
+  std::vector<Oxts> const* oxts;
+  std::vector<std::uint64_t> const* frame_points;  // points of every frame of the run (from the file sizes)
+  std::size_t max_batch_frames;
+  bool three_knots, timing;
+};
+std::mutex g_cout_mu;
+
+void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t const last, int const worker) {
+  if (first >= last) return;
   struct Pinned {
     kmc_ctx* ctx = nullptr;
     float* p = nullptr;
@@ -245,29 +277,24 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
     std::vector<hip::FramePoses> frames;
     std::vector<hip::FrameTrajectory> trajectories;  // KMC_RUN_KNOTS=3
   };
-
-  bool const timing = [] { char const* e = std::getenv("KMC_RUN_TIMING"); return e && e[0] == '1'; }();
-  // KMC_RUN_KNOTS=3: interpolate along the piecewise geodesic through the three OXTS poses around the frame, used as they
-  // are, instead of first reducing them to the two scan-end poses like MakeFrame does (data_io.cpp:253-269).
-  bool const three_knots = [] { char const* e = std::getenv("KMC_RUN_KNOTS"); return e && e[0] == '3'; }();
   using clk = std::chrono::steady_clock;
   auto const secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  auto const& t_start = *in.t_start;
+  auto const& t_mid = *in.t_mid;
+  auto const& t_end = *in.t_end;
+  auto const& oxts = *in.oxts;
 
   // plan: file sizes decide the batch boundaries and the buffer size
   std::vector<BatchPlan> plans;
   std::size_t max_points = 0;
-  for (std::size_t b0 = 1; b0 + 1 < n_frames; b0 += kMaxBatchFrames) {
+  for (std::size_t b0 = first; b0 < last; b0 += in.max_batch_frames) {
     BatchPlan plan;
     plan.first = b0;
-    plan.last = std::min(b0 + kMaxBatchFrames, n_frames - 1);
+    plan.last = std::min(b0 + in.max_batch_frames, last);
     plan.offsets.push_back(0);
     for (std::size_t i = plan.first; i < plan.last; ++i) {
-      plan.files.push_back(velodyne / Path("data/" + IdToZeroPaddedString(i) + ".bin"));
-      std::error_code ec;
-      auto const bytes = fs::file_size(plan.files.back(), ec);
-      if (ec) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + plan.files.back().string());
-      if (bytes % 4 != 0) throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + plan.files.back().string());
-      plan.offsets.push_back(plan.offsets.back() + bytes / 16);
+      plan.files.push_back(in.velodyne / Path("data/" + IdToZeroPaddedString(i) + ".bin"));
+      plan.offsets.push_back(plan.offsets.back() + (*in.frame_points)[i]);
     }
     max_points = std::max<std::size_t>(max_points, static_cast<std::size_t>(plan.offsets.back()));
     plans.push_back(std::move(plan));
@@ -313,8 +340,13 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
           std::size_t const i = plan.first + j;
           std::ifstream is{plan.files[j], std::ios::in | std::ios::binary};
           if (!is.is_open()) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + plan.files[j].string());
-          is.read(reinterpret_cast<char*>(set.in.p + 4 * plan.offsets[j]), static_cast<std::streamsize>((plan.offsets[j + 1] - plan.offsets[j]) * 16));
-          if (three_knots) {
+          auto const want = static_cast<std::streamsize>((plan.offsets[j + 1] - plan.offsets[j]) * 16);
+          is.read(reinterpret_cast<char*>(set.in.p + 4 * plan.offsets[j]), want);
+          // a file that shrank or failed since the planning pass would leave the previous batch's bytes in this slot
+          if (is.gcount() != want || is.bad())
+            throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + plan.files[j].string() +
+                                     " (changed while the run was in progress)");
+          if (in.three_knots) {
             hip::FrameTrajectory ft;
             ft.trajectory.times = {oxts[i - 1].stamp, oxts[i].stamp, oxts[i + 1].stamp};
             ft.trajectory.poses = {OxtsToPose(oxts[i - 1]), OxtsToPose(oxts[i]), OxtsToPose(oxts[i + 1])};
@@ -347,7 +379,8 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
         if (!wait_for(set, State::kDone)) return;
         auto const t0 = clk::now();
         for (std::size_t j = 0; j < plan.files.size(); ++j) {
-          WriteRaw(out_dir, plan.first + j, set.out.p + 4 * plan.offsets[j], static_cast<std::size_t>(plan.offsets[j + 1] - plan.offsets[j]));
+          WriteRaw(in.out_dir, plan.first + j, set.out.p + 4 * plan.offsets[j], static_cast<std::size_t>(plan.offsets[j + 1] - plan.offsets[j]));
+          std::lock_guard<std::mutex> lock(g_cout_mu);
           std::cout << "Motion compensated pointcloud number: " << plan.first + j << std::endl;  // handlers.cpp:63
         }
         t_write += secs(t0, clk::now());
@@ -362,7 +395,7 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
       BufferSet& set = sets[k % 2];
       if (!wait_for(set, State::kReady)) break;
       auto const t0 = clk::now();
-      if (three_knots) hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.trajectories, set.out.p);
+      if (in.three_knots) hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.trajectories, set.out.p);
       else hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.frames, set.out.p);
       t_gpu += secs(t0, clk::now());
       publish(set, State::kDone);
@@ -373,9 +406,93 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
   reader.join();
   writer.join();
   if (failure) std::rethrow_exception(failure);
-  if (timing)
-    std::cerr << "kmc run timing, busy seconds per stage: context+pinned " << t_ctx << "  read " << t_read << "  gpu round trip " << t_gpu
-              << "  write " << t_write << "\n";
+  if (in.timing) {
+    std::lock_guard<std::mutex> lock(g_cout_mu);
+    std::cerr << "kmc run timing, worker " << worker << " (device " << hip::GetDevice() << ", frames [" << first << ", " << last
+              << ")), busy seconds per stage: context+pinned " << t_ctx << "  read " << t_read << "  gpu round trip " << t_gpu << "  write "
+              << t_write << "\n";
+  }
+}
+}  // namespace
+
+void MotionCompensateRun(Path const run_folder) {  // :41-65
+  Path const velodyne{run_folder / Path{"velodyne_points"}};
+  std::size_t const n_frames{NumberOfFilesInDirectory(velodyne / Path("data"))};
+  Path const out_dir{velodyne / Path("data_motion_compensated")};
+  if (!fs::is_directory(out_dir) || !fs::exists(out_dir)) fs::create_directory(out_dir);
+  if (n_frames == 0) return;
+  CopyOverUncompensatedFirstAndLastFrame(run_folder);
+  if (n_frames < 3) return;
+
+  // every text file is parsed once per run
+  auto const t_start = LoadAllTimeStamps(velodyne / Path("timestamps_start.txt"));
+  auto const t_mid = LoadAllTimeStamps(velodyne / Path("timestamps.txt"));
+  auto const t_end = LoadAllTimeStamps(velodyne / Path("timestamps_end.txt"));
+  auto const t_oxts = LoadAllTimeStamps(run_folder / Path("oxts/timestamps.txt"));
+  if (t_start.size() < n_frames || t_mid.size() < n_frames || t_end.size() < n_frames || t_oxts.size() < n_frames)
+    throw std::runtime_error("timestamp files are shorter than the number of velodyne frames in " + run_folder.string());
+  std::vector<Oxts> oxts(n_frames);
+  for (std::size_t i = 0; i < n_frames; ++i) oxts[i] = LoadOxtsWithStamp(run_folder, i, t_oxts[i]);
+
+  // points per frame, from the file sizes: they decide the batch boundaries, the buffer sizes and the split across devices
+  std::vector<std::uint64_t> frame_points(n_frames, 0);
+  for (std::size_t i = 1; i + 1 < n_frames; ++i) {
+    Path const file{velodyne / Path("data/" + IdToZeroPaddedString(i) + ".bin")};
+    std::error_code ec;
+    auto const bytes = fs::file_size(file, ec);
+    if (ec) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + file.string());
+    if (bytes % 4 != 0) throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + file.string());
+    frame_points[i] = bytes / 16;
+  }
+
+  RunInputs in;
+  in.velodyne = velodyne;
+  in.out_dir = out_dir;
+  in.t_start = &t_start;
+  in.t_mid = &t_mid;
+  in.t_end = &t_end;
+  in.oxts = &oxts;
+  in.frame_points = &frame_points;
+  in.max_batch_frames = [] {  // page-locking costs ~0.3 ms/MiB, so modest batches win for one-off runs
+    char const* e = std::getenv("KMC_RUN_BATCH_FRAMES");
+    long const v = e ? std::atol(e) : 0;
+    return static_cast<std::size_t>(v > 0 ? std::min(v, 4096L) : 16L);
+  }();
+  in.timing = [] { char const* e = std::getenv("KMC_RUN_TIMING"); return e && e[0] == '1'; }();
+  // KMC_RUN_KNOTS=3: interpolate along the piecewise geodesic through the three OXTS poses around the frame, used as they
+  // are, instead of first reducing them to the two scan-end poses like MakeFrame does (data_io.cpp:253-269).
+  in.three_knots = [] { char const* e = std::getenv("KMC_RUN_KNOTS"); return e && e[0] == '3'; }();
+
+  // The frames of a run are independent (handlers.cpp:55-64 reads nothing it wrote): frames 1 .. n-2 are cut into one
+  // CONTIGUOUS range per device, balanced on points (kmc_frame_ranges_balanced -- the split the per-rank launch uses), and
+  // every range runs its own read / deskew / write pipeline on its own device context.  KMC_DEVICES=0,1,... or
+  // kmc::hip::SetRunDevices select the devices (an id may repeat: two contexts on one GPU); default = the calling thread's.
+  std::vector<int> const devices = hip::GetRunDevices();
+  std::uint32_t const n_parts = static_cast<std::uint32_t>(std::min<std::size_t>(devices.size(), n_frames - 2));
+  std::vector<std::uint32_t> bounds(n_parts + 1);
+  {
+    int const rc = kmc_frame_ranges_balanced(frame_points.data() + 1, static_cast<std::uint32_t>(n_frames - 2), n_parts, bounds.data());
+    if (rc != KMC_OK) detail::throw_status(rc, "kmc_frame_ranges_balanced");
+  }
+  if (n_parts == 1 && devices[0] == hip::GetDevice()) {  // the common case: no extra thread, the caller's own context
+    DeskewFrameRange(in, 1, n_frames - 1, 0);
+    return;
+  }
+  std::vector<std::thread> workers;
+  std::vector<std::exception_ptr> errors(n_parts);
+  for (std::uint32_t r = 0; r < n_parts; ++r) {
+    workers.emplace_back([&, r] {
+      try {
+        hip::SetDevice(devices[r]);  // this worker thread's context lives on its device
+        DeskewFrameRange(in, 1 + bounds[r], 1 + bounds[r + 1], static_cast<int>(r));
+      } catch (...) {
+        errors[r] = std::current_exception();
+      }
+    });
+  }
+  for (auto& w : workers) w.join();
+  for (auto const& e : errors)
+    if (e) std::rethrow_exception(e);
 }
 
 }  // namespace kmc

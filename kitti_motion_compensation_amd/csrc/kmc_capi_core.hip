@@ -317,6 +317,29 @@ int kmc_interpolate_trajectory(const kmc_oxts* o1, const kmc_oxts* o2, double ti
   return KMC_OK;
 }
 
+int kmc_frame_ranges_balanced(const uint64_t* frame_points, uint32_t n_frames, uint32_t n_parts, uint32_t* bounds_out) {
+  if (!bounds_out || n_parts == 0 || (n_frames && !frame_points)) return KMC_ERR_INVALID_ARG;
+  unsigned __int128 total = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) total += frame_points[f];
+  bounds_out[0] = 0;
+  bounds_out[n_parts] = n_frames;
+  if (total == 0) {  // by frame count: sizes differ by at most one frame, earlier parts get the extra
+    const uint32_t base = n_frames / n_parts, extra = n_frames % n_parts;
+    for (uint32_t r = 1; r < n_parts; ++r) bounds_out[r] = r * base + std::min(r, extra);
+    return KMC_OK;
+  }
+  // midpoint of frame f = acc + size / 2 >= r total / parts   <=>   (2 acc + size) parts >= 2 r total
+  unsigned __int128 acc = 0;
+  uint32_t r = 1;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const unsigned __int128 lhs = (2 * acc + frame_points[f]) * n_parts;
+    while (r < n_parts && lhs >= 2 * (unsigned __int128)r * total) bounds_out[r++] = f;
+    acc += frame_points[f];
+  }
+  while (r < n_parts) bounds_out[r++] = n_frames;
+  return KMC_OK;
+}
+
 int kmc_make_frame_poses(const kmc_oxts* o_nm1, const kmc_oxts* o_n, const kmc_oxts* o_np1, double stamp_start,
                          double stamp_end, double T_start_out[12], double T_end_out[12]) {
   int rc = kmc_interpolate_trajectory(o_nm1, o_n, stamp_start, T_start_out);

@@ -21,25 +21,36 @@ def frame_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
 
 def frame_range_balanced(frame_sizes: Sequence[int], rank: int, world: int) -> Tuple[int, int]:
     """Contiguous range chosen on POINT counts (mixed frame sizes, BASELINE.json configs[4]): rank r owns the frames whose
-    point-prefix midpoint falls into [r, r+1) * total / world.  Ranges are contiguous, disjoint and cover every frame."""
-    if world <= 0 or not (0 <= rank < world):
+    point-prefix midpoint falls into [r, r+1) * total / world.  Ranges are contiguous, disjoint and cover every frame.
+    Integer arithmetic, the same definition as the C-ABI's kmc_frame_ranges_balanced (which MotionCompensateRun's multi-device
+    driver uses); tests/test_sharding_gloo.py holds the two against each other."""
+    b = balanced_bounds(frame_sizes, world)
+    if not (0 <= rank < world):
         raise ValueError((rank, world))
-    total = sum(frame_sizes)
+    return b[rank], b[rank + 1]
+
+
+def balanced_bounds(frame_sizes: Sequence[int], world: int) -> List[int]:
+    """bounds[0..world]: part r = frames [bounds[r], bounds[r+1])."""
+    if world <= 0:
+        raise ValueError(world)
+    n = len(frame_sizes)
+    total = sum(int(s) for s in frame_sizes)
     if total == 0:
-        return frame_range(len(frame_sizes), rank, world)
+        return [frame_range(n, r, world)[0] for r in range(world)] + [n]
     bounds = [0] * (world + 1)
-    bounds[world] = len(frame_sizes)
+    bounds[world] = n
     acc, r = 0, 1
     for i, s in enumerate(frame_sizes):
-        mid = acc + s / 2.0
-        while r < world and mid >= r * total / world:
+        lhs = (2 * acc + int(s)) * world  # midpoint acc + s/2 >= r total / world, without rounding
+        while r < world and lhs >= 2 * r * total:
             bounds[r] = i
             r += 1
-        acc += s
+        acc += int(s)
     while r < world:
-        bounds[r] = len(frame_sizes)
+        bounds[r] = n
         r += 1
-    return bounds[rank], bounds[rank + 1]
+    return bounds
 
 
 def multi_drive_ranges(drive_frame_counts: Sequence[int], rank: int, world: int) -> List[Tuple[int, int, int]]:

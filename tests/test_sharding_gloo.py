@@ -102,3 +102,24 @@ def test_world_size_2_gloo_reduction():
 
 def test_single_process_reduction_is_identity():
     assert sharding.reduce_throughput(None, None, 10, 2.0, 1.0) == (10.0, 2.0, 1.0)
+
+
+def test_c_abi_split_is_the_python_split():
+    """kmc_frame_ranges_balanced (what MotionCompensateRun's multi-device driver cuts a run with) against
+    sharding.balanced_bounds (what the per-rank launch uses): one definition, two implementations."""
+    from kitti_motion_compensation_amd import capi
+
+    rng = np.random.default_rng(5)
+    cases = [[], [0, 0, 0], [5, 0, 0, 5], [1], [7] * 9, [0, 9, 0], list(rng.integers(0, 3, 40)),
+             list(rng.integers(90_000, 130_000, size=660)), list(rng.integers(1, 2**40, size=97)), [2**63, 2**63, 2**63 - 1, 1]]
+    for sizes in cases:
+        for parts in (1, 2, 3, 4, 8, 13):
+            got = capi.frame_ranges_balanced(sizes, parts).tolist()
+            want = sharding.balanced_bounds([int(s) for s in sizes], parts)
+            assert got == want, (sizes[:8], parts)
+            assert got[0] == 0 and got[-1] == len(sizes) and all(a <= b for a, b in zip(got, got[1:]))
+    # near-equal point counts per part on KITTI-like sizes
+    sizes = [int(s) for s in rng.integers(90_000, 130_000, size=660)]
+    b = capi.frame_ranges_balanced(sizes, 8).tolist()
+    pts = [sum(sizes[b[r]:b[r + 1]]) for r in range(8)]
+    assert max(pts) - min(pts) <= 2 * max(sizes)
