@@ -11,6 +11,11 @@ far beyond the 256 MiB Infinity Cache, so the GB/s are HBM GB/s) issued as ONE l
 C-ABI (kmc_hip_deskew_batch_f32, KMC_MEM_DEVICE: inputs resident in HBM before the timed region starts).
 Every rank processes its own batch (frame-sharded, weak scaling); RCCL is used only to reduce the counters.
 
+The same invocation then measures, at every N, BASELINE.json configs[3] -- the stream north_star scales on: 10 M-point
+frames x 8 000, rank r owning the contiguous frame range sharding.frame_range(8000, r, N) -- on a stated timed subset of
+each rank's range, and reports it as the "configs3" object of the same JSON line (the headline stays configs[1] at every N,
+so the N = 1 line of a scaling sweep is the BENCH line).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,17 +35,24 @@ BYTES_PER_POINT = 32    # algorithmic: 16 B {x,y,z,intensity} read + 16 B writte
 POINTS_PER_FRAME = 1_000_000
 SEED = 0x4B4D43
 SPIN_UP_STEPS = 12  # untimed, before the W warm-up steps (see main)
+C3_FRAMES_TOTAL = 8000          # BASELINE.json configs[3]: 10 M points per frame x 8 k frames, frame-sharded
+C3_POINTS_PER_FRAME = 10_000_000
+C3_YAW_PER_FRAME = 0.03         # |phi| ~ 0.03 rad per frame
+C3_FRAMES_PER_LAUNCH = 8        # one batched launch = 8 frames = 80 M points = 2.56 GB of traffic
 
 
-def make_workload(capi, n_frames, rank, yaw_per_frame=0.0):
+def make_workload(capi, n_frames, rank, yaw_per_frame=0.0, first_frame=None):
     """configs[1] trajectory: yaw = roll = pitch = 0, 10 m/s east; OXTS at T0 + {.05,.15,.25}, scan T0 + {.10,.15,.20}.
-    yaw_per_frame != 0 turns it into configs[3]'s constant-twist track (|phi| ~ 0.03 per frame)."""
+    yaw_per_frame != 0 turns it into configs[3]'s constant-twist track (|phi| ~ 0.03 per frame).  Frame f of the call is frame
+    first_frame + f of the drive (default: rank * n_frames)."""
     v = 10.0
     dlon = v * 0.1 * 180.0 / (np.pi * 6378137.0)
     params = []
+    if first_frame is None:
+        first_frame = rank * n_frames
     for f in range(n_frames):
-        Tz = 47072.0 + 0.1 * (f + rank * n_frames)
-        k0 = f + rank * n_frames
+        Tz = 47072.0 + 0.1 * ((f + first_frame) % 8000)  # seconds since midnight stay in the reference's range
+        k0 = f + first_frame
         ox = [capi.Oxts(stamp=Tz + 0.05 + 0.1 * i, lat=0.0, lon=dlon * (k0 + i), alt=0, roll=0, pitch=0,
                         yaw=((yaw_per_frame * (k0 + i) + np.pi) % (2 * np.pi)) - np.pi if yaw_per_frame else 0) for i in range(3)]
         t0, tm, t1 = Tz + 0.10, Tz + 0.15, Tz + 0.20
@@ -121,7 +133,7 @@ def live_traffic(frames_per_step, points_per_frame, yaw_per_frame, calibration):
     for counter, factor in (("FETCH_SIZE", calibration["fetch_correction_factor"]), ("WRITE_SIZE", calibration["write_correction_factor"])):
         out = tempfile.mkdtemp(prefix="kmc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--frames-per-step", str(frames_per_step),
+               "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--no-configs3", "--frames-per-step", str(frames_per_step),
                "--points-per-frame", str(points_per_frame), "--yaw-per-frame", str(yaw_per_frame)]
         env = dict(os.environ)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "KMC_BENCH_FORCE_DIST"):
@@ -140,6 +152,75 @@ def live_traffic(frames_per_step, points_per_frame, yaw_per_frame, calibration):
         total += sum(vals) / len(vals) * 1024.0 * factor  # counters are in KiB
     return total
 
+def run_configs3(capi, sharding, torch, ctx, dist, rank, world, d_in, d_out, timed_frames, check):
+    """BASELINE.json configs[3] -- the stream north_star scales on: 10 M-point frames x 8 000, rank r owns the contiguous
+    frame range sharding.frame_range(8000, r, world) (motion_compensation.cpp:22-25's callers make frames independent).
+    Timed: the first `timed_frames` frames of the rank's range, C3_FRAMES_PER_LAUNCH frames per batched launch, over >= 2
+    rotating buffer groups of distinct device-generated frames (sub-ranges of the headline's resident buffers), constant-
+    twist track with |phi| ~ 0.03 rad per frame.  The per-frame f64 host pre-step (MakeFrame + Log, ~1 us per frame in the C++
+    driver) is done before the timed region, like the headline's.  Outside the timed region the rank's first and last timed
+    frames are checked against the oracle (full 10 M points each).  -> dict of this rank's counters."""
+    per, B = C3_POINTS_PER_FRAME, C3_FRAMES_PER_LAUNCH
+    groups = (d_in.shape[0] // per) // B
+    assert groups >= 2, "configs3 needs at least two rotating buffer groups"
+    begin, end = sharding.frame_range(C3_FRAMES_TOTAL, rank, world)
+    T = min(timed_frames, end - begin)
+    T -= T % B
+    assert T >= B
+    n_data = groups * B  # distinct frames resident per rank
+    for j in range(n_data):
+        ctx.synth_points(d_in[j * per:(j + 1) * per], per, SEED + 0xC3000000 + begin + j)
+    work = make_workload(capi, T, rank, C3_YAW_PER_FRAME, first_frame=begin)
+    launches = []
+    offsets = np.arange(B + 1, dtype=np.uint64) * per
+    for l in range(T // B):
+        g = l % groups
+        launches.append((d_in[g * B * per:(g + 1) * B * per], d_out[g * B * per:(g + 1) * B * per],
+                         capi.params_array([w[0] for w in work[l * B:(l + 1) * B]])))
+
+    def sweep():
+        for a, b, prm in launches:
+            ctx.deskew_batch_f32(a, b, offsets, prm, None)
+
+    for a, b, prm in launches[:min(len(launches), 2 * groups)]:  # untimed: table ring sized, clocks up
+        ctx.deskew_batch_f32(a, b, offsets, prm, None)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_begin()
+    sweep()
+    ev_ms = ctx.timer_end()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    res = {"range": (begin, end), "timed_frames": T, "points": float(T * per), "wall": wall, "ev_s": ev_ms * 1e-3, "parity_err": 0.0,
+           "groups": groups}
+    if check:  # parity, outside any timing: first and last timed frame of the rank, whole frames, FAITHFUL oracle
+        from oracle import oracle as orc
+
+        worst = 0.0
+        for f in (0, T - 1):
+            j = ((f // B) % groups) * B + f % B  # where frame f's points live
+            src = d_in[j * per:(j + 1) * per]
+            dst = d_out[:per]
+            ctx.deskew_batch_f32(src, dst, np.array([0, per], dtype=np.uint64), capi.params_array([work[f][0]]), None)
+            torch.cuda.synchronize()
+            pts, got = src.cpu().numpy(), dst.cpu().numpy()
+            (t_s, t_m, t_e), oxs = work[f][1], work[f][2]
+            oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
+            rc, A, Bp = orc.make_frame_poses(oo[0], oo[1], oo[2], t_s, t_e)
+            ref = orc.deskew_xyzi_f32(pts, t_s, A, t_e, Bp, t_m, mode=orc.FAITHFUL)
+            assert rc == orc.OK and ref["rc"] == orc.OK
+            err = np.linalg.norm(got[:, :3] - ref["xyz_f64"], axis=1) / np.maximum(np.linalg.norm(ref["xyz_f64"], axis=1), 1e-3)
+            assert np.array_equal(got[:, 3].view(np.uint32), pts[:, 3].view(np.uint32)), "configs3: intensity not bit-identical"
+            worst = max(worst, float(err.max()))
+        assert worst <= 1e-5, f"configs3 parity violated on rank {rank}: {worst:.3e}"
+        res["parity_err"] = worst
+    return res
+
 
 def main():
     global POINTS_PER_FRAME
@@ -152,9 +233,12 @@ def main():
                     help="1000000 = BASELINE.json configs[1] (the default, the headline); 10000000 with --frames-per-step 24 "
                          "--yaw-per-frame 0.03 = the per-GPU share of configs[3]'s 10 M-point-per-frame stream")
     ap.add_argument("--yaw-per-frame", type=float, default=0.0)
-    ap.add_argument("--live-traffic", action="store_true",
-                    help="measure roofline.traffic now (two extra rocprofv3 --pmc child runs, ~1 minute) instead of scaling the "
-                         "per-point figure of the committed PMC passes (profiles/pmc_traffic.json)")
+    ap.add_argument("--live-traffic", action="store_true", help="(default at N = 1; kept for older command lines)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child runs of the same workload, ~1 minute, "
+                         "N = 1 only); the per-point figure of the committed PMC passes (profiles/pmc_traffic.json) is scaled instead")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the configs[3] leg (10 M-point frames, frame-sharded)")
+    ap.add_argument("--configs3-frames", type=int, default=480, help="timed frames per rank of the configs[3] leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
     ap.add_argument("--rotate", type=int, default=1, help="number of in/out buffer pairs cycled through by the steps")
@@ -245,24 +329,45 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t_begin
 
-    # the job's ONLY collective: SUM of points, MAX of times (RCCL all-reduce when N > 1)
-    pts_total, t_max, ev_max_s = sharding.reduce_throughput(dist, reduce_dev, float(n * args.steps), wall, ev_ms * 1e-3)
+    # the sample the cpu_baseline leg needs, before the configs[3] leg reuses the buffers
+    cpu_sample = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        k_cpu = min(args.cpu_sample_frames, F, max(1, 32_000_000 // POINTS_PER_FRAME))  # ~10-30 s of single-thread oracle work
+        cpu_sample = (k_cpu, d_in[:k_cpu * POINTS_PER_FRAME].cpu().numpy(), d_outs[(state["k"] - 1) % R][:POINTS_PER_FRAME].cpu().numpy())
+
+    # ---- configs[3] leg: the 10 M-point-per-frame stream, rank r on frames frame_range(8000, r, N) ----
+    c3 = None
+    if not args.no_configs3 and n >= 2 * C3_FRAMES_PER_LAUNCH * C3_POINTS_PER_FRAME:
+        c3 = run_configs3(capi, sharding, torch, ctx, dist, rank, world, d_in, d_out, args.configs3_frames, check=not args.no_cpu_baseline)
+
+    # the job's ONLY collective (RCCL when N > 1): one all_gather of every rank's counters; SUM of points, MAX of times
+    sums, maxes = sharding.reduce_counters(
+        dist, reduce_dev, [float(n * args.steps), c3["points"] if c3 else 0.0],
+        [wall, ev_ms * 1e-3, c3["wall"] if c3 else 0.0, c3["ev_s"] if c3 else 0.0, c3["parity_err"] if c3 else 0.0])
+    pts_total, t_max = sums[0], maxes[0]
 
     if rank == 0:
-        kernel_ms = ev_ms / args.steps  # average launch duration of the dominant kernel, HIP events, this rank
-        achieved = BYTES_PER_POINT * n / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs of
-        # this same command, corrected as MI355X_MICROARCH.md section HBM prescribes; tools/summarize_profiles.py).
-        # Counters cannot be read from inside the process, so the figure is per-point and scaled to this launch size.
-        traffic = None
+        step_ms = ev_ms / args.steps  # HIP-event time of the timed region / steps on this rank's launch stream: the kernel plus
+        # whatever the stream waited for between two launches (per-step table upload, host-side table build)
+        achieved = BYTES_PER_POINT * n / (step_ms * 1e-3) / 1e9
+        # HBM bytes per launch: measured in THIS run at N = 1 (two rocprofv3 --pmc child runs of the same workload, FETCH_SIZE
+        # and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md's HBM section prescribes with the factors
+        # profiles/pmc_traffic.json derived from the copy kernel); if the box does not allow counter collection, or N > 1, the
+        # per-point figure of the committed passes is scaled to this launch size -- traffic_source says which.
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fjson:
                 tj = json.load(fjson)
             traffic = round(tj["hbm_bytes_per_point"] * n)
-            if args.live_traffic and world == 1:
+            traffic_source = "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command), per point x points per launch"
+            if world == 1 and dist is None and not args.no_live_traffic:
                 live = live_traffic(F, POINTS_PER_FRAME, args.yaw_per_frame, tj)
-                traffic = round(live) if live else traffic
+                if live:
+                    traffic = round(live)
+                    traffic_source = "measured in this run: rocprofv3 --pmc child runs of this invocation (FETCH_SIZE, WRITE_SIZE passes)"
+                else:
+                    traffic_source += " -- counter collection was not possible on this box"
         out = {
             "metric": "M points/sec deskewed",
             "value": round(pts_total / t_max / 1e6, 1),
@@ -286,17 +391,31 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "traffic_source": "rocprofv3 --pmc child runs of this invocation" if (args.live_traffic and world == 1 and traffic) else
-                                  "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command), per point x points per launch",
-                "bytes_per_point": BYTES_PER_POINT, "points_per_launch": n, "kernel_ms_avg": round(kernel_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "bytes_per_point": BYTES_PER_POINT, "points_per_launch": n, "kernel_ms_avg": round(step_ms, 4),
+                "kernel_ms_avg_is": "HIP-event time of the timed region on the launch stream / steps (one launch per step)",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            k = min(args.cpu_sample_frames, F, max(1, 32_000_000 // POINTS_PER_FRAME))  # ~10-30 s of single-thread oracle work
-            sample = d_in[:k * POINTS_PER_FRAME].cpu().numpy()
-            gpu_frame0 = d_outs[(state["k"] - 1) % R][:POINTS_PER_FRAME].cpu().numpy()
-            out["cpu_baseline"], out["parity_spot_check"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k, gpu_frame0)
+        if c3:
+            t3 = maxes[2]
+            out["configs3"] = {
+                "workload": f"configs[3]: synthetic {C3_POINTS_PER_FRAME}-point frames x {C3_FRAMES_TOTAL}, |phi| ~ {C3_YAW_PER_FRAME} rad per frame, "
+                            f"frame-sharded: rank r owns frames sharding.frame_range({C3_FRAMES_TOTAL}, r, {world}); timed = the first "
+                            f"{c3['timed_frames']} frames of every rank's range, {C3_FRAMES_PER_LAUNCH} frames per batched launch over {c3['groups']} rotating "
+                            "buffer groups of distinct device-generated frames; no data-path collective",
+                "frames_total": C3_FRAMES_TOTAL, "points_per_frame": C3_POINTS_PER_FRAME,
+                "rank_frame_ranges": [list(sharding.frame_range(C3_FRAMES_TOTAL, r, world)) for r in range(world)],
+                "timed_frames_per_rank": c3["timed_frames"], "frames_per_launch": C3_FRAMES_PER_LAUNCH,
+                "value": round(sums[1] / t3 / 1e6, 1), "unit": "Mpts/s",
+                "ms_per_frame": round(t3 / c3["timed_frames"] * 1e3, 4),
+                "achieved_GBps_rank0": round(BYTES_PER_POINT * c3["points"] / c3["ev_s"] / 1e9, 1),
+                "frac_of_peak_rank0": round(BYTES_PER_POINT * c3["points"] / c3["ev_s"] / 1e9 / HBM_PEAK_GBPS, 4),
+                "parity_first_last_frame_per_rank": ({"max_rel_err": maxes[4], "bar": 1e-5, "oracle": "FAITHFUL, whole 10 M-point frames"}
+                                                     if not args.no_cpu_baseline else None),
+            }
+        if cpu_sample is not None:
+            k_cpu, sample, gpu_frame0 = cpu_sample
+            out["cpu_baseline"], out["parity_spot_check"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k_cpu, gpu_frame0)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist:

@@ -77,15 +77,26 @@ def make_batches(frame_sizes: Sequence[int], begin: int, end: int, max_points: i
         i = j
 
 
-def reduce_throughput(dist, device, points: float, seconds: float, kernel_seconds: float = 0.0):
-    """The job's only collective: SUM of points, MAX of times.  `dist` is torch.distributed (backend nccl == RCCL on the
-    GPU box, gloo on CPU) or None for a single process.  Returns (total_points, max_seconds, max_kernel_seconds)."""
+def reduce_counters(dist, device, sums: Sequence[float], maxes: Sequence[float]):
+    """The job's ONLY collective: every rank contributes one small vector, ONE all_gather (RCCL on the GPU box, gloo on CPU;
+    ~100 bytes per rank: latency-bound, link bandwidth is irrelevant); SUM over the first block, MAX over the second, computed
+    identically on every rank.  `dist` is torch.distributed or None for a single process.  -> (sums, maxes) as float lists."""
+    sums = [float(v) for v in sums]
+    maxes = [float(v) for v in maxes]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return float(points), float(seconds), float(kernel_seconds)
+        return sums, maxes
     import torch
 
-    tmax = torch.tensor([seconds, kernel_seconds], dtype=torch.float64, device=device)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tsum = torch.tensor([float(points)], dtype=torch.float64, device=device)
-    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-    return tsum[0].item(), tmax[0].item(), tmax[1].item()
+    world = dist.get_world_size()
+    mine = torch.tensor(sums + maxes, dtype=torch.float64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    everyone = torch.stack(parts).cpu()
+    k = len(sums)
+    return everyone[:, :k].sum(dim=0).tolist(), everyone[:, k:].max(dim=0).values.tolist()
+
+
+def reduce_throughput(dist, device, points: float, seconds: float, kernel_seconds: float = 0.0):
+    """SUM of points, MAX of times through reduce_counters.  Returns (total_points, max_seconds, max_kernel_seconds)."""
+    s, m = reduce_counters(dist, device, [points], [seconds, kernel_seconds])
+    return s[0], m[0], m[1]

@@ -74,6 +74,8 @@ def _worker(rank, world, port, q):
         secs = 1.0 + 0.5 * rank
         dist.barrier()
         total, tmax, kmax = sharding.reduce_throughput(dist, torch.device("cpu"), pts, secs, secs / 2)
+        sums, maxes = sharding.reduce_counters(dist, torch.device("cpu"), [pts, 1.0], [secs, float(rank), -1.0 - rank])
+        assert sums == [float(sum(sizes)), 2.0] and maxes == [1.5, 1.0, -1.0]  # one all_gather, SUM block and MAX block
         q.put((rank, b, e, total, tmax, kmax))
     finally:
         dist.destroy_process_group()

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-                        "--frames-per-step", "16", "--cpu-sample-frames", "1"], capture_output=True, text=True, timeout=900)
+                        "--frames-per-step", "176", "--cpu-sample-frames", "1", "--configs3-frames", "24", "--no-live-traffic"],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -34,11 +35,18 @@ def test_bench_prints_one_contract_line():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert d["parity_spot_check"]["max_rel_err"] <= 1e-5 and d["parity_spot_check"]["intensity_bit_identical"]
     assert d["value"] > 50_000  # > 50 G points/s even on a short, cold run
+    assert "committed" in rf["traffic_source"]  # --no-live-traffic: the committed figure, and the line says so
+    # the configs[3] leg of the same invocation: 10 M-point frames, the rank's contiguous frame range, oracle-checked
+    c3 = d["configs3"]
+    assert c3["frames_total"] == 8000 and c3["points_per_frame"] == 10_000_000
+    assert c3["rank_frame_ranges"] == [[0, 8000]] and c3["timed_frames_per_rank"] == 24
+    assert c3["value"] > 50_000 and c3["unit"] == "Mpts/s"
+    assert c3["parity_first_last_frame_per_rank"]["max_rel_err"] <= 1e-5
 
 
 @pytest.mark.gpu
 def test_bench_rccl_path_initialises_and_reduces_on_one_gpu():
-    """WORLD_SIZE = 1 with the RCCL process group forced on: barrier + the two all-reduces of the counters run through RCCL."""
+    """WORLD_SIZE = 1 with the RCCL process group forced on: the barriers and the one all_gather of the counters run through RCCL."""
     env = dict(os.environ, KMC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
                         "--frames-per-step", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
@@ -55,34 +63,42 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     env = dict(os.environ, KMC_BENCH_BACKEND="gloo", KMC_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
-           "--frames-per-step", "32"]
+           "--frames-per-step", "176", "--configs3-frames", "16"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
-    assert d["config"]["frames_per_step_per_gpu"] == 32 and "x2" in d["config"]["parallelism"]
+    assert d["config"]["frames_per_step_per_gpu"] == 176 and "x2" in d["config"]["parallelism"]
     # two ranks share one GPU here: the aggregate is about one GPU's rate (each rank gets half), never two GPUs' worth
     assert 50_000 < d["value"] < 260_000
     # whole-job aggregate = all ranks' points / max-rank time
-    assert abs(d["value"] - 2 * 32 * 1_000_000 * 8 / (d["ms_per_step"] * 8 * 1e-3) / 1e6) / d["value"] < 0.02
+    assert abs(d["value"] - 2 * 176 * 1_000_000 * 8 / (d["ms_per_step"] * 8 * 1e-3) / 1e6) / d["value"] < 0.02
+    # the configs[3] leg: rank r deskews frames sharding.frame_range(8000, r, 2) of the 10 M-point stream; every rank checked
+    # its first and last timed frame against the oracle; the aggregate is all ranks' points / max-rank time
+    c3 = d["configs3"]
+    assert c3["rank_frame_ranges"] == [[0, 4000], [4000, 8000]] and c3["timed_frames_per_rank"] == 16
+    assert abs(c3["value"] - 2 * 16 * 10_000_000 / (c3["ms_per_frame"] * 16 * 1e-3) / 1e6) / c3["value"] < 0.02
+    assert 20_000 < c3["value"] < 260_000
+    assert c3["parity_first_last_frame_per_rank"]["max_rel_err"] <= 1e-5
 
 
 @pytest.mark.gpu
 def test_bench_live_traffic_matches_the_algorithmic_bytes():
-    """--live-traffic: HBM bytes per launch from rocprofv3 --pmc child runs of the same invocation (FETCH_SIZE and WRITE_SIZE in
-    separate passes) -- within 1 % of 32 B x points per launch, i.e. nothing is re-read."""
+    """The default at N = 1: HBM bytes per launch from rocprofv3 --pmc child runs of the same invocation (FETCH_SIZE and WRITE_SIZE
+    in separate passes) -- within 1 % of 32 B x points per launch, i.e. nothing is re-read."""
     import shutil
 
     if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
         pytest.skip("rocprofv3 not installed")
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames-per-step", "64",
-                        "--no-cpu-baseline", "--live-traffic"], capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     rf = d["roofline"]
-    if "child runs" not in rf["traffic_source"]:
+    if "measured in this run" not in rf["traffic_source"]:
+        assert "not possible" in rf["traffic_source"]  # the fallback is announced in the line itself
         pytest.skip("PMC counters could not be collected on this box (bench.py fell back to the committed passes)")
     assert abs(rf["traffic"] / (32.0 * rf["points_per_launch"]) - 1.0) < 0.01
