@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define KMC_ABI_VERSION 1
+#define KMC_ABI_VERSION 2
 
 /* ---- status codes ---- */
 #define KMC_OK 0
@@ -165,12 +165,33 @@ int kmc_frame_ranges_balanced(const uint64_t* frame_points, uint32_t n_frames, u
  *   s    = frac - x_req                                trajectory_interpolation.cpp:49-51
  *   p'   = Exp(s * twist) * p                          motion_compensation.cpp:9-14 (closed form)
  * and intensity is passed through bit-identically.  32 algorithmic bytes per point (16 read + 16 written).
- * xyzi_in and xyzi_out must be 16-byte aligned and must not partially overlap (in == out is allowed).  Device-resident
+ * Device-resident xyzi_in and xyzi_out must be 16-byte aligned (host buffers: 4-byte, they are only copied) and must not
+ * partially overlap (in == out is allowed).  Device-resident
  * pointers may be any 16-byte-aligned addresses (sub-ranges of a larger buffer): the kernels cut their tiles on the 1 KiB lines
  * of the output; full speed needs the input to sit at the same offset within its 1 KiB line (e.g. the same index range of
  * two allocator-aligned buffers), otherwise ~6 % is lost to split loads. */
 int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint64_t n,
                        const kmc_frame_params* params, int mem_kind, kmc_stats* out_stats);
+
+/* ---- a stream of SEPARATE frames (BASELINE.json configs[1] literally: one 1 M-point frame per call) --------------------------
+ * On one HIP stream every launch waits for the last wave of the launch before it, so between two frames the chip drains and
+ * refills: 6.9 us per 1 M-point frame = 4.6 TB/s where the kernel alone sustains 6.8.  The frames of this path are independent
+ * (motion_compensation.cpp:22-25 reads nothing a previous frame wrote), so they may overlap: with frame queues on,
+ * device-resident kmc_hip_deskew_f32 calls are issued round-robin over `queues` HIP streams (hardware queues) of the context --
+ * measured 5.1 us per 1 M-point frame = 6.3 TB/s with two queues (tools/stream_probe.hip).
+ *   - queues = 1 (default): every call on the context's stream, strictly in order (the behaviour of ABI version 1).
+ *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls are NOT ordered with each other.  The first frame
+ *     after a join waits for everything issued on the context's stream before it (its producers); kmc_hip_frame_queue_join()
+ *     makes the context's stream wait for every frame issued so far (device-side, the host does not block).  Every other entry
+ *     point, kmc_hip_synchronize(), kmc_hip_timer_end() and kmc_hip_set_stream() join first, so anything issued after the frames
+ *     sees their results.  With kmc_hip_enable_timing() on, calls stay on the context's stream (per-call times need order). */
+int kmc_hip_set_frame_queues(kmc_ctx* ctx, int queues);
+int kmc_hip_frame_queue_join(kmc_ctx* ctx);
+/* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
+ * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues (at least two for this call) and joined:
+ * the call as a whole is ordered on the context's stream like any other.  Same per-point results as kmc_hip_deskew_f32. */
+int kmc_hip_deskew_frames_f32(kmc_ctx* ctx, const float* const* xyzi_in, float* const* xyzi_out, const uint64_t* n_points,
+                              const kmc_frame_params* params, uint32_t n_frames, kmc_stats* out_stats);
 
 /* Batched variant: n_frames frames concatenated in one buffer; frame f owns points
  * [offsets[f], offsets[f+1]).  offsets (n_frames+1 entries) and params (n_frames entries) are HOST arrays.

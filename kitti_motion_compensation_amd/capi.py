@@ -131,6 +131,9 @@ SIGNATURES = {
     "kmc_make_frame_poses": (C.c_int, [C.POINTER(Oxts), C.POINTER(Oxts), C.POINTER(Oxts), C.c_double, C.c_double, _dp, _dp]),
     "kmc_frame_ranges_balanced": (C.c_int, [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "kmc_hip_deskew_f32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(FrameParams), C.c_int, C.POINTER(Stats)]),
+    "kmc_hip_set_frame_queues": (C.c_int, [_vp, C.c_int]),
+    "kmc_hip_frame_queue_join": (C.c_int, [_vp]),
+    "kmc_hip_deskew_frames_f32": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(FrameParams), C.c_uint32, C.POINTER(Stats)]),
     "kmc_hip_deskew_batch_f32": (
         C.c_int,
         [_vp, _vp, _vp, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(FrameParams), _vp, C.c_int, C.POINTER(Stats)],
@@ -384,6 +387,30 @@ class Context:
         st = Stats()
         rc = lib().kmc_hip_deskew_f32(self._h, _ptr(xyzi_in, np.float32), _ptr(xyzi_out, np.float32), n, C.byref(params), kind, C.byref(st))
         self._check(rc, "kmc_hip_deskew_f32")
+        return st
+
+    def set_frame_queues(self, queues: int):
+        """queues > 1: device-resident deskew_f32 calls go round-robin over that many HIP streams and may overlap (see kmc_hip.h)."""
+        self._check(lib().kmc_hip_set_frame_queues(self._h, int(queues)), "kmc_hip_set_frame_queues")
+
+    def frame_queue_join(self):
+        self._check(lib().kmc_hip_frame_queue_join(self._h), "kmc_hip_frame_queue_join")
+
+    def prepare_frames(self, pairs, params_list):
+        """pairs: [(device_in, device_out), ...] of (n_f, 4) float32 device tensors.  -> opaque argument pack for deskew_frames_f32
+        (built once, reusable: the per-call cost is then one ctypes call)."""
+        nf = len(pairs)
+        ins = (_vp * nf)(*[p[0].data_ptr() for p in pairs])
+        outs = (_vp * nf)(*[p[1].data_ptr() for p in pairs])
+        ns = (C.c_uint64 * nf)(*[int(p[0].shape[0]) for p in pairs])
+        prm = params_list if isinstance(params_list, C.Array) else params_array(params_list)
+        return (ins, outs, ns, prm, nf, pairs)
+
+    def deskew_frames_f32(self, pack) -> Stats:
+        """A stream of separate device-resident frames in one call (kmc_hip_deskew_frames_f32); `pack` from prepare_frames."""
+        ins, outs, ns, prm, nf, _ = pack
+        st = Stats()
+        self._check(lib().kmc_hip_deskew_frames_f32(self._h, ins, outs, ns, prm, nf, C.byref(st)), "kmc_hip_deskew_frames_f32")
         return st
 
     def deskew_batch_f32(self, xyzi_in, xyzi_out, offsets, params_list, frame_idx_out=None) -> Stats:

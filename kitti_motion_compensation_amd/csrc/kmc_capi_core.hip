@@ -45,6 +45,38 @@ int ensure_pipeline(kmc_ctx* c) {
   return KMC_OK;
 }
 
+int fq_stream(kmc_ctx* c, hipStream_t* out) {
+  if (c->fq_count <= 1) {
+    *out = c->stream;
+    return KMC_OK;
+  }
+  if (!c->fq_forked) {  // the frames must not start before what the caller has already issued on `stream` (their producers)
+    KMC_HIP_TRY(c, hipEventRecord(c->fq_fork, c->stream));
+    for (int q = 0; q < c->fq_count; ++q) {
+      KMC_HIP_TRY(c, hipStreamWaitEvent(c->fq[q], c->fq_fork, 0));
+      c->fq_used[q] = false;
+    }
+    c->fq_forked = true;
+    c->fq_next = 0;
+  }
+  const int q = c->fq_next;
+  c->fq_next = (q + 1) % c->fq_count;
+  c->fq_used[q] = true;
+  *out = c->fq[q];
+  return KMC_OK;
+}
+
+int fq_join(kmc_ctx* c) {
+  if (!c->fq_forked) return KMC_OK;
+  for (int q = 0; q < c->fq_count; ++q) {
+    if (!c->fq_used[q]) continue;
+    KMC_HIP_TRY(c, hipEventRecord(c->fq_done[q], c->fq[q]));
+    KMC_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->fq_done[q], 0));
+  }
+  c->fq_forked = false;
+  return KMC_OK;
+}
+
 int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
   const int slot_id = c->next_slot;
   const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
@@ -156,6 +188,7 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   for (auto& ev : c->group_consumed)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fq_fork, hipEventDisableTiming);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     kmc_hip_destroy(c);
@@ -180,6 +213,11 @@ void kmc_hip_destroy(kmc_ctx* c) {
     if (c->ev_kernel[b]) (void)hipEventDestroy(c->ev_kernel[b]);
     if (c->ev_d2h[b]) (void)hipEventDestroy(c->ev_d2h[b]);
   }
+  for (int q = 0; q < kmc_ctx::kMaxFrameQueues; ++q) {
+    if (c->fq[q]) { (void)hipStreamSynchronize(c->fq[q]); (void)hipStreamDestroy(c->fq[q]); }
+    if (c->fq_done[q]) (void)hipEventDestroy(c->fq_done[q]);
+  }
+  if (c->fq_fork) (void)hipEventDestroy(c->fq_fork);
   if (c->d_tmp) (void)hipFree(c->d_tmp);
   if (c->d_traj) (void)hipFree(c->d_traj);
   if (c->h_traj) (void)hipHostFree(c->h_traj);
@@ -200,22 +238,56 @@ void kmc_hip_destroy(kmc_ctx* c) {
   delete c;
 }
 
+// The context is single-stream: its scratch buffers, table slots and their "consumed" markers are ordered on `stream` only.
+// Switching streams therefore first drains what the old stream still has in flight from this context (a growth
+// of the scratch or of a table slot on the new stream would otherwise free memory under kernels of the old one).
+static int switch_stream(kmc_ctx* c, hipStream_t next) {
+  if (next == c->stream) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const int rc = fq_join(c);
+  if (rc != KMC_OK) return rc;
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  for (auto& busy : c->group_busy) busy = false;
+  c->stream = next;
+  return KMC_OK;
+}
+
 int kmc_hip_set_stream(kmc_ctx* c, void* hip_stream) {
   if (!c) return KMC_ERR_INVALID_ARG;
-  c->stream = (hipStream_t)hip_stream;  // literally: NULL is HIP's legacy default stream
-  return KMC_OK;
+  return switch_stream(c, (hipStream_t)hip_stream);  // literally: NULL is HIP's legacy default stream
 }
 
 int kmc_hip_use_own_stream(kmc_ctx* c) {
   if (!c) return KMC_ERR_INVALID_ARG;
-  c->stream = c->own_stream;
-  return KMC_OK;
+  return switch_stream(c, c->own_stream);
 }
 
 int kmc_hip_synchronize(kmc_ctx* c) {
   if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_ENTER(c);
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
   return KMC_OK;
+}
+
+int kmc_hip_set_frame_queues(kmc_ctx* c, int queues) {
+  if (!c || queues < 1 || queues > kmc_ctx::kMaxFrameQueues) return KMC_ERR_INVALID_ARG;
+  KMC_ENTER(c);
+  for (int q = 0; q < queues; ++q) {
+    if (queues > 1 && !c->fq[q]) {
+      KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->fq[q], hipStreamNonBlocking));
+      KMC_HIP_TRY(c, hipEventCreateWithFlags(&c->fq_done[q], hipEventDisableTiming));
+    }
+  }
+  c->fq_count = queues;
+  c->fq_next = 0;
+  return KMC_OK;
+}
+
+int kmc_hip_frame_queue_join(kmc_ctx* c) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  return fq_join(c);
 }
 
 int kmc_hip_enable_timing(kmc_ctx* c, int enabled) {
@@ -257,12 +329,14 @@ int kmc_hip_force_tier(kmc_ctx* c, int tier) {
 
 int kmc_hip_timer_begin(kmc_ctx* c) {
   if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_ENTER(c);
   KMC_HIP_TRY(c, hipEventRecord(c->ev_t0, c->stream));
   return KMC_OK;
 }
 
 int kmc_hip_timer_end(kmc_ctx* c, float* elapsed_ms) {
   if (!c || !elapsed_ms) return KMC_ERR_INVALID_ARG;
+  KMC_ENTER(c);  // the stopwatch covers the frames issued on the frame queues too
   KMC_HIP_TRY(c, hipEventRecord(c->ev_t1, c->stream));
   KMC_HIP_TRY(c, hipEventSynchronize(c->ev_t1));
   KMC_HIP_TRY(c, hipEventElapsedTime(elapsed_ms, c->ev_t0, c->ev_t1));
@@ -273,7 +347,7 @@ int kmc_hip_host_alloc(kmc_ctx* c, size_t bytes, void** out) {
   if (!c || !out) return KMC_ERR_INVALID_ARG;
   *out = nullptr;
   if (bytes == 0) return KMC_OK;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_ENTER(c);
   KMC_HIP_TRY(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
   return KMC_OK;
 }

@@ -54,18 +54,70 @@ void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, c
 }
 }  // namespace
 
+// ---- helpers of the single-frame entry points ----
+namespace {
+// one device-resident frame on stream `s` (arguments already validated)
+int issue_frame(kmc_ctx* c, hipStream_t s, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params, int* tier_out) {
+  const int tier = pick_tier(c, params, 1);
+  FrameRec f;
+  std::memset(&f, 0, sizeof(f));
+  fill_rec(*params, &f);
+  FrameRecD d;
+  fill_recd(*params, &d);
+  if (tier_out) *tier_out = tier;
+  if (n == 0) return KMC_OK;
+  launch_frame(c, s, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, KMC_MEM_DEVICE));
+  KMC_HIP_TRY(c, hipGetLastError());
+  return KMC_OK;
+}
+int check_frame_args(const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params, int mem_kind) {
+  if (!params || (n && (!xyzi_in || !xyzi_out))) return KMC_ERR_INVALID_ARG;
+  // device pointers feed 16-byte vector accesses; host buffers are only ever the source / destination of copies
+  if (mem_kind == KMC_MEM_DEVICE && (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 3u) return KMC_ERR_INVALID_ARG;
+  if (!params_ok(params)) return KMC_ERR_INVALID_ARG;
+  if (!(params->x_req >= 0.0 && params->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  return KMC_OK;
+}
+}  // namespace
+
 extern "C" {
 
 // ---- hot path: single frame, f32 -----------------------------------------------------------------
 int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params,
                        int mem_kind, kmc_stats* st) {
-  if (!c || !params || (n && (!xyzi_in || !xyzi_out))) return KMC_ERR_INVALID_ARG;
+  if (!c) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
-  if (!params_ok(params)) return KMC_ERR_INVALID_ARG;
-  if (!(params->x_req >= 0.0 && params->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
+  {
+    const int rc_args = check_frame_args(xyzi_in, xyzi_out, n, params, mem_kind);
+    if (rc_args != KMC_OK) return rc_args;
+  }
   if (st) std::memset(st, 0, sizeof(*st));
   KMC_HIP_TRY(c, hipSetDevice(c->device));
+  CallTimer tm(c);
+  if (mem_kind == KMC_MEM_DEVICE) {
+    // frame queues on (kmc_hip_set_frame_queues) and no per-call timing: the frame goes to the next queue and is NOT ordered
+    // with the frames before it -- they are independent -- until the next join
+    hipStream_t s = c->stream;
+    if (c->fq_count > 1 && !c->timing) {
+      const int rc_q = fq_stream(c, &s);
+      if (rc_q != KMC_OK) return rc_q;
+    } else {
+      const int rc_j = fq_join(c);
+      if (rc_j != KMC_OK) return rc_j;
+    }
+    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    int tier = 0;
+    const int rc_issue = issue_frame(c, s, xyzi_in, xyzi_out, n, params, &tier);
+    if (rc_issue != KMC_OK) return rc_issue;
+    if (st) { st->n_points = n; st->variant = (uint32_t)tier; st->n_launches = n ? 1 : 0; }
+    if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    return tm.end_call(st);
+  }
+  {
+    const int rc_j = fq_join(c);
+    if (rc_j != KMC_OK) return rc_j;
+  }
   const int tier = pick_tier(c, params, 1);
   FrameRec f;
   std::memset(&f, 0, sizeof(f));
@@ -74,15 +126,6 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   fill_recd(*params, &d);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
-  CallTimer tm(c);
-  if (mem_kind == KMC_MEM_DEVICE) {
-    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    launch_frame(c, c->stream, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, mem_kind));
-    KMC_HIP_TRY(c, hipGetLastError());
-    if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    if (st) st->n_launches = 1;
-    return tm.end_call(st);
-  }
   // KMC_MEM_HOST: upload / compute / download on three streams over a ring of device slots, so that the H2D of chunk
   // k+1, the kernel of chunk k and the D2H of chunk k-1 run concurrently (PCIe is full duplex; DESIGN.md "host buffers")
   int rc = ensure_pipeline(c);
@@ -115,6 +158,43 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   return tm.end_call(st);
 }
 
+// ---- hot path: a stream of separate frames --------------------------------------------------------
+int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* const* xyzi_out, const uint64_t* n_points,
+                              const kmc_frame_params* params, uint32_t n_frames, kmc_stats* st) {
+  if (!c || (n_frames && (!xyzi_in || !xyzi_out || !n_points || !params))) return KMC_ERR_INVALID_ARG;
+  if (st) std::memset(st, 0, sizeof(*st));
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const int rc_args = check_frame_args(xyzi_in[f], xyzi_out[f], n_points[f], &params[f], KMC_MEM_DEVICE);
+    if (rc_args != KMC_OK) return rc_args;
+  }
+  KMC_ENTER(c);
+  CallTimer tm(c);
+  if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  // at least two queues for this call, whatever the context's setting: that is the point of handing over several frames
+  const int saved = c->fq_count;
+  if (saved < 2) {
+    const int rc_set = kmc_hip_set_frame_queues(c, 2);
+    if (rc_set != KMC_OK) return rc_set;
+  }
+  uint64_t total = 0;
+  int tier_max = 0, rc = KMC_OK;
+  for (uint32_t f = 0; f < n_frames && rc == KMC_OK; ++f) {
+    hipStream_t s;
+    rc = fq_stream(c, &s);
+    int tier = 0;
+    if (rc == KMC_OK) rc = issue_frame(c, s, xyzi_in[f], xyzi_out[f], n_points[f], &params[f], &tier);
+    tier_max = std::max(tier_max, tier);
+    total += n_points[f];
+  }
+  const int rc_join = fq_join(c);  // `stream` waits for every frame: the call as a whole is ordered like any other
+  c->fq_count = saved;
+  if (rc != KMC_OK) return rc;
+  if (rc_join != KMC_OK) return rc_join;
+  if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (st) { st->n_points = total; st->variant = (uint32_t)tier_max; st->n_launches = n_frames; }
+  return tm.end_call(st);
+}
+
 // ---- hot path: batch of frames, f32 ---------------------------------------------------------------
 int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets, uint32_t n_frames,
                              const kmc_frame_params* params, uint32_t* frame_idx_out, int mem_kind, kmc_stats* st) {
@@ -129,8 +209,9 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   }
   const uint64_t n = n_frames ? offsets[n_frames] : 0;
   if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  // 16-byte alignment is a requirement of the kernels' vector accesses: device pointers only (host buffers are copied)
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
+  KMC_ENTER(c);
   const int tier = pick_tier(c, params, n_frames);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
@@ -226,7 +307,7 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   if (st) std::memset(st, 0, sizeof(*st));
   if (st) { st->n_points = n; st->variant = 3; }
   if (n == 0) return KMC_OK;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_ENTER(c);
 
   FrameRec64 f;
   const kmc_host::Vec3 rho = {params->twist[0], params->twist[1], params->twist[2]};
@@ -298,7 +379,7 @@ int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, 
   if (!c || (n && (!x || !y || !stamps_out))) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
   if (n == 0) return KMC_OK;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_ENTER(c);
   const size_t col = n * sizeof(double);
   const double *dx = x, *dy = y;
   double* dout = stamps_out;

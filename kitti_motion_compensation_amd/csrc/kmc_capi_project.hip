@@ -35,15 +35,15 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   if (!c || !rig || (n && (!xyzi_in || !uv || !bgrv))) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
   if (xyzi_out && !deskew) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)uv & 15u) || ((uintptr_t)bgrv & 3u)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)uv & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) || ((uintptr_t)bgrv & (mem_kind == KMC_MEM_DEVICE ? 3u : 0u))) return KMC_ERR_INVALID_ARG;
   if (!rig_ok(rig)) return KMC_ERR_INVALID_ARG;
   if (deskew) {
     if (!params_ok(deskew)) return KMC_ERR_INVALID_ARG;
     if (!(deskew->x_req >= 0.0 && deskew->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
   }
   if (st) std::memset(st, 0, sizeof(*st));
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_ENTER(c);
   const int tier = deskew ? pick_tier(c, deskew, 1) : -1;
   FrameRec f;
   std::memset(&f, 0, sizeof(f));
@@ -101,12 +101,12 @@ int kmc_hip_project_f64cols(kmc_ctx* c, const double* x, const double* y, const 
                             int32_t* uv, uint8_t* bgrv, int mem_kind, kmc_stats* st) {
   if (!c || !rig || (n && (!x || !y || !z || !uv || !bgrv))) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)uv & 15u) || ((uintptr_t)bgrv & 3u)) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)uv & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) || ((uintptr_t)bgrv & (mem_kind == KMC_MEM_DEVICE ? 3u : 0u))) return KMC_ERR_INVALID_ARG;
   if (!rig_ok(rig)) return KMC_ERR_INVALID_ARG;
   if (st) std::memset(st, 0, sizeof(*st));
   if (st) { st->n_points = n; st->variant = 4; }
   if (n == 0) return KMC_OK;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_ENTER(c);
   const CameraRigRec g = rig_rec(rig);
   const double *dx = x, *dy = y, *dz = z;
   v2i* d_uv = (v2i*)uv;

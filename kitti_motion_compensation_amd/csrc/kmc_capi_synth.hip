@@ -6,7 +6,7 @@ extern "C" {
 int kmc_hip_synth_points(kmc_ctx* c, float* xyzi_out_device, uint64_t n, uint64_t seed) {
   if (!c || (n && !xyzi_out_device)) return KMC_ERR_INVALID_ARG;
   if (n == 0) return KMC_OK;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_ENTER(c);
   const int grid = grid_for(c, (n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(synth_points<0>, dim3(grid), dim3(kBlock), 0, c->stream, (v4f*)xyzi_out_device, n, seed);
   KMC_HIP_TRY(c, hipGetLastError());

@@ -153,7 +153,7 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
                             uint32_t* bracket_idx_out, int mem_kind, kmc_stats* st) {
   if (!c || (n && (!xyzi_in || !xyzi_out))) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
   if (!(stamp_start < stamp_end)) return KMC_ERR_DEGENERATE;
   if (st) std::memset(st, 0, sizeof(*st));
   TrajHost th;
@@ -162,7 +162,7 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   // every point stamp lies in [stamp_start, stamp_end]: the trajectory has to cover the scan
   if (!(knot_times[0] <= stamp_start && stamp_end <= knot_times[n_knots - 1])) return KMC_ERR_TIME_OUT_OF_RANGE;
   if (!(requested_time >= stamp_start && requested_time <= stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_ENTER(c);
   const int tier = traj_tier(c, th, stamp_start, stamp_end);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
@@ -236,8 +236,8 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
     if (offsets[f + 1] < offsets[f]) return KMC_ERR_INVALID_ARG;
   const uint64_t n = n_frames ? offsets[n_frames] : 0;
   if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
-  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & 15u) return KMC_ERR_INVALID_ARG;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
+  KMC_ENTER(c);
 
   // host pre-step per frame (f64): segments, anchors, M_k
   std::vector<TrajHost> th(n_frames);
@@ -347,7 +347,7 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   if (rc != KMC_OK) return rc;
   if (st) { st->n_points = n; st->variant = 3; }
   if (n == 0) return KMC_OK;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  KMC_ENTER(c);
   TrajSeg64 segs[kMaxSegments];
   std::memset(segs, 0, sizeof(segs));
   for (uint32_t k = 0; k < th.n_seg; ++k) {

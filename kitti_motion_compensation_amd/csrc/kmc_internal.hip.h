@@ -73,6 +73,16 @@ struct kmc_ctx {
   bool traj_in_flight = false;
   void* d_tmp = nullptr; // grow-only scratch for the f64 / batch host paths
   size_t tmp_cap = 0;
+  // frame queues (kmc_hip_set_frame_queues): device-resident single-frame calls are issued round-robin over fq_count streams
+  // (hardware queues) so that consecutive, independent frames overlap instead of draining the chip between two launches
+  static constexpr int kMaxFrameQueues = 4;
+  int fq_count = 1;                  // 1 = off: every launch on `stream`
+  int fq_next = 0;
+  bool fq_forked = false;            // frames have been issued on the queues since the last join
+  hipStream_t fq[kMaxFrameQueues] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fq_done[kMaxFrameQueues] = {nullptr, nullptr, nullptr, nullptr};
+  bool fq_used[kMaxFrameQueues] = {false, false, false, false};
+  hipEvent_t fq_fork = nullptr;      // "everything issued on `stream` so far", which the queues wait for
 };
 
 namespace kmc_impl {
@@ -97,6 +107,19 @@ inline int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
   } while (0)
 
 int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n);
+
+// frame queues: fq_stream() hands out the stream of the next frame (forking from `stream` first if necessary), fq_join() makes
+// `stream` wait for every frame issued since the fork (device-side waits, the host does not block)
+int fq_stream(kmc_ctx* c, hipStream_t* out);
+int fq_join(kmc_ctx* c);
+
+// what every entry point that issues work on `stream` starts with
+#define KMC_ENTER(ctx)                                      \
+  do {                                                      \
+    KMC_HIP_TRY(ctx, hipSetDevice((ctx)->device));          \
+    const int rc_join_ = fq_join(ctx);                      \
+    if (rc_join_ != KMC_OK) return rc_join_;                \
+  } while (0)
 
 template <typename REC>
 void fill_rec(const kmc_frame_params& p, REC* r) {

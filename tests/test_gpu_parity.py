@@ -756,3 +756,60 @@ def test_device_buffers_at_any_16_byte_offset(ctx, torch_mod, kitti, shift_in, s
         check(big, ref, [(idx, ref_f, 1), (idx2, ref_br, 9)])
     finally:
         ctx.set_stream(None)
+
+
+# ---- frame queues: a stream of separate frames over several hardware queues -------------------------------------------
+def test_frame_queues_same_bits_and_ordering(torch_mod, ctx):
+    """kmc_hip_set_frame_queues / kmc_hip_deskew_frames_f32: consecutive independent frames are issued round-robin over 2-4 HIP
+    streams.  Same bits as the in-order path; a producer issued on the context's stream BEFORE the frames and a consumer issued
+    AFTER the join see the right data (fork / join through events, no host sync)."""
+    torch = torch_mod
+    n, nf = 200_003, 24
+    params = [capi.FrameParams.make([1.3, 0.05 * (f % 3), -0.02, 0.002, -0.004, 0.03 + 0.001 * f], (f % 5) / 4.0) for f in range(nf)]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for _ in range(nf)]
+    want = []
+    for f in range(nf):
+        ctx.synth_points(ins[f], n, 900 + f)
+        o = torch.empty_like(ins[f])
+        ctx.deskew_f32(ins[f], o, params[f])
+        want.append(o)
+    torch.cuda.synchronize()
+    try:
+        for queues in (2, 3, 4):
+            ctx.set_frame_queues(queues)
+            # producer on the context's stream (torch's current stream), then the frames, then a consumer after the join
+            srcs = [torch.zeros_like(ins[f]) for f in range(nf)]
+            outs = [torch.zeros_like(ins[f]) for f in range(nf)]
+            for f in range(nf):
+                srcs[f].copy_(ins[f])                      # producer: must have finished before frame f starts
+            for f in range(nf):
+                ctx.deskew_f32(srcs[f], outs[f], params[f])  # unordered among themselves
+            ctx.frame_queue_join()
+            total = sum(o.view(torch.int32).to(torch.int64).sum() for o in outs)   # consumer on the context's stream
+            expect = sum(o.view(torch.int32).to(torch.int64).sum() for o in want)
+            assert int(total) == int(expect), queues
+            for f in range(nf):
+                assert torch.equal(outs[f].view(torch.int32), want[f].view(torch.int32)), (queues, f)
+            # the one-call form: joined on return, whatever the context's setting
+            outs2 = [torch.zeros_like(ins[f]) for f in range(nf)]
+            pack = ctx.prepare_frames(list(zip(ins, outs2)), params)
+            st = ctx.deskew_frames_f32(pack)
+            assert st.n_points == n * nf and st.n_launches == nf
+            got = torch.stack(outs2)  # consumer on the context's stream, no explicit sync before it
+            assert torch.equal(got.view(torch.int32), torch.stack(want).view(torch.int32)), queues
+        # other entry points join by themselves: a batched call right after queued frames sees their results
+        ctx.set_frame_queues(2)
+        mid = [torch.zeros_like(ins[0]) for _ in range(4)]
+        for f in range(4):
+            ctx.deskew_f32(ins[f], mid[f], params[f])
+        ctx.frame_queue_join()  # a torch op on the same stream is not a kmc entry point: join explicitly before it
+        cat = torch.cat(mid)
+        again = torch.empty_like(cat)
+        offsets = np.arange(5, dtype=np.uint64) * n
+        ident = capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5)
+        ctx.deskew_batch_f32(cat, again, offsets, [ident] * 4, None)
+        torch.cuda.synchronize()
+        assert torch.equal(again.view(torch.int32), torch.cat(want[:4]).view(torch.int32))
+    finally:
+        ctx.set_frame_queues(1)

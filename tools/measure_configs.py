@@ -56,7 +56,22 @@ def main():
     ms = timed(one_frame, 480)
     res["config2_single_1M_frame_per_launch"] = {"ms_per_launch": ms, "Mpts_s": n / ms / 1e3, "GBps": 32 * n / ms / 1e6,
                                                   "note": "24 rotating buffer pairs (768 MB) so data comes from HBM; includes launch gaps"}
-    del bufs
+    # the same stream of separate frames over the context's frame queues (kmc_hip_set_frame_queues): neighbours overlap instead of
+    # draining the chip between two launches.  Through kmc_hip_deskew_frames_f32 (480 frames per call) so that Python's per-call
+    # cost is not what is measured, and frame by frame through kmc_hip_deskew_f32 for the caller who gets its frames one at a time.
+    pack = ctx.prepare_frames([bufs[k % len(bufs)] for k in range(480)], [turn] * 480)
+    for queues in (2, 3):
+        ctx.set_frame_queues(queues)
+        ms = timed(lambda: ctx.deskew_frames_f32(pack), 8, warm=2) / 480
+        res[f"config2_single_1M_frame_per_launch_{queues}_frame_queues"] = {
+            "ms_per_launch": ms, "Mpts_s": n / ms / 1e3, "GBps": 32 * n / ms / 1e6, "frac_of_8TBps": 32 * n / ms / 1e6 / 8000,
+            "note": "kmc_hip_deskew_frames_f32: 480 separate 1 M-point frames per call, same 24 rotating buffer pairs"}
+        state["k"] = 0
+        ms = timed(one_frame, 480)
+        res[f"config2_frame_by_frame_calls_{queues}_frame_queues"] = {"ms_per_launch": ms, "Mpts_s": n / ms / 1e3, "GBps": 32 * n / ms / 1e6,
+                                                                    "note": "kmc_hip_deskew_f32 per frame from Python (ctypes call cost included)"}
+    ctx.set_frame_queues(1)
+    del bufs, pack
 
     # ---- config 4 unit: 10 M-point frames, single-frame kernel, rotating pairs ----
     n = 10_000_000
