@@ -178,9 +178,11 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * refills: 6.9 us per 1 M-point frame = 4.6 TB/s where the kernel alone sustains 6.8.  The frames of this path are independent
  * (motion_compensation.cpp:22-25 reads nothing a previous frame wrote), so they may overlap: with frame queues on,
  * device-resident kmc_hip_deskew_f32 calls are issued round-robin over `queues` HIP streams (hardware queues) of the context --
- * measured 5.1 us per 1 M-point frame = 6.3 TB/s with two queues (tools/stream_probe.hip).
+ * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip, tools/fq_probe.hip).
  *   - queues = 1 (default): every call on the context's stream, strictly in order (the behaviour of ABI version 1).
- *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls are NOT ordered with each other.  The first frame
+ *   - queues = 2..4: consecutive DEVICE-RESIDENT kmc_hip_deskew_f32 / kmc_hip_deskew_batch_f32 / kmc_hip_deskew_traj_batch_f32
+ *     calls are NOT ordered with each other (a drive-sized batched launch of ~60 us gains ~5 % from overlapping its ramp-up and
+ *     tail with its neighbours').  The first frame
  *     after a join waits for everything issued on the context's stream before it (its producers); kmc_hip_frame_queue_join()
  *     makes the context's stream wait for every frame issued so far (device-side, the host does not block).  Every other entry
  *     point, kmc_hip_synchronize(), kmc_hip_timer_end() and kmc_hip_set_stream() join first, so anything issued after the frames
@@ -188,7 +190,7 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
 int kmc_hip_set_frame_queues(kmc_ctx* ctx, int queues);
 int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
- * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues (at least two for this call) and joined:
+ * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues (four for this call if they are off) and joined:
  * the call as a whole is ordered on the context's stream like any other.  Same per-point results as kmc_hip_deskew_f32. */
 int kmc_hip_deskew_frames_f32(kmc_ctx* ctx, const float* const* xyzi_in, float* const* xyzi_out, const uint64_t* n_points,
                               const kmc_frame_params* params, uint32_t n_frames, kmc_stats* out_stats);

@@ -20,6 +20,10 @@ int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n) {
 int ensure_tmp(kmc_ctx* c, size_t bytes) {
   if (bytes <= c->tmp_cap) return KMC_OK;
   if (c->d_tmp) {
+    {
+      const int rc_join = fq_join(c);
+      if (rc_join != KMC_OK) return rc_join;
+    }
     KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     KMC_HIP_TRY(c, hipFree(c->d_tmp));
     c->d_tmp = nullptr;
@@ -82,12 +86,21 @@ int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
   const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
   c->next_slot = (c->next_slot + 1) % kmc_ctx::kTableSlots;
   if (slot_id % kmc_ctx::kSlotsPerGroup == 0 && c->group_busy[group_id]) {
-    KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
+    if (c->group_queue_mask[group_id]) {
+      for (int q = 0; q < kmc_ctx::kMaxFrameQueues; ++q)
+        if (c->group_queue_mask[group_id] & (1u << q)) KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed_q[group_id][q]));
+    } else {
+      KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
+    }
     c->group_busy[group_id] = false;
   }
   if (need > c->slots[slot_id].cap) {
     // grow EVERY slot at once (so that steady state never allocates again); slots may still be referenced by kernels in
     // flight: drain first
+    {
+      const int rc_join = fq_join(c);
+      if (rc_join != KMC_OK) return rc_join;
+    }
     KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     const size_t cap = std::max<size_t>(64 * 1024, need * 2);
@@ -117,7 +130,16 @@ int slot_upload(kmc_ctx* c, int slot_id, size_t bytes) {
 int slot_end(kmc_ctx* c, int slot_id) {
   if (slot_id % kmc_ctx::kSlotsPerGroup == kmc_ctx::kSlotsPerGroup - 1) {
     const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
-    KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
+    unsigned mask = 0;
+    if (c->fq_forked) {  // launches since the fork went to the frame queues: a marker on each queue in use
+      for (int q = 0; q < c->fq_count; ++q) {
+        if (!c->fq_used[q]) continue;
+        KMC_HIP_TRY(c, hipEventRecord(c->group_consumed_q[group_id][q], c->fq[q]));
+        mask |= 1u << q;
+      }
+    }
+    if (!mask) KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
+    c->group_queue_mask[group_id] = mask;
     c->group_busy[group_id] = true;
   }
   return KMC_OK;
@@ -187,6 +209,9 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming);
   for (auto& ev : c->group_consumed)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  for (auto& per_queue : c->group_consumed_q)
+    for (auto& ev : per_queue)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fq_fork, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -218,6 +243,8 @@ void kmc_hip_destroy(kmc_ctx* c) {
     if (c->fq_done[q]) (void)hipEventDestroy(c->fq_done[q]);
   }
   if (c->fq_fork) (void)hipEventDestroy(c->fq_fork);
+  for (auto& sp : c->fq_spacer)
+    if (sp) (void)hipStreamDestroy(sp);
   if (c->d_tmp) (void)hipFree(c->d_tmp);
   if (c->d_traj) (void)hipFree(c->d_traj);
   if (c->h_traj) (void)hipHostFree(c->h_traj);
@@ -229,6 +256,9 @@ void kmc_hip_destroy(kmc_ctx* c) {
   }
   for (auto& ev : c->group_consumed)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& per_queue : c->group_consumed_q)
+    for (auto& ev : per_queue)
+      if (ev) (void)hipEventDestroy(ev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->d_counter) (void)hipFree(c->d_counter);
   hipEvent_t evs[] = {c->ev_k0, c->ev_k1, c->ev_c0, c->ev_c1, c->ev_t0, c->ev_t1};
@@ -273,6 +303,16 @@ int kmc_hip_synchronize(kmc_ctx* c) {
 int kmc_hip_set_frame_queues(kmc_ctx* c, int queues) {
   if (!c || queues < 1 || queues > kmc_ctx::kMaxFrameQueues) return KMC_ERR_INVALID_ARG;
   KMC_ENTER(c);
+  if (queues > 1 && !c->fq[0]) {
+    // HIP multiplexes its streams onto a few hardware queues in creation order, and two streams that share one are serialised
+    // through barrier packets -- slower than a single stream.  Measured on MI355X / ROCm 7.2 (tools/fq_probe.hip, C and
+    // Python hosts): with the frame queues created right behind the context's own two streams a 1 M-point frame costs
+    // 5.6-7.8 us (erratic), with two idle streams created in between 5.1-5.2 us with four queues, every time.
+    // KMC_FQ_SPACERS overrides the count (tuning knob).
+    const char* sp = std::getenv("KMC_FQ_SPACERS");
+    const int spacers = sp ? std::max(0, std::min(8, std::atoi(sp))) : 2;
+    for (int k = 0; k < spacers && k < 8; ++k) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->fq_spacer[k], hipStreamNonBlocking));
+  }
   for (int q = 0; q < queues; ++q) {
     if (queues > 1 && !c->fq[q]) {
       KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->fq[q], hipStreamNonBlocking));

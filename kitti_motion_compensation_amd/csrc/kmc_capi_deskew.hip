@@ -170,10 +170,10 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
   KMC_ENTER(c);
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  // at least two queues for this call, whatever the context's setting: that is the point of handing over several frames
+  // the context's setting if frame queues are on, else four for this call: that is the point of handing over several frames
   const int saved = c->fq_count;
   if (saved < 2) {
-    const int rc_set = kmc_hip_set_frame_queues(c, 2);
+    const int rc_set = kmc_hip_set_frame_queues(c, kmc_ctx::kMaxFrameQueues);
     if (rc_set != KMC_OK) return rc_set;
   }
   uint64_t total = 0;
@@ -211,7 +211,18 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
   // 16-byte alignment is a requirement of the kernels' vector accesses: device pointers only (host buffers are copied)
   if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
-  KMC_ENTER(c);
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  // device-resident batches are independent of each other like single frames: with frame queues on they go round-robin over
+  // the queues too, so that consecutive launches overlap their ramp-up and tail (matters for drive-sized launches, ~60 us)
+  const bool queued = mem_kind == KMC_MEM_DEVICE && c->fq_count > 1 && !c->timing && n_frames && offsets[n_frames] != 0;
+  hipStream_t launch_stream = c->stream;
+  if (queued) {
+    const int rc_q = fq_stream(c, &launch_stream);
+    if (rc_q != KMC_OK) return rc_q;
+  } else {
+    const int rc_j = fq_join(c);
+    if (rc_j != KMC_OK) return rc_j;
+  }
   const int tier = pick_tier(c, params, n_frames);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
@@ -275,9 +286,9 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const int grid = grid_for(c, n_tiles);
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
   switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
-    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    case kSeries3: launch_batch_t<kSeries3>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    default: launch_batch_t<kTrig>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
   {

@@ -237,7 +237,8 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   const uint64_t n = n_frames ? offsets[n_frames] : 0;
   if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
   if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
-  KMC_ENTER(c);
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const bool queued = mem_kind == KMC_MEM_DEVICE && c->fq_count > 1 && !c->timing && n != 0;  // see kmc_hip_deskew_batch_f32
 
   // host pre-step per frame (f64): segments, anchors, M_k
   std::vector<TrajHost> th(n_frames);
@@ -256,6 +257,11 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   if (c->force_tier >= 0 && c->force_tier <= 2) tier = c->force_tier;
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
+  hipStream_t launch_stream = c->stream;
+  {
+    const int rc_q = queued ? fq_stream(c, &launch_stream) : fq_join(c);
+    if (rc_q != KMC_OK) return rc_q;
+  }
 
   const uint32_t head = head_of(xyzi_out, mem_kind);
   const uint64_t nv = n + head;
@@ -312,8 +318,8 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   uint32_t* v_bidx = d_bidx ? d_bidx - head : nullptr;
 #define KMC_LAUNCH_TRAJ_BATCH(T)                                                                                                   \
   do {                                                                                                                             \
-    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
-    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);     \
+    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, launch_stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
+    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, launch_stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);     \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;

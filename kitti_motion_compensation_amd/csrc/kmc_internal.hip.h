@@ -55,6 +55,10 @@ struct kmc_ctx {
   TableSlot slots[kTableSlots];
   hipEvent_t group_consumed[kSlotGroups] = {nullptr, nullptr, nullptr, nullptr};  // kernels of the group finished
   bool group_busy[kSlotGroups] = {false, false, false, false};
+  // with frame queues on, the launches of a group are spread over the queues: one marker per queue (a marker recorded on a
+  // queue after the group's last launch covers everything issued on that queue before it)
+  hipEvent_t group_consumed_q[kSlotGroups][4] = {};
+  unsigned group_queue_mask[kSlotGroups] = {0, 0, 0, 0};
   int next_slot = 0;
   hipStream_t copy_stream = nullptr;
   // host-staging buffers
@@ -83,6 +87,7 @@ struct kmc_ctx {
   hipEvent_t fq_done[kMaxFrameQueues] = {nullptr, nullptr, nullptr, nullptr};
   bool fq_used[kMaxFrameQueues] = {false, false, false, false};
   hipEvent_t fq_fork = nullptr;      // "everything issued on `stream` so far", which the queues wait for
+  hipStream_t fq_spacer[8] = {};     // idle streams created before the queues (hardware-queue mapping, see kmc_hip_set_frame_queues)
 };
 
 namespace kmc_impl {
@@ -183,7 +188,8 @@ int ensure_pipeline(kmc_ctx* c);           // streams, events and device slots o
 //              slot if `need` bytes do not fit;
 // slot_upload: one H2D copy of the slot's pinned staging on the side stream, then a HOST wait for that tiny copy -- the
 //              launch that follows has no cross-stream dependency, so back-to-back launches keep the ~2 us same-stream boundary;
-// slot_end   : after the launch; records one "consumed" marker per group of launches on the compute stream.
+// slot_end   : after the launch; records one "consumed" marker per group of launches on the compute stream (on every frame
+//              queue in use when the launches went to the frame queues).
 int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out);
 int slot_upload(kmc_ctx* c, int slot_id, size_t bytes);
 int slot_end(kmc_ctx* c, int slot_id);

@@ -237,14 +237,26 @@ def test_edge_points_signed_zero_and_axes(ctx, kitti):
     assert np.abs(out[:, :3].astype(np.float64) - ref["xyz_f64"]).max() < 1e-5
 
 
-def test_invalid_arguments(ctx, kitti):
+def test_invalid_arguments(torch_mod, ctx, kitti):
     xyzi, P1 = kitti
     P1, P2 = _poses(P1, TRAJECTORIES["straight"])
     params = _params(P1, P2)
+    # HOST buffers are only copied: a 4-byte-aligned view (numpy slice, std::vector<float>::data() + k) is fine ...
     buf = np.zeros(4 * 16 + 1, dtype=np.float32)
-    mis = buf[1:].reshape(-1, 4)  # 4-byte aligned only
+    buf[1:] = xyzi[:16].reshape(-1)
+    mis = buf[1:].reshape(-1, 4)
+    assert mis.ctypes.data % 16 != 0
+    out_buf = np.zeros(4 * 16 + 1, dtype=np.float32)
+    got = out_buf[1:].reshape(-1, 4)
+    ctx.deskew_f32(mis, got, params)
+    want = np.empty((16, 4), dtype=np.float32)
+    ctx.deskew_f32(xyzi[:16].copy(), want, params)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # ... DEVICE pointers feed 16-byte vector accesses and must be 16-byte aligned
+    d = torch_mod.zeros(4 * 16 + 4, dtype=torch_mod.float32, device="cuda")
+    d_mis = d[1:1 + 64].view(-1, 4)
     with pytest.raises(capi.KmcError) as e:
-        ctx.deskew_f32(mis, np.empty_like(mis), params)
+        ctx.deskew_f32(d_mis, d_mis, params)
     assert e.value.status == capi.ERR_INVALID_ARG
     bad = capi.FrameParams.make(params.twist_np(), 1.5)  # requested time outside the scan
     with pytest.raises(capi.KmcError) as e:

@@ -60,7 +60,7 @@ def main():
     # draining the chip between two launches.  Through kmc_hip_deskew_frames_f32 (480 frames per call) so that Python's per-call
     # cost is not what is measured, and frame by frame through kmc_hip_deskew_f32 for the caller who gets its frames one at a time.
     pack = ctx.prepare_frames([bufs[k % len(bufs)] for k in range(480)], [turn] * 480)
-    for queues in (2, 3):
+    for queues in (2, 3, 4):
         ctx.set_frame_queues(queues)
         ms = timed(lambda: ctx.deskew_frames_f32(pack), 8, warm=2) / 480
         res[f"config2_single_1M_frame_per_launch_{queues}_frame_queues"] = {
@@ -146,6 +146,13 @@ def main():
     ms = timed(drive, 300)
     res["config3_drive_108_frames_one_launch"] = {"points": ntot, "ms_per_drive": ms, "Mpts_s": ntot / ms / 1e3, "GBps": 32 * ntot / ms / 1e6,
                                                   "note": "13 M points = 418 MB traffic per launch (3 rotating sets); fixed ~5 us launch cost is 8 % of 62 us"}
+    # consecutive drives over the frame queues: independent launches overlap their ramp-up and tail
+    for queues in (2, 4):
+        ctx.set_frame_queues(queues)
+        ms_q = timed(drive, 300)
+        res[f"config3_drive_108_frames_one_launch_{queues}_frame_queues"] = {"ms_per_drive": ms_q, "Mpts_s": ntot / ms_q / 1e3, "GBps": 32 * ntot / ms_q / 1e6,
+                                                                              "frac_of_8TBps": 32 * ntot / ms_q / 1e6 / 8000}
+    ctx.set_frame_queues(1)
     # the same drive frame by frame (what a per-frame caller pays)
     def per_frame():
         a, b = sets[0]

@@ -37,6 +37,7 @@ def main():
         frames.append(dict(times=times, poses=poses, stamp_start=t0, stamp_end=t1, requested_time=0.5 * (t0 + t1)))
         params.append(capi.FrameParams.make([1.3, 0.02, 0, 0, 0, 0.03], 0.5))
     parr = capi.params_array(params)
+    frames = ctx.prepare_traj_frames(frames)  # the ctypes pack, built once (Python's dict -> struct conversion is not the library's cost)
     cases = {
         "batched 2-pose (deskew_batch_f32)": lambda: ctx.deskew_batch_f32(d_in, d_out, offsets, parr),
         "batched 3-knot (deskew_traj_batch_f32)": lambda: ctx.deskew_traj_batch_f32(d_in, d_out, offsets, frames),
