@@ -34,10 +34,28 @@ int ensure_tmp(kmc_ctx* c, size_t bytes) {
   return KMC_OK;
 }
 
+int ensure_pipe_streams(kmc_ctx* c) {
+  for (int b = 0; b < 3; ++b)
+    if (!c->pipe[b]) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe[b], hipStreamNonBlocking));
+  return KMC_OK;
+}
+
+int ensure_events(kmc_ctx* c, size_t count) {
+  while (c->ev_pool.size() < count) {
+    hipEvent_t ev = nullptr;
+    KMC_HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ev_pool.push_back(ev);
+  }
+  return KMC_OK;
+}
+
 int ensure_pipeline(kmc_ctx* c) {
   if (c->stage_cap) return KMC_OK;
   const size_t bytes = kHostChunkPoints * sizeof(v4f);
-  for (int b = 0; b < 3; ++b) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe[b], hipStreamNonBlocking));
+  {
+    const int rc_streams = ensure_pipe_streams(c);
+    if (rc_streams != KMC_OK) return rc_streams;
+  }
   for (int b = 0; b < kmc_ctx::kPipeSlots; ++b) {
     KMC_HIP_TRY(c, hipMalloc(&c->d_stage_in[b], bytes));
     KMC_HIP_TRY(c, hipMalloc(&c->d_stage_out[b], bytes));
@@ -93,7 +111,14 @@ int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
       KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
     }
     c->group_busy[group_id] = false;
+  } else if (slot_id % kmc_ctx::kSlotsPerGroup == 0 && c->group_dirty[group_id]) {
+    // the previous lap through this group ended without a marker (a call failed between slot_begin and slot_end): its
+    // launches may still read the tables -- drain instead of guessing
+    const int rc_join = fq_join(c);
+    if (rc_join != KMC_OK) return rc_join;
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
+  c->group_dirty[group_id] = true;
   if (need > c->slots[slot_id].cap) {
     // grow EVERY slot at once (so that steady state never allocates again); slots may still be referenced by kernels in
     // flight: drain first
@@ -114,6 +139,8 @@ int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
       each.cap = cap;
     }
     for (auto& busy : c->group_busy) busy = false;
+    for (auto& dirty : c->group_dirty) dirty = false;
+    c->group_dirty[group_id] = true;
   }
   *slot_id_out = slot_id;
   return KMC_OK;
@@ -141,6 +168,7 @@ int slot_end(kmc_ctx* c, int slot_id) {
     if (!mask) KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
     c->group_queue_mask[group_id] = mask;
     c->group_busy[group_id] = true;
+    c->group_dirty[group_id] = false;
   }
   return KMC_OK;
 }
@@ -231,6 +259,7 @@ void kmc_hip_destroy(kmc_ctx* c) {
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (int b = 0; b < 3; ++b)
     if (c->pipe[b]) { (void)hipStreamSynchronize(c->pipe[b]); (void)hipStreamDestroy(c->pipe[b]); }
+  for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
   for (int b = 0; b < kmc_ctx::kPipeSlots; ++b) {
     if (c->d_stage_in[b]) (void)hipFree(c->d_stage_in[b]);
     if (c->d_stage_out[b]) (void)hipFree(c->d_stage_out[b]);
@@ -279,6 +308,7 @@ static int switch_stream(kmc_ctx* c, hipStream_t next) {
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
   KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   for (auto& busy : c->group_busy) busy = false;
+  for (auto& dirty : c->group_dirty) dirty = false;
   c->stream = next;
   return KMC_OK;
 }

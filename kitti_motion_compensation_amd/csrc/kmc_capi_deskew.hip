@@ -3,6 +3,9 @@
 // f64 -> device-precision frame records, launch geometry, optional host staging; all per-point work is in kmc_kernels.hip.h.
 #include "kmc_internal.hip.h"
 
+#include <atomic>
+#include <thread>
+
 namespace {
 
 // ---- template dispatch ---------------------------------------------------------------------------
@@ -78,6 +81,85 @@ int check_frame_args(const float* xyzi_in, float* xyzi_out, uint64_t n, const km
   if (!params_ok(params)) return KMC_ERR_INVALID_ARG;
   if (!(params->x_req >= 0.0 && params->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
   return KMC_OK;
+}
+// ---- the f64 Eigen-layout route on HOST buffers of >= kF64PipelineMinPoints points: a duplex chunk pipeline ---------------
+// PCIe is full duplex (measured on the MI355X box: 50 GB/s each way alone, 43 GB/s each way together,
+// tools/f64_route_probe.hip), but "upload everything, run, download everything" uses one direction at a time: 12.96 ms for
+// a 10 M-point frame (400 MB up, 320 MB down).  Here the frame is cut into chunks of kF64ChunkPoints points; the calling
+// thread uploads chunk k+1 and launches its kernel while a helper thread downloads chunk k (copies from / to pageable
+// memory block their caller, hence the second thread).  The device scratch holds the whole frame, so chunks never wait for a
+// buffer.
+constexpr uint64_t kF64PipelineMinPoints = 1ull << 20;
+constexpr uint64_t kF64ChunkPoints = 1ull << 20;
+
+int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
+                                  uint64_t n, const FrameRec64& f, double* ox, double* oy, double* oz, double* ow, kmc_stats* st) {
+  const size_t col = n * sizeof(double);
+  int rc = ensure_tmp(c, 9 * col);
+  if (rc != KMC_OK) return rc;
+  rc = ensure_pipe_streams(c);
+  if (rc != KMC_OK) return rc;
+  const uint64_t n_chunks = (n + kF64ChunkPoints - 1) / kF64ChunkPoints;
+  rc = ensure_events(c, 2 * n_chunks);
+  if (rc != KMC_OK) return rc;
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  double* base = (double*)c->d_tmp;
+  double* cols[9];
+  for (int i = 0; i < 9; ++i) cols[i] = base + (size_t)i * n;
+  const bool down_w = ow != nullptr;
+  hipStream_t s_up = c->pipe[0], s_run = c->pipe[1], s_down = c->pipe[2];
+  KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), s_run));
+
+  std::atomic<uint64_t> launched{0};   // chunks whose kernel-done event has been recorded
+  std::atomic<bool> abort_flag{false};
+  hipError_t down_error = hipSuccess;
+  std::thread downloader([&] {
+    hipError_t e = hipSetDevice(c->device);
+    for (uint64_t k = 0; k < n_chunks && e == hipSuccess; ++k) {
+      while (launched.load(std::memory_order_acquire) <= k) {
+        if (abort_flag.load(std::memory_order_acquire)) return;
+        std::this_thread::yield();
+      }
+      const uint64_t off = k * kF64ChunkPoints, m = std::min<uint64_t>(kF64ChunkPoints, n - off);
+      e = hipStreamWaitEvent(s_down, c->ev_pool[2 * k + 1], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync(ox + off, cols[5] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess) e = hipMemcpyAsync(oy + off, cols[6] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess) e = hipMemcpyAsync(oz + off, cols[7] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess && down_w) e = hipMemcpyAsync(ow + off, cols[8] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+    down_error = e;
+  });
+  hipError_t up_error = hipSuccess;
+  for (uint64_t k = 0; k < n_chunks && up_error == hipSuccess; ++k) {
+    const uint64_t off = k * kF64ChunkPoints, m = std::min<uint64_t>(kF64ChunkPoints, n - off);
+    hipError_t e = hipMemcpyAsync(cols[0] + off, x + off, m * sizeof(double), hipMemcpyHostToDevice, s_up);
+    if (e == hipSuccess) e = hipMemcpyAsync(cols[1] + off, y + off, m * sizeof(double), hipMemcpyHostToDevice, s_up);
+    if (e == hipSuccess) e = hipMemcpyAsync(cols[2] + off, z + off, m * sizeof(double), hipMemcpyHostToDevice, s_up);
+    if (e == hipSuccess && w) e = hipMemcpyAsync(cols[3] + off, w + off, m * sizeof(double), hipMemcpyHostToDevice, s_up);
+    if (e == hipSuccess) e = hipMemcpyAsync(cols[4] + off, stamps + off, m * sizeof(double), hipMemcpyHostToDevice, s_up);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_pool[2 * k], s_up);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s_run, c->ev_pool[2 * k], 0);
+    if (e == hipSuccess) {
+      const int grid = grid_for(c, (m + 127) / 128);
+      hipLaunchKernelGGL(deskew_f64cols<0>, dim3(grid), dim3(64), 0, s_run, cols[0] + off, cols[1] + off, cols[2] + off, w ? cols[3] + off : nullptr,
+                         cols[4] + off, m, f, cols[5] + off, cols[6] + off, cols[7] + off, down_w ? cols[8] + off : nullptr, c->d_counter);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(c->ev_pool[2 * k + 1], s_run);
+    if (e == hipSuccess) launched.store(k + 1, std::memory_order_release);
+    up_error = e;
+  }
+  if (up_error != hipSuccess) abort_flag.store(true, std::memory_order_release);
+  downloader.join();
+  if (up_error != hipSuccess) return fail_hip(c, up_error, "f64 host pipeline (upload / launch)");
+  if (down_error != hipSuccess) return fail_hip(c, down_error, "f64 host pipeline (download)");
+  unsigned long long bad = 0;
+  KMC_HIP_TRY(c, hipMemcpyAsync(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost, s_run));
+  KMC_HIP_TRY(c, hipStreamSynchronize(s_run));
+  KMC_HIP_TRY(c, hipStreamSynchronize(s_up));
+  if (st) { st->n_launches = (uint32_t)n_chunks; st->n_out_of_range = bad; }
+  return bad ? KMC_ERR_TIME_OUT_OF_RANGE : KMC_OK;
 }
 }  // namespace
 
@@ -338,24 +420,29 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   const double *dx = x, *dy = y, *dz = z, *dw = w, *ds = stamps;
   double *dox = ox, *doy = oy, *doz = oz, *dow = ow;
   const size_t col = n * sizeof(double);
+  // (Recognising a homogeneous column of ones on the host and skipping its two transfers was measured and dropped: scanning
+  // and refilling it costs what moving it over PCIe costs -- 12 + 9 us against 37 us saved at 123 k points, and it serialises
+  // with the pageable copies; tools/f64_route_probe.hip.)
+  if (mem_kind == KMC_MEM_HOST && n >= kF64PipelineMinPoints) return deskew_f64cols_host_pipelined(c, x, y, z, w, stamps, n, f, ox, oy, oz, ow, st);
   if (mem_kind == KMC_MEM_HOST) {
     int rc = ensure_tmp(c, 9 * col);
     if (rc != KMC_OK) return rc;
     double* base = (double*)c->d_tmp;
     double* cols[9];
     for (int i = 0; i < 9; ++i) cols[i] = base + (size_t)i * n;
+    const bool up_w = w != nullptr;
     // an Eigen::MatrixX4d is ONE column-major block: x, y, z, w follow each other -> one copy instead of four (each
-    // pageable copy has a fixed cost of tens of microseconds, which is what a 123 k-point frame is made of)
-    if (y == x + n && z == y + n && (!w || w == z + n)) {
-      KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, (w ? 4 : 3) * col, hipMemcpyHostToDevice, c->stream));
+    // copy has a fixed cost of ~20 us, which is what a 123 k-point frame is made of)
+    if (y == x + n && z == y + n && (!up_w || w == z + n)) {
+      KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, (up_w ? 4 : 3) * col, hipMemcpyHostToDevice, c->stream));
     } else {
       KMC_HIP_TRY(c, hipMemcpyAsync(cols[0], x, col, hipMemcpyHostToDevice, c->stream));
       KMC_HIP_TRY(c, hipMemcpyAsync(cols[1], y, col, hipMemcpyHostToDevice, c->stream));
       KMC_HIP_TRY(c, hipMemcpyAsync(cols[2], z, col, hipMemcpyHostToDevice, c->stream));
-      if (w) KMC_HIP_TRY(c, hipMemcpyAsync(cols[3], w, col, hipMemcpyHostToDevice, c->stream));
+      if (up_w) KMC_HIP_TRY(c, hipMemcpyAsync(cols[3], w, col, hipMemcpyHostToDevice, c->stream));
     }
     KMC_HIP_TRY(c, hipMemcpyAsync(cols[4], stamps, col, hipMemcpyHostToDevice, c->stream));
-    dx = cols[0]; dy = cols[1]; dz = cols[2]; dw = w ? cols[3] : nullptr; ds = cols[4];
+    dx = cols[0]; dy = cols[1]; dz = cols[2]; dw = up_w ? cols[3] : nullptr; ds = cols[4];
     dox = cols[5]; doy = cols[6]; doz = cols[7]; dow = ow ? cols[8] : nullptr;
   }
   CallTimer tm(c);
@@ -369,13 +456,14 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   unsigned long long bad = 0;
   KMC_HIP_TRY(c, hipMemcpyAsync(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
   if (mem_kind == KMC_MEM_HOST) {
-    if (oy == ox + n && oz == oy + n && (!ow || ow == oz + n)) {  // one column-major block again
-      KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, (ow ? 4 : 3) * col, hipMemcpyDeviceToHost, c->stream));
+    const bool down_w = ow != nullptr;
+    if (oy == ox + n && oz == oy + n && (!down_w || ow == oz + n)) {  // one column-major block again
+      KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, (down_w ? 4 : 3) * col, hipMemcpyDeviceToHost, c->stream));
     } else {
       KMC_HIP_TRY(c, hipMemcpyAsync(ox, dox, col, hipMemcpyDeviceToHost, c->stream));
       KMC_HIP_TRY(c, hipMemcpyAsync(oy, doy, col, hipMemcpyDeviceToHost, c->stream));
       KMC_HIP_TRY(c, hipMemcpyAsync(oz, doz, col, hipMemcpyDeviceToHost, c->stream));
-      if (ow) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
+      if (down_w) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
     }
   }
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the out-of-range verdict is part of the call's result

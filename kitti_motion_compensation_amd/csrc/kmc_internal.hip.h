@@ -55,6 +55,8 @@ struct kmc_ctx {
   TableSlot slots[kTableSlots];
   hipEvent_t group_consumed[kSlotGroups] = {nullptr, nullptr, nullptr, nullptr};  // kernels of the group finished
   bool group_busy[kSlotGroups] = {false, false, false, false};
+  bool group_dirty[kSlotGroups] = {false, false, false, false};  // slots handed out since the group's last marker (an error
+                                                                 // return between slot_begin and slot_end leaves no marker)
   // with frame queues on, the launches of a group are spread over the queues: one marker per queue (a marker recorded on a
   // queue after the group's last launch covers everything issued on that queue before it)
   hipEvent_t group_consumed_q[kSlotGroups][4] = {};
@@ -71,6 +73,7 @@ struct kmc_ctx {
   hipEvent_t ev_kernel[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_d2h[kPipeSlots] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_cap = 0;  // bytes per buffer
+  std::vector<hipEvent_t> ev_pool;  // grow-only events of the chunked f64 host route (two per chunk)
   void* d_traj = nullptr; // segment tables of the N-knot trajectory kernels (16 x TrajSeg32 + 16 x TrajSeg64)
   void* h_traj = nullptr; // pinned staging of the same size
   hipEvent_t ev_traj = nullptr;  // last upload from h_traj has completed
@@ -182,6 +185,8 @@ inline int ppt_of(const kmc_ctx* c) {
 
 int ensure_tmp(kmc_ctx* c, size_t bytes);  // grow-only device scratch of the host-buffer paths
 int ensure_pipeline(kmc_ctx* c);           // streams, events and device slots of the three-stage host pipeline
+int ensure_pipe_streams(kmc_ctx* c);       // only its three streams
+int ensure_events(kmc_ctx* c, size_t count);  // at least `count` events in ev_pool
 
 // ---- ring of table slots (batch tables and trajectory segment tables) ---------------------------------------------------
 // slot_begin : picks the next slot, waits (host) until the kernels of its group from the previous lap are done, grows every

@@ -341,6 +341,7 @@ typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
 
 __device__ __forceinline__ void deskew_one_f64(double px, double py, double pz, double pw, double t, const FrameRec64& f, double& rx,
                                                double& ry, double& rz, bool& in_range) {
+#pragma clang fp contract(off)  // the fraction of the trajectory is the reference's (t - t1) / (t2 - t1), each operation rounded
   in_range = (t >= f.t_start) && (t <= f.t_end);  // TimeIsInRange, trajectory_interpolation.cpp:47
   if (in_range) {
     const double xi = (t - f.t_start) / f.dur;  // FractionOfTrajectory, :49-51 (a true divide, like the reference)
@@ -410,6 +411,9 @@ template <int kInstance = 0>  // a template only so that the header can be inclu
 __global__ __launch_bounds__(64) void pseudo_timestamps_f64(const double* __restrict__ x, const double* __restrict__ y,
                                                             uint64_t n, double start, double end,
                                                             double* __restrict__ stamps) {
+  // every operation individually rounded like the reference's build (plain -O3, no FMA): start + frac * dur must not become one
+  // fma, or a stamp at the scan seam can land on the other side of the reference's t <= t_end assert (trajectory_interpolation.cpp:32)
+#pragma clang fp contract(off)
   constexpr double kPi = 3.14159265358979323846;
   const double dur = end - start;
   const uint64_t n_tiles = (n + 127) / 128;

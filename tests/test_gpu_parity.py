@@ -464,6 +464,54 @@ def test_f64cols_out_of_range_stamps_are_reported(ctx, kitti):
     assert rc_o == orc.ERR_TIME_OUT_OF_RANGE and nbad_o == 3
 
 
+def test_f64cols_host_route_large_frame_is_pipelined_and_identical(torch_mod, ctx):
+    """Host buffers of >= 2^20 points take the duplex chunk pipeline (upload of chunk k+1, kernel, download of chunk k in
+    parallel, a helper thread for the downloads): same bits as the device-resident call on the same data, a column of ones is
+    neither uploaded nor downloaded, a general w column is honoured, out-of-range stamps are still counted and reported."""
+    torch = torch_mod
+    n = 2_500_017  # 3 chunks, the last one ragged and odd
+    xyzi = capi.synth_points_host(n, 31337)
+    cloud = np.concatenate([xyzi[:, :3].astype(np.float64), np.ones((n, 1))], axis=1)
+    cols = np.ascontiguousarray(cloud.T)  # one column-major block like Eigen: rows = the four columns
+    stamps = orc.pseudo_timestamps(cloud, T0, T1)
+    P1 = orc.Affine.from_Rt(orc.so3_exp([0.01, -0.02, 0.7]), [12.5, -3.0, 0.4])
+    A, B = _poses(P1, TRAJECTORIES["hard_turn"])
+    params = _params(A, B)
+    # reference: the device-resident call
+    d_cols = torch.from_numpy(cols).cuda()
+    d_st = torch.from_numpy(stamps).cuda()
+    d_out = torch.empty_like(d_cols)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.deskew_f64cols(d_cols[0], d_cols[1], d_cols[2], d_cols[3], d_st, T0, T1, params, d_out[0], d_out[1], d_out[2], d_out[3])
+    torch.cuda.synchronize()
+    want = d_out.cpu().numpy()
+    out = np.full((4, n), np.nan)
+    rc, st = ctx.deskew_f64cols(cols[0], cols[1], cols[2], cols[3], stamps, T0, T1, params, out[0], out[1], out[2], out[3])
+    assert rc == capi.OK and st.n_launches == 3 and st.n_out_of_range == 0
+    assert np.array_equal(out.view(np.uint64), want.view(np.uint64))
+    assert np.all(out[3] == 1.0)
+    sel = slice(0, n, 97)
+    rc_o, nbad, ref = orc.motion_compensate_frame(cloud[sel], stamps[sel], T0, A, T1, B, TREQ)
+    assert rc_o == orc.OK
+    assert util.rel_point_error(out[:3, sel].T, ref[:, :3]).max() <= REL_TOL_F64
+    # a general homogeneous column (not all ones) is uploaded, used (translation scaled by w) and returned
+    cols2 = cols.copy()
+    cols2[3, ::5] = 0.5
+    d_cols2 = torch.from_numpy(cols2).cuda()
+    ctx.deskew_f64cols(d_cols2[0], d_cols2[1], d_cols2[2], d_cols2[3], d_st, T0, T1, params, d_out[0], d_out[1], d_out[2], d_out[3])
+    torch.cuda.synchronize()
+    out2 = np.full((4, n), np.nan)
+    ctx.deskew_f64cols(cols2[0], cols2[1], cols2[2], cols2[3], stamps, T0, T1, params, out2[0], out2[1], out2[2], out2[3])
+    assert np.array_equal(out2.view(np.uint64), d_out.cpu().numpy().view(np.uint64)) and np.array_equal(out2[3], cols2[3])
+    assert not np.array_equal(out2[0], out[0])
+    # out-of-range stamps in different chunks
+    bad = stamps.copy()
+    bad[[5, 1_200_000, n - 1]] = [T0 - 1e-6, T1 + 1e-6, 0.0]
+    rc, st = ctx.deskew_f64cols(cols[0], cols[1], cols[2], cols[3], bad, T0, T1, params, out[0], out[1], out[2], out[3], raise_on_range=False)
+    assert rc == capi.ERR_TIME_OUT_OF_RANGE and st.n_out_of_range == 3
+    assert np.isnan(out[0][[5, 1_200_000, n - 1]]).all()
+
+
 def test_pseudo_timestamps_f64(ctx, kitti, kats):
     xyzi, _ = kitti
     x = xyzi[:, 0].astype(np.float64)
