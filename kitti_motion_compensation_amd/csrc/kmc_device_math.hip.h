@@ -229,7 +229,26 @@ __device__ __forceinline__ bool knot_ge(float x, float y, float knot_c, float ck
   return !lt;
 }
 
-// ---- f64 path (Eigen-layout API): closed form in double, series below theta^2 = 0.04 -----------------
+// Coefficient tables of the f64 routines, in constant memory: read at wave-uniform addresses they arrive through scalar loads
+// in SGPRs.  As literals the compiler materialises all ~40 of them in VGPR pairs and hoists them out of the kernels' tile loops
+// (measured: 102-170 VGPRs instead of 34-60 for the f32 kernels, 122 instead of 84 for the Eigen-layout kernel).
+__constant__ double kRedoTable[42] = {
+    // [0..11]  atan(r) / r in r^2, highest degree first (degree-11 fit on r^2 <= tan^2(pi/8), tools/gen_atan_coeffs.py --f64)
+    -1.78108398111324964e-02, 3.79703151591785637e-02, -5.03530597010270892e-02, 5.84692471107266312e-02,
+    -6.66295840125903926e-02, 7.69204593125487474e-02, -9.09089684393908082e-02, 1.11111107461531272e-01,
+    -1.42857142792741643e-01, 1.99999999999410899e-01, -3.33333333333331205e-01, 1.0,
+    // [12..19] sin t / t in t^2:        (-1)^k / (2k+1)!, k = 7..0
+    -1.0 / 1307674368000.0, 1.0 / 6227020800.0, -1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0, 1.0,
+    // [20..27] (1 - cos t) / t^2:       (-1)^k / (2k+2)!
+    -1.0 / 20922789888000.0, 1.0 / 87178291200.0, -1.0 / 479001600.0, 1.0 / 3628800.0, -1.0 / 40320.0, 1.0 / 720.0, -1.0 / 24.0, 0.5,
+    // [28..35] (t - sin t) / t^3:       (-1)^k / (2k+3)!
+    -1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0,
+    // [36..41] tan(pi/8), pi/4, pi/2, pi, 2 pi, spare -- even these: as literals they are hoisted into VGPR pairs like the rest
+    0.41421356237309503, 0.78539816339744831, 1.5707963267948966, 3.14159265358979323846, 6.28318530717958647692, 0.0};
+
+using cdouble_p = const double __attribute__((address_space(4)))*;  // constant address space: uniform reads are scalar loads
+
+// ---- f64 path (Eigen-layout API): closed form in double ---------------------------------------------
 struct FrameRec64 {
   double phi[3], rho[3], c1[3], c2[3];
   double phi2;
@@ -245,22 +264,30 @@ struct TrajSeg64 {
   int pad;
 };
 
+// alpha = A s, beta = B s^2, gamma = C s^3 with A = sin t / t, B = (1 - cos t) / t^2, C = (t - sin t) / t^3, t = |s phi|:
+// 8-term series at t / 8 (truncation < 1e-19 for t <= 4), then three angle doublings
+//     A(2x) = A(x) cos x,  cos x = 1 - x^2 B(x);   B(2x) = A(x)^2 / 2;   C(2x) = (C(x) + A(x) B(x)) / 4
+// -- no cancellation anywhere, no trig, no divide, no branch.  (Round 1 switched between a 7-term series and a half-angle
+// sincos at t^2 = 0.04; ocml's f64 sincos carries its large-argument reduction along: 122 VGPRs and 4 waves per SIMD for the
+// Eigen-layout kernel.)
 __device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, double& alpha, double& beta, double& gamma) {
   const double s2 = s * s;
-  const double u = s2 * phi2;
-  double A, B, C;
-  if (u < 0.04) {
-    A = 1.0 + u * (-1.0 / 6 + u * (1.0 / 120 + u * (-1.0 / 5040 + u * (1.0 / 362880 + u * (-1.0 / 39916800 + u * (1.0 / 6227020800.0))))));
-    B = 0.5 + u * (-1.0 / 24 + u * (1.0 / 720 + u * (-1.0 / 40320 + u * (1.0 / 3628800 + u * (-1.0 / 479001600 + u * (1.0 / 87178291200.0))))));
-    C = 1.0 / 6 + u * (-1.0 / 120 + u * (1.0 / 5040 + u * (-1.0 / 362880 + u * (1.0 / 39916800 + u * (-1.0 / 6227020800.0 + u * (1.0 / 1307674368000.0))))));
-  } else {
-    const double th = sqrt(u);
-    double sh, ch;
-    sincos(0.5 * th, &sh, &ch);
-    const double sn = 2.0 * sh * ch;
-    A = sn / th;
-    B = 2.0 * sh * sh / u;
-    C = (th - sn) / (u * th);
+  double u = __builtin_ldexp(s2 * phi2, -6);  // (t / 8)^2
+  const cdouble_p t = (cdouble_p)kRedoTable;  // [12..19] A, [20..27] B, [28..35] C, highest degree first
+  double A = t[12], B = t[20], C = t[28];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    A = __builtin_fma(A, u, t[12 + k]);
+    B = __builtin_fma(B, u, t[20 + k]);
+    C = __builtin_fma(C, u, t[28 + k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double cosx = __builtin_fma(-u, B, 1.0);
+    C = __builtin_ldexp(__builtin_fma(A, B, C), -2);
+    B = 0.5 * A * A;
+    A = A * cosx;
+    u *= 4.0;
   }
   alpha = A * s;
   beta = B * s2;
@@ -292,30 +319,12 @@ __device__ __forceinline__ void deskew_point_f64(double x, double y, double z, d
 // Written for a SMALL register footprint, not for speed: the redo is compiled into every f32 kernel, and those must keep
 // their 8 waves per SIMD (<= 64 VGPRs).  ocml's f64 atan2 alone takes 60 VGPRs and its sincos drags in the large-argument
 // reduction; the two routines below are straight Horner chains (constants through SGPRs) and fit next to the f32 path.
-
-// Their coefficient tables live in constant memory and are read through an address the optimiser cannot see through
-// (opaque_table): as literals the compiler hoists all ~40 of them out of the kernels' tile loops into VGPR pairs --
-// measured: 102-170 VGPRs instead of 34-60, or 140-300 bytes of scratch per lane under an occupancy attribute.
-__constant__ double kRedoTable[42] = {
-    // [0..11]  atan(r) / r in r^2, highest degree first (degree-11 fit on r^2 <= tan^2(pi/8), tools/gen_atan_coeffs.py --f64)
-    -1.78108398111324964e-02, 3.79703151591785637e-02, -5.03530597010270892e-02, 5.84692471107266312e-02,
-    -6.66295840125903926e-02, 7.69204593125487474e-02, -9.09089684393908082e-02, 1.11111107461531272e-01,
-    -1.42857142792741643e-01, 1.99999999999410899e-01, -3.33333333333331205e-01, 1.0,
-    // [12..19] sin t / t in t^2:        (-1)^k / (2k+1)!, k = 7..0
-    -1.0 / 1307674368000.0, 1.0 / 6227020800.0, -1.0 / 39916800.0, 1.0 / 362880.0, -1.0 / 5040.0, 1.0 / 120.0, -1.0 / 6.0, 1.0,
-    // [20..27] (1 - cos t) / t^2:       (-1)^k / (2k+2)!
-    -1.0 / 20922789888000.0, 1.0 / 87178291200.0, -1.0 / 479001600.0, 1.0 / 3628800.0, -1.0 / 40320.0, 1.0 / 720.0, -1.0 / 24.0, 0.5,
-    // [28..35] (t - sin t) / t^3:       (-1)^k / (2k+3)!
-    -1.0 / 355687428096000.0, 1.0 / 1307674368000.0, -1.0 / 6227020800.0, 1.0 / 39916800.0, -1.0 / 362880.0, 1.0 / 5040.0, -1.0 / 120.0, 1.0 / 6.0,
-    // [36..41] tan(pi/8), pi/4, pi/2, pi, 2 pi, spare -- even these: as literals they are hoisted into VGPR pairs like the rest
-    0.41421356237309503, 0.78539816339744831, 1.5707963267948966, 3.14159265358979323846, 6.28318530717958647692, 0.0};
-
-// All tables of the redo -- the coefficients above and the frame / segment records -- are read through constant-address-space
+//
+// All tables of the redo -- the coefficients of kRedoTable and the frame / segment records -- are read through constant-address-space
 // pointers (uniform address -> scalar loads into SGPRs, no VGPRs for constants) that pass through an empty volatile asm
 // tied to the previous phase's result (`after`).  That pins every group of table reads behind the arithmetic that precedes
 // it, so that at most 12-24 SGPRs of table are live at any time.  Left to itself the compiler loads the 36 coefficients and
 // the whole record up front (80+ SGPRs: spills, and a private segment for the kernel).
-using cdouble_p = const double __attribute__((address_space(4)))*;
 __device__ __forceinline__ cdouble_p after(cdouble_p t, double dep) {
   asm volatile("" : "+s"(t) : "v"(dep));
   return t;
