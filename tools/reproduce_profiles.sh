@@ -11,9 +11,9 @@ O=$ROOT/gpurun_out/$TAG
 mkdir -p "$O"
 export TMPDIR=/tmp
 run() { echo "== $*" >&2; "$@"; }
-run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o bench -- python bench.py --no-cpu-baseline > "$O/bench_kt.log" 2>&1
-run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$O/bench_fetch.log" 2>&1
-run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > "$O/bench_write.log" 2>&1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o bench -- python bench.py --no-cpu-baseline --no-live-traffic --no-configs3 > "$O/bench_kt.log" 2>&1
+run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-configs3 > "$O/bench_fetch.log" 2>&1
+run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-configs3 > "$O/bench_write.log" 2>&1
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/cal_fetch" -o tune -- kitti_motion_compensation_amd/lib/kmc_tune 67108864 1 1 > "$O/cal_fetch.csv" 2>/dev/null
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/cal_write" -o tune -- kitti_motion_compensation_amd/lib/kmc_tune 67108864 1 1 > "$O/cal_write.csv" 2>/dev/null
 run kitti_motion_compensation_amd/lib/kmc_tune 67108864 5 10 > "$O/tune.csv" 2> "$O/tune.err"
