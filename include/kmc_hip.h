@@ -180,9 +180,7 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * device-resident kmc_hip_deskew_f32 calls are issued round-robin over `queues` HIP streams (hardware queues) of the context --
  * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip, tools/fq_probe.hip).
  *   - queues = 1 (default): every call on the context's stream, strictly in order (the behaviour of ABI version 1).
- *   - queues = 2..4: consecutive DEVICE-RESIDENT kmc_hip_deskew_f32 / kmc_hip_deskew_batch_f32 / kmc_hip_deskew_traj_batch_f32
- *     calls are NOT ordered with each other (a drive-sized batched launch of ~60 us gains ~5 % from overlapping its ramp-up and
- *     tail with its neighbours').  The first frame
+ *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls are NOT ordered with each other.  The first frame
  *     after a join waits for everything issued on the context's stream before it (its producers); kmc_hip_frame_queue_join()
  *     makes the context's stream wait for every frame issued so far (device-side, the host does not block).  Every other entry
  *     point, kmc_hip_synchronize(), kmc_hip_timer_end() and kmc_hip_set_stream() join first, so anything issued after the frames

@@ -104,12 +104,7 @@ int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
   const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
   c->next_slot = (c->next_slot + 1) % kmc_ctx::kTableSlots;
   if (slot_id % kmc_ctx::kSlotsPerGroup == 0 && c->group_busy[group_id]) {
-    if (c->group_queue_mask[group_id]) {
-      for (int q = 0; q < kmc_ctx::kMaxFrameQueues; ++q)
-        if (c->group_queue_mask[group_id] & (1u << q)) KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed_q[group_id][q]));
-    } else {
-      KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
-    }
+    KMC_HIP_TRY(c, hipEventSynchronize(c->group_consumed[group_id]));
     c->group_busy[group_id] = false;
   } else if (slot_id % kmc_ctx::kSlotsPerGroup == 0 && c->group_dirty[group_id]) {
     // the previous lap through this group ended without a marker (a call failed between slot_begin and slot_end): its
@@ -157,16 +152,7 @@ int slot_upload(kmc_ctx* c, int slot_id, size_t bytes) {
 int slot_end(kmc_ctx* c, int slot_id) {
   if (slot_id % kmc_ctx::kSlotsPerGroup == kmc_ctx::kSlotsPerGroup - 1) {
     const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
-    unsigned mask = 0;
-    if (c->fq_forked) {  // launches since the fork went to the frame queues: a marker on each queue in use
-      for (int q = 0; q < c->fq_count; ++q) {
-        if (!c->fq_used[q]) continue;
-        KMC_HIP_TRY(c, hipEventRecord(c->group_consumed_q[group_id][q], c->fq[q]));
-        mask |= 1u << q;
-      }
-    }
-    if (!mask) KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
-    c->group_queue_mask[group_id] = mask;
+    KMC_HIP_TRY(c, hipEventRecord(c->group_consumed[group_id], c->stream));
     c->group_busy[group_id] = true;
     c->group_dirty[group_id] = false;
   }
@@ -237,9 +223,6 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming);
   for (auto& ev : c->group_consumed)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-  for (auto& per_queue : c->group_consumed_q)
-    for (auto& ev : per_queue)
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fq_fork, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -285,9 +268,6 @@ void kmc_hip_destroy(kmc_ctx* c) {
   }
   for (auto& ev : c->group_consumed)
     if (ev) (void)hipEventDestroy(ev);
-  for (auto& per_queue : c->group_consumed_q)
-    for (auto& ev : per_queue)
-      if (ev) (void)hipEventDestroy(ev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->d_counter) (void)hipFree(c->d_counter);
   hipEvent_t evs[] = {c->ev_k0, c->ev_k1, c->ev_c0, c->ev_c1, c->ev_t0, c->ev_t1};

@@ -293,18 +293,11 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
   // 16-byte alignment is a requirement of the kernels' vector accesses: device pointers only (host buffers are copied)
   if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
-  // device-resident batches are independent of each other like single frames: with frame queues on they go round-robin over
-  // the queues too, so that consecutive launches overlap their ramp-up and tail (matters for drive-sized launches, ~60 us)
-  const bool queued = mem_kind == KMC_MEM_DEVICE && c->fq_count > 1 && !c->timing && n_frames && offsets[n_frames] != 0;
+  // Batched launches always go to the context's stream, after a join: routing them over the frame queues was measured and
+  // dropped -- their table uploads on the side stream end up sharing hardware queues with the launches (a 13 M-point drive:
+  // 64 us in order, 74 us over two queues, 188 us over four; tools/measure_configs.py, gpurun_out/r02/measure_configs.json).
+  KMC_ENTER(c);
   hipStream_t launch_stream = c->stream;
-  if (queued) {
-    const int rc_q = fq_stream(c, &launch_stream);
-    if (rc_q != KMC_OK) return rc_q;
-  } else {
-    const int rc_j = fq_join(c);
-    if (rc_j != KMC_OK) return rc_j;
-  }
   const int tier = pick_tier(c, params, n_frames);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
@@ -416,6 +409,8 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   f.t_start = stamp_start;
   f.t_end = stamp_end;
   f.dur = stamp_end - stamp_start;
+  f.halvings = (f.phi2 <= 0.25) ? 0 : 3;  // |s| <= 1 inside the scan
+  f.pad = 0;
 
   const double *dx = x, *dy = y, *dz = z, *dw = w, *ds = stamps;
   double *dox = ox, *doy = oy, *doz = oz, *dow = ow;

@@ -55,6 +55,8 @@ void fill_rec64(const kmc_host::Twist& f, FrameRec64* r) {
   r->c1[0] = c1.x; r->c1[1] = c1.y; r->c1[2] = c1.z;
   r->c2[0] = c2.x; r->c2[1] = c2.y; r->c2[2] = c2.z;
   r->phi2 = kmc_host::dot(f.phi, f.phi);
+  r->halvings = (r->phi2 <= 0.25) ? 0 : 3;  // |s| <= 1 inside a segment
+  r->pad = 0;
 }
 
 // direction (cos, sin) of the knot azimuth alpha = pi - 2 pi c; exact on the quarter turns
@@ -237,8 +239,7 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   const uint64_t n = n_frames ? offsets[n_frames] : 0;
   if (n && (!xyzi_in || !xyzi_out)) return KMC_ERR_INVALID_ARG;
   if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
-  const bool queued = mem_kind == KMC_MEM_DEVICE && c->fq_count > 1 && !c->timing && n != 0;  // see kmc_hip_deskew_batch_f32
+  KMC_ENTER(c);  // batched launches stay on the context's stream, see kmc_hip_deskew_batch_f32
 
   // host pre-step per frame (f64): segments, anchors, M_k
   std::vector<TrajHost> th(n_frames);
@@ -258,10 +259,6 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
   hipStream_t launch_stream = c->stream;
-  {
-    const int rc_q = queued ? fq_stream(c, &launch_stream) : fq_join(c);
-    if (rc_q != KMC_OK) return rc_q;
-  }
 
   const uint32_t head = head_of(xyzi_out, mem_kind);
   const uint64_t nv = n + head;

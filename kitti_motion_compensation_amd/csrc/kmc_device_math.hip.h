@@ -254,6 +254,8 @@ struct FrameRec64 {
   double phi2;
   double x_req;
   double t_start, t_end, dur;
+  int halvings;  // the series is evaluated at t / 2^halvings and doubled back: 0 for |phi| <= 0.5 rad (every vehicle), else 3
+  int pad;
 };
 
 // f64 trajectory segment (global-memory table, read by the f64 Eigen-layout trajectory kernel)
@@ -265,14 +267,15 @@ struct TrajSeg64 {
 };
 
 // alpha = A s, beta = B s^2, gamma = C s^3 with A = sin t / t, B = (1 - cos t) / t^2, C = (t - sin t) / t^3, t = |s phi|:
-// 8-term series at t / 8 (truncation < 1e-19 for t <= 4), then three angle doublings
+// 8-term series at t / 2^h (truncation < 1e-19 for t / 2^h <= 0.5), then h angle doublings
 //     A(2x) = A(x) cos x,  cos x = 1 - x^2 B(x);   B(2x) = A(x)^2 / 2;   C(2x) = (C(x) + A(x) B(x)) / 4
-// -- no cancellation anywhere, no trig, no divide, no branch.  (Round 1 switched between a 7-term series and a half-angle
-// sincos at t^2 = 0.04; ocml's f64 sincos carries its large-argument reduction along: 122 VGPRs and 4 waves per SIMD for the
-// Eigen-layout kernel.)
-__device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, double& alpha, double& beta, double& gamma) {
+// -- no cancellation anywhere, no trig, no divide; h is a per-frame constant chosen on the host (0 up to 0.5 rad of rotation
+// per scan, 3 beyond: wave-uniform loop).  (Round 1 switched per point between a 7-term series and a half-angle sincos at
+// t^2 = 0.04; ocml's f64 sincos carries its large-argument reduction along: 122 VGPRs and 4 waves per SIMD for the
+// Eigen-layout kernel, 54 now.)
+__device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, int halvings, double& alpha, double& beta, double& gamma) {
   const double s2 = s * s;
-  double u = __builtin_ldexp(s2 * phi2, -6);  // (t / 8)^2
+  double u = __builtin_ldexp(s2 * phi2, -2 * halvings);  // (t / 2^h)^2
   const cdouble_p t = (cdouble_p)kRedoTable;  // [12..19] A, [20..27] B, [28..35] C, highest degree first
   double A = t[12], B = t[20], C = t[28];
 #pragma unroll
@@ -281,8 +284,7 @@ __device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, doub
     B = __builtin_fma(B, u, t[20 + k]);
     C = __builtin_fma(C, u, t[28 + k]);
   }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < halvings; ++k) {
     const double cosx = __builtin_fma(-u, B, 1.0);
     C = __builtin_ldexp(__builtin_fma(A, B, C), -2);
     B = 0.5 * A * A;
@@ -297,7 +299,7 @@ __device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, doub
 __device__ __forceinline__ void deskew_point_f64(double x, double y, double z, double w, double s, const FrameRec64& f,
                                                  double& ox, double& oy, double& oz) {
   double al, be, ga;
-  se3_coefficients_f64(s, f.phi2, al, be, ga);
+  se3_coefficients_f64(s, f.phi2, f.halvings, al, be, ga);
   const double q1x = f.phi[1] * z - f.phi[2] * y;
   const double q1y = f.phi[2] * x - f.phi[0] * z;
   const double q1z = f.phi[0] * y - f.phi[1] * x;

@@ -57,10 +57,6 @@ struct kmc_ctx {
   bool group_busy[kSlotGroups] = {false, false, false, false};
   bool group_dirty[kSlotGroups] = {false, false, false, false};  // slots handed out since the group's last marker (an error
                                                                  // return between slot_begin and slot_end leaves no marker)
-  // with frame queues on, the launches of a group are spread over the queues: one marker per queue (a marker recorded on a
-  // queue after the group's last launch covers everything issued on that queue before it)
-  hipEvent_t group_consumed_q[kSlotGroups][4] = {};
-  unsigned group_queue_mask[kSlotGroups] = {0, 0, 0, 0};
   int next_slot = 0;
   hipStream_t copy_stream = nullptr;
   // host-staging buffers
@@ -193,8 +189,7 @@ int ensure_events(kmc_ctx* c, size_t count);  // at least `count` events in ev_p
 //              slot if `need` bytes do not fit;
 // slot_upload: one H2D copy of the slot's pinned staging on the side stream, then a HOST wait for that tiny copy -- the
 //              launch that follows has no cross-stream dependency, so back-to-back launches keep the ~2 us same-stream boundary;
-// slot_end   : after the launch; records one "consumed" marker per group of launches on the compute stream (on every frame
-//              queue in use when the launches went to the frame queues).
+// slot_end   : after the launch; records one "consumed" marker per group of launches on the compute stream.
 int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out);
 int slot_upload(kmc_ctx* c, int slot_id, size_t bytes);
 int slot_end(kmc_ctx* c, int slot_id);

@@ -351,8 +351,11 @@ __device__ __forceinline__ void deskew_one_f64(double px, double py, double pz, 
   }
 }
 
+// At most 4 waves per SIMD on purpose: every wave streams nine columns, and with the 7 waves its 52 VGPRs would allow the
+// kernel is 2-3 % slower (189-196 us against 183-186 us per 16 M points, A/B on one box) -- more concurrent streams, more
+// DRAM page conflicts.
 template <int kInstance = 0>  // a template only so that the header can be included by several translation units
-__global__ __launch_bounds__(64) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                      const double* __restrict__ z, const double* __restrict__ w,
                                                      const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
                                                      double* __restrict__ ox, double* __restrict__ oy,
@@ -679,7 +682,7 @@ __device__ __forceinline__ void traj_one_f64(double px, double py, double pz, do
 
 // same geometry as deskew_f64cols: one wave per workgroup, two consecutive points per lane, 16-byte column accesses
 template <int kInstance = 0>  // a template only so that the header can be included by several translation units
-__global__ __launch_bounds__(64) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, const double* __restrict__ w,
                                                           const double* __restrict__ stamps, uint64_t n,
                                                           const TrajSeg64* __restrict__ segs, uint32_t n_seg,
