@@ -38,7 +38,8 @@ SPIN_UP_STEPS = 12  # untimed, before the W warm-up steps (see main)
 C3_FRAMES_TOTAL = 8000          # BASELINE.json configs[3]: 10 M points per frame x 8 k frames, frame-sharded
 C3_POINTS_PER_FRAME = 10_000_000
 C3_YAW_PER_FRAME = 0.03         # |phi| ~ 0.03 rad per frame
-C3_FRAMES_PER_LAUNCH = 8        # one batched launch = 8 frames = 80 M points = 2.56 GB of traffic
+C3_FRAMES_PER_LAUNCH = 24       # one batched launch = 24 frames = 240 M points = 7.68 GB of traffic
+C3_BUFFER_GROUPS = 2            # rotating buffer groups of C3_FRAMES_PER_LAUNCH distinct frames each (15.4 GB in + out)
 
 
 def make_workload(capi, n_frames, rank, yaw_per_frame=0.0, first_frame=None):
@@ -152,17 +153,17 @@ def live_traffic(frames_per_step, points_per_frame, yaw_per_frame, calibration):
         total += sum(vals) / len(vals) * 1024.0 * factor  # counters are in KiB
     return total
 
-def run_configs3(capi, sharding, torch, ctx, dist, rank, world, d_in, d_out, timed_frames, check):
+def run_configs3(capi, sharding, torch, ctx, dist, rank, world, dev, timed_frames, frames_per_launch, check):
     """BASELINE.json configs[3] -- the stream north_star scales on: 10 M-point frames x 8 000, rank r owns the contiguous
     frame range sharding.frame_range(8000, r, world) (motion_compensation.cpp:22-25's callers make frames independent).
     Timed: the first `timed_frames` frames of the rank's range, C3_FRAMES_PER_LAUNCH frames per batched launch, over >= 2
-    rotating buffer groups of distinct device-generated frames (sub-ranges of the headline's resident buffers), constant-
+    rotating buffer groups of distinct device-generated frames (their own resident buffers), constant-
     twist track with |phi| ~ 0.03 rad per frame.  The per-frame f64 host pre-step (MakeFrame + Log, ~1 us per frame in the C++
     driver) is done before the timed region, like the headline's.  Outside the timed region the rank's first and last timed
     frames are checked against the oracle (full 10 M points each).  -> dict of this rank's counters."""
-    per, B = C3_POINTS_PER_FRAME, C3_FRAMES_PER_LAUNCH
-    groups = (d_in.shape[0] // per) // B
-    assert groups >= 2, "configs3 needs at least two rotating buffer groups"
+    per, B, groups = C3_POINTS_PER_FRAME, frames_per_launch, C3_BUFFER_GROUPS
+    d_in = torch.empty((groups * B * per, 4), dtype=torch.float32, device=dev)
+    d_out = torch.empty_like(d_in)
     begin, end = sharding.frame_range(C3_FRAMES_TOTAL, rank, world)
     T = min(timed_frames, end - begin)
     T -= T % B
@@ -197,7 +198,7 @@ def run_configs3(capi, sharding, torch, ctx, dist, rank, world, d_in, d_out, tim
         dist.barrier()
     wall = time.perf_counter() - t0
     res = {"range": (begin, end), "timed_frames": T, "points": float(T * per), "wall": wall, "ev_s": ev_ms * 1e-3, "parity_err": 0.0,
-           "groups": groups}
+           "groups": groups, "frames_per_launch": B}
     if check:  # parity, outside any timing: first and last timed frame of the rank, whole frames, FAITHFUL oracle
         from oracle import oracle as orc
 
@@ -239,6 +240,7 @@ def main():
                          "N = 1 only); the per-point figure of the committed PMC passes (profiles/pmc_traffic.json) is scaled instead")
     ap.add_argument("--no-configs3", action="store_true", help="skip the configs[3] leg (10 M-point frames, frame-sharded)")
     ap.add_argument("--configs3-frames", type=int, default=480, help="timed frames per rank of the configs[3] leg")
+    ap.add_argument("--configs3-frames-per-launch", type=int, default=C3_FRAMES_PER_LAUNCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
     ap.add_argument("--rotate", type=int, default=1, help="number of in/out buffer pairs cycled through by the steps")
@@ -337,8 +339,11 @@ def main():
 
     # ---- configs[3] leg: the 10 M-point-per-frame stream, rank r on frames frame_range(8000, r, N) ----
     c3 = None
-    if not args.no_configs3 and n >= 2 * C3_FRAMES_PER_LAUNCH * C3_POINTS_PER_FRAME:
-        c3 = run_configs3(capi, sharding, torch, ctx, dist, rank, world, d_in, d_out, args.configs3_frames, check=not args.no_cpu_baseline)
+    if not args.no_configs3:
+        del d_in, d_out, d_ins, d_outs  # the headline's 8 GB; the leg allocates its own buffers
+        torch.cuda.empty_cache()
+        c3 = run_configs3(capi, sharding, torch, ctx, dist, rank, world, dev, args.configs3_frames, args.configs3_frames_per_launch,
+                          check=not args.no_cpu_baseline)
 
     # the job's ONLY collective (RCCL when N > 1): one all_gather of every rank's counters; SUM of points, MAX of times
     sums, maxes = sharding.reduce_counters(
@@ -401,11 +406,11 @@ def main():
             out["configs3"] = {
                 "workload": f"configs[3]: synthetic {C3_POINTS_PER_FRAME}-point frames x {C3_FRAMES_TOTAL}, |phi| ~ {C3_YAW_PER_FRAME} rad per frame, "
                             f"frame-sharded: rank r owns frames sharding.frame_range({C3_FRAMES_TOTAL}, r, {world}); timed = the first "
-                            f"{c3['timed_frames']} frames of every rank's range, {C3_FRAMES_PER_LAUNCH} frames per batched launch over {c3['groups']} rotating "
+                            f"{c3['timed_frames']} frames of every rank's range, {c3['frames_per_launch']} frames per batched launch over {c3['groups']} rotating "
                             "buffer groups of distinct device-generated frames; no data-path collective",
                 "frames_total": C3_FRAMES_TOTAL, "points_per_frame": C3_POINTS_PER_FRAME,
                 "rank_frame_ranges": [list(sharding.frame_range(C3_FRAMES_TOTAL, r, world)) for r in range(world)],
-                "timed_frames_per_rank": c3["timed_frames"], "frames_per_launch": C3_FRAMES_PER_LAUNCH,
+                "timed_frames_per_rank": c3["timed_frames"], "frames_per_launch": c3["frames_per_launch"],
                 "value": round(sums[1] / t3 / 1e6, 1), "unit": "Mpts/s",
                 "ms_per_frame": round(t3 / c3["timed_frames"] * 1e3, 4),
                 "achieved_GBps_rank0": round(BYTES_PER_POINT * c3["points"] / c3["ev_s"] / 1e9, 1),

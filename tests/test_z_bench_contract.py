@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-                        "--frames-per-step", "176", "--cpu-sample-frames", "1", "--configs3-frames", "24", "--no-live-traffic"],
+                        "--frames-per-step", "176", "--cpu-sample-frames", "1", "--configs3-frames", "24", "--configs3-frames-per-launch", "8", "--no-live-traffic"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -63,7 +63,7 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     env = dict(os.environ, KMC_BENCH_BACKEND="gloo", KMC_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
-           "--frames-per-step", "176", "--configs3-frames", "16"]
+           "--frames-per-step", "176", "--configs3-frames", "16", "--configs3-frames-per-launch", "8"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
