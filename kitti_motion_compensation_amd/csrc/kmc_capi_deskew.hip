@@ -65,6 +65,7 @@ int issue_frame(kmc_ctx* c, hipStream_t s, const float* xyzi_in, float* xyzi_out
   FrameRec f;
   std::memset(&f, 0, sizeof(f));
   fill_rec(*params, &f);
+  f.pre2 = guard_pre2(*params);
   FrameRecD d;
   fill_recd(*params, &d);
   if (tier_out) *tier_out = tier;
@@ -204,6 +205,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   FrameRec f;
   std::memset(&f, 0, sizeof(f));
   fill_rec(*params, &f);
+  f.pre2 = guard_pre2(*params);
   FrameRecD d;
   fill_recd(*params, &d);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }

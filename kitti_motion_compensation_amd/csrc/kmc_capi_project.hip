@@ -49,7 +49,7 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   std::memset(&f, 0, sizeof(f));
   FrameRecD fd;
   std::memset(&fd, 0, sizeof(fd));
-  if (deskew) { fill_rec(*deskew, &f); fill_recd(*deskew, &fd); }
+  if (deskew) { fill_rec(*deskew, &f); f.pre2 = guard_pre2(*deskew); fill_recd(*deskew, &fd); }
   if (st) { st->n_points = n; st->variant = (uint32_t)(tier < 0 ? 4 : tier); }
   if (n == 0) return KMC_OK;
   const CameraRigRec g = rig_rec(rig);

@@ -95,7 +95,8 @@ void fill_traj_segs(const TrajHost& th, double stamp_start, double stamp_end, Tr
     r.m20 = (float)th.M[k].L.m[2][0]; r.m21 = (float)th.M[k].L.m[2][1]; r.m22 = (float)th.M[k].L.m[2][2]; r.tz = (float)th.M[k].t.z;
     knot_direction(ck, &r.knot_cos, &r.knot_sin);
     r.flags = (k == th.r ? kSegIdentity : 0u) | (ck <= 0.0 ? kKnotAlwaysGe : 0u) | (ck > 1.0 ? kKnotNeverGe : 0u);
-    r.guard2 = (k == th.r) ? 0.0f : (float)kmc_host::dot(th.M[k].t, th.M[k].t);
+    r.pre2 = (k == th.r) ? kGuardPre * (float)kmc_host::dot(th.f[k].rho, th.f[k].rho)
+                         : kGuardPreTraj * (float)(kmc_host::dot(th.f[k].rho, th.f[k].rho) + kmc_host::dot(th.M[k].t, th.M[k].t));
     TrajSegD& d = segs64[k];
     {
       kmc_frame_params fd = fp;

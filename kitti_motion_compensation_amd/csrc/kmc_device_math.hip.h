@@ -27,7 +27,7 @@ using v4f = float __attribute__((ext_vector_type(4)));
 struct alignas(16) FrameRec {
   float phi_x, phi_y, phi_z, phi2;  // phi, |phi|^2
   float rho_x, rho_y, rho_z, s0;    // rho, s0 = 0.5 - x_req   (s = s0 - azimuth_turns)
-  float c1_x, c1_y, c1_z, pad0;     // c1 = phi x rho
+  float c1_x, c1_y, c1_z, pre2;     // c1 = phi x rho; pre2 = kGuardPre * |rho|^2: first stage of the near-origin guard
   float c2_x, c2_y, c2_z, pad1;     // c2 = phi x (phi x rho)
 };
 
@@ -172,12 +172,16 @@ __device__ __forceinline__ v4f deskew_point(const v4f p, const FrameRec& f) {
 //     16 |p'|^2 < |p|^2 + scale2,     scale2 = |rho|^2  (+ |t_k|^2 of the anchor transform for trajectory segments),
 // is redone the reference's way -- f64 atan2, f64 exponential, one cast at the end.  Outside the guard
 // |p'| >= (|p| + |rho|) / (4 sqrt 2), so the f32 error stays below ~6 x 3 eps = 1.1e-6 relative.  The branch is wave-uniform
-// (ballot) and is never taken on real scans (nothing returns from within a metre of the sensor head): the kernels stay
-// on the HBM roofline, with ~10 more VALU instructions per point for the two norms.
+// (ballot) and is never taken on real scans (nothing returns from within a metre of the sensor head).
+// Two stages keep the common case at ~5 VALU instructions per point: the correction moves a point by at most |rho| (+ |t_k|)
+// -- |J| <= 1, |s| <= 1, rotations preserve norms --, so the test above can only hold for 3 |p| < 5 (|rho| + |t_k|), hence for
+//     |p'|^2 < pre2 = kGuardPre * scale2        (kGuardPre = 1.1 (25/9 + 1) / 16, resp. 1.1 (50/9 + 1) / 16 with a |t_k|),
+// a per-frame constant; only a wave with a lane below it evaluates the exact test.  The margin of 10 % covers every rounding,
+// so "stage 1 and stage 2" decides exactly like stage 2 alone, whoever computed pre2.
+constexpr float kGuardPre = 0.26f, kGuardPreTraj = 0.46f;
+__device__ __forceinline__ float norm2(const v4f p) { return __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z)); }
 __device__ __forceinline__ bool lost_significance(const v4f p, const v4f o, float scale2) {
-  const float n_in = __builtin_fmaf(p.x, p.x, __builtin_fmaf(p.y, p.y, p.z * p.z));
-  const float n_out = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, o.z * o.z));
-  return 16.0f * n_out < n_in + scale2;  // false for NaN: non-finite points keep the f32 result
+  return 16.0f * norm2(o) < norm2(p) + scale2;  // false for NaN: non-finite points keep the f32 result
 }
 // |rho|^2 of the record in device precision; ONE definition, so that a two-knot trajectory takes exactly the decisions of
 // the two-pose kernels (their results are bit-identical, tests/test_trajectory.py)
@@ -194,7 +198,7 @@ struct alignas(16) TrajSeg32 {
   float phi_x, phi_y, phi_z, phi2;
   float rho_x, rho_y, rho_z, s0;     // s = s0 - turns * g
   float c1_x, c1_y, c1_z, g;         // g = scan duration / segment duration
-  float c2_x, c2_y, c2_z, guard2;    // |t|^2 of the anchor transform (0 for the anchor's own segment): near-origin guard
+  float c2_x, c2_y, c2_z, pre2;      // near-origin guard, stage 1: kGuardPreTraj * (|rho|^2 + |t|^2), t = the anchor transform's translation
   float m00, m01, m02, tx;           // M_k rows with the translation in the 4th column
   float m10, m11, m12, ty;
   float m20, m21, m22, tz;
@@ -450,6 +454,7 @@ __device__ __forceinline__ v4f deskew_point_redo_f64(const v4f p, cdouble_p rec)
 // among them -- one turn unless the wave straddles a frame boundary) so that the record is always read at a wave-uniform
 // address.
 __device__ __forceinline__ bool needs_redo(const v4f p, const v4f o, const FrameRec& f) {
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(norm2(o) < f.pre2) == 0, 1)) return false;  // stage 1, wave-uniform
   return lost_significance(p, o, rho_norm2(f.rho_x, f.rho_y, f.rho_z));
 }
 template <typename STORE>

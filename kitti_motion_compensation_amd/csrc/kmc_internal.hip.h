@@ -138,6 +138,10 @@ void fill_rec(const kmc_frame_params& p, REC* r) {
   r->c1_x = (float)c1.x; r->c1_y = (float)c1.y; r->c1_z = (float)c1.z;
   r->c2_x = (float)c2.x; r->c2_y = (float)c2.y; r->c2_z = (float)c2.z;
 }
+// near-origin guard, stage 1 threshold of a two-pose frame (kmc_device_math.hip.h)
+inline float guard_pre2(const kmc_frame_params& p) {
+  return kGuardPre * (float)(p.twist[0] * p.twist[0] + p.twist[1] * p.twist[1] + p.twist[2] * p.twist[2]);
+}
 
 // the same constants in f64, for the near-origin guard's redo (kmc_device_math.hip.h)
 inline void fill_recd(const kmc_frame_params& p, FrameRecD* d) {

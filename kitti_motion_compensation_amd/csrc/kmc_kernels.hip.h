@@ -184,7 +184,7 @@ __device__ __forceinline__ FrameRec to_frame(const BatchRec& r) {
   FrameRec f;
   f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
   f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
-  f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pad0 = 0.f;
+  f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pre2 = kGuardPre * rho_norm2(r.rho_x, r.rho_y, r.rho_z);  // no room in the 64-byte record
   f.c2_x = r.c2_x; f.c2_y = r.c2_y; f.c2_z = r.c2_z; f.pad1 = 0.f;
   return f;
 }
@@ -455,7 +455,7 @@ __device__ __forceinline__ v4f traj_point(const v4f p, const TrajSeg32& r, bool&
   FrameRec f;
   f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
   f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
-  f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pad0 = 0.f;
+  f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pre2 = 0.f;
   f.c2_x = r.c2_x; f.c2_y = r.c2_y; f.c2_z = r.c2_z; f.pad1 = 0.f;
   const float turns = azimuth_turns(p.x, p.y);
   const float s = __builtin_fmaf(-turns, r.g, r.s0);
@@ -468,7 +468,12 @@ __device__ __forceinline__ v4f traj_point(const v4f p, const TrajSeg32& r, bool&
     o.w = q.w;
     q = o;
   }
-  redo = lost_significance(p, q, rho_norm2(r.rho_x, r.rho_y, r.rho_z) + r.guard2);
+  redo = false;
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(norm2(q) < r.pre2) != 0, 0)) {  // stage 1 of the near-origin guard, wave-uniform
+    // exact scale: |rho|^2 for the anchor's own segment (bit for bit the two-pose kernels' decision), else |rho|^2 + |t|^2 back from pre2
+    const float rho2 = rho_norm2(r.rho_x, r.rho_y, r.rho_z);
+    redo = lost_significance(p, q, (r.flags & kSegIdentity) ? rho2 : r.pre2 * (1.0f / kGuardPreTraj));
+  }
   return q;
 }
 // cold half: `segs64[k]` is the f64 twin of the lane's segment record; a waterfall over the brackets of the flagged lanes keeps
