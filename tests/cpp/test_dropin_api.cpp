@@ -508,6 +508,25 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
       ASSERT_TRUE(worst <= 1e-5);
     }
   }
+  CASE("MotionCompensateRun over several device contexts (kmc::hip::SetRunDevices): the same files");
+  {
+    // the multi-device driver on the one GPU of the test box: three workers, each with its own context on device 0 and its
+    // own contiguous frame range; byte-identical to what the single-context run wrote above (2-pose mode)
+    Path const run{tmp + "/run_0005_sync"};
+    Path const out_dir{run / "velodyne_points/data_motion_compensated"};
+    std::filesystem::remove_all(out_dir);
+    MotionCompensateRun(run);
+    std::vector<std::vector<float>> single;
+    for (std::size_t i = 0; i < 5; ++i) single.push_back(read_bin(out_dir / (IdToZeroPaddedString(i) + ".bin")));
+    std::filesystem::remove_all(out_dir);
+    hip::SetRunDevices({0, 0, 0});
+    ASSERT_EQ(hip::GetRunDevices().size(), 3u);
+    MotionCompensateRun(run);
+    hip::SetRunDevices({});
+    ASSERT_EQ(hip::GetRunDevices().size(), 1u);
+    ASSERT_EQ(NumberOfFilesInDirectory(out_dir), 5u);
+    for (std::size_t i = 0; i < 5; ++i) ASSERT_TRUE(read_bin(out_dir / (IdToZeroPaddedString(i) + ".bin")) == single[i]);
+  }
   CASE("hip::MotionCompensateKittiClouds with per-frame trajectories vs the single-frame trajectory call");
   {
     std::vector<float> const raw = read_bin(data_folder / "velodyne_points/data/0000000000.bin");
