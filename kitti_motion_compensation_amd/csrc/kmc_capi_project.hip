@@ -17,6 +17,14 @@ bool rig_is_pinhole(const kmc_camera_rig* g) {
   }
   return true;
 }
+// ... and the same fx, cx, fy, cy (bit for bit) in all four: the kernel computes fx x + cx z and fy y + cy z once
+int rig_kind(const kmc_camera_rig* g) {
+  if (!rig_is_pinhole(g)) return kRigGeneral;
+  for (int c = 1; c < 4; ++c)
+    for (int k : {0, 2, 5, 6})
+      if (std::memcmp(&g->P_rect[c][k], &g->P_rect[0][k], sizeof(double)) != 0) return kRigPinhole;
+  return kRigSharedIntrinsics;
+}
 CameraRigRec rig_rec(const kmc_camera_rig* g) {
   CameraRigRec r;
   std::memcpy(r.T, g->tf_c00_lo, sizeof(r.T));
@@ -24,6 +32,7 @@ CameraRigRec rig_rec(const kmc_camera_rig* g) {
   std::memcpy(r.P, g->P_rect, sizeof(r.P));
   r.max_range = g->max_range;
   r.range_den = g->max_range - 0.01;  // camera_model.cpp:28
+  r.range_rcp = 1.0 / r.range_den;
   return r;
 }
 }  // namespace
@@ -72,11 +81,12 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, (n + 63) / 64);
-  const bool pinhole = rig_is_pinhole(rig);
+  const int kind = rig_kind(rig);
 #define KMC_LAUNCH_PROJECT(T)                                                                                                     \
   do {                                                                                                                            \
-    if (pinhole) hipLaunchKernelGGL((project_f32<T, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
-    else hipLaunchKernelGGL((project_f32<T, false>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd);       \
+    if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL((project_f32<T, kRigSharedIntrinsics>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
+    else if (kind == kRigPinhole) hipLaunchKernelGGL((project_f32<T, kRigPinhole>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
+    else hipLaunchKernelGGL((project_f32<T, kRigGeneral>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd);       \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_PROJECT(kSeries3); break;
@@ -131,8 +141,10 @@ int kmc_hip_project_f64cols(kmc_ctx* c, const double* x, const double* y, const 
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, (n + 63) / 64);
-  if (rig_is_pinhole(rig)) hipLaunchKernelGGL(project_f64cols<true>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
-  else hipLaunchKernelGGL(project_f64cols<false>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
+  const int kind = rig_kind(rig);
+  if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL(project_f64cols<kRigSharedIntrinsics>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
+  else if (kind == kRigPinhole) hipLaunchKernelGGL(project_f64cols<kRigPinhole>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
+  else hipLaunchKernelGGL(project_f64cols<kRigGeneral>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {

@@ -526,6 +526,7 @@ struct CameraRigRec {
   double P[4][12];   // P_rect_0c, row-major 3x4
   double max_range;  // camera_model.hpp:8
   double range_den;  // max_range - 0.01, camera_model.cpp:28
+  double range_rcp;  // ~ 1 / range_den: first guess of the colour ramp's quotient, confirmed or redone exactly per point
 };
 using v2i = int __attribute__((ext_vector_type(2)));
 using v4i = int __attribute__((ext_vector_type(4)));
@@ -549,9 +550,9 @@ __device__ __forceinline__ bool trunc_quotients_fast(double a, double b, double 
   r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
   r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
   const double qa = a * r, qb = b * r;
-  constexpr double kEps = 0x1p-36;
-  const bool sure_a = __builtin_fabs(qa - __builtin_rint(qa)) > kEps * __builtin_fmax(1.0, __builtin_fabs(qa)) && __builtin_fabs(qa) < 2147483000.0;
-  const bool sure_b = __builtin_fabs(qb - __builtin_rint(qb)) > kEps * __builtin_fmax(1.0, __builtin_fabs(qb)) && __builtin_fabs(qb) < 2147483000.0;
+  constexpr double kEps = 0x1p-36;  // the margin kEps (1 + |q|) >= kEps max(1, |q|): one fma instead of max + mul, a little more cautious
+  const bool sure_a = __builtin_fabs(qa - __builtin_rint(qa)) > __builtin_fma(__builtin_fabs(qa), kEps, kEps) && __builtin_fabs(qa) < 2147483000.0;
+  const bool sure_b = __builtin_fabs(qb - __builtin_rint(qb)) > __builtin_fma(__builtin_fabs(qb), kEps, kEps) && __builtin_fabs(qb) < 2147483000.0;
   ta = (int)qa;
   tb = (int)qb;
   return sure_a && sure_b;
@@ -559,7 +560,7 @@ __device__ __forceinline__ bool trunc_quotients_fast(double a, double b, double 
 
 // P_rect_c * r for one camera, :9.  STRUCTURED: the products with the literal 0s and 1 of a pinhole matrix are skipped.
 template <bool STRUCTURED>
-__device__ __forceinline__ void camera_rows(const double* P, const double r[3], double h[3]) {
+__device__ __forceinline__ void camera_rows(cdouble_p P, const double r[3], double h[3]) {
 #pragma clang fp contract(off)
   if constexpr (STRUCTURED) {
     h[0] = (P[0] * r[0] + P[2] * r[2]) + P[3];
@@ -571,21 +572,37 @@ __device__ __forceinline__ void camera_rows(const double* P, const double r[3], 
   }
 }
 
+// The rig is 71 doubles = 142 SGPRs' worth of wave-uniform constants: more than a wave has.  As a by-value kernel argument the
+// compiler preloads all of it and spills (round 1: 124 v_writelane + 124 v_readlane in a ~700-instruction kernel).  It is
+// therefore read through the kernel-argument segment in phases (`after`, see the guarded redo): T, R and the range constants up
+// front, cameras 0-1 once the camera-frame point exists, cameras 2-3 once the rectified point exists.
+constexpr int kRigT = 0, kRigR = 12, kRigP = 21, kRigMaxRange = 69, kRigRangeDen = 70, kRigRangeRcp = 71;
+static_assert(offsetof(CameraRigRec, T) == 8 * kRigT && offsetof(CameraRigRec, R) == 8 * kRigR && offsetof(CameraRigRec, P) == 8 * kRigP &&
+                  offsetof(CameraRigRec, max_range) == 8 * kRigMaxRange && offsetof(CameraRigRec, range_den) == 8 * kRigRangeDen &&
+                  offsetof(CameraRigRec, range_rcp) == 8 * kRigRangeRcp,
+              "project_point indexes CameraRigRec as an array of doubles");
+
 // -> validity; uv[c] = pixel cv::circle would be centred on; bgrv = {255-cs, cs, 255-cs, 1} packed little-endian.
 // STRUCTURED: every P_rect has the pinhole shape [fx 0 cx tx; 0 fy cy ty; 0 0 1 tz] (all KITTI calibrations do); skipping
 // its zeros changes no result for finite coordinates (x + (+-0) = x, 1 * x = x).  A point whose rectified coordinates
 // are not finite (0 * inf = NaN matters there) or whose quotients are not certain takes the plain sequence below.
 // Most of a scan is behind the cameras or beyond max_range, and neighbouring points share that fate: a wave in which no
 // lane passes the test of :21-24 skips the four cameras altogether (wave-uniform branch).
-template <bool STRUCTURED>
-__device__ __forceinline__ bool project_point(double x, double y, double z, const CameraRigRec& g, v2i uv[4], uint32_t& bgrv) {
+// RIG: 0 general P_rect, 1 pinhole P_rect (kRigPinhole), 2 pinhole with the SAME fx, cx, fy, cy in all four cameras
+// (kRigSharedIntrinsics; every KITTI rectified rig): fx x + cx z and fy y + cy z are then the same rounded values for the four
+// cameras and are computed once -- identical operations on identical operands, so still bit-exact.
+constexpr int kRigGeneral = 0, kRigPinhole = 1, kRigSharedIntrinsics = 2;
+template <int RIG>
+__device__ __forceinline__ bool project_point(double x, double y, double z, cdouble_p g, v2i uv[4], uint32_t& bgrv) {
 #pragma clang fp contract(off)
+  constexpr bool STRUCTURED = RIG != kRigGeneral;
   double c[3], r[3];
+  const cdouble_p T = g + kRigT, R = g + kRigR;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) c[k] = ((g.T[4 * k] * x + g.T[4 * k + 1] * y) + g.T[4 * k + 2] * z) + g.T[4 * k + 3];  // :75
+  for (int k = 0; k < 3; ++k) c[k] = ((T[4 * k] * x + T[4 * k + 1] * y) + T[4 * k + 2] * z) + T[4 * k + 3];  // :75
 #pragma unroll
-  for (int k = 0; k < 3; ++k) r[k] = ((g.R[3 * k] * c[0] + g.R[3 * k + 1] * c[1]) + g.R[3 * k + 2] * c[2]) + 0.0;  // :81
-  const bool valid = !((r[2] < 0.01) || (r[2] > g.max_range) || (r[1] > 1.25));                                  // :21-24
+  for (int k = 0; k < 3; ++k) r[k] = ((R[3 * k] * c[0] + R[3 * k + 1] * c[1]) + R[3 * k + 2] * c[2]) + 0.0;  // :81
+  const bool valid = !((r[2] < 0.01) || (r[2] > g[kRigMaxRange]) || (r[1] > 1.25));                         // :21-24
   if (__builtin_amdgcn_ballot_w64(valid) == 0) {
 #pragma unroll
     for (int cam = 0; cam < 4; ++cam) uv[cam].x = uv[cam].y = (int)0x80000000;
@@ -593,20 +610,34 @@ __device__ __forceinline__ bool project_point(double x, double y, double z, cons
     return false;
   }
   bool sure = __builtin_fabs(r[0]) < __builtin_inf() && __builtin_fabs(r[1]) < __builtin_inf() && __builtin_fabs(r[2]) < __builtin_inf();
+  cdouble_p P = after(g, c[0]) + kRigP;  // cameras 0 and 1: their loads may start as soon as the camera-frame point exists
+  if constexpr (RIG == kRigSharedIntrinsics) {
+    const double a0 = P[0] * r[0] + P[2] * r[2];  // :9, rows 0 and 1 of P_rect without their last column
+    const double a1 = P[5] * r[1] + P[6] * r[2];
 #pragma unroll
-  for (int cam = 0; cam < 4; ++cam) {
-    double h[3];
-    camera_rows<STRUCTURED>(g.P[cam], r, h);
-    int tu, tv;
-    sure &= trunc_quotients_fast(h[0], h[1], h[2], tu, tv);
-    uv[cam].x = tu;
-    uv[cam].y = tv;
+    for (int cam = 0; cam < 4; ++cam) {
+      int tu, tv;
+      sure &= trunc_quotients_fast(a0 + P[12 * cam + 3], a1 + P[12 * cam + 7], r[2] + P[12 * cam + 11], tu, tv);
+      uv[cam].x = tu;
+      uv[cam].y = tv;
+    }
+  } else {
+#pragma unroll
+    for (int cam = 0; cam < 4; ++cam) {
+      if (cam == 2) P = after(g, r[0]) + kRigP;  // cameras 2 and 3
+      double h[3];
+      camera_rows<STRUCTURED>(P + 12 * cam, r, h);
+      int tu, tv;
+      sure &= trunc_quotients_fast(h[0], h[1], h[2], tu, tv);
+      uv[cam].x = tu;
+      uv[cam].y = tv;
+    }
   }
   if (__builtin_expect(valid && !sure, 0)) {  // the reference's own sequence: general rows, two IEEE divisions (:9, :12, :31)
 #pragma unroll 1
     for (int cam = 0; cam < 4; ++cam) {
       double h[3];
-      camera_rows<false>(g.P[cam], r, h);
+      camera_rows<false>(after(g, r[2]) + kRigP + 12 * cam, r, h);
       uv[cam].x = trunc_i32(h[0] / h[2]);
       uv[cam].y = trunc_i32(h[1] / h[2]);
     }
@@ -615,7 +646,11 @@ __device__ __forceinline__ bool project_point(double x, double y, double z, cons
 #pragma unroll
     for (int cam = 0; cam < 4; ++cam) uv[cam].x = uv[cam].y = (int)0x80000000;
   }
-  const double cs = 255.0 * (r[2] / g.range_den);  // :28-29
+  // colour ramp, :28-29: cs = 255 (z / (max_range - 0.01)), of which only the two ROUNDED bytes are used.  The quotient through the
+  // host's reciprocal is within ~1e-13 of the reference's; the bytes can only differ if cs sits that close to a half-integer, and
+  // exactly those lanes (and NaNs: the comparison is false for them) redo the IEEE division.
+  double cs = 255.0 * (r[2] * g[kRigRangeRcp]);
+  if (__builtin_expect(valid && !(__builtin_fabs((cs - __builtin_floor(cs)) - 0.5) > 1e-9), 0)) cs = 255.0 * (r[2] / g[kRigRangeDen]);
   const uint32_t a = sat_u8(255.0 - cs), b = sat_u8(cs);
   bgrv = valid ? (a | (b << 8) | (a << 16) | (1u << 24)) : 0u;  // :32
   return valid;

@@ -800,13 +800,15 @@ __device__ __forceinline__ void store_uv_tile(v2i* __restrict__ uv, uint64_t til
   tile_store<kPolicyDefault>(r, 1024u + tid * 16u, __builtin_bit_cast(v4f, hi));
 }
 
-template <int TIER, bool STRUCTURED>
+template <int TIER, int RIG>
 __global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, uint64_t n, CameraRigRec g, FrameRec f,
                                                   v4f* __restrict__ cloud_out, v2i* __restrict__ uv,
                                                   uint32_t* __restrict__ bgrv, FrameRecD d) {
-  // `d` is read through the kernel-argument segment only, see deskew_frame_f32
+  // `g` and `d` are read through the kernel-argument segment only, see project_point and deskew_frame_f32
   struct ArgLayout { const v4f* in; uint64_t n; CameraRigRec g; FrameRec f; v4f* cloud_out; v2i* uv; uint32_t* bgrv; FrameRecD d; };
-  const cdouble_p d_rec = (cdouble_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, d));
+  const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  const cdouble_p d_rec = (cdouble_p)(kernarg + offsetof(ArgLayout, d));
+  const cdouble_p g_rec = (cdouble_p)(kernarg + offsetof(ArgLayout, g));
   __shared__ v4i xpose[128];
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + 63) / 64;
@@ -827,16 +829,18 @@ __global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, ui
     }
     v2i px[4];
     uint32_t col;
-    const bool drawn = project_point<STRUCTURED>((double)p.x, (double)p.y, (double)p.z, g, px, col);
+    const bool drawn = project_point<RIG>((double)p.x, (double)p.y, (double)p.z, g_rec, px, col);
     store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
     if (live) __builtin_nontemporal_store(col, bgrv + i);
   }
 }
 
-template <bool STRUCTURED>
+template <int RIG>
 __global__ __launch_bounds__(64) void project_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                       const double* __restrict__ z, uint64_t n, CameraRigRec g,
                                                       v2i* __restrict__ uv, uint32_t* __restrict__ bgrv) {
+  struct ArgLayout { const double* x; const double* y; const double* z; uint64_t n; CameraRigRec g; v2i* uv; uint32_t* bgrv; };
+  const cdouble_p g_rec = (cdouble_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, g));
   __shared__ v4i xpose[128];
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + 63) / 64;
@@ -847,8 +851,8 @@ __global__ __launch_bounds__(64) void project_f64cols(const double* __restrict__
     const uint64_t j = live ? i : n - 1;
     v2i px[4];
     uint32_t col;
-    const bool drawn = project_point<STRUCTURED>(__builtin_nontemporal_load(x + j), __builtin_nontemporal_load(y + j),
-                                                 __builtin_nontemporal_load(z + j), g, px, col);
+    const bool drawn = project_point<RIG>(__builtin_nontemporal_load(x + j), __builtin_nontemporal_load(y + j),
+                                                 __builtin_nontemporal_load(z + j), g_rec, px, col);
     store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
     if (live) __builtin_nontemporal_store(col, bgrv + i);
   }

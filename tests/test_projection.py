@@ -235,13 +235,17 @@ def test_gpu_project_synthetic_1m_and_special_values(ctx, kitti_xyzi):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dense", [False, True])
-def test_gpu_project_exact_integer_pixels(ctx, dense):
+@pytest.mark.parametrize("kind", ["shared", "pinhole", "dense"])
+def test_gpu_project_exact_integer_pixels(ctx, kind):
     """Points that project EXACTLY onto integer pixel coordinates (and the int-range ends): the lanes whose approximate
-    quotient sits on an integer must take the IEEE-division path and still agree bit for bit."""
+    quotient sits on an integer must take the IEEE-division path and still agree bit for bit.  Three kernel variants: all four
+    cameras with the same intrinsics (fx x + cx z shared), pinhole cameras with different intrinsics, dense P_rect."""
     from kitti_motion_compensation_amd import capi
 
     tf, R, P = _pinhole(f=512.0, cx=600.0, cy=180.0)
+    dense = kind == "dense"
+    if kind == "pinhole":  # pinhole zeros kept, but every camera its own focal lengths / principal point / baseline
+        P = [p + np.array([[16.0 * c, 0, 4.0 * c, -30.0 * c], [0, 8.0 * c, 2.0 * c, 0.5 * c], [0, 0, 0, 0.001 * c]]) for c, p in enumerate(P)]
     if dense:  # a P_rect without the pinhole zeros -> the general kernel variant
         P = [p + np.array([[0, 0.25, 0, 0], [0.5, 0, 0, 0], [0, 0, 0, 0.0]]) for p in P]
         P[2] = P[2] + np.array([[0, 0, 0, 0], [0, 0, 0, 0], [0.001, 0.002, 0, 0.003]])
@@ -259,11 +263,39 @@ def test_gpu_project_exact_integer_pixels(ctx, dense):
     uv_ref, bgrv_ref = orc.project_xyzi_f32(pts, orig)
     assert np.array_equal(uv, uv_ref) and np.array_equal(bgrv, bgrv_ref)
     if not dense:
-        assert np.array_equal(uv[:600, 0, 0], np.arange(300, 900))   # z = 0.5 row: exact integers
+        assert np.array_equal(uv[:600, 0, 0], np.arange(300, 900))   # z = 0.5 row: exact integers (camera 0 keeps f = 512, cx = 600)
 
 
 @pytest.mark.gpu
-def test_gpu_project_dense_rig_1m(ctx):
+def test_gpu_project_colour_on_half_integers(ctx):
+    """cs = 255 z / (max_range - 0.01) EXACTLY on k + 0.5 for k = 0 .. 254 (max_range - 0.01 == 127.5, z = (k + 0.5) / 2): the bytes
+    are cv::saturate_cast's half-to-even roundings of cs and 255 - cs.  The kernel guesses the quotient through a reciprocal and
+    must notice that these points sit on a rounding boundary and redo the IEEE division (camera_model.cpp:28-32)."""
+    from kitti_motion_compensation_amd import capi
+
+    max_range = 127.5 + 0.01
+    assert max_range - 0.01 == 127.5
+    tf, R, P = _pinhole()
+    k = np.arange(255, dtype=np.float64)
+    z = (k + 0.5) / 2.0
+    pts = np.zeros((3 * 255, 4), dtype=np.float32)
+    pts[:, 2] = np.concatenate([z, np.nextafter(z.astype(np.float32), np.float32(np.inf)), np.nextafter(z.astype(np.float32), np.float32(-np.inf))])
+    pts[:, 0] = 0.01 * pts[:, 2]
+    rig, orig = capi.CameraRig.make(tf, R, P, max_range), orc.camera_rig(tf, R, P, max_range)
+    n = pts.shape[0]
+    uv = np.zeros((n, 4, 2), dtype=np.int32)
+    bgrv = np.zeros((n, 4), dtype=np.uint8)
+    ctx.project_f32(pts, rig, uv, bgrv)
+    uv_ref, bgrv_ref = orc.project_xyzi_f32(pts, orig)
+    assert np.array_equal(uv, uv_ref) and np.array_equal(bgrv, bgrv_ref)
+    assert bgrv_ref[:255, 3].all()
+    # half to even on the exact half-integers: cs = k + 0.5 -> k if k is even, k + 1 if odd
+    assert np.array_equal(bgrv_ref[:255, 1], np.where(k % 2 == 0, k, k + 1).astype(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense", "pinhole"])
+def test_gpu_project_dense_rig_1m(ctx, kind):
     from kitti_motion_compensation_amd import capi
 
     rng = np.random.default_rng(11)
@@ -273,6 +305,10 @@ def test_gpu_project_dense_rig_1m(ctx):
     tf = np.hstack([np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]]) + 0.05 * rng.standard_normal((3, 3)), rng.standard_normal((3, 1))])
     R_rect = np.eye(3) + 0.02 * rng.standard_normal((3, 3))
     P = [np.array([[700.0, 0, 600, 40], [0, 700, 180, 0], [0, 0, 1, 0]]) + 0.01 * rng.standard_normal((3, 4)) for _ in range(4)]
+    if kind == "pinhole":  # four different pinhole cameras: the zeros and the one of [fx 0 cx tx; 0 fy cy ty; 0 0 1 tz] restored
+        for p in P:
+            p[0, 1] = p[1, 0] = p[2, 0] = p[2, 1] = 0.0
+            p[2, 2] = 1.0
     rig, orig = capi.CameraRig.make(tf, R_rect, P, 60.0), orc.camera_rig(tf, R_rect, P, 60.0)
     uv = np.zeros((n, 4, 2), dtype=np.int32)
     bgrv = np.zeros((n, 4), dtype=np.uint8)
