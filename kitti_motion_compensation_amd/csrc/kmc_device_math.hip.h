@@ -251,6 +251,11 @@ __constant__ double kRedoTable[42] = {
     0.41421356237309503, 0.78539816339744831, 1.5707963267948966, 3.14159265358979323846, 6.28318530717958647692, 0.0};
 
 using cdouble_p = const double __attribute__((address_space(4)))*;  // constant address space: uniform reads are scalar loads
+// `t`, but not before `dep` exists: an empty volatile asm that ties a table pointer to the data flow (see the guarded redo below)
+__device__ __forceinline__ cdouble_p after(cdouble_p t, double dep) {
+  asm volatile("" : "+s"(t) : "v"(dep));
+  return t;
+}
 
 // ---- f64 path (Eigen-layout API): closed form in double ---------------------------------------------
 struct FrameRec64 {
@@ -280,14 +285,21 @@ struct TrajSeg64 {
 __device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, int halvings, double& alpha, double& beta, double& gamma) {
   const double s2 = s * s;
   double u = __builtin_ldexp(s2 * phi2, -2 * halvings);  // (t / 2^h)^2
-  const cdouble_p t = (cdouble_p)kRedoTable;  // [12..19] A, [20..27] B, [28..35] C, highest degree first
-  double A = t[12], B = t[20], C = t[28];
+  // [12..19] A, [20..27] B, [28..35] C, highest degree first; one series after the other, each behind the previous one's
+  // result: 16 SGPRs of coefficients at a time instead of 48 (with all 24 resident the Eigen-layout kernel spilled SGPRs
+  // through VGPR lanes: 52 v_writelane + 123 v_readlane)
+  cdouble_p t = after((cdouble_p)kRedoTable, u);
+  double A = t[12];
 #pragma unroll
-  for (int k = 1; k < 8; ++k) {
-    A = __builtin_fma(A, u, t[12 + k]);
-    B = __builtin_fma(B, u, t[20 + k]);
-    C = __builtin_fma(C, u, t[28 + k]);
-  }
+  for (int k = 1; k < 8; ++k) A = __builtin_fma(A, u, t[12 + k]);
+  t = after(t, A);
+  double B = t[20];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) B = __builtin_fma(B, u, t[20 + k]);
+  t = after(t, B);
+  double C = t[28];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) C = __builtin_fma(C, u, t[28 + k]);
   for (int k = 0; k < halvings; ++k) {
     const double cosx = __builtin_fma(-u, B, 1.0);
     C = __builtin_ldexp(__builtin_fma(A, B, C), -2);
@@ -331,10 +343,6 @@ __device__ __forceinline__ void deskew_point_f64(double x, double y, double z, d
 // tied to the previous phase's result (`after`).  That pins every group of table reads behind the arithmetic that precedes
 // it, so that at most 12-24 SGPRs of table are live at any time.  Left to itself the compiler loads the 36 coefficients and
 // the whole record up front (80+ SGPRs: spills, and a private segment for the kernel).
-__device__ __forceinline__ cdouble_p after(cdouble_p t, double dep) {
-  asm volatile("" : "+s"(t) : "v"(dep));
-  return t;
-}
 __device__ __forceinline__ uint32_t opaque_uniform(uint32_t v) {  // a wave-uniform value the optimiser cannot trace back
   asm volatile("" : "+s"(v));
   return v;
