@@ -21,6 +21,7 @@
 #include "kitti_motion_compensation/data_io.hpp"
 #include "kitti_motion_compensation/data_types.hpp"
 #include "kitti_motion_compensation/handlers.hpp"
+#include "kmc_hip.h"
 #include "kitti_motion_compensation/lie_algebra.hpp"
 #include "kitti_motion_compensation/motion_compensation.hpp"
 #include "kitti_motion_compensation/timestamp_mocking.hpp"
@@ -182,6 +183,42 @@ static void host_cases(std::string const& golden) {
     ASSERT_FLOAT_EQ(cloud(123396, 1), -1.39499998092651);
     ASSERT_FLOAT_EQ(cloud(123396, 2), -2.58999991416931);
     ASSERT_FLOAT_EQ(intensities(123396), 0.0);
+  }
+  CASE("run devices: KMC_DEVICES / kmc::hip::SetRunDevices (host logic of the multi-device MotionCompensateRun)");
+  {
+    unsetenv("KMC_DEVICES");
+    hip::SetRunDevices({});
+    ASSERT_EQ(hip::GetRunDevices().size(), 1u);            // default: the calling thread's device
+    ASSERT_EQ(hip::GetRunDevices()[0], hip::GetDevice());
+    setenv("KMC_DEVICES", "0,1,2,3,4,5,6,7", 1);
+    ASSERT_EQ(hip::GetRunDevices().size(), 8u);
+    ASSERT_EQ(hip::GetRunDevices()[5], 5);
+    setenv("KMC_DEVICES", "3,3", 1);                       // an id may repeat: two contexts on one GPU
+    ASSERT_EQ(hip::GetRunDevices().size(), 2u);
+    hip::SetRunDevices({1, 0});                            // the setter wins over the environment
+    ASSERT_EQ(hip::GetRunDevices()[0], 1);
+    hip::SetRunDevices({});
+    setenv("KMC_DEVICES", "0,x", 1);
+    bool threw = false;
+    try { (void)hip::GetRunDevices(); } catch (std::invalid_argument const&) { threw = true; }
+    ASSERT_TRUE(threw);
+    threw = false;
+    try { hip::SetRunDevices({0, -1}); } catch (std::invalid_argument const&) { threw = true; }
+    ASSERT_TRUE(threw);
+    unsetenv("KMC_DEVICES");
+    // the split the driver cuts a run with (kmc_frame_ranges_balanced): contiguous, complete, balanced on points
+    std::vector<std::uint64_t> const sizes{120000, 90000, 130000, 110000, 0, 125000, 95000, 118000, 121000, 99000};
+    std::uint32_t bounds[4];
+    ASSERT_EQ(kmc_frame_ranges_balanced(sizes.data(), 10, 3, bounds), KMC_OK);
+    ASSERT_EQ(bounds[0], 0u);
+    ASSERT_EQ(bounds[3], 10u);
+    ASSERT_TRUE(bounds[1] <= bounds[2]);
+    std::uint64_t part[3] = {0, 0, 0};
+    for (int r = 0; r < 3; ++r)
+      for (std::uint32_t f = bounds[r]; f < bounds[r + 1]; ++f) part[r] += sizes[f];
+    ASSERT_TRUE(part[0] + part[1] + part[2] == 1008000u);
+    for (int r = 0; r < 3; ++r) ASSERT_TRUE(part[r] > 336000u - 130000u && part[r] < 336000u + 130000u);
+    ASSERT_EQ(kmc_frame_ranges_balanced(sizes.data(), 10, 0, bounds), KMC_ERR_INVALID_ARG);
   }
   CASE("utils");  // utils.cpp:10-38
   {
