@@ -183,7 +183,7 @@ def run_configs3(capi, sharding, torch, ctx, dist, rank, world, dev, timed_frame
         for a, b, prm in launches:
             ctx.deskew_batch_f32(a, b, offsets, prm, None)
 
-    for a, b, prm in launches[:min(len(launches), 2 * groups)]:  # untimed: table ring sized, clocks up
+    for a, b, prm in launches[:min(len(launches), 4 * groups)]:  # untimed: table ring sized, clocks up, TLBs of the fresh buffers warm
         ctx.deskew_batch_f32(a, b, offsets, prm, None)
     torch.cuda.synchronize()
     if dist:
@@ -239,7 +239,7 @@ def main():
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child runs of the same workload, ~1 minute, "
                          "N = 1 only); the per-point figure of the committed PMC passes (profiles/pmc_traffic.json) is scaled instead")
     ap.add_argument("--no-configs3", action="store_true", help="skip the configs[3] leg (10 M-point frames, frame-sharded)")
-    ap.add_argument("--configs3-frames", type=int, default=480, help="timed frames per rank of the configs[3] leg")
+    ap.add_argument("--configs3-frames", type=int, default=960, help="timed frames per rank of the configs[3] leg")
     ap.add_argument("--configs3-frames-per-launch", type=int, default=C3_FRAMES_PER_LAUNCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
