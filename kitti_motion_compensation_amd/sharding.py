@@ -2,7 +2,7 @@
 
 The deskew path shards trivially: points within a frame are independent and frames are independent given their own
 (T_start, T_end).  A drive is split into CONTIGUOUS frame ranges, one per rank; no point data ever crosses GPUs and the
-only collective of a job is the reduction of the throughput counters (RCCL all-reduce on the GPU box, gloo in the CPU
+only collective of a job is ONE all_gather of the throughput counters (RCCL on the GPU box, gloo in the CPU
 tests).  Plumbing only -- no compute here.
 """
 from __future__ import annotations
