@@ -873,3 +873,45 @@ def test_frame_queues_same_bits_and_ordering(torch_mod, ctx):
         assert torch.equal(again.view(torch.int32), torch.cat(want[:4]).view(torch.int32))
     finally:
         ctx.set_frame_queues(1)
+
+
+def test_switching_streams_drains_the_context(torch_mod, ctx):
+    """A context is single-stream: its table slots and scratch are ordered on ONE stream.  kmc_hip_set_stream therefore drains the
+    old stream before it switches -- a table growth on the new stream must not free memory under kernels of the old one.
+    Big batch on stream A, switch, a batch on stream B whose tables are larger than any so far (forces the growth): both results
+    must be what the single-frame kernel gives."""
+    torch = torch_mod
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    n_big, f_big = 8_000_000, 4
+    params = [capi.FrameParams.make([1.3, 0.05, -0.02, 0.002, -0.004, 0.03 + 0.001 * f], 0.5) for f in range(f_big)]
+    a = torch.empty((n_big * f_big, 4), dtype=torch.float32, device="cuda")
+    tmp = capi.Context(0)
+    tmp.synth_points(a, n_big * f_big, 4242)
+    tmp.synchronize()
+    tmp.close()
+    out_a = torch.zeros_like(a)
+    own = capi.Context(0)  # a fresh context: its slot ring still has the minimum capacity
+    try:
+        own.set_stream(sa.cuda_stream)
+        own.deskew_batch_f32(a, out_a, np.arange(f_big + 1, dtype=np.uint64) * n_big, params, None)
+        own.set_stream(sb.cuda_stream)  # drains stream A
+        f_many = 40_000                  # 40 000 records of 64 + 128 bytes: far beyond the initial slot capacity
+        sizes = np.full(f_many, 64, dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+        m = int(offs[-1])
+        out_b = torch.zeros((m, 4), dtype=torch.float32, device="cuda")
+        own.deskew_batch_f32(a[:m], out_b, offs, [params[f % f_big] for f in range(f_many)], None)
+        own.synchronize()
+        sa.synchronize()
+        for f in range(f_big):  # stream A's batch
+            want = torch.empty((n_big, 4), dtype=torch.float32, device="cuda")
+            own.deskew_f32(a[f * n_big:(f + 1) * n_big], want, params[f])
+            own.synchronize()
+            assert torch.equal(out_a[f * n_big:(f + 1) * n_big].view(torch.int32), want.view(torch.int32)), f
+        for f in (0, 1, 17, f_many - 1):  # stream B's batch, sampled
+            want = torch.empty((64, 4), dtype=torch.float32, device="cuda")
+            own.deskew_f32(a[f * 64:(f + 1) * 64], want, params[f % f_big])
+            own.synchronize()
+            assert torch.equal(out_b[f * 64:(f + 1) * 64].view(torch.int32), want.view(torch.int32)), f
+    finally:
+        own.close()
