@@ -75,7 +75,7 @@ typedef struct kmc_stats {
   uint64_t n_points;       /* points processed by the call */
   uint64_t n_out_of_range; /* points whose stamp was outside [stamp_start, stamp_end] (f64 path only) */
   uint32_t n_launches;     /* kernel launches issued */
-  uint32_t variant;        /* kernel tier used: 0 = series3 (theta<=0.25), 1 = series5 (theta<=1), 2 = trig */
+  uint32_t variant;        /* kernel tier used: 0 = series3 (theta<=0.25), 1 = series5 (theta<=1), 2 = wide polynomial (theta<=3.25), 3 = trig (any) */
   float kernel_ms;         /* HIP-event time of the kernel launches (only if timing was enabled) */
   float total_ms;          /* HIP-event time of the whole call incl. H2D/D2H staging (only if timing enabled) */
 } kmc_stats;
@@ -115,7 +115,7 @@ int kmc_hip_device_info(kmc_ctx* ctx, kmc_device_info* out);
  * grid-striding over tiles), 0 = default = one tile per workgroup; points_per_thread = 1, 2, 4 or 8 (0 = default 1). */
 int kmc_hip_set_launch_config(kmc_ctx* ctx, int blocks_per_cu, int points_per_thread);
 
-/* Testing hook: force the series/trig tier of the f32 kernels (-1 = automatic selection from |phi|). */
+/* Testing hook: force the coefficient tier (0..3, see kmc_stats.variant) of the f32 kernels (-1 = automatic selection from |phi|). */
 int kmc_hip_force_tier(kmc_ctx* ctx, int tier);
 
 /* HIP-event stopwatch on the ctx stream: begin records an event, end records another, waits for it and

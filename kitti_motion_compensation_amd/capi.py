@@ -27,7 +27,7 @@ ERR_DEGENERATE = -6
 MEM_HOST = 0
 MEM_DEVICE = 1
 
-TIER_SERIES3, TIER_SERIES5, TIER_TRIG = 0, 1, 2
+TIER_SERIES3, TIER_SERIES5, TIER_WIDE, TIER_TRIG = 0, 1, 2, 3
 
 
 class FrameParams(C.Structure):

@@ -5,7 +5,7 @@
 namespace kmc_impl {
 
 int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n) {
-  if (c->force_tier >= 0 && c->force_tier <= 2) return c->force_tier;
+  if (c->force_tier >= 0 && c->force_tier <= kTrig) return c->force_tier;
   double theta_max = 0.0;
   for (uint32_t i = 0; i < n; ++i) {
     const double* f = p[i].twist;
@@ -13,8 +13,7 @@ int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n) {
     const double smax = std::fmax(std::fabs(p[i].x_req), std::fabs(1.0 - p[i].x_req));  // frac in [0,1]
     theta_max = std::fmax(theta_max, phi * smax);
   }
-  if (!(theta_max <= 1.0)) return kTrig;  // also catches NaN
-  return theta_max <= 0.25 ? kSeries3 : kSeries5;
+  return tier_of_theta(theta_max);
 }
 
 int ensure_tmp(kmc_ctx* c, size_t bytes) {
@@ -372,7 +371,7 @@ int kmc_hip_set_launch_config(kmc_ctx* c, int blocks_per_cu, int points_per_thre
 }
 
 int kmc_hip_force_tier(kmc_ctx* c, int tier) {
-  if (!c || tier < -1 || tier > 2) return KMC_ERR_INVALID_ARG;
+  if (!c || tier < -1 || tier > kTrig) return KMC_ERR_INVALID_ARG;
   c->force_tier = tier;
   return KMC_OK;
 }

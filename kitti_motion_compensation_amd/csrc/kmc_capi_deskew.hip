@@ -33,6 +33,7 @@ void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f*
   switch (tier) {
     case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head, d); break;
     case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head, d); break;
+    case kWide: launch_frame_t<kWide>(ppt, s, grid, in, out, n, f, head, d); break;
     default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head, d); break;
   }
 }
@@ -365,6 +366,7 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   switch (tier) {
     case kSeries3: launch_batch_t<kSeries3>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
     case kSeries5: launch_batch_t<kSeries5>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    case kWide: launch_batch_t<kWide>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
     default: launch_batch_t<kTrig>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());

@@ -91,6 +91,7 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   switch (tier) {
     case kSeries3: KMC_LAUNCH_PROJECT(kSeries3); break;
     case kSeries5: KMC_LAUNCH_PROJECT(kSeries5); break;
+    case kWide: KMC_LAUNCH_PROJECT(kWide); break;
     case kTrig: KMC_LAUNCH_PROJECT(kTrig); break;
     default: KMC_LAUNCH_PROJECT(-1); break;
   }

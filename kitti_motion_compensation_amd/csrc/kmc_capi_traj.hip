@@ -137,14 +137,13 @@ int upload_traj(kmc_ctx* c, const void* src, size_t off, size_t bytes) {
 }
 
 int traj_tier(const kmc_ctx* c, const TrajHost& th, double span_lo, double span_hi) {
-  if (c->force_tier >= 0 && c->force_tier <= 2) return c->force_tier;
+  if (c->force_tier >= 0 && c->force_tier <= kTrig) return c->force_tier;
   // |s| <= 1 inside a segment except for the anchor segment (|x - x_r| <= 1 as well); the scan may stick out of the first /
   // last segment by at most the knots' coverage, which build_trajectory() / the callers have verified -> bound by 1.
   (void)span_lo; (void)span_hi;
   double theta_max = 0.0;
   for (uint32_t k = 0; k < th.n_seg; ++k) theta_max = std::fmax(theta_max, kmc_host::norm(th.f[k].phi));
-  if (!(theta_max <= 1.0)) return kTrig;
-  return theta_max <= 0.25 ? kSeries3 : kSeries5;
+  return tier_of_theta(theta_max);
 }
 }  // namespace
 
@@ -211,6 +210,7 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ(kSeries3); break;
     case kSeries5: KMC_LAUNCH_TRAJ(kSeries5); break;
+    case kWide: KMC_LAUNCH_TRAJ(kWide); break;
     default: KMC_LAUNCH_TRAJ(kTrig); break;
   }
 #undef KMC_LAUNCH_TRAJ
@@ -256,7 +256,7 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
     seg_stride = std::max(seg_stride, th[f].n_seg);
     tier = std::max(tier, traj_tier(c, th[f], fr.stamp_start, fr.stamp_end));
   }
-  if (c->force_tier >= 0 && c->force_tier <= 2) tier = c->force_tier;
+  if (c->force_tier >= 0 && c->force_tier <= kTrig) tier = c->force_tier;
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
   hipStream_t launch_stream = c->stream;
@@ -322,6 +322,7 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;
     case kSeries5: KMC_LAUNCH_TRAJ_BATCH(kSeries5); break;
+    case kWide: KMC_LAUNCH_TRAJ_BATCH(kWide); break;
     default: KMC_LAUNCH_TRAJ_BATCH(kTrig); break;
   }
 #undef KMC_LAUNCH_TRAJ_BATCH

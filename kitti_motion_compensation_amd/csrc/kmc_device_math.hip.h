@@ -46,7 +46,10 @@ struct alignas(16) FrameRecD {
 static_assert(sizeof(FrameRecD) == 128, "FrameRecD must stay one 128-byte record");
 static_assert(sizeof(FrameRec) == 64, "FrameRec must stay one 64-byte record");
 
-enum Tier : int { kSeries3 = 0, kSeries5 = 1, kTrig = 2 };
+// Coefficient tiers of the f32 kernels, each valid on the domain of the ones before it (a batch runs the tier of its widest
+// frame).  theta = |phi| * max|s| is known on the host: 0.25 / 1 / 3.25 rad are the upper ends of the first three.
+enum Tier : int { kSeries3 = 0, kSeries5 = 1, kWide = 2, kTrig = 3 };
+constexpr double kThetaSeries3 = 0.25, kThetaSeries5 = 1.0, kThetaWide = 3.25;
 
 // atan2(y, x) / (2 pi) in [-0.5, 0.5], i.e. the azimuth in turns.  timestamp_mocking.cpp:46 needs
 // frac = (pi - atan2(y,x)) / 2pi = 0.5 - azimuth_turns.  Octant reduction + degree-7 polynomial in q^2
@@ -110,7 +113,31 @@ __device__ __forceinline__ Coef se3_coefficients(float s, float phi2) {
     C = __builtin_fmaf(C, u, 1.0f / 5040.0f);
     C = __builtin_fmaf(C, u, -1.0f / 120.0f);
     C = __builtin_fmaf(C, u, 1.0f / 6.0f);
-  } else {  // any angle: half-angle forms (no 1 - cos cancellation); series below theta^2 = 1/16
+  } else if constexpr (TIER == kWide) {
+    // theta <= 3.25: everything a frame between two poses can reach (|phi| <= pi out of Log, |s| <= 1).  A, B, C are entire
+    // functions of u; interpolated at the Chebyshev nodes of [0, 3.25^2] (tools/gen_wide_coeffs.py): degree 6 / 5 / 5, fit
+    // error 1.2e-9 / 6.8e-9 / 4.6e-10 absolute, f32 Horner error 1.4e-7 / 4.8e-8 / 1.6e-8 -- 16 fma, no sqrt, no division,
+    // no sincos: the kernel stays on the HBM roofline where the trig tier below is VALU-bound.
+    A = 1.3453622937920073e-10f;
+    A = __builtin_fmaf(A, u, -2.4683949106929504e-08f);
+    A = __builtin_fmaf(A, u, 2.7531152682058746e-06f);
+    A = __builtin_fmaf(A, u, -0.0001984030968742445f);
+    A = __builtin_fmaf(A, u, 0.008333316072821617f);
+    A = __builtin_fmaf(A, u, -0.1666666567325592f);
+    A = __builtin_fmaf(A, u, 1.0f);
+    B = -1.752682554645446e-09f;
+    B = __builtin_fmaf(B, u, 2.716992923978978e-07f);
+    B = __builtin_fmaf(B, u, -2.478064016031567e-05f);
+    B = __builtin_fmaf(B, u, 0.0013888373505324125f);
+    B = __builtin_fmaf(B, u, -0.04166661947965622f);
+    B = __builtin_fmaf(B, u, 0.5f);
+    C = -1.3804320186938668e-10f;
+    C = __builtin_fmaf(C, u, 2.4790514530081964e-08f);
+    C = __builtin_fmaf(C, u, -2.754315346464864e-06f);
+    C = __builtin_fmaf(C, u, 0.00019840920867864043f);
+    C = __builtin_fmaf(C, u, -0.008333330042660236f);
+    C = __builtin_fmaf(C, u, 0.1666666716337204f);
+  } else {  // any angle (a caller-supplied twist beyond pi): half-angle forms (no 1 - cos cancellation); series below theta^2 = 1/16
     const float As = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 120.0f, -1.0f / 6.0f), u, 1.0f);
     const float Bs = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 720.0f, -1.0f / 24.0f), u, 0.5f);
     const float Cs = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 5040.0f, -1.0f / 120.0f), u, 1.0f / 6.0f);

@@ -110,6 +110,13 @@ inline int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
     if (_e != hipSuccess) return fail_hip(ctx, _e, #expr); \
   } while (0)
 
+// the cheapest tier valid up to theta_max = max over the frames of |phi| * max|s| (NaN -> the any-angle tier)
+inline int tier_of_theta(double theta_max) {
+  if (theta_max <= kThetaSeries3) return kSeries3;
+  if (theta_max <= kThetaSeries5) return kSeries5;
+  if (theta_max <= kThetaWide) return kWide;
+  return kTrig;
+}
 int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n);
 
 // frame queues: fq_stream() hands out the stream of the next frame (forking from `stream` first if necessary), fq_join() makes

@@ -30,7 +30,7 @@ TRAJECTORIES = {
     "gentle_turn": [1.3, 0.05, -0.02, 0.001, -0.002, 0.03],
     "hard_turn": [2.9, -0.3, 0.1, 0.02, 0.01, -0.1],
     "spin": [0.4, 0.1, 0.0, 0.1, -0.3, 0.6],       # series5 tier
-    "tumble": [0.4, 0.1, 0.0, 0.3, -0.9, 2.2],     # trig tier
+    "tumble": [0.4, 0.1, 0.0, 0.3, -0.9, 2.2],     # wide tier (theta = 1.2 rad at the mid-scan anchor)
 }
 
 
@@ -111,7 +111,7 @@ def test_kitti_frame_vs_oracle_device(torch_mod, ctx, kitti, name):
     params = _params(P1, P2)
     got, st = _run_device(torch_mod, ctx, xyzi, params)
     assert st.n_points == xyzi.shape[0] and st.n_launches == 1
-    expected_tier = {"spin": capi.TIER_SERIES5, "tumble": capi.TIER_TRIG}.get(name, capi.TIER_SERIES3)
+    expected_tier = {"spin": capi.TIER_SERIES5, "tumble": capi.TIER_WIDE}.get(name, capi.TIER_SERIES3)
     assert st.variant == expected_tier
     _check(got, xyzi, _oracle(xyzi, P1, P2))
     if name == "stationary":  # Log(P1^-1 P1) is zero up to ~1e-16 rounding: the cloud must come back unchanged
@@ -154,10 +154,11 @@ def test_host_pipeline_many_chunks_matches_device_path(torch_mod, ctx, kitti):
     _check(out[sel], xyzi[sel], _oracle(xyzi[sel], P1, P2, mode=orc.HOISTED))
 
 
-@pytest.mark.parametrize("theta,tier", [(0.2499, 0), (0.2501, 1), (0.9999, 1), (1.0001, 2), (3.0, 2)])
+@pytest.mark.parametrize("theta,tier", [(0.2499, 0), (0.2501, 1), (0.9999, 1), (1.0001, 2), (2.0, 2), (3.0, 2), (3.1415, 2)])
 def test_tier_boundaries_keep_the_bar(torch_mod, ctx, kitti, theta, tier):
-    """The host picks the series/trig tier from |phi| * max|s|; at the edges of each tier's validity (0.25 rad, 1 rad) the
-    truncated series must still sit far inside the 1e-5 bar.  requested_time = stamp_start makes max|s| = 1."""
+    """The host picks the coefficient tier from |phi| * max|s|; at the edges of each tier's validity (0.25 rad, 1 rad, and pi --
+    the most two poses can be apart -- for the wide polynomial) the truncated series must still sit far inside the 1e-5 bar.
+    requested_time = stamp_start makes max|s| = 1."""
     xyzi, P1 = kitti
     axis = np.array([0.3, -0.5, 0.81])
     axis /= np.linalg.norm(axis)
@@ -170,14 +171,14 @@ def test_tier_boundaries_keep_the_bar(torch_mod, ctx, kitti, theta, tier):
 
 
 def test_every_tier_and_tiling_agree(torch_mod, ctx, kitti):
-    """All three coefficient tiers are valid below 0.25 rad and must agree with the oracle; tiling never changes bits."""
+    """All four coefficient tiers are valid below 0.25 rad and must agree with the oracle; tiling never changes bits."""
     xyzi, P1 = kitti
     P1, P2 = _poses(P1, TRAJECTORIES["hard_turn"])
     params = _params(P1, P2)
     ref = _oracle(xyzi, P1, P2)
     base = None
     try:
-        for tier in (capi.TIER_SERIES3, capi.TIER_SERIES5, capi.TIER_TRIG):
+        for tier in (capi.TIER_SERIES3, capi.TIER_SERIES5, capi.TIER_WIDE, capi.TIER_TRIG):
             ctx.force_tier(tier)
             got, st = _run_device(torch_mod, ctx, xyzi, params)
             assert st.variant == tier
@@ -193,6 +194,37 @@ def test_every_tier_and_tiling_agree(torch_mod, ctx, kitti):
     finally:
         ctx.force_tier(-1)
         ctx.set_launch_config(0, 0)
+
+
+@pytest.mark.parametrize("theta", [3.3, 5.0, 9.0])
+def test_caller_supplied_twist_beyond_pi_runs_the_any_angle_tier(torch_mod, ctx, kitti, theta):
+    """Two poses are never more than pi apart (Log), but the C-ABI also accepts a raw twist: beyond 3.25 rad the host must
+    leave the wide polynomial (fitted on theta <= 3.25) for the any-angle tier.  Reference: the oracle's lie::Exp
+    (lie_algebra.cpp:83-92) applied point by point to Exp(s f) p, s = frac(p) - x_req."""
+    xyzi = kitti[0][::41].copy()
+    axis = np.array([0.2, -0.4, 0.89])
+    twist = np.array([1.1, 0.2, -0.05, *(theta * axis / np.linalg.norm(axis))])
+    x_req = 0.0
+    got, st = _run_device(torch_mod, ctx, xyzi, capi.FrameParams.make(twist, x_req))
+    assert st.variant == capi.TIER_TRIG
+    p = xyzi[:, :3].astype(np.float64)
+    frac = (np.pi - np.arctan2(p[:, 1], p[:, 0])) / (2 * np.pi)  # timestamp_mocking.cpp:46-63
+    want = np.empty_like(p)
+    for i in range(p.shape[0]):
+        T = orc.se3_exp(list((frac[i] - x_req) * twist))
+        want[i] = np.array(list(T.R)).reshape(3, 3) @ p[i] + np.array(list(T.t))
+    assert np.array_equal(got[:, 3].view(np.uint32), xyzi[:, 3].view(np.uint32))
+    assert util.rel_point_error(got[:, :3], want).max() <= REL_TOL
+    # ... and the wide tier, forced onto a frame inside ITS domain, agrees with the any-angle tier there
+    inside = capi.FrameParams.make(twist * (3.2 / theta), x_req)
+    a, st_a = _run_device(torch_mod, ctx, xyzi, inside)
+    assert st_a.variant == capi.TIER_WIDE
+    try:
+        ctx.force_tier(capi.TIER_TRIG)
+        b, _ = _run_device(torch_mod, ctx, xyzi, inside)
+    finally:
+        ctx.force_tier(-1)
+    assert util.rel_point_error(a[:, :3], b[:, :3].astype(np.float64)).max() <= 2e-6
 
 
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 255, 256, 1023, 1024, 1025, 2047, 2048, 2049, 100_003])

@@ -23,12 +23,13 @@ T0, T1 = 47072.283701593, 47072.386973931
 IDENT = np.hstack([np.eye(3), np.zeros((3, 1))])
 
 # twist = [rho; phi]; |phi| * max|s| decides the kernel tier (pick_tier, kmc_capi_core.hip: theta <= 0.25 series3, <= 1
-# series5, trig beyond).  The twists below lie inside their tier's domain for every x_req; the tests pin the tier with
+# series5, <= 3.25 the wide polynomial, the any-angle trig tier beyond).  The twists below lie inside their tier's domain for every x_req; the tests pin the tier with
 # kmc_hip_force_tier so that a frame whose x_req happens to halve max|s| is still run by the kernel under test.
 TIER_TWISTS = {
     0: dict(rho=[1.5, 0.3, 0.05], phi=[0.002, 0.004, 0.03]),   # series3
     1: dict(rho=[1.5, 0.3, 0.05], phi=[0.05, -0.1, 0.6]),      # series5
-    2: dict(rho=[1.2, 0.4, 0.10], phi=[0.2, -0.5, 1.9]),       # trig
+    2: dict(rho=[1.2, 0.4, 0.10], phi=[0.2, -0.5, 1.9]),       # wide polynomial
+    3: dict(rho=[1.2, 0.4, 0.10], phi=[0.2, -0.5, 1.9]),       # any-angle (trig) tier, on the same frames
 }
 
 
@@ -124,7 +125,7 @@ def _is_hard(pts, ref):
     return np.linalg.norm(ref, axis=1) < np.linalg.norm(pts[:, :3].astype(np.float64), axis=1) / 50.0
 
 
-@pytest.mark.parametrize("tier", [0, 1, 2])
+@pytest.mark.parametrize("tier", [0, 1, 2, 3])
 def test_single_frame_near_origin_host_and_device(ctx, tier):
     import torch
 
@@ -159,7 +160,7 @@ def test_single_frame_near_origin_host_and_device(ctx, tier):
 
 def test_batched_near_origin_all_tiers_and_bit_exact_indices(ctx):
     rng = np.random.default_rng(7)
-    for tier in (0, 1, 2):
+    for tier in (0, 1, 2, 3):
         ctx.force_tier(tier)
         nf = 300
         sizes = rng.choice([0, 1, 63, 64, 65, 200, 777], nf, p=[.03, .05, .1, .2, .1, .32, .2])
@@ -230,7 +231,7 @@ def _rt(poses):
     return np.stack([p.rt12().reshape(3, 4) for p in poses])
 
 
-@pytest.mark.parametrize("tier", [0, 1, 2])
+@pytest.mark.parametrize("tier", [0, 1, 2, 3])
 def test_trajectory_kernels_near_origin(ctx, tier):
     rng = np.random.default_rng(300 + tier)
     hard = total = 0
@@ -285,7 +286,7 @@ def test_fused_projection_writes_the_guarded_cloud(ctx, golden_dir):
     rng = np.random.default_rng(11)
     tf, R_rect, P = util.load_kitti_calibration(golden_dir)
     rig = capi.CameraRig.make(tf, R_rect, P)
-    for tier in (0, 1, 2):
+    for tier in (0, 1, 2, 3):
         ctx.force_tier(tier)
         twist, x_req, p_star = _frame(rng, tier)
         pts = _scatter(rng, p_star, 10_001)

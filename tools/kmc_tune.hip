@@ -547,6 +547,7 @@ int main(int argc, char** argv) {
   es.push_back({frame_variant<kSeries3, 4, kNtBoth, false>("s3_ppt4_nt"), kAll});
   es.push_back({frame_variant<kSeries3, 1, kNtBoth, true>("s3_ppt1_nt_ocml"), kZero});
   es.push_back({frame_variant<kSeries5, 1, kNtBoth, false>("s5_ppt1_nt"), kZero});
+  es.push_back({frame_variant<kWide, 1, kNtBoth, false>("wide_ppt1_nt"), kZero});
   es.push_back({frame_variant<kTrig, 1, kNtBoth, false>("trig_ppt1_nt"), kZero});
   es.push_back({batch_variant<1, false>("batch1M_ppt1"), kAll});
   es.push_back({batch_variant<1, false, 64>("batch1M_ppt1_b64"), kZero});

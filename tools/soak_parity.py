@@ -29,7 +29,7 @@ def random_twist(rng):
     elif kind == 3:
         phi *= 10           # series5 tier
     elif kind == 4:
-        phi *= 60           # trig tier
+        phi *= 60           # wide tier (two poses never need the any-angle tier)
         th = np.linalg.norm(phi)
         if th > 2.8:        # stay inside the principal branch of Log: beyond pi the reference itself takes the short way round
             phi *= 2.8 / th
@@ -125,7 +125,7 @@ def near_origin_round(ctx, rng, acc):
     """Points built ON the cancellation p ~ -s rho (tests/test_near_origin.py's construction), single-frame and batched."""
     from tests import test_near_origin as tno
 
-    tier = int(rng.integers(0, 3))
+    tier = int(rng.integers(0, 4))
     nf = int(rng.integers(1, 40))
     sizes = rng.choice([1, 63, 64, 65, 500, 4000], nf)
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
