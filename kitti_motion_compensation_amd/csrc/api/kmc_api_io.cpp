@@ -371,7 +371,7 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
       fail(std::current_exception());
     }
   });
-  std::thread writer([&] {
+  auto const write_batches = [&] {
     try {
       for (std::size_t k = 0; k < plans.size(); ++k) {
         BufferSet& set = sets[k % 2];
@@ -389,7 +389,15 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
     } catch (...) {
       fail(std::current_exception());
     }
-  });
+  };
+  std::thread writer;
+  try {
+    writer = std::thread(write_batches);
+  } catch (...) {  // no second thread to be had: release the reader before reporting it
+    fail(std::current_exception());
+    reader.join();
+    throw;
+  }
   try {
     for (std::size_t k = 0; k < plans.size(); ++k) {
       BufferSet& set = sets[k % 2];
@@ -480,17 +488,24 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
   }
   std::vector<std::thread> workers;
   std::vector<std::exception_ptr> errors(n_parts);
-  for (std::uint32_t r = 0; r < n_parts; ++r) {
-    workers.emplace_back([&, r] {
-      try {
-        hip::SetDevice(devices[r]);  // this worker thread's context lives on its device
-        DeskewFrameRange(in, 1 + bounds[r], 1 + bounds[r + 1], static_cast<int>(r));
-      } catch (...) {
-        errors[r] = std::current_exception();
-      }
-    });
+  workers.reserve(n_parts);
+  std::exception_ptr spawn_error;
+  for (std::uint32_t r = 0; r < n_parts && !spawn_error; ++r) {
+    try {
+      workers.emplace_back([&, r] {
+        try {
+          hip::SetDevice(devices[r]);  // this worker thread's context lives on its device
+          DeskewFrameRange(in, 1 + bounds[r], 1 + bounds[r + 1], static_cast<int>(r));
+        } catch (...) {
+          errors[r] = std::current_exception();
+        }
+      });
+    } catch (...) {  // the system refused a thread: the workers already running finish their ranges, then the caller hears about it
+      spawn_error = std::current_exception();
+    }
   }
   for (auto& w : workers) w.join();
+  if (spawn_error) std::rethrow_exception(spawn_error);
   for (auto const& e : errors)
     if (e) std::rethrow_exception(e);
 }
