@@ -569,28 +569,36 @@ using v4i = int __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int trunc_i32(double v) {  // cv::Point(double, double): cvttsd2si semantics
   return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (int)0x80000000;
 }
-__device__ __forceinline__ uint32_t sat_u8(double v) {  // cv::saturate_cast<uchar>(double): cvRound (half to even) + clamp
-  const double r = __builtin_rint(v);
-  return (r == r) ? (uint32_t)(r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r)) : 0u;
+__device__ __forceinline__ uint32_t sat_u8(double v) {  // cv::saturate_cast<uchar>(double): cvRound (half to even) + clamp, NaN -> 0
+  // v_max_f64 / v_min_f64 return the other operand for a NaN: the clamp is also the NaN guard (two instructions where the
+  // compare-and-select form took seven)
+  return (uint32_t)__builtin_fmin(__builtin_fmax(__builtin_rint(v), 0.0), 255.0);
 }
 
 // (trunc(a / d), trunc(b / d)) with the IEEE quotients' values, without two IEEE divisions on the common path: the
-// quotients are first approximated through ONE refined reciprocal (relative error < 2^-45); their truncations equal the
-// exact ones unless an integer lies within that error of the approximation, i.e. unless the approximation sits within
-// 2^-36 * max(1, |q|) of an integer (or is not a finite value inside the int range, whose ends are integers too).
-// Returns whether both truncations are certain; the caller redoes the point with real divisions otherwise (about once
-// in 1e8 coordinates).
-__device__ __forceinline__ bool trunc_quotients_fast(double a, double b, double d, int& ta, int& tb) {
+// quotients are first approximated through ONE reciprocal refined by ONE Newton step (v_rcp_f64 is good to 2^-23 at worst per
+// the ISA manual, 2^-24.4 measured over 2^33 denominators, tools/rcp_probe.hip: after the step 2^-48.6 measured, < 2^-44 by the bound); their
+// truncations equal the exact ones unless an integer lies within that error of the approximation, i.e. unless the
+// approximation sits within 2^-36 * max(1, |q|) of an integer (or is not a finite value inside the int range, whose ends are
+// integers too) -- a margin 2^8 wider than the error.  Returns whether both truncations are certain; the caller redoes the point
+// with real divisions otherwise (about once in 1e8 coordinates).  One margin for the pair, from the larger quotient: wider than
+// needed for the smaller one, which only sends a few more points to the exact path.  NaN or infinite quotients (d = 0) fail the
+// `>` comparisons and are therefore never "certain".
+// The verdict comes back as a LANE MASK (ballot): the caller combines the masks of the four cameras with scalar ANDs; as `bool`s
+// the compiler materialised every one of them in a VGPR and combined them with 16-bit vector logic (~25 VALU instructions).
+__device__ __forceinline__ uint64_t trunc_quotients_fast(double a, double b, double d, int& ta, int& tb) {
   double r = __builtin_amdgcn_rcp(d);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
   r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
   const double qa = a * r, qb = b * r;
   constexpr double kEps = 0x1p-36;  // the margin kEps (1 + |q|) >= kEps max(1, |q|): one fma instead of max + mul, a little more cautious
-  const bool sure_a = __builtin_fabs(qa - __builtin_rint(qa)) > __builtin_fma(__builtin_fabs(qa), kEps, kEps) && __builtin_fabs(qa) < 2147483000.0;
-  const bool sure_b = __builtin_fabs(qb - __builtin_rint(qb)) > __builtin_fma(__builtin_fabs(qb), kEps, kEps) && __builtin_fabs(qb) < 2147483000.0;
+  const double big = __builtin_fmax(__builtin_fabs(qa), __builtin_fabs(qb));
+  const double margin = __builtin_fma(big, kEps, kEps);
+  const uint64_t sure_a = __builtin_amdgcn_ballot_w64(__builtin_fabs(qa - __builtin_rint(qa)) > margin);
+  const uint64_t sure_b = __builtin_amdgcn_ballot_w64(__builtin_fabs(qb - __builtin_rint(qb)) > margin);
+  const uint64_t in_range = __builtin_amdgcn_ballot_w64(big < 2147483000.0);
   ta = (int)qa;
   tb = (int)qb;
-  return sure_a && sure_b;
+  return sure_a & sure_b & in_range;
 }
 
 // P_rect_c * r for one camera, :9.  STRUCTURED: the products with the literal 0s and 1 of a pinhole matrix are skipped.
@@ -638,13 +646,16 @@ __device__ __forceinline__ bool project_point(double x, double y, double z, cdou
 #pragma unroll
   for (int k = 0; k < 3; ++k) r[k] = ((R[3 * k] * c[0] + R[3 * k + 1] * c[1]) + R[3 * k + 2] * c[2]) + 0.0;  // :81
   const bool valid = !((r[2] < 0.01) || (r[2] > g[kRigMaxRange]) || (r[1] > 1.25));                         // :21-24
-  if (__builtin_amdgcn_ballot_w64(valid) == 0) {
+  const uint64_t valid_m = __builtin_amdgcn_ballot_w64(valid);
+  if (valid_m == 0) {
 #pragma unroll
     for (int cam = 0; cam < 4; ++cam) uv[cam].x = uv[cam].y = (int)0x80000000;
     bgrv = 0u;
     return false;
   }
-  bool sure = __builtin_fabs(r[0]) < __builtin_inf() && __builtin_fabs(r[1]) < __builtin_inf() && __builtin_fabs(r[2]) < __builtin_inf();
+  // lanes whose truncations are certain, as a lane mask (scalar logic; see trunc_quotients_fast)
+  uint64_t sure = __builtin_amdgcn_ballot_w64(__builtin_fabs(r[0]) < __builtin_inf()) & __builtin_amdgcn_ballot_w64(__builtin_fabs(r[1]) < __builtin_inf()) &
+                  __builtin_amdgcn_ballot_w64(__builtin_fabs(r[2]) < __builtin_inf());
   cdouble_p P = after(g, c[0]) + kRigP;  // cameras 0 and 1: their loads may start as soon as the camera-frame point exists
   if constexpr (RIG == kRigSharedIntrinsics) {
     const double a0 = P[0] * r[0] + P[2] * r[2];  // :9, rows 0 and 1 of P_rect without their last column
@@ -668,13 +679,16 @@ __device__ __forceinline__ bool project_point(double x, double y, double z, cdou
       uv[cam].y = tv;
     }
   }
-  if (__builtin_expect(valid && !sure, 0)) {  // the reference's own sequence: general rows, two IEEE divisions (:9, :12, :31)
+  const uint64_t redo = valid_m & ~sure;
+  if (__builtin_expect(redo != 0, 0)) {  // wave-uniform, cold
+    if ((redo >> __lane_id()) & 1) {     // the reference's own sequence: general rows, two IEEE divisions (:9, :12, :31)
 #pragma unroll 1
-    for (int cam = 0; cam < 4; ++cam) {
-      double h[3];
-      camera_rows<false>(after(g, r[2]) + kRigP + 12 * cam, r, h);
-      uv[cam].x = trunc_i32(h[0] / h[2]);
-      uv[cam].y = trunc_i32(h[1] / h[2]);
+      for (int cam = 0; cam < 4; ++cam) {
+        double h[3];
+        camera_rows<false>(after(g, r[2]) + kRigP + 12 * cam, r, h);
+        uv[cam].x = trunc_i32(h[0] / h[2]);
+        uv[cam].y = trunc_i32(h[1] / h[2]);
+      }
     }
   }
   if (!valid) {
