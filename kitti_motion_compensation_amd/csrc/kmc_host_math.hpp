@@ -119,13 +119,36 @@ inline bool polar_rotation(const Mat3& L, Mat3* out) {
 
 // so(3) log: phi = vee(k (R - R^T)), k = theta / (2 sin theta); first-order below 1e-6 rad
 // (same branch point as lie_algebra.cpp:37-49 so both sides agree bit-for-bit on which form is used).
+// Conditioning: the reference takes theta = acos((tr R - 1) / 2) and divides by sin(theta).  acos next to -1 returns theta with
+// an absolute error of 1e-16 / (pi - theta), so next to pi sin(theta) ~ pi - theta and with it the whole of phi carry a
+// RELATIVE error of 1e-16 / (pi - theta)^2: 1e-8 at 1e-4 rad from a half turn, every digit at 1e-8 rad (measured against the
+// oracle, which restates the reference's formula: tests/test_host_prestep.py).  Here sin(theta) is taken from where it is
+// exact -- the norm of the antisymmetric part, |vee(R - R^T)| / 2 -- and theta from atan2(sin, cos); within 1.4e-3 rad of pi
+// the axis comes from the symmetric part, (R + R^T) / 2 = cos I + (1 - cos) a a^T, and only its sign from the antisymmetric
+// one.  phi is then good to ~1e-15 for every rotation, the half turn itself included (where either sign of the axis is a
+// logarithm).  Away from pi the value is the reference's up to rounding.
 inline Vec3 so3_log(const Mat3& R) {
   double c = 0.5 * (R.m[0][0] + R.m[1][1] + R.m[2][2]) - 0.5;
   c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
-  const double theta = std::acos(c);
+  const Vec3 v = {R.m[2][1] - R.m[1][2], R.m[0][2] - R.m[2][0], R.m[1][0] - R.m[0][1]};  // 2 sin(theta) a
+  const double s = 0.5 * norm(v);
+  const double theta = std::atan2(s, c);
   if (theta < 1e-6) return {R.m[2][1], R.m[0][2], R.m[1][0]};
-  const double k = 0.5 * theta / std::sin(theta);
-  return {k * (R.m[2][1] - R.m[1][2]), k * (R.m[0][2] - R.m[2][0]), k * (R.m[1][0] - R.m[0][1])};
+  if (c > -1.0 + 1e-6) return (0.5 * theta / s) * v;
+  // next to a half turn
+  double S[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) S[i][j] = 0.5 * (R.m[i][j] + R.m[j][i]);
+  const int i = (S[0][0] >= S[1][1] && S[0][0] >= S[2][2]) ? 0 : (S[1][1] >= S[2][2] ? 1 : 2);
+  const double one_minus_c = 1.0 - c;
+  double a[3];
+  a[i] = std::sqrt(std::fmax(0.0, (S[i][i] - c) / one_minus_c));  // >= 1/sqrt(3): the largest component of a unit vector
+  for (int j = 0; j < 3; ++j)
+    if (j != i) a[j] = S[i][j] / (one_minus_c * a[i]);
+  Vec3 axis = {a[0], a[1], a[2]};
+  axis = (1.0 / norm(axis)) * axis;
+  if (dot(axis, v) < 0.0) axis = -1.0 * axis;
+  return theta * axis;
 }
 
 // J^-1(phi) t = t - 1/2 phi x t + kappa phi x (phi x t),  kappa = (1 - (th/2) cot(th/2)) / th^2

@@ -44,6 +44,43 @@ def test_frame_params_match_oracle_log(step, golden_dir):
     assert p.x_req == (tr - t0) / (t1 - t0)
 
 
+def test_log_next_to_a_half_turn_is_exact_where_the_references_formula_is_not():
+    """lie_algebra.cpp:37-49 takes theta = acos((tr R - 1) / 2) and divides by sin(theta): next to pi that loses
+    1e-16 / (pi - theta)^2 of phi -- 6e-8 at 1e-4 rad from a half turn, everything at 1e-8 rad.  The oracle restates that formula
+    (it is the checker, so it must); the product's host Log takes sin(theta) from the antisymmetric part and, next to pi, the
+    axis from the symmetric part (kmc_host_math.hpp so3_log) and returns the twist that WAS exponentiated, the half turn itself
+    included.  Consequence for parity, stated here where it is measured: within ~1e-4 rad of a half turn per scan the
+    reference's own result carries the error of the right-hand column, and nothing can agree with it more closely than that."""
+    rng = np.random.default_rng(1)
+    ident = np.hstack([np.eye(3), np.zeros((3, 1))])
+    t0, t1 = 47072.283701593, 47072.386973931
+    reference_formula_err = {}
+    for delta in (1.0, 1e-2, 1.4e-3, 1e-3, 1e-4, 1e-5, 1e-6, 1e-8, 0.0):
+        worst_host = worst_ref = 0.0
+        for _ in range(100):
+            axis = rng.normal(size=3)
+            axis /= np.linalg.norm(axis)
+            twist = np.concatenate([rng.normal(size=3), (np.pi - delta) * axis])
+            T = orc.se3_exp(list(twist))
+            host = capi.frame_params_from_poses(ident, _rt(T), t0, t1, t0).twist_np()
+            ref = np.array(orc.se3_log(T))
+            e_host = np.abs(host[3:] - twist[3:]).max()
+            e_ref = np.abs(ref[3:] - twist[3:]).max()
+            if delta == 0.0:  # both signs of the axis are logarithms of a half turn
+                e_host = min(e_host, np.abs(host[3:] + twist[3:]).max())
+                e_ref = min(e_ref, np.abs(ref[3:] + twist[3:]).max())
+                host_T = orc.se3_exp(list(host))
+                assert np.allclose(_rt(host_T), _rt(T), atol=1e-12)  # whichever sign: it exponentiates back to the pose
+            else:
+                assert np.abs(host[:3] - twist[:3]).max() < 1e-12
+            worst_host, worst_ref = max(worst_host, e_host), max(worst_ref, e_ref)
+        assert worst_host < 1e-13, (delta, worst_host)
+        reference_formula_err[delta] = worst_ref
+    assert reference_formula_err[1.0] < 1e-14                # away from pi the two are the same numbers
+    assert reference_formula_err[1e-4] > 1e-9                # ... and this is the reference's own conditioning, not the product's
+    assert reference_formula_err[1e-6] > 1e-6
+
+
 def test_frame_params_reference_kat_constants(kats):
     """test_motion_compensation.cpp fixture: lon 0 / 1e-5 / 2e-5 deg -> pure x translation, no rotation."""
     k = kats["motion_compensate_frame"]
