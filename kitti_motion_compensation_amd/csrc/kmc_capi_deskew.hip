@@ -298,9 +298,8 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (((uintptr_t)xyzi_in | (uintptr_t)xyzi_out) & (mem_kind == KMC_MEM_DEVICE ? 15u : 3u)) return KMC_ERR_INVALID_ARG;
   // Batched launches always go to the context's stream, after a join: routing them over the frame queues was measured and
   // dropped -- their table uploads on the side stream end up sharing hardware queues with the launches (a 13 M-point drive:
-  // 64 us in order, 74 us over two queues, 188 us over four; tools/measure_configs.py, gpurun_out/r02/measure_configs.json).
+  // 64 us in order, 74 us over two queues, 188 us over four; tools/measure_configs.py, profiles/r02_measure_configs.json).
   KMC_ENTER(c);
-  hipStream_t launch_stream = c->stream;
   const int tier = pick_tier(c, params, n_frames);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
@@ -364,10 +363,10 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const int grid = grid_for(c, n_tiles);
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
   switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
-    case kWide: launch_batch_t<kWide>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
-    default: launch_batch_t<kTrig>(ppt, launch_stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    case kWide: launch_batch_t<kWide>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
   {

@@ -259,7 +259,6 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   if (c->force_tier >= 0 && c->force_tier <= kTrig) tier = c->force_tier;
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
-  hipStream_t launch_stream = c->stream;
 
   const uint32_t head = head_of(xyzi_out, mem_kind);
   const uint64_t nv = n + head;
@@ -316,8 +315,8 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   uint32_t* v_bidx = d_bidx ? d_bidx - head : nullptr;
 #define KMC_LAUNCH_TRAJ_BATCH(T)                                                                                                   \
   do {                                                                                                                             \
-    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, launch_stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
-    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, launch_stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);     \
+    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
+    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);     \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;
