@@ -602,6 +602,23 @@ def test_full_size_properties_10M(torch_mod, ctx):
     xyzi = d_in[sel].cpu().numpy()
     got = d_out[sel].cpu().numpy()
     _check(got, xyzi, _oracle(xyzi, A, B, mode=orc.HOISTED))
+    # (5) moving the requested time moves the WHOLE compensated cloud by one rigid transform: with f = Log(T_start^-1 T_end),
+    #     p'(x_req) = Exp((x_i - x_req) f) p, and exponentials of the same twist commute, so p'(b) = Exp((a - b) f) p'(a) for every
+    #     point -- all 10 M of them, against one 3x4 matrix from the oracle's lie::Exp (RelativePoseBetweenTimes,
+    #     trajectory_interpolation.cpp:43-45, is exactly this statement)
+    twist = np.array([1.9, -0.3, 0.08, 0.01, -0.03, 0.25])
+    xa, xb = 0.2, 0.85
+    d_b = torch.empty_like(d_in)
+    ctx.deskew_f32(d_in, d_out, capi.FrameParams.make(twist, xa))
+    ctx.deskew_f32(d_in, d_b, capi.FrameParams.make(twist, xb))
+    torch.cuda.synchronize()
+    T_ab = orc.se3_exp(list((xa - xb) * twist))
+    R = torch.tensor(np.array(list(T_ab.R)).reshape(3, 3), dtype=torch.float64, device="cuda")
+    t = torch.tensor(list(T_ab.t), dtype=torch.float64, device="cuda")
+    moved = d_out[:, :3].double() @ R.T + t
+    err = (moved - d_b[:, :3].double()).norm(dim=1) / d_b[:, :3].double().norm(dim=1).clamp_min(1e-3)
+    assert err.max().item() < 2e-6, err.max().item()
+    assert torch.equal(d_b[:, 3].view(torch.int32), d_in[:, 3].view(torch.int32))
 
 
 # ---- scale and speed guards ------------------------------------------------------------------------------------------
