@@ -178,11 +178,16 @@ inline bool params_ok(const kmc_frame_params* p) {
   return std::isfinite(p->x_req);
 }
 
-inline int grid_for(const kmc_ctx* c, uint64_t n_tiles) {
+inline int grid_for(const kmc_ctx* c, uint64_t n_tiles, uint32_t threads_per_block = kLaunchBlock) {
   // default: one tile per workgroup -- the hardware dispatcher streaming 64-point tiles beats a persistent grid-stride loop
   // (6.8 vs 5.2-5.8 TB/s, profiles/r01_tune.csv); blocks_per_cu > 0 caps the grid instead (in units of 256 threads per CU).
-  const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu * (kBlock / kLaunchBlock) : 0x7fffffffull;
-  return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, cap));
+  // The dispatch packet carries the grid in WORK-ITEMS in 32 bits.  Beyond 2^32 / threads_per_block workgroups (4.29 G points for
+  // 64-point tiles -- 137 GB of cloud in + out, which this GPU holds) the runtime does NOT refuse the launch: it wraps the grid
+  // modulo 2^32 work-items and reports success (tools/grid_probe.hip, profiles/r02_grid_probe.txt: 67 108 865 blocks run as one).
+  // The grid therefore stops below the limit and the kernels' tile loops (t += gridDim.x) take the rest in a second pass.
+  const uint64_t hw = 0xFFFFFFFFull / threads_per_block;
+  const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu * (kBlock / kLaunchBlock) : hw;
+  return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, std::min(cap, hw)));
 }
 
 inline int ppt_of(const kmc_ctx* c) {

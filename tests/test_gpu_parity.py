@@ -656,6 +656,50 @@ def test_beyond_4GiB_buffers_use_64bit_indexing(torch_mod, ctx):
         assert int(d_idx[pos].item()) == want, pos
 
 
+def test_beyond_2_32_work_items_the_tile_loop_takes_over(torch_mod, ctx):
+    """2^32 + 64 017 points = 68.7 GB per buffer (MI355X holds 288 GB): more 64-point tiles than a dispatch can carry workgroups
+    (the packet's grid is 32 bits of work-items; the runtime wraps a larger grid modulo 2^32 and reports success,
+    tools/grid_probe.hip), so the library cuts the grid below the limit and the kernels' tile loops run a second pass.  Single-frame
+    and batched kernels; checked on slices at the start, either side of the 2^32-work-item mark and at the end."""
+    torch = torch_mod
+    n = (1 << 32) + 64_017
+    need = 2 * n * 16 + n * 4 + (2 << 30)
+    free, _ = torch.cuda.mem_get_info()
+    if free < need:
+        pytest.skip(f"needs {need >> 30} GiB of free HBM, the box has {free >> 30}")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    ctx.synth_points(d_in, n, 777)
+    d_out = torch.zeros_like(d_in)
+    rho = [1.7, -0.4, 0.05]
+    params = capi.FrameParams.make([*rho, 0, 0, 0], 0.25)
+    st = ctx.deskew_f32(d_in, d_out, params)
+    torch.cuda.synchronize()
+    assert st.n_points == n
+    mark = ((1 << 32) // 64) * 64  # first point of the first tile of the second pass
+
+    def check(out):
+        for lo in (0, mark - 50_000, mark + 64 * 1000 - 50_000, n - 100_000):
+            a = d_in[lo:lo + 100_000].double()
+            b = out[lo:lo + 100_000].double()
+            frac = (np.pi - torch.atan2(a[:, 1], a[:, 0])) / (2 * np.pi)
+            want = a[:, :3] + (frac - 0.25)[:, None] * torch.tensor(rho, dtype=torch.float64, device="cuda")[None, :]
+            assert (b[:, :3] - want).abs().max().item() < 2e-5, lo
+            assert torch.equal(a[:, 3], b[:, 3]), lo
+
+    check(d_out)
+    d_out.zero_()
+    offsets = np.array([0, 3_000_000_000, mark + 5, n], dtype=np.uint64)
+    d_idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.deskew_batch_f32(d_in, d_out, offsets, [params] * 3, d_idx)
+    torch.cuda.synchronize()
+    check(d_out)
+    for pos, want in ((0, 0), (2_999_999_999, 0), (3_000_000_000, 1), (mark + 4, 1), (mark + 5, 2), (n - 1, 2)):
+        assert int(d_idx[pos].item()) == want, pos
+    del d_in, d_out, d_idx
+    torch.cuda.empty_cache()
+
+
 def test_throughput_guard_batched_kernel(torch_mod, ctx):
     """Regression guard, not a benchmark: the batched kernel on 64 x 1 M points must stay above 5.0 TB/s
     (bench.py measures 6.8-6.9 TB/s on 256 M points; a persistent-loop or un-hinted variant would land at 5.2-6.4 and a
