@@ -69,7 +69,11 @@ std::vector<Time> LoadAllTimeStamps(Path const& file) {
     if (line.empty()) continue;
     auto const tokens = TokenizeString(line);
     if (tokens.size() < 2) throw std::runtime_error("Malformed timestamp line in " + file.string());
-    out.push_back(MmHhSsToSeconds(tokens[1]));
+    try {
+      out.push_back(MmHhSsToSeconds(tokens[1]));
+    } catch (std::logic_error const&) {  // substr / stoi / stod on a token that is not HH:MM:SS.fraction
+      throw std::runtime_error("Malformed timestamp line in " + file.string() + ": " + line);
+    }
   }
   return out;
 }
@@ -77,8 +81,12 @@ std::vector<Time> LoadAllTimeStamps(Path const& file) {
 Oxts ParseOxtsLine(std::string const& line, Time stamp, Path const& file) {
   auto const t = TokenizeString(line);
   if (t.size() < 11) throw std::runtime_error("Malformed OXTS packet: " + file.string());
-  return Oxts{stamp, std::stod(t[0]), std::stod(t[1]), std::stod(t[2]), std::stod(t[3]), std::stod(t[4]),
-              std::stod(t[5]), std::stod(t[8]), std::stod(t[9]), std::stod(t[10])};  // data_io.cpp:56-65
+  try {
+    return Oxts{stamp, std::stod(t[0]), std::stod(t[1]), std::stod(t[2]), std::stod(t[3]), std::stod(t[4]),
+                std::stod(t[5]), std::stod(t[8]), std::stod(t[9]), std::stod(t[10])};  // data_io.cpp:56-65
+  } catch (std::logic_error const&) {  // a field that is not a number
+    throw std::runtime_error("Malformed OXTS packet: " + file.string());
+  }
 }
 
 Oxts LoadOxtsWithStamp(Path const& folder, std::size_t frame_id, Time stamp) {

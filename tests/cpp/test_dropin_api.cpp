@@ -12,10 +12,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <fstream>
+#include <stdexcept>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
+
+#include <unistd.h>
 
 #include "kitti_motion_compensation/camera_model.hpp"
 #include "kitti_motion_compensation/data_io.hpp"
@@ -265,6 +270,58 @@ static void host_cases(std::string const& golden) {
       threw = true;
     }
     ASSERT_TRUE(threw);
+  }
+
+  // ---- damaged inputs: every reader reports (std::runtime_error naming the file), none reads past what the file holds.  The
+  // reference exits the process, indexes past its fixed buffer or lets std::stoi's exception escape (data_io.cpp:27-30, :115).
+  CASE("KmcRobustness.DamagedInputsAreReportedNotRead");
+  {
+    namespace fs = std::filesystem;
+    fs::path const root{fs::temp_directory_path() / ("kmc_damaged_" + std::to_string(static_cast<unsigned long long>(::getpid())))};
+    fs::remove_all(root);
+    fs::create_directories(root / "velodyne_points" / "data");
+    fs::create_directories(root / "oxts" / "data");
+    auto const write_text = [](fs::path const& f, std::string const& text) { std::ofstream os{f}; os << text; };
+    auto const write_bytes = [](fs::path const& f, std::size_t n) { std::ofstream os{f, std::ios::binary}; std::vector<char> z(n, 0); os.write(z.data(), static_cast<std::streamsize>(n)); };
+    auto const throws_runtime_error = [](auto&& fn) {
+      try { fn(); } catch (std::runtime_error const&) { return true; } catch (...) { return false; }
+      return false;
+    };
+    // timestamps: a good line, then lines that are not "<date> HH:MM:SS.fraction"
+    write_text(root / "good.txt", "2011-09-26 13:02:25.964389445\n2011-09-26 13:02:26.067662\n");
+    ASSERT_TRUE(std::fabs(LoadTimeStamp(root / "good.txt", 1) - (13 * 3600 + 2 * 60 + 26.067662)) < 1e-9);
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadTimeStamp(root / "good.txt", 2); }));          // no such line
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadTimeStamp(root / "missing.txt", 0); }));       // no such file
+    write_text(root / "one_token.txt", "garbage\n");
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadTimeStamp(root / "one_token.txt", 0); }));
+    write_text(root / "short_token.txt", "2011-09-26 13:0\n");
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadTimeStamp(root / "short_token.txt", 0); }));
+    write_text(root / "letters.txt", "2011-09-26 ab:cd:ef.gh\n");
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadTimeStamp(root / "letters.txt", 0); }));
+    // point clouds: whole points only, a size that is not a multiple of a float is refused, an empty file is an empty cloud
+    KittiPclLoader loader;
+    write_bytes(root / "empty.bin", 0);
+    ASSERT_EQ(std::get<0>(loader.LoadPointcloud(root / "empty.bin")).rows(), 0);
+    write_bytes(root / "one_point_and_a_float.bin", 20);
+    ASSERT_EQ(std::get<0>(loader.LoadPointcloud(root / "one_point_and_a_float.bin")).rows(), 1);
+    write_bytes(root / "odd.bin", 18);
+    ASSERT_TRUE(throws_runtime_error([&] { (void)loader.LoadPointcloud(root / "odd.bin"); }));
+    ASSERT_TRUE(throws_runtime_error([&] { (void)loader.LoadPointcloud(root / "missing.bin"); }));
+    write_bytes(root / "big.bin", 16 * 300000);  // more points than the reference's fixed 250 000-point buffer holds (data_io.hpp:17)
+    ASSERT_EQ(std::get<0>(loader.LoadPointcloud(root / "big.bin")).rows(), 300000);
+    // OXTS packets
+    write_text(root / "oxts" / "timestamps.txt", "2011-09-26 13:02:25.964389445\n2011-09-26 13:02:26.064389445\n2011-09-26 13:02:26.164389445\n");
+    write_text(root / "oxts" / "data" / "0000000000.txt", "49.0 8.4 112.8 0.02 0.0 -1.2\n");  // too few fields
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadOxts(root, 0); }));
+    write_text(root / "oxts" / "data" / "0000000001.txt", "49.0 8.4 112.8 0.02 x.y -1.2 0 0 1 2 3\n");  // a field that is not a number
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadOxts(root, 1); }));
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadOxts(root, 2); }));  // no such packet
+    // a run whose timestamp files are shorter than its frame list is refused before any frame is touched
+    for (int i = 0; i < 4; ++i) write_bytes(root / "velodyne_points" / "data" / (IdToZeroPaddedString(static_cast<std::size_t>(i)) + ".bin"), 16 * 10);
+    for (char const* name : {"timestamps_start.txt", "timestamps.txt", "timestamps_end.txt"})
+      write_text(root / "velodyne_points" / name, "2011-09-26 13:02:25.964389445\n2011-09-26 13:02:26.064389445\n");
+    ASSERT_TRUE(throws_runtime_error([&] { MotionCompensateRun(root); }));
+    fs::remove_all(root);
   }
 }
 
