@@ -18,7 +18,11 @@ std::vector<double> CalibrationValues(std::string const& line, std::size_t expec
   std::vector<std::string> const tokens{TokenizeString(line)};
   if (tokens.size() < expected + 1) throw std::runtime_error(std::string("Malformed calibration line (") + what + "): " + line);
   std::vector<double> values(expected);
-  for (std::size_t i = 0; i < expected; ++i) values[i] = std::stod(tokens[i + 1]);
+  try {
+    for (std::size_t i = 0; i < expected; ++i) values[i] = std::stod(tokens[i + 1]);
+  } catch (std::logic_error const&) {  // a field that is not a number
+    throw std::runtime_error(std::string("Malformed calibration line (") + what + "): " + line);
+  }
   return values;
 }
 Matrix3d Matrix3FromRowMajor(std::vector<double> const& v) {

@@ -316,6 +316,11 @@ static void host_cases(std::string const& golden) {
     write_text(root / "oxts" / "data" / "0000000001.txt", "49.0 8.4 112.8 0.02 x.y -1.2 0 0 1 2 3\n");  // a field that is not a number
     ASSERT_TRUE(throws_runtime_error([&] { (void)LoadOxts(root, 1); }));
     ASSERT_TRUE(throws_runtime_error([&] { (void)LoadOxts(root, 2); }));  // no such packet
+    // calibration files: a field that is not a number, a file that ends early
+    write_text(root / "calib_velo_to_cam.txt", "calib_time: 15-Mar-2012 11:37:16\nR: 1 0 0 0 one 0 0 0 1\nT: 0 0 0\n");
+    ASSERT_TRUE(throws_runtime_error([&] { (void)LoadLidarExtrinsics(root, true); }));
+    write_text(root / "calib_cam_to_cam.txt", "calib_time: 09-Jan-2012 13:57:47\ncorner_dist: 9.95e-02\nS_00: 1392 512\n");
+    ASSERT_TRUE(throws_runtime_error([&] { (void)viz::LoadCameraCalibrations(root); }));
     // a run whose timestamp files are shorter than its frame list is refused before any frame is touched
     for (int i = 0; i < 4; ++i) write_bytes(root / "velodyne_points" / "data" / (IdToZeroPaddedString(static_cast<std::size_t>(i)) + ".bin"), 16 * 10);
     for (char const* name : {"timestamps_start.txt", "timestamps.txt", "timestamps_end.txt"})
