@@ -180,7 +180,8 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * device-resident kmc_hip_deskew_f32 calls are issued round-robin over `queues` HIP streams (hardware queues) of the context --
  * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip, tools/fq_probe.hip).
  *   - queues = 1 (default): every call on the context's stream, strictly in order (the behaviour of ABI version 1).
- *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls are NOT ordered with each other.  The first frame
+ *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls -- and kmc_hip_deskew_traj_f32(KMC_MEM_DEVICE) calls with
+ *     at most four knots -- are NOT ordered with each other.  The first frame
  *     after a join waits for everything issued on the context's stream before it (its producers); kmc_hip_frame_queue_join()
  *     makes the context's stream wait for every frame issued so far (device-side, the host does not block).  Every other entry
  *     point, kmc_hip_synchronize(), kmc_hip_timer_end() and kmc_hip_set_stream() join first, so anything issued after the frames
@@ -223,7 +224,11 @@ int kmc_hip_deskew_f64cols(kmc_ctx* ctx, const double* x, const double* y, const
  * kmc_hip_deskew_f32 / kmc_hip_deskew_f64cols.
  * bracket_idx_out (optional, NULL to skip; same mem_kind as the points): per-point segment index k -- the integer
  * "timestamp index".  In the f32 entry point it is decided by trig-free half-plane tests on (x, y) so that it is bit-exact
- * against the CPU oracle; in the f64 entry point by f64 compares of the caller's stamps against the knot times. */
+ * against the CPU oracle; in the f64 entry point by f64 compares of the caller's stamps against the knot times.
+ * kmc_hip_deskew_traj_f32 on KMC_MEM_DEVICE points with n_knots <= 4 (north_star's three bracketing poses included) passes its
+ * segment records in the kernel arguments: no table upload, the host never waits, and with frame queues on
+ * (kmc_hip_set_frame_queues) consecutive calls overlap like kmc_hip_deskew_f32 calls do -- 12 us per call instead of 29.  Longer
+ * trajectories and host buffers go through a device table (same kernel body, same bits) on the context's stream. */
 int kmc_hip_deskew_traj_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint64_t n, const double* knot_times,
                             const double* knot_poses, uint32_t n_knots, double stamp_start, double stamp_end,
                             double requested_time, uint32_t* bracket_idx_out, int mem_kind, kmc_stats* out_stats);

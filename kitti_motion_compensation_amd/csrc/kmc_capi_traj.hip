@@ -164,10 +164,58 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   // every point stamp lies in [stamp_start, stamp_end]: the trajectory has to cover the scan
   if (!(knot_times[0] <= stamp_start && stamp_end <= knot_times[n_knots - 1])) return KMC_ERR_TIME_OUT_OF_RANGE;
   if (!(requested_time >= stamp_start && requested_time <= stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
-  KMC_ENTER(c);
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const bool inline_records = mem_kind == KMC_MEM_DEVICE && th.n_seg <= (uint32_t)kInlineSegments;
+  const bool queued = inline_records && c->fq_count > 1 && !c->timing;  // goes to a frame queue: not ordered with the frames before it
+  if (!queued) {
+    rc = fq_join(c);
+    if (rc != KMC_OK) return rc;
+  }
   const int tier = traj_tier(c, th, stamp_start, stamp_end);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
+
+  static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
+#define KMC_LAUNCH_TRAJ(T, INL, STREAM, SEGS, SEGS64, ...)                                                                          \
+  do {                                                                                                                              \
+    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
+    else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__);      \
+  } while (0)
+#define KMC_LAUNCH_TRAJ_TIER(INL, STREAM, SEGS, SEGS64, ...)                                        \
+  switch (tier) {                                                                                   \
+    case kSeries3: KMC_LAUNCH_TRAJ(kSeries3, INL, STREAM, SEGS, SEGS64, __VA_ARGS__); break;        \
+    case kSeries5: KMC_LAUNCH_TRAJ(kSeries5, INL, STREAM, SEGS, SEGS64, __VA_ARGS__); break;        \
+    case kWide: KMC_LAUNCH_TRAJ(kWide, INL, STREAM, SEGS, SEGS64, __VA_ARGS__); break;              \
+    default: KMC_LAUNCH_TRAJ(kTrig, INL, STREAM, SEGS, SEGS64, __VA_ARGS__); break;                 \
+  }
+
+  if (inline_records) {
+    // A short trajectory on device-resident points -- north_star's "three bracketing poses" -- carries its segment records in the
+    // kernel arguments: no table slot, no upload, nothing for the host to wait for.  Like kmc_hip_deskew_f32 the call may then go
+    // to a frame queue (kmc_hip_set_frame_queues).  Same records, same kernel body: same bits as the table path below.
+    TrajInline inl;
+    std::memset(&inl, 0, sizeof(inl));
+    fill_traj_segs(th, stamp_start, stamp_end, inl.s, inl.d);
+    hipStream_t s = c->stream;
+    if (queued) {
+      rc = fq_stream(c, &s);
+      if (rc != KMC_OK) return rc;
+    }
+    const v4f* d_in = (const v4f*)xyzi_in;
+    v4f* d_out = (v4f*)xyzi_out;
+    uint32_t* d_idx = bracket_idx_out;
+    CallTimer tm(c);
+    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    const uint32_t head = head_of(xyzi_out, mem_kind);
+    const uint64_t nv = n + head;
+    const int grid = grid_for(c, (nv + 63) / 64);
+    uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
+    KMC_LAUNCH_TRAJ_TIER(true, s, (const TrajSeg32*)nullptr, (const TrajSegD*)nullptr, inl)
+    KMC_HIP_TRY(c, hipGetLastError());
+    if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    if (st) st->n_launches = 1;
+    return tm.end_call(st);
+  }
 
   // slot layout: [TrajSeg32 x kMaxSegments | TrajSegD x kMaxSegments]
   int slot_id = 0;
@@ -195,24 +243,14 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   CallTimer tm(c);
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
   const uint32_t head = head_of(xyzi_out, mem_kind);
   const uint64_t nv = n + head;
   const int grid = grid_for(c, (nv + 63) / 64);
   const TrajSeg32* d_segs = (const TrajSeg32*)c->slots[slot_id].d_buf;
   const TrajSegD* d_segs64 = (const TrajSegD*)(c->slots[slot_id].d_buf + kMaxSegments * sizeof(TrajSeg32));
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
-#define KMC_LAUNCH_TRAJ(T)                                                                                                          \
-  do {                                                                                                                              \
-    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_segs, th.n_seg, v_idx, head, d_segs64); \
-    else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_segs, th.n_seg, v_idx, head, d_segs64);      \
-  } while (0)
-  switch (tier) {
-    case kSeries3: KMC_LAUNCH_TRAJ(kSeries3); break;
-    case kSeries5: KMC_LAUNCH_TRAJ(kSeries5); break;
-    case kWide: KMC_LAUNCH_TRAJ(kWide); break;
-    default: KMC_LAUNCH_TRAJ(kTrig); break;
-  }
+  KMC_LAUNCH_TRAJ_TIER(false, c->stream, d_segs, d_segs64, TrajInline{})
+#undef KMC_LAUNCH_TRAJ_TIER
 #undef KMC_LAUNCH_TRAJ
   KMC_HIP_TRY(c, hipGetLastError());
   rc = slot_end(c, slot_id);

@@ -490,13 +490,28 @@ __device__ __forceinline__ void traj_redo_lanes(bool redo, const v4f p, const Tr
   }
 }
 
-template <int TIER, int NT, bool WRITE_IDX>
+// INLINE: the segment records of a short trajectory (<= kInlineSegments, i.e. up to four knots -- the three bracketing poses
+// north_star names fit) travel IN THE KERNEL ARGUMENTS: no table slot, no upload, no host wait -- the call is as asynchronous as
+// the two-pose kmc_hip_deskew_f32 and may go over the frame queues.  `inl` is never named in the body (the compiler would
+// preload 1.1 KB of it into SGPRs and spill): the staging loop and the cold redo read it through the kernel-argument segment.
+constexpr int kInlineSegments = 3;
+struct TrajInline {
+  TrajSeg32 s[kInlineSegments];
+  TrajSegD d[kInlineSegments];
+};
+template <int TIER, int NT, bool WRITE_IDX, bool INLINE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                      const TrajSeg32* __restrict__ segs, uint32_t n_seg,
                                                      uint32_t* __restrict__ bracket_out, uint32_t head,
-                                                     const TrajSegD* __restrict__ segs64) {
+                                                     const TrajSegD* __restrict__ segs64, TrajInline inl) {
   // `head`: dead leading indices, see deskew_frame_f32
   constexpr int BLOCK = 64;
+  if constexpr (INLINE) {
+    struct ArgLayout { const v4f* in; v4f* out; uint64_t n; const TrajSeg32* segs; uint32_t n_seg; uint32_t* bracket_out; uint32_t head; const TrajSegD* segs64; TrajInline inl; };
+    const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    segs = (const TrajSeg32*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, s));
+    segs64 = (const TrajSegD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, d));
+  }
   __shared__ TrajSeg32 lds[kMaxSegments];
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;

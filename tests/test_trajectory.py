@@ -150,6 +150,49 @@ def test_three_bracketing_poses_vs_oracle_and_bit_exact_indices(ctx, kitti):
 
 
 @pytest.mark.gpu
+def test_short_trajectories_ride_in_the_kernel_arguments(kitti):
+    """Up to four knots (three segments) on device-resident points: the segment records are kernel arguments -- no table slot, no
+    upload, no host wait -- and the call may go over the frame queues like kmc_hip_deskew_f32.  Longer trajectories, and host
+    buffers, take the table path.  Same records, same kernel body: the two paths give the same bits (points and bracket
+    indices), in order and over four queues, at 16-byte-aligned sub-range offsets too."""
+    import torch
+
+    xyzi, P1 = kitti
+    n = xyzi.shape[0]
+    steps = [[0.7, 0.02, -0.01, 0.001, -0.002, 0.018], [0.66, 0.02, 0.0, -0.001, 0.001, 0.02], [0.71, -0.01, 0.01, 0.0, 0.002, 0.022],
+             [0.69, 0.0, 0.0, 0.001, 0.0, 0.019]]
+    c = capi.Context(0)
+    try:
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_in = torch.from_numpy(xyzi).cuda()
+        for n_knots in (2, 3, 4, 5):  # 5 knots = 4 segments: beyond the inline limit, table path on the device as well
+            lo, hi = T0 - 0.004, T1 + 0.004
+            times = list(np.linspace(lo, hi, n_knots))
+            poses = _chain(P1, steps[:n_knots - 1])
+            want = np.empty_like(xyzi)
+            want_k = np.empty(n, dtype=np.uint32)
+            c.deskew_traj_f32(xyzi, want, times, _rt(poses), T0, T1, TREQ, want_k)  # host buffers: table path
+            assert np.array_equal(want_k, orc.bracket_indices_f32(xyzi, times, T0, T1))
+            assert len(np.unique(want_k)) == n_knots - 1
+            for queues in (1, 4):
+                c.set_frame_queues(queues)
+                outs = [torch.zeros((n + 8, 4), dtype=torch.float32, device="cuda") for _ in range(6)]
+                idx = [torch.full((n,), 99, dtype=torch.int32, device="cuda") for _ in range(6)]
+                for k, (o, ix) in enumerate(zip(outs, idx)):
+                    c.deskew_traj_f32(d_in, o[k:k + n], times, _rt(poses), T0, T1, TREQ, ix if k % 2 == 0 else None, n=n)
+                c.frame_queue_join()
+                torch.cuda.synchronize()
+                for k, (o, ix) in enumerate(zip(outs, idx)):
+                    assert np.array_equal(o[k:k + n].cpu().numpy().view(np.uint32), want.view(np.uint32)), (n_knots, queues, k)
+                    assert bool((o[:k] == 0).all()) and bool((o[k + n:] == 0).all()), "wrote outside the frame"
+                    if k % 2 == 0:
+                        assert np.array_equal(ix.cpu().numpy().view(np.uint32), want_k), (n_knots, queues, k)
+            c.set_frame_queues(1)
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_many_knots_quarter_turn_boundaries_and_edge_points(ctx, kitti):
     """Knots exactly on the quarter turns (exact directions), knots outside the scan, and points on the axes / signed zeros."""
     xyzi, P1 = kitti

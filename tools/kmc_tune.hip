@@ -299,7 +299,7 @@ static Variant traj_lib_variant(const char* label) {
   v.ppt = 1;
   v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
     hipLaunchKernelGGL((deskew_traj_f32<kSeries3, kPolicyDefault, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in, out, n,
-                       g_traj_segs, 2u, (uint32_t*)nullptr, 0u, (const TrajSegD*)g_traj_segs64);
+                       g_traj_segs, 2u, (uint32_t*)nullptr, 0u, (const TrajSegD*)g_traj_segs64, TrajInline{});
   };
   return v;
 }
