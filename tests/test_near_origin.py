@@ -251,6 +251,21 @@ def test_trajectory_kernels_near_origin(ctx, tier):
         assert np.array_equal(br, orc.bracket_indices_f32(pts, times, T0, T1)), "bracket indices must stay bit-exact"
         hard += int(_is_hard(pts, ref["xyz_f64"]).sum())
         total += pts.shape[0]
+        # device-resident points: a trajectory this short rides in the kernel arguments, and the redo reads its f64 records from
+        # there (the host-buffer call above went through the device table) -- same bits, in place as well
+        import torch
+
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_in = torch.from_numpy(pts).cuda()
+        d_out = torch.empty_like(d_in)
+        d_br = torch.empty(pts.shape[0], dtype=torch.int32, device="cuda")
+        ctx.deskew_traj_f32(d_in, d_out, times, _rt(poses), T0, T1, t_req, d_br)
+        ctx.deskew_traj_f32(d_in, d_in, times, _rt(poses), T0, T1, t_req)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), out.view(np.uint32)), "kernel-argument records: different bits"
+        assert np.array_equal(d_in.cpu().numpy().view(np.uint32), out.view(np.uint32)), "in place: different bits"
+        assert np.array_equal(d_br.cpu().numpy().view(np.uint32), br)
+        ctx.set_stream(None)
     # batched N-knot kernel: every frame its own trajectory and its own cancellation point
     nf = 40
     sizes = rng.choice([1, 63, 64, 65, 300, 1000], nf)
