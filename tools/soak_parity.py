@@ -154,6 +154,78 @@ def near_origin_round(ctx, rng, acc):
     acc["near_origin_rounds"] += 1
 
 
+def _rt(T):
+    return np.hstack([np.array(list(T.R)).reshape(3, 3), np.array(list(T.t)).reshape(3, 1)])
+
+
+def random_trajectory(rng):
+    """2..6 knots covering the scan (uneven spacing, an interior knot may sit anywhere inside it), poses chained from random twists"""
+    n_knots = int(rng.integers(2, 7))
+    lo = T0 - float(rng.choice([0.0, 1e-4, 0.03, 0.08]))
+    hi = T1 + float(rng.choice([0.0, 1e-4, 0.03, 0.08]))
+    inner = np.sort(lo + (hi - lo) * rng.random(n_knots - 2)) if n_knots > 2 else np.array([])
+    times = np.concatenate([[lo], inner, [hi]])
+    if np.any(np.diff(times) < 1e-4):
+        times = np.linspace(lo, hi, n_knots)
+    start = orc.se3_exp(list(rng.normal(0, [3.0, 3.0, 0.5, 0.05, 0.05, 1.0])))
+    poses = [start]
+    for k in range(n_knots - 1):
+        dt = (times[k + 1] - times[k]) / (T1 - T0)
+        poses.append(orc.affine_mul(poses[-1], orc.se3_exp(list(random_twist(rng) * 0.3 * dt))))
+    t_req = float(rng.choice([T0, T1, 0.5 * (T0 + T1), T0 + rng.random() * (T1 - T0)]))
+    return [float(t) for t in times], poses, t_req
+
+
+def traj_round(ctx, rng, acc, torch):
+    """The N-knot kernels against the oracle's chain: single-frame through host buffers (device table) and device-resident
+    (records in the kernel arguments up to four knots), batched with one trajectory per frame; bracket indices bit-exact."""
+    times, poses, t_req = random_trajectory(rng)
+    n = int(rng.choice([1, 63, 64, 65, 1000, 123397, 600_011]))
+    pts = random_points(rng, n)
+    P = np.stack([_rt(T) for T in poses])
+    out = np.empty_like(pts)
+    br = np.empty(n, dtype=np.uint32)
+    ctx.deskew_traj_f32(pts, out, times, P, T0, T1, t_req, br)
+    ref = orc.deskew_xyzi_f32_traj(pts, T0, T1, times, poses, t_req)
+    check_cloud(acc, "traj", pts, out, ref["xyz_f64"], dict(times=times, t_req=t_req, knots=len(times)))
+    acc["traj_index_mismatch"] += int(np.count_nonzero(br != orc.bracket_indices_f32(pts, times, T0, T1)))
+    acc["traj_intensity_mismatch"] += int(np.count_nonzero(out[:, 3].view(np.uint32) != pts[:, 3].view(np.uint32)))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_in = torch.from_numpy(pts).cuda()
+    d_out = torch.empty_like(d_in)
+    d_br = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.deskew_traj_f32(d_in, d_out, times, P, T0, T1, t_req, d_br)
+    torch.cuda.synchronize()
+    ctx.set_stream(None)
+    acc["traj_device_vs_host_mismatch"] += int(np.count_nonzero(d_out.cpu().numpy().view(np.uint32) != out.view(np.uint32)))
+    acc["traj_device_vs_host_mismatch"] += int(np.count_nonzero(d_br.cpu().numpy().view(np.uint32) != br))
+    acc["traj_points"] += n
+    # batched: every frame its own trajectory
+    nf = int(rng.integers(1, 24))
+    sizes = rng.choice([0, 1, 63, 64, 65, 777, 16385, 60000], nf)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    nb = int(offsets[-1])
+    if nb == 0:
+        return
+    bpts = random_points(rng, nb)
+    trajs = [random_trajectory(rng) for _ in range(nf)]
+    frames = [dict(times=t, poses=np.stack([_rt(T) for T in ps]), stamp_start=T0, stamp_end=T1, requested_time=tr) for t, ps, tr in trajs]
+    bout = np.empty_like(bpts)
+    fidx = np.empty(nb, dtype=np.uint32)
+    bidx = np.empty(nb, dtype=np.uint32)
+    ctx.deskew_traj_batch_f32(bpts, bout, offsets, frames, frame_idx_out=fidx, bracket_idx_out=bidx)
+    acc["traj_index_mismatch"] += int(np.count_nonzero(fidx != np.repeat(np.arange(nf, dtype=np.uint32), sizes)))
+    for f in rng.choice(nf, min(nf, 4), replace=False):
+        a, b = int(offsets[f]), int(offsets[f + 1])
+        if a == b:
+            continue
+        t, ps, tr = trajs[f]
+        ref = orc.deskew_xyzi_f32_traj(bpts[a:b], T0, T1, t, ps, tr)
+        check_cloud(acc, "traj", bpts[a:b], bout[a:b], ref["xyz_f64"], dict(times=t, t_req=tr, knots=len(t), batched=True))
+        acc["traj_index_mismatch"] += int(np.count_nonzero(bidx[a:b] != orc.bracket_indices_f32(bpts[a:b], t, T0, T1)))
+    acc["traj_points"] += nb
+
+
 def projection_round(ctx, rng, acc, calib):
     n = int(rng.choice([1000, 123397, 1 << 20, 4_000_003]))
     pts = random_points(rng, n)
@@ -239,16 +311,17 @@ def main():
     calib = util.load_kitti_calibration(os.path.join(ROOT, "tests", "golden"))
     acc = dict(seed=seed, seconds=budget, rounds=0, deskew_points=0, deskew_intensity_mismatch=0, batch_points=0, batch_index_mismatch=0, projection_points=0, projection_drawn=0,
                projection_int_mismatch=0, oracle_threads=orc.num_threads())
-    for key in ("deskew", "batch"):
+    for key in ("deskew", "batch", "traj"):
         acc.update({key + "_max_rel_err": 0.0, key + "_max_rel_err_literal": 0.0, key + "_max_err_over_scale": 0.0,
                     key + "_near_origin_points": 0})
     t_end = time.time() + budget
     import torch
 
     acc.update(subrange_points=0, subrange_failures=0, f64_points=0, f64_max_rel_err=0.0, near_origin_rounds=0,
-               near_origin_single_vs_batch_mismatch=0, near_origin_single_vs_batch_points=0)
+               near_origin_single_vs_batch_mismatch=0, near_origin_single_vs_batch_points=0,
+               traj_points=0, traj_index_mismatch=0, traj_intensity_mismatch=0, traj_device_vs_host_mismatch=0)
     while time.time() < t_end:
-        r = acc["rounds"] % 6
+        r = acc["rounds"] % 7
         if r == 0:
             deskew_round(ctx, rng, acc)
         elif r == 1:
@@ -259,8 +332,10 @@ def main():
             subrange_round(ctx, rng, acc, torch)
         elif r == 4:
             near_origin_round(ctx, rng, acc)
-        else:
+        elif r == 5:
             f64_round(ctx, rng, acc)
+        else:
+            traj_round(ctx, rng, acc, torch)
         acc["rounds"] += 1
         if checkpoint and time.time() - last_checkpoint > 60.0:
             last_checkpoint = time.time()
@@ -271,7 +346,9 @@ def main():
                      and acc["deskew_max_err_over_scale"] <= 2e-6 and acc["batch_max_err_over_scale"] <= 2e-6
                      and acc["subrange_failures"] == 0 and acc["f64_max_rel_err"] <= 1e-9
                      and acc["batch_index_mismatch"] == 0 and acc["projection_int_mismatch"] == 0
-                     and acc["near_origin_single_vs_batch_mismatch"] == 0)
+                     and acc["near_origin_single_vs_batch_mismatch"] == 0
+                     and acc["traj_max_rel_err_literal"] <= 1e-5 and acc["traj_max_err_over_scale"] <= 2e-6 and acc["traj_index_mismatch"] == 0
+                     and acc["traj_intensity_mismatch"] == 0 and acc["traj_device_vs_host_mismatch"] == 0)
     print(json.dumps(acc))
     sys.exit(0 if acc["ok"] else 1)
 
