@@ -133,7 +133,15 @@ def near_origin_round(ctx, rng, acc):
     pts = np.empty((n, 4), dtype=np.float32)
     frames = []
     for f in range(nf):
-        twist, x_req, p_star = tno._frame(rng, tier, jitter=0.3)
+        while True:
+            twist, x_req, p_star = tno._frame(rng, tier, jitter=0.3)
+            # Within ~1e-3 rad of a half turn per scan the reference's Log (acos / sin, lie_algebra.cpp:37-49), which the oracle
+            # restates, loses 1e-16 / (pi - theta)^2 of the twist: it is no reference at the 1e-6 level there (DESIGN.md section 8,
+            # tests/test_host_prestep.py).  Such frames are counted and redrawn here; tests/test_near_origin.py pins one of them
+            # against the exact exponential instead.
+            if abs(np.linalg.norm(twist[3:]) - np.pi) > 2e-3:
+                break
+            acc["half_turn_frames_redrawn"] += 1
         frames.append((twist, x_req))
         pts[int(offsets[f]):int(offsets[f + 1])] = tno._scatter(rng, p_star, int(sizes[f]))
     out = np.empty_like(pts)
@@ -319,7 +327,7 @@ def main():
 
     acc.update(subrange_points=0, subrange_failures=0, f64_points=0, f64_max_rel_err=0.0, near_origin_rounds=0,
                near_origin_single_vs_batch_mismatch=0, near_origin_single_vs_batch_points=0,
-               traj_points=0, traj_index_mismatch=0, traj_intensity_mismatch=0, traj_device_vs_host_mismatch=0)
+               traj_points=0, traj_index_mismatch=0, traj_intensity_mismatch=0, traj_device_vs_host_mismatch=0, half_turn_frames_redrawn=0)
     while time.time() < t_end:
         r = acc["rounds"] % 7
         if r == 0:
