@@ -182,14 +182,17 @@ static Variant seq_variant(const char* label) {
 }
 
 // occupancy sensitivity: the same one-wave kernel with a dynamic-LDS reservation that caps the workgroups per CU
-template <int LDS_BYTES>
+// PPT > 1: the same sweep with two / four tiles per wave, i.e. the bytes in flight per CU = workgroups per CU x PPT KiB -- is the
+// optimum between "32 one-tile waves" (32 KiB) and "32 two-tile waves" (64 KiB)?
+template <int LDS_BYTES, int PPT = 1>
 static Variant occ_variant(const char* label) {
   Variant v;
   v.name = label;
-  v.ppt = 1;
+  v.ppt = PPT;
   v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
     static const FrameRec f = make_rec();
-    hipLaunchKernelGGL((deskew_frame_f32<kSeries3, 1, kPolicyDefault, false, 64>), dim3((unsigned)((n + 63) / 64)), dim3(64), LDS_BYTES, s, in, out, n, f, 0u, make_recd());
+    constexpr uint64_t kTile = 64 * PPT;
+    hipLaunchKernelGGL((deskew_frame_f32<kSeries3, PPT, kPolicyDefault, false, 64>), dim3((unsigned)((n + kTile - 1) / kTile)), dim3(64), LDS_BYTES, s, in, out, n, f, 0u, make_recd());
   };
   return v;
 }
@@ -527,6 +530,15 @@ int main(int argc, char** argv) {
   es.push_back({occ_variant<10200>("occ_16_per_cu"), kZero});
   es.push_back({occ_variant<13600>("occ_12_per_cu"), kZero});
   es.push_back({occ_variant<20400>("occ_8_per_cu"), kZero});
+  es.push_back({occ_variant<0, 2>("occ_32_per_cu_ppt2"), kZero});      // 64 KiB of loads in flight per CU
+  es.push_back({occ_variant<5800, 2>("occ_28_per_cu_ppt2"), kZero});   // 56
+  es.push_back({occ_variant<6800, 2>("occ_24_per_cu_ppt2"), kZero});   // 48
+  es.push_back({occ_variant<8100, 2>("occ_20_per_cu_ppt2"), kZero});   // 40
+  es.push_back({occ_variant<10200, 2>("occ_16_per_cu_ppt2"), kZero});  // 32
+  es.push_back({occ_variant<13600, 2>("occ_12_per_cu_ppt2"), kZero});  // 24
+  es.push_back({occ_variant<10200, 4>("occ_16_per_cu_ppt4"), kZero});  // 64
+  es.push_back({occ_variant<13600, 4>("occ_12_per_cu_ppt4"), kZero});  // 48
+  es.push_back({occ_variant<20400, 4>("occ_8_per_cu_ppt4"), kZero});   // 32
   es.push_back({xcd_variant<64>("x_xcdcontig_b64"), kZero});
   es.push_back({xcd_variant<256>("x_xcdcontig_b256"), kZero});
   es.push_back({policy_variant<1, 1>("x_pol_nt_nt"), kZero});
