@@ -303,7 +303,8 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   const uint64_t chunk = 1ull << kChunkShift;
   const uint64_t n_coarse = (nv + chunk - 1) / chunk + 1;
   const size_t frecs_bytes = ((size_t)n_frames * sizeof(TrajFrameRec) + 255) & ~(size_t)255;
-  const size_t segs_bytes = ((size_t)n_frames * seg_stride * sizeof(TrajSeg32) + 255) & ~(size_t)255;
+  // + kInlineSegments spare records: the kernel loads the first two interior knot slots of a frame unconditionally
+  const size_t segs_bytes = (((size_t)n_frames * seg_stride + kInlineSegments) * sizeof(TrajSeg32) + 255) & ~(size_t)255;
   const size_t segd_bytes = ((size_t)n_frames * seg_stride * sizeof(TrajSegD) + 255) & ~(size_t)255;  // f64 twins (guard redo)
   const size_t need = frecs_bytes + segs_bytes + segd_bytes + (size_t)n_coarse * sizeof(uint2);
   int slot_id = 0;
@@ -320,7 +321,11 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
     h_frecs[f].end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
     h_frecs[f].n_seg = th[f].n_seg;
     h_frecs[f].pad = 0;
-    fill_traj_segs(th[f], frames[f].stamp_start, frames[f].stamp_end, h_segs + (size_t)f * seg_stride, h_segd + (size_t)f * seg_stride);
+    TrajSeg32* fs = h_segs + (size_t)f * seg_stride;
+    fill_traj_segs(th[f], frames[f].stamp_start, frames[f].stamp_end, fs, h_segd + (size_t)f * seg_stride);
+    h_frecs[f].c1 = th[f].n_seg > 1 ? fs[1].knot_c : 0.f;  // the SAME f32 values the records hold
+    h_frecs[f].c2 = th[f].n_seg > 2 ? fs[2].knot_c : 0.f;
+    h_frecs[f].pad2[0] = h_frecs[f].pad2[1] = 0;
   }
   build_coarse(offsets, n_frames, nv, head, h_coarse);
   rc = slot_upload(c, slot_id, need);

@@ -48,20 +48,31 @@ static_assert(sizeof(FrameRec) == 64, "FrameRec must stay one 64-byte record");
 
 // Coefficient tiers of the f32 kernels, each valid on the domain of the ones before it (a batch runs the tier of its widest
 // frame).  theta = |phi| * max|s| is known on the host: 0.25 / 1 / 3.25 rad are the upper ends of the first three.
-enum Tier : int { kSeries3 = 0, kSeries5 = 1, kWide = 2, kTrig = 3 };
+enum Tier : int { kSeries3 = 0, kSeries5 = 1, kWide = 2, kTrig = 3, kTrigOcml = 4 /* tuner only */ };
 constexpr double kThetaSeries3 = 0.25, kThetaSeries5 = 1.0, kThetaWide = 3.25;
 
 // atan2(y, x) / (2 pi) in [-0.5, 0.5], i.e. the azimuth in turns.  timestamp_mocking.cpp:46 needs
 // frac = (pi - atan2(y,x)) / 2pi = 0.5 - azimuth_turns.  Octant reduction + degree-7 polynomial in q^2
-// (tools/gen_atan_coeffs.py; 1.0e-8 turns max error) -- ~30 VALU ops instead of ocml atan2f's ~55 plus a multiply.
+// (tools/gen_atan_coeffs.py; 1.0e-8 turns max error) -- ~22 VALU ops instead of ocml atan2f's ~55 plus a multiply.
 // Signed zeros follow IEEE atan2: (+0,+0) -> 0, (-0, x<0 or x=-0) -> -0.5, (+0, x=-0) -> +0.5.
+// The quotient q = min / max: round 3 takes it as min * v_rcp_f32(max) (1 ulp, 2 instructions) instead of the IEEE division
+// (10): these kernels keep their SIMDs ~60 % busy, so VALU instructions are not free (kmc_kernels.hip.h, N-knot section).  The
+// reciprocal neither accepts nor returns denormals, so a wave that holds a lane whose larger coordinate is outside
+// [2^-126, 2^126] (zero, denormal, > 8.5e37, infinite, NaN -- nothing a LiDAR returns) redoes THAT lane's division the IEEE
+// way: a wave-uniform, cold branch.  Error of the fast quotient: 1.5 ulp of q <= 1, i.e. < 3e-8 turns after the polynomial.
 __device__ __forceinline__ float azimuth_turns(float x, float y) {
   const float ax = __builtin_fabsf(x);
   const float ay = __builtin_fabsf(y);
   const float mx = __builtin_fmaxf(ax, ay);
   const float mn = __builtin_fminf(ax, ay);
-  float q = mn / mx;             // IEEE divide (handles denormals); 0/0 -> NaN fixed below
-  q = (mx == 0.0f) ? 0.0f : q;   // atan2(0, 0) = 0 like libm
+  float q = mn * __builtin_amdgcn_rcpf(mx);
+  const bool tame = (mx >= 1.17549435e-38f) & (mx <= 8.5e37f);  // false for NaN
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!tame) != 0, 0)) {  // cold; only the odd lanes take the other quotient, so a
+                                                                        // point's result never depends on its neighbours
+    float qi = mn / mx;              // IEEE divide (handles denormals); 0/0 -> NaN fixed below
+    qi = (mx == 0.0f) ? 0.0f : qi;   // atan2(0, 0) = 0 like libm
+    q = tame ? q : qi;
+  }
   const float t = q * q;
   float p = -0.0007257134420797229f;
   p = __builtin_fmaf(p, t, 0.003784787142649293f);
@@ -137,7 +148,45 @@ __device__ __forceinline__ Coef se3_coefficients(float s, float phi2) {
     C = __builtin_fmaf(C, u, 0.00019840920867864043f);
     C = __builtin_fmaf(C, u, -0.008333330042660236f);
     C = __builtin_fmaf(C, u, 0.1666666716337204f);
-  } else {  // any angle (a caller-supplied twist beyond pi): half-angle forms (no 1 - cos cancellation); series below theta^2 = 1/16
+  } else if constexpr (TIER == kTrig) {
+    // any angle (a caller-supplied raw twist beyond 3.25 rad; two poses are never more than pi apart).  Half-angle forms (no
+    // 1 - cos cancellation), series below theta^2 = 1/16.  Round 3: no ocml sincosf (its Payne-Hanek slow path rides along), no
+    // IEEE divide or sqrt -- 1/theta is v_rsq_f32 + one Newton step, theta/2 is reduced to [-pi/4, pi/4] with a two-constant
+    // Cody-Waite step (the fma keeps n * pio2_hi exact) and sin / cos come from the classic degree-7 / degree-8 kernels
+    // (|error| < 7e-8 on the reduced range).  ~40 VALU instead of ~150: the tier is HBM-bound like the polynomial ones.  The
+    // angle itself carries the f32 rounding of theta (6e-8 * theta rad) whatever the method, so the 1e-5 bar holds up to
+    // theta ~ 50 rad and degrades linearly beyond.
+    const float As = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 120.0f, -1.0f / 6.0f), u, 1.0f);
+    const float Bs = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 720.0f, -1.0f / 24.0f), u, 0.5f);
+    const float Cs = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 5040.0f, -1.0f / 120.0f), u, 1.0f / 6.0f);
+    const float uu = __builtin_fmaxf(u, 1e-12f);
+    float inv_th = __builtin_amdgcn_rsqf(uu);                                   // 1 ulp
+    inv_th = __builtin_fmaf(0.5f * inv_th, __builtin_fmaf(-uu * inv_th, inv_th, 1.0f), inv_th);  // Newton: ~0.6 ulp
+    const float th = uu * inv_th;
+    const float h = 0.5f * th;
+    const float nq = __builtin_rintf(h * 0.63661977236758134f);                 // quadrant count of theta / 2
+    float r = __builtin_fmaf(-nq, 1.57079637050628662109375f, h);               // pio2_hi (exact product inside the fma)
+    r = __builtin_fmaf(-nq, -4.37113900018624283e-8f, r);                       // pio2_lo
+    const float r2 = r * r;
+    float sr = __builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f);
+    sr = __builtin_fmaf(sr, r2, -1.6666654611e-1f);
+    sr = __builtin_fmaf(sr * r2, r, r);                                         // sin r
+    float cr = __builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f);
+    cr = __builtin_fmaf(cr, r2, 4.166664568298827e-2f);
+    cr = __builtin_fmaf(cr * r2, r2, __builtin_fmaf(-0.5f, r2, 1.0f));          // cos r
+    // theta / 2 = r + nq pi/2:  sin^2(theta / 2) = sin^2 r (nq even) | cos^2 r (nq odd);  sin theta = +-2 sin r cos r
+    const bool odd = (((int)nq) & 1) != 0;
+    const float sh2 = odd ? cr * cr : sr * sr;
+    const float sn = (odd ? -2.0f : 2.0f) * (sr * cr);
+    const float inv_u = inv_th * inv_th;
+    const float At = sn * inv_th;
+    const float Bt = 2.0f * sh2 * inv_u;
+    const float Ct = (th - sn) * inv_u * inv_th;
+    const bool small = u < 0.0625f;
+    A = small ? As : At;
+    B = small ? Bs : Bt;
+    C = small ? Cs : Ct;
+  } else {  // kTrigOcml: round 2's any-angle tier through ocml sincosf and IEEE divides; kept for the tuner's A/B only
     const float As = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 120.0f, -1.0f / 6.0f), u, 1.0f);
     const float Bs = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 720.0f, -1.0f / 24.0f), u, 0.5f);
     const float Cs = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 5040.0f, -1.0f / 120.0f), u, 1.0f / 6.0f);
@@ -258,6 +307,24 @@ __device__ __forceinline__ bool knot_ge(float x, float y, float knot_c, float ck
     else lt = !yneg || cross > 0.0f || (cross == 0.0f && dot < 0.0f);
   }
   return !lt;
+}
+
+// The same predicate without control flow: every comparison is evaluated (they are cheap and have no side effects) and combined
+// with bitwise logic, so the compiler emits ~12 VALU / SALU instructions instead of a dozen scalar branches.  Identical IEEE
+// operations on identical operands in the same order -> the identical boolean.
+__device__ __forceinline__ bool knot_ge_flat(float x, float y, float knot_c, float ck, float sk, uint32_t flags) {
+#pragma clang fp contract(off)
+  const bool xneg = (__float_as_uint(x) >> 31) != 0;
+  const bool yneg = (__float_as_uint(y) >> 31) != 0;
+  const bool origin = (x == 0.0f) & (y == 0.0f);
+  const float fs = xneg ? (yneg ? 1.0f : 0.0f) : 0.5f;
+  const float cross = ck * y - sk * x;
+  const float dot = ck * x + sk * y;
+  const bool before = (cross > 0.0f) | ((cross == 0.0f) & (dot < 0.0f));
+  const bool lt_ring = (knot_c <= 0.5f) ? (!yneg & before) : (!yneg | before);
+  const bool lt = origin ? (fs < knot_c) : lt_ring;
+  const bool ge = !lt;
+  return (flags & kKnotAlwaysGe) ? true : ((flags & kKnotNeverGe) ? false : ge);
 }
 
 // Coefficient tables of the f64 routines, in constant memory: read at wave-uniform addresses they arrive through scalar loads

@@ -438,26 +438,34 @@ __global__ __launch_bounds__(64) void pseudo_timestamps_f64(const double* __rest
 // ------------------------------------------------------------------------------------------------
 // N-knot trajectory kernels (the 3-argument MotionCompensateFrame(Frame, Trajectory, Time) overload)
 // ------------------------------------------------------------------------------------------------
-// One wave per workgroup (measured best, profiles/r01_tune.csv rows traj_*: 6.68 TB/s against 6.12 for records fetched
-// through scalar loads after the bracket is known, and 5.9-6.2 for 256-thread workgroups):
-//   1. the wave issues its point load first;
-//   2. it stages the segment records -- the twists of the bracketing poses and their anchor transforms, 128 B each --
-//      into LDS (one 16-byte slot per lane; the table round trip hides under the HBM latency of the points);
-//   3. every lane finds its bracket with the trig-free knot tests (an integer, bit-exact against the oracle); each test
-//      reads the knot's 16-byte slot at a uniform LDS address, i.e. one broadcast ds_read_b128;
-//   4. a wave whose lanes share one bracket -- all but the few waves that contain a knot's azimuth -- broadcasts it through
-//      readfirstlane and reads its record at a uniform LDS address; a wave that straddles a knot gathers per lane;
-//   5. fused exp-map + rotate + translate per lane, then the 3x4 anchor transform unless the segment is the anchor's own.
+// Round 3 (profiles/r03_tune_traj.csv): NO LDS.  The measurements that shaped it, 64 Mi points, three knots, one box:
+//     two-pose kernel 313 us | round-2 kernel (records staged in LDS by every wave) 328-334 | this one 318-322
+//   * these kernels are not purely HBM-bound: a wave64 instruction occupies its 16-lane SIMD for four cycles, so the ~110 VALU
+//     instructions of a point keep the SIMD busy ~60 % of the time a wave's 2 KiB take at 6.8 TB/s.  An experiment kernel with
+//     the bracket known in advance ran at the two-pose rate (318 us); the trig-free bracket test alone -- ~14 VALU
+//     instructions and a dozen scalar branches per knot -- cost 13 us, the dependent record fetch 6 us;
+//   * so the bracket is now decided from the azimuth the deskew computes anyway (one subtraction and two compares per knot), and
+//     only a wave with a lane within kKnotMargin of a knot, or with a point that is not a normal number, repeats the decision
+//     with the exact half-plane tests -- which is what makes the index bit-exact against the CPU oracle;
+//   * per-segment records are wave-uniform data: they are fetched through SCALAR loads into SGPRs -- from the kernel-argument
+//     segment for short trajectories (INLINE: no table, no upload, the call stays asynchronous), else from a device table; the
+//     knot slots arrive while the points are still in flight, the record of the wave's bracket right after the points (a
+//     scalar-cache hit).  A wave whose lanes disagree (it contains a knot's azimuth) takes one turn per distinct bracket
+//     (waterfall).  Staging the records in LDS first (round 2) cost an extra vector load, LDS traffic and a longer dependent
+//     chain per wave; moving that staging in front of the point load was slower still (350 us), and keeping both records of a
+//     three-knot trajectory in SGPRs for the whole wave spills (the trap handler leaves 78 SGPRs at 8 waves per SIMD: 410 us).
 // `redo`: the near-origin guard's verdict (kmc_device_math); flagged lanes are not stored by the hot path but recomputed in f64
 // by traj_redo_lanes after it.
+using seg_cp = const TrajSeg32 __attribute__((address_space(4)))*;
+using v4u_cp = const v4u __attribute__((address_space(4)))*;
+
 template <int TIER>
-__device__ __forceinline__ v4f traj_point(const v4f p, const TrajSeg32& r, bool& redo) {
+__device__ __forceinline__ v4f traj_point(const v4f p, const float turns, const TrajSeg32& r, bool& redo) {
   FrameRec f;
   f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
   f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
   f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pre2 = 0.f;
   f.c2_x = r.c2_x; f.c2_y = r.c2_y; f.c2_z = r.c2_z; f.pad1 = 0.f;
-  const float turns = azimuth_turns(p.x, p.y);
   const float s = __builtin_fmaf(-turns, r.g, r.s0);
   v4f q = deskew_point_s<TIER>(p, s, f);
   if (!(r.flags & kSegIdentity)) {
@@ -490,10 +498,88 @@ __device__ __forceinline__ void traj_redo_lanes(bool redo, const v4f p, const Tr
   }
 }
 
+// Bracket of every lane's point among the n_seg segments at `segs` (uniform address; slot 7 of record j is the START knot of
+// segment j).  Fast decision from the scan fraction 0.5 - turns, exact half-plane decision for the whole wave when any lane is
+// within kKnotMargin of a knot or holds a coordinate pair that is not made of normal numbers.  Why the two agree outside the
+// margin: the exact test decides the sign of |p| sin(angle between the point and the knot direction) with a rounding error below
+// 3e-7 |p| for normal numbers, the knot direction and knot_c are f32 roundings of the same f64 fraction (3e-8 turns), and
+// azimuth_turns is within 1e-8 turns (+ 6e-8 for the subtraction): everything is decided identically beyond ~1e-7 turns; the
+// margin is a thousand times that.  Zero, denormal, infinite and NaN coordinates never take the fast decision.
+constexpr float kKnotMargin = 1e-4f;  // turns (0.036 degrees: ~0.4 % of the waves of a ring-ordered scan take the exact path per knot)
+__device__ __forceinline__ uint32_t bracket_exact(const v4f p, seg_cp segs, uint32_t n_seg) {
+  uint32_t k = 0;
+  for (uint32_t j = 1; j < n_seg; ++j) {  // interior knots
+    const v4u kn = ((v4u_cp)(segs + j))[7];  // {knot_cos, knot_sin, flags, knot_c}
+    k += knot_ge_flat(p.x, p.y, __uint_as_float(kn.w), __uint_as_float(kn.x), __uint_as_float(kn.y), kn.z) ? 1u : 0u;
+  }
+  return k;
+}
+// the first two interior knots' scan fractions, scalar-loaded BEFORE the wave touches its points (the loads then overlap the
+// points' flight; issued behind the first use of the points they would each cost a scalar-cache round trip on the critical path)
+struct KnotPre { float c1, c2; };
+__device__ __forceinline__ KnotPre preload_knots(seg_cp segs) {
+  // records beyond n_seg exist in every table / argument block (kInlineSegments spare records); their content is ignored
+  uint32_t c1 = ((v4u_cp)(segs + 1))[7].w, c2 = ((v4u_cp)(segs + 2))[7].w;
+  asm volatile("" : "+s"(c1), "+s"(c2));  // pins the two loads HERE: left alone the optimiser sinks them into the branch that uses them
+  return {__uint_as_float(c1), __uint_as_float(c2)};
+}
+__device__ __forceinline__ uint32_t bracket_of(const v4f p, const float turns, seg_cp segs, uint32_t n_seg, const KnotPre kp) {
+  const float frac = 0.5f - turns;
+  // +normal is class bit 8: false for NaN / infinity (either coordinate), for (0, 0) and for pairs of denormals
+  bool ambiguous = !__builtin_amdgcn_classf(__builtin_fabsf(p.x) + __builtin_fabsf(p.y), 0x100);
+  uint32_t k = 0;
+  if (n_seg <= 3) {  // up to four knots
+    const float d1 = frac - kp.c1, d2 = frac - kp.c2;
+    const bool u1 = n_seg > 1, u2 = n_seg > 2;
+    k = ((u1 & (d1 >= 0.0f)) ? 1u : 0u) + ((u2 & (d2 >= 0.0f)) ? 1u : 0u);
+    ambiguous |= (u1 & !(__builtin_fabsf(d1) >= kKnotMargin)) | (u2 & !(__builtin_fabsf(d2) >= kKnotMargin));
+  } else {
+    for (uint32_t j = 1; j < n_seg; ++j) {
+      const float d = frac - __uint_as_float(((v4u_cp)(segs + j))[7].w);
+      k += (d >= 0.0f) ? 1u : 0u;
+      ambiguous |= !(__builtin_fabsf(d) >= kKnotMargin);
+    }
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(ambiguous) != 0, 0)) k = bracket_exact(p, segs, n_seg);  // wave-uniform
+  return k;
+}
+
+// The lanes in `mine` (all of one trajectory, whose records start at `segs`) compute, store and report: one turn per distinct
+// bracket among them, the record of that bracket through scalar loads.  `seg_base` = index of segs[0] in the f64 twin table.
+// Returns the lanes' brackets; sets redo / redo_seg for the lanes the near-origin guard wants redone.
+template <int TIER, int NT>
+__device__ __forceinline__ uint32_t traj_lanes(const v4f p, const float turns, bool mine, bool storable, seg_cp segs, uint32_t n_seg, const KnotPre kp,
+                                               uint32_t seg_base, __amdgpu_buffer_rsrc_t rout, uint32_t tid, bool& redo_any, uint32_t& redo_seg) {
+  const uint32_t k = bracket_of(p, turns, segs, n_seg, kp);
+  uint64_t todo = __builtin_amdgcn_ballot_w64(mine);
+  while (todo != 0) {  // one turn unless the lanes straddle a knot
+    const uint32_t ku = opaque_uniform((uint32_t)__builtin_amdgcn_readlane((int)k, __builtin_ctzll(todo)));
+    const bool now = mine && k == ku;
+    TrajSeg32 r;
+    {
+      const v4u_cp rc = (v4u_cp)(segs + ku);  // uniform address: scalar loads
+      v4u w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w[q] = rc[q];
+      __builtin_memcpy(&r, w, sizeof(r));
+    }
+    bool redo;
+    const v4f q = traj_point<TIER>(p, turns, r, redo);
+    redo = redo && now && storable;
+    if (redo) {
+      redo_any = true;
+      redo_seg = seg_base + ku;
+    }
+    if (now && storable && !redo) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
+    todo &= ~__builtin_amdgcn_ballot_w64(now);
+  }
+  return k;
+}
+
 // INLINE: the segment records of a short trajectory (<= kInlineSegments, i.e. up to four knots -- the three bracketing poses
 // north_star names fit) travel IN THE KERNEL ARGUMENTS: no table slot, no upload, no host wait -- the call is as asynchronous as
 // the two-pose kmc_hip_deskew_f32 and may go over the frame queues.  `inl` is never named in the body (the compiler would
-// preload 1.1 KB of it into SGPRs and spill): the staging loop and the cold redo read it through the kernel-argument segment.
+// preload 1.1 KB of it into SGPRs and spill): everything reads it through the kernel-argument segment.
 constexpr int kInlineSegments = 3;
 struct TrajInline {
   TrajSeg32 s[kInlineSegments];
@@ -505,78 +591,63 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                      uint32_t* __restrict__ bracket_out, uint32_t head,
                                                      const TrajSegD* __restrict__ segs64, TrajInline inl) {
   // `head`: dead leading indices, see deskew_frame_f32
+  static_assert((NT & kStoreSc1) != 0, "the N-knot kernels store through the tile descriptor");
   constexpr int BLOCK = 64;
+  seg_cp segs_c;
   if constexpr (INLINE) {
     struct ArgLayout { const v4f* in; v4f* out; uint64_t n; const TrajSeg32* segs; uint32_t n_seg; uint32_t* bracket_out; uint32_t head; const TrajSegD* segs64; TrajInline inl; };
     const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    segs = (const TrajSeg32*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, s));
+    segs_c = (seg_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, s));
     segs64 = (const TrajSegD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, d));
+  } else {
+    segs_c = (seg_cp)(uintptr_t)segs;  // written by the host before the launch: constant for the kernel
   }
-  __shared__ TrajSeg32 lds[kMaxSegments];
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;
-  bool staged = false;
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const uint64_t base = t * BLOCK;
     const uint64_t i = base + tid;
     const bool alive = i < n && i >= head;
-    const v4f p = load_point<NT>(in + (i < head ? head : (i < n ? i : n - 1)));  // dead lanes re-read a live point
-    if (!staged) {
-      for (uint32_t w = tid; w < n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs)[w];
-      __syncthreads();  // single-wave workgroup: orders the wave's own LDS writes before its reads
-      staged = true;
-    }
-    uint32_t k = 0;
-    for (uint32_t j = 1; j < n_seg; ++j) {  // interior knots
-      const v4f kn = reinterpret_cast<const v4f*>(&lds[j])[7];  // {knot_cos, knot_sin, flags, knot_c}
-      k += knot_ge(p.x, p.y, kn.w, kn.x, kn.y, __float_as_uint(kn.z)) ? 1u : 0u;
-    }
-    const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
-    const uint32_t ks = __all(k == k0) ? k0 : k;  // uniform bracket -> uniform LDS address (broadcast), else per-lane gather
-    bool redo;
-    const v4f q = traj_point<TIER>(p, lds[ks], redo);
-    redo = redo && alive;
-    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
-    if constexpr (NT & kStoreSc1) {
-      if (i >= head && !redo) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
-    } else {
-      if (alive && !redo) store_point<NT>(out + i, q);
-    }
+    // loads and stores through per-tile descriptors that end with the buffers: no per-lane address arithmetic, the ragged tail is
+    // clipped by the hardware.  The `head` dead lanes of tile 0 must not touch memory in front of the caller's range (it need not
+    // be mapped): the descriptor of tile 0 starts at the first live point and their offsets wrap to 4 GiB, out of its range.
+    // Clipped lanes read zeros and are never stored.
+    const uint32_t h0 = t == 0 ? head : 0u;
+    const __amdgpu_buffer_rsrc_t rin = tile_rsrc(in + base + h0, (n - base - h0) * sizeof(v4f));
+    const v4f p = tile_load<NT>(rin, (tid - h0) * (uint32_t)sizeof(v4f));
+    const KnotPre kp = preload_knots(segs_c);
+    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));
+    __builtin_amdgcn_sched_barrier(0);  // everything above is issued before the wave waits for its points
+    const float turns = azimuth_turns(p.x, p.y);
+    bool redo_any = false;
+    uint32_t redo_seg = 0;
+    const uint32_t k = traj_lanes<TIER, NT>(p, turns, true, i >= head, segs_c, n_seg, kp, 0u, rout, tid, redo_any, redo_seg);
     if constexpr (WRITE_IDX) {
       if (alive) __builtin_nontemporal_store(k, bracket_out + i);
     }
-    traj_redo_lanes(redo, p, segs64, k, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
+    traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
   }
 }
 
 // Batched N-knot kernel: many frames in one launch, every frame with its own trajectory (its own segment records).
 // Per frame a 16-byte header {end offset, segment count} and `seg_stride` slots in the segment table (frame f's records start
-// at f * seg_stride, so their address does not wait for the header load); the frame of a tile is found exactly like in
-// deskew_batch_f32 (coarse table, scalar loads), then the tile's frame stages ITS segments into LDS and runs the body of
-// deskew_traj_f32.  A tile that straddles frame boundaries walks the frames it touches one after the other (wave-uniform
-// loop): stage, let the lanes of that frame compute, next.  Outputs the per-point frame index and bracket index on demand.
-struct alignas(16) TrajFrameRec {
+// at f * seg_stride, so their address does not wait for the header load; the table ends with kInlineSegments spare records so
+// that the unconditional knot loads of bracket_of stay inside it); the frame of a tile is found exactly like in
+// deskew_batch_f32 (coarse table, scalar loads) while the tile's points are in flight.  The tile then walks the frames it
+// touches -- ONE for all but the tiles that straddle a frame boundary -- and the lanes of each frame run the body of
+// deskew_traj_f32 on that frame's records.  Outputs the per-point frame index and bracket index on demand.
+struct alignas(32) TrajFrameRec {
   uint32_t end_lo, end_hi;  // offsets[f+1]
   uint32_t n_seg;
   uint32_t pad;
+  float c1, c2;             // scan fractions of the first two interior knots (what bracket_of needs before the points land): with
+  uint32_t pad2[2];         // them in the header a tile's early look-ups touch ONE line of the frame's tables
 };
+static_assert(sizeof(TrajFrameRec) == 32, "TrajFrameRec must stay one 32-byte record");
 __device__ __forceinline__ uint64_t rec_end(const TrajFrameRec& r) { return ((uint64_t)r.end_hi << 32) | r.end_lo; }
 
-template <int TIER>
-__device__ __forceinline__ v4f traj_lane(const v4f p, const TrajSeg32* lds, uint32_t n_seg, uint32_t& k_out, bool& redo) {
-  uint32_t k = 0;
-  for (uint32_t j = 1; j < n_seg; ++j) {  // interior knots
-    const v4f kn = reinterpret_cast<const v4f*>(&lds[j])[7];  // {knot_cos, knot_sin, flags, knot_c}
-    k += knot_ge(p.x, p.y, kn.w, kn.x, kn.y, __float_as_uint(kn.z)) ? 1u : 0u;
-  }
-  const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
-  const uint32_t ks = __all(k == k0) ? k0 : k;
-  k_out = k;
-  return traj_point<TIER>(p, lds[ks], redo);
-}
-
 template <int TIER, int NT, bool WRITE_IDX>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == kTrig || WRITE_IDX) ? 6 : 8, 8))) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                            const TrajFrameRec* __restrict__ frecs,
                                                            const TrajSeg32* __restrict__ segs,
                                                            uint32_t seg_stride, const uint2* __restrict__ coarse,
@@ -584,8 +655,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == kTr
                                                            uint32_t* __restrict__ bracket_out, uint32_t head,
                                                            const TrajSegD* __restrict__ segs64) {
   // `head`: dead leading indices, see deskew_frame_f32 (the host has shifted the pointers and every offset by it)
+  static_assert((NT & kStoreSc1) != 0, "the N-knot kernels store through the tile descriptor");
   constexpr int BLOCK = 64;
-  __shared__ TrajSeg32 lds[kMaxSegments];
+  const seg_cp segs_c = (seg_cp)(uintptr_t)segs;  // written by the host before the launch: constant for the kernel
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -593,7 +665,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == kTr
     const uint64_t i = base + tid;
     const uint64_t tile_end = base + BLOCK <= n ? base + BLOCK : n;
     const bool alive = i < n && i >= head;
-    const v4f p = load_point<NT>(in + (i < head ? head : (i < n ? i : n - 1)));  // dead lanes re-read a live point
+    const uint32_t h0 = t == 0 ? head : 0u;  // see deskew_traj_f32
+    const __amdgpu_buffer_rsrc_t rin = tile_rsrc(in + base + h0, (n - base - h0) * sizeof(v4f));
+    const v4f p = tile_load<NT>(rin, (tid - h0) * (uint32_t)sizeof(v4f));
     // frame of the tile's first point (wave-uniform)
     const uint64_t c = base >> kChunkShift;
     const uint2 entry = coarse[c];
@@ -610,27 +684,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == kTr
       f0 = lo;
     }
     TrajFrameRec r = frecs[f0];
-    __syncthreads();  // the previous tile's LDS readers are done (one-wave workgroup: a wait, not a barrier)
-    // stage frame f0's slots (all seg_stride of them: the copy does not depend on the header) while the header arrives
-    for (uint32_t w = tid; w < seg_stride * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + (uint64_t)f0 * seg_stride)[w];
+    KnotPre kp0;
+    {
+      uint32_t k1 = __float_as_uint(r.c1), k2 = __float_as_uint(r.c2);
+      asm volatile("" : "+s"(k1), "+s"(k2));  // pins the header load in front of the points' first use
+      kp0 = {__uint_as_float(k1), __uint_as_float(k2)};
+      // (Warming the scalar cache with the frame's first two records through four one-dword loads at this point was measured and
+      // dropped: 360 us against 327 us per 64 M points -- the extra scalar traffic costs more than the misses it avoids.)
+    }
+    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
+    const bool one_frame = rec_end(r) >= tile_end;
+    __builtin_amdgcn_sched_barrier(0);  // the whole look-up chain above is issued before the wave waits for its points
+    const float turns = azimuth_turns(p.x, p.y);
     // near-origin guard: flagged lanes remember their segment (frame * seg_stride + bracket) and are redone in f64 at the end
-    // of the tile -- ONE cold site for both paths below
+    // of the tile -- ONE cold site
     bool redo_any = false;
     uint32_t redo_seg = 0;
-    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
-    if (rec_end(r) >= tile_end) {
-      __syncthreads();
-      uint32_t k;
-      bool redo;
-      const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k, redo);
-      redo = redo && alive;
-      redo_any = redo;
-      redo_seg = f0 * seg_stride + k;
-      if constexpr (NT & kStoreSc1) {
-        if (i >= head && !redo) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
-      } else {
-        if (alive && !redo) store_point<NT>(out + i, q);
-      }
+    if (__builtin_expect(one_frame, 1)) {  // the tile lies in ONE frame: all but ~n_frames of the n / 64 tiles
+      const uint32_t k = traj_lanes<TIER, NT>(p, turns, true, i >= head, segs_c + (uint64_t)f0 * seg_stride, r.n_seg, kp0, f0 * seg_stride, rout, tid, redo_any, redo_seg);
       if constexpr (WRITE_IDX) {
         if (alive) {
           if (frame_idx_out) __builtin_nontemporal_store(f0, frame_idx_out + i);
@@ -640,30 +711,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == kTr
     } else {
       uint32_t fi = f0;
       uint64_t begin = base;
-      while (true) {
+      while (true) {  // the frames that own points of this tile, in order (empty frames are skipped)
         const uint64_t e = rec_end(r);
-        const bool mine = i >= begin && i < e && alive;
-        if (e > begin) {  // frame fi owns at least one point of the tile (empty frames are skipped)
-          if (fi != f0) {
-            for (uint32_t w = tid; w < r.n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs + (uint64_t)fi * seg_stride)[w];
-          }
-          __syncthreads();
-          uint32_t k;
-          bool redo;
-          const v4f q = traj_lane<TIER>(p, lds, r.n_seg, k, redo);
-          redo = redo && mine;
-          if (redo) {
-            redo_any = true;
-            redo_seg = fi * seg_stride + k;
-          }
-          if (mine) {
-            if (!redo) store_point<NT>(out + i, q);
-            if constexpr (WRITE_IDX) {
-              if (frame_idx_out) frame_idx_out[i] = fi;
-              if (bracket_out) bracket_out[i] = k;
+        if (e > begin) {
+          const bool mine = i >= begin && i < e;
+          const uint32_t k = traj_lanes<TIER, NT>(p, turns, mine, i >= head, segs_c + (uint64_t)fi * seg_stride, r.n_seg, KnotPre{r.c1, r.c2}, fi * seg_stride, rout, tid, redo_any, redo_seg);
+          if constexpr (WRITE_IDX) {
+            if (mine && alive) {
+              if (frame_idx_out) __builtin_nontemporal_store(fi, frame_idx_out + i);
+              if (bracket_out) __builtin_nontemporal_store(k, bracket_out + i);
             }
           }
-          __syncthreads();
           begin = e;
         }
         if (e >= tile_end || fi + 1 >= n_frames) break;
@@ -671,7 +729,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TIER == kTr
         r = frecs[fi];
       }
     }
-    traj_redo_lanes(redo_any, p, segs64, redo_seg, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
+    traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
   }
 }
 

@@ -221,91 +221,7 @@ static Variant policy_variant(const char* label) {
   return v;
 }
 
-// ---- trajectory-kernel experiments ---------------------------------------------------------------------------------
-static TrajSegD* g_traj_segs64 = nullptr;  // zero-filled f64 twins (guard redo; not reached by the tuner's data)
-static TrajSeg32* g_traj_segs = nullptr;  // 2 segments: knots at scan fractions -0.5, 0.5, 1.5 (the OXTS triple)
-
-static void build_traj() {
-  TrajSeg32 h[2];
-  std::memset(h, 0, sizeof(h));
-  const FrameRec f = make_rec();
-  for (int k = 0; k < 2; ++k) {
-    TrajSeg32& r = h[k];
-    r.phi_x = f.phi_x; r.phi_y = f.phi_y; r.phi_z = f.phi_z; r.phi2 = f.phi2;
-    r.rho_x = f.rho_x; r.rho_y = f.rho_y; r.rho_z = f.rho_z;
-    r.c1_x = f.c1_x; r.c1_y = f.c1_y; r.c1_z = f.c1_z;
-    r.c2_x = f.c2_x; r.c2_y = f.c2_y; r.c2_z = f.c2_z;
-    const float ck = k == 0 ? -0.5f : 0.5f;
-    r.g = 1.0f;
-    r.s0 = (0.5f - ck) * r.g - (k == 1 ? 0.0f : 0.0f);
-    r.m00 = 0.9998f; r.m01 = -0.02f; r.m02 = 0.001f; r.tx = 0.3f;
-    r.m10 = 0.02f; r.m11 = 0.9998f; r.m12 = -0.002f; r.ty = -0.01f;
-    r.m20 = -0.001f; r.m21 = 0.002f; r.m22 = 1.0f; r.tz = 0.02f;
-    r.knot_cos = k == 0 ? -1.0f : 1.0f; r.knot_sin = 0.0f;
-    r.knot_c = ck;
-    r.flags = (k == 1 ? kSegIdentity : 0u) | (ck <= 0.0f ? kKnotAlwaysGe : 0u);
-  }
-  CK(hipMalloc((void**)&g_traj_segs, sizeof(h)));
-  CK(hipMemcpy(g_traj_segs, h, sizeof(h), hipMemcpyHostToDevice));
-  CK(hipMalloc((void**)&g_traj_segs64, 2 * sizeof(TrajSegD)));
-  CK(hipMemset(g_traj_segs64, 0, 2 * sizeof(TrajSegD)));
-}
-
-// LDS-staged variant: the workgroup stages the records once and walks TPW consecutive tiles
-template <int BLOCK, int TPW>
-__global__ __launch_bounds__(BLOCK) void traj_lds(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
-                                                  const TrajSeg32* __restrict__ segs, uint32_t n_seg,
-                                                  const TrajSegD* __restrict__ segs64) {
-  __shared__ TrajSeg32 lds[kMaxSegments];
-  const uint32_t tid = threadIdx.x;
-  const uint64_t first = (uint64_t)blockIdx.x * TPW * BLOCK;
-  v4f p[TPW];
-#pragma unroll
-  for (int u = 0; u < TPW; ++u) {
-    const uint64_t i = first + (uint64_t)u * BLOCK + tid;
-    p[u] = load_point<kNtBoth>(in + (i < n ? i : n - 1));
-  }
-  for (uint32_t w = tid; w < n_seg * 8; w += BLOCK) reinterpret_cast<v4f*>(lds)[w] = reinterpret_cast<const v4f*>(segs)[w];
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < TPW; ++u) {
-    const uint64_t i = first + (uint64_t)u * BLOCK + tid;
-    uint32_t k = 0;
-    for (uint32_t j = 1; j < n_seg; ++j) {
-      const v4f kn = reinterpret_cast<const v4f*>(&lds[j])[7];
-      k += knot_ge(p[u].x, p[u].y, kn.w, kn.x, kn.y, __float_as_uint(kn.z)) ? 1u : 0u;
-    }
-    const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
-    const uint32_t ks = __all(k == k0) ? k0 : k;
-    bool redo;  // experiment kernel: the near-origin guard's verdict is ignored (the tuner's synthetic scans never raise it)
-    const v4f q = traj_point<kSeries3>(p[u], lds[ks], redo);
-    (void)segs64;
-    if (i < n) store_point<kNtBoth>(out + i, q);
-  }
-}
-
-template <int BLOCK, int TPW>
-static Variant traj_lds_variant(const char* label) {
-  Variant v;
-  v.name = label;
-  v.ppt = TPW;
-  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
-    const uint64_t per = (uint64_t)BLOCK * TPW;
-    hipLaunchKernelGGL((traj_lds<BLOCK, TPW>), dim3((unsigned)((n + per - 1) / per)), dim3(BLOCK), 0, s, in, out, n, g_traj_segs, 2u, (const TrajSegD*)g_traj_segs64);
-  };
-  return v;
-}
-
-static Variant traj_lib_variant(const char* label) {
-  Variant v;
-  v.name = label;
-  v.ppt = 1;
-  v.launch = [](hipStream_t s, const v4f* in, v4f* out, uint64_t n, int) {
-    hipLaunchKernelGGL((deskew_traj_f32<kSeries3, kPolicyDefault, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in, out, n,
-                       g_traj_segs, 2u, (uint32_t*)nullptr, 0u, (const TrajSegD*)g_traj_segs64, TrajInline{});
-  };
-  return v;
-}
+// (the trajectory-kernel experiments of rounds 1-2 moved to kmc_tune_r3.hip together with round 2's LDS kernel)
 
 template <int TIER, int PPT, int NT, bool OCML, int BLOCK = kBlock>
 static Variant frame_variant(const char* label) {
@@ -479,7 +395,6 @@ int main(int argc, char** argv) {
   }
   CK(hipStreamSynchronize(s));
 
-  build_traj();
   build_tables(&g_bt_big, n, 1000000);
   build_tables(&g_bt_small, n, 123397);
   struct Entry { Variant v; std::vector<int> bpcs; };
@@ -507,13 +422,6 @@ int main(int argc, char** argv) {
   es.push_back({frame_variant<kSeries3, 1, kNtBoth | kBufLoad, false, 64>("s3_b64_bufld_bufst_nt"), kZero});
   es.push_back({frame_variant<kSeries3, 1, kNtBoth | kStoreSc1, false, 256>("s3_b256_gld_bufst_sc1nt"), kZero});
   es.push_back({frame_variant<kSeries3, 2, kNtBoth | kStoreSc1 | kBufLoad, false, 64>("s3_b64_ppt2_buf_sc1nt"), kZero});
-  es.push_back({traj_lib_variant("traj_lib"), kZero});
-  es.push_back({traj_lds_variant<64, 1>("traj_lds_b64_t1"), kZero});
-  es.push_back({traj_lds_variant<64, 4>("traj_lds_b64_t4"), kZero});
-  es.push_back({traj_lds_variant<256, 1>("traj_lds_b256_t1"), kZero});
-  es.push_back({traj_lds_variant<256, 2>("traj_lds_b256_t2"), kZero});
-  es.push_back({traj_lds_variant<256, 4>("traj_lds_b256_t4"), kZero});
-  es.push_back({traj_lds_variant<1024, 1>("traj_lds_b1024_t1"), kZero});
   es.push_back({dyn_variant<1, 32>("dyn_c1_w32"), kZero});
   es.push_back({dyn_variant<2, 32>("dyn_c2_w32"), kZero});
   es.push_back({dyn_variant<4, 32>("dyn_c4_w32"), kZero});
