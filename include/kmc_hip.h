@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define KMC_ABI_VERSION 2
+#define KMC_ABI_VERSION 3
 
 /* ---- status codes ---- */
 #define KMC_OK 0
@@ -53,7 +53,13 @@ extern "C" {
 
 typedef enum kmc_mem_kind {
   KMC_MEM_HOST = 0,  /* pageable or pinned host memory: the library stages H2D / D2H (PCIe-bound) */
-  KMC_MEM_DEVICE = 1 /* device memory of the ctx's GPU: zero-copy, the roofline path */
+  KMC_MEM_DEVICE = 1, /* device memory of the ctx's GPU: zero-copy, the roofline path */
+  KMC_MEM_HOST_MAPPED = 2 /* page-locked host memory the device can address (kmc_host_pool_alloc, kmc_hip_host_alloc, hipHostMalloc):
+                             the kernel reads and writes it IN PLACE over the link -- one launch, upload and download overlapped, no
+                             staging copies -- and the call returns when the results are in host memory.  Accepted by
+                             kmc_hip_deskew_f32, kmc_hip_deskew_f64cols, kmc_hip_deskew_traj_f64cols and kmc_hip_pseudo_timestamps_f64;
+                             the f64 entry points also take this route by themselves when every KMC_MEM_HOST pointer they are given
+                             lies in a block of the pool below (which is what the C++ drop-in's containers are made of). */
 } kmc_mem_kind;
 
 typedef struct kmc_ctx kmc_ctx; /* opaque */
@@ -75,7 +81,9 @@ typedef struct kmc_stats {
   uint64_t n_points;       /* points processed by the call */
   uint64_t n_out_of_range; /* points whose stamp was outside [stamp_start, stamp_end] (f64 path only) */
   uint32_t n_launches;     /* kernel launches issued */
-  uint32_t variant;        /* kernel tier used: 0 = series3 (theta<=0.25), 1 = series5 (theta<=1), 2 = wide polynomial (theta<=3.25), 3 = trig (any) */
+  uint32_t variant;        /* f32 deskew entry points: the coefficient tier used: 0 = series3 (theta<=0.25), 1 = series5 (theta<=1), 2 = wide
+                              polynomial (theta<=3.25), 3 = any angle.  Other routes: 4 = projection without deskew, 5 = the f64 Eigen-layout
+                              kernels (kmc_hip_deskew_f64cols, kmc_hip_deskew_traj_f64cols) */
   float kernel_ms;         /* HIP-event time of the kernel launches (only if timing was enabled) */
   float total_ms;          /* HIP-event time of the whole call incl. H2D/D2H staging (only if timing enabled) */
 } kmc_stats;
@@ -129,6 +137,18 @@ int kmc_hip_timer_end(kmc_ctx* ctx, float* elapsed_ms);
 int kmc_hip_host_alloc(kmc_ctx* ctx, size_t bytes, void** out);
 int kmc_hip_host_free(kmc_ctx* ctx, void* ptr);
 
+/* Process-wide pool of page-locked, device-addressable host memory (no context needed; thread-safe).  Pinning a block costs ~100 us
+ * or more, so freed blocks are cached (at most KMC_HOST_POOL_MAX_MB, default 2048, of free blocks) and reused.  The C++ drop-in's
+ * Pointcloud / VectorXd allocate from it, which lets MotionCompensateFrame(Frame const&, Time) run as ONE kernel on the caller's
+ * own containers.  kmc_host_pool_alloc: KMC_OK, or KMC_ERR_NO_DEVICE when there is no HIP device (or KMC_HOST_POOL=0) -- the caller
+ * then uses ordinary memory and the staged KMC_MEM_HOST route.  kmc_host_pool_free: 1 if `ptr` was a live pool block (now
+ * recycled), 0 if it is not the pool's.  kmc_host_pool_owns: 1 if [ptr, ptr + bytes) lies inside ONE live block.
+ * kmc_host_pool_trim: unpins every cached free block, returns how many. */
+int kmc_host_pool_alloc(size_t bytes, void** out);
+int kmc_host_pool_free(void* ptr);
+int kmc_host_pool_owns(const void* ptr, size_t bytes);
+int kmc_host_pool_trim(void);
+
 /* ------------------------------------------------------------------------------------------------
  * host pre-step (f64, pure host code, usable without a GPU)
  * ---------------------------------------------------------------------------------------------- */
@@ -181,12 +201,17 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip, tools/fq_probe.hip).
  *   - queues = 1 (default): every call on the context's stream, strictly in order (the behaviour of ABI version 1).
  *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls -- and kmc_hip_deskew_traj_f32(KMC_MEM_DEVICE) calls with
- *     at most four knots -- are NOT ordered with each other.  The first frame
- *     after a join waits for everything issued on the context's stream before it (its producers); kmc_hip_frame_queue_join()
- *     makes the context's stream wait for every frame issued so far (device-side, the host does not block).  Every other entry
- *     point, kmc_hip_synchronize(), kmc_hip_timer_end() and kmc_hip_set_stream() join first, so anything issued after the frames
- *     sees their results.  With kmc_hip_enable_timing() on, calls stay on the context's stream (per-call times need order). */
+ *     at most four knots -- are NOT ordered with each other.  EVERY queued frame waits (device-side) for what has been issued on
+ *     the context's stream up to its call -- its producers --, so the usual loop "produce frame k on the stream, deskew it" is safe;
+ *     what is NOT ordered is later work on the context's stream against frames still in flight: a producer that OVERWRITES a buffer
+ *     a queued frame reads or writes must follow a join.  kmc_hip_frame_queue_join() makes the context's stream wait for every
+ *     frame issued so far (device-side, the host does not block).  Every other entry point, kmc_hip_synchronize(),
+ *     kmc_hip_timer_end() and kmc_hip_set_stream() join first, so anything issued after the frames sees their results.  With
+ *     kmc_hip_enable_timing() on, calls stay on the context's stream (per-call times need order).
+ *   - kmc_hip_set_frame_queue_order(ctx, 0): only the FIRST frame after a join waits for the context's stream (round 2's behaviour:
+ *     saves one event record + wait per frame); for callers whose frames are all produced before the first call. */
 int kmc_hip_set_frame_queues(kmc_ctx* ctx, int queues);
+int kmc_hip_set_frame_queue_order(kmc_ctx* ctx, int after_producers);
 int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
  * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues (four for this call if they are off) and joined:

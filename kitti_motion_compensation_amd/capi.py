@@ -26,6 +26,7 @@ ERR_DEGENERATE = -6
 
 MEM_HOST = 0
 MEM_DEVICE = 1
+MEM_HOST_MAPPED = 2
 
 TIER_SERIES3, TIER_SERIES5, TIER_WIDE, TIER_TRIG = 0, 1, 2, 3
 
@@ -125,6 +126,10 @@ SIGNATURES = {
     "kmc_hip_timer_end": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "kmc_hip_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "kmc_hip_host_free": (C.c_int, [_vp, _vp]),
+    "kmc_host_pool_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "kmc_host_pool_free": (C.c_int, [_vp]),
+    "kmc_host_pool_owns": (C.c_int, [_vp, C.c_size_t]),
+    "kmc_host_pool_trim": (C.c_int, []),
     "kmc_frame_params_from_poses": (C.c_int, [_dp, _dp, C.c_double, C.c_double, C.c_double, C.POINTER(FrameParams)]),
     "kmc_oxts_to_pose": (C.c_int, [C.POINTER(Oxts), C.c_double, _dp]),
     "kmc_interpolate_trajectory": (C.c_int, [C.POINTER(Oxts), C.POINTER(Oxts), C.c_double, _dp]),
@@ -133,6 +138,7 @@ SIGNATURES = {
     "kmc_hip_deskew_f32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(FrameParams), C.c_int, C.POINTER(Stats)]),
     "kmc_hip_set_frame_queues": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_frame_queue_join": (C.c_int, [_vp]),
+    "kmc_hip_set_frame_queue_order": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_deskew_frames_f32": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(FrameParams), C.c_uint32, C.POINTER(Stats)]),
     "kmc_hip_deskew_batch_f32": (
         C.c_int,
@@ -293,6 +299,38 @@ def frame_ranges_balanced(frame_points, n_parts: int) -> np.ndarray:
     return bounds
 
 
+class PooledArray:
+    """A float64 / float32 / uint32 numpy array living in a block of the C-ABI's page-locked host pool (kmc_host_pool_alloc):
+    the f64 entry points run IN PLACE on such arrays (no staging copies).  Keep the object alive while `.a` is in use."""
+
+    def __init__(self, shape, dtype=np.float64):
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = _vp()
+        rc = lib().kmc_host_pool_alloc(max(n * dt.itemsize, 1), C.byref(p))
+        if rc != OK:
+            raise KmcError(rc, "kmc_host_pool_alloc")
+        self._p = p
+        buf = (C.c_char * (n * dt.itemsize)).from_address(p.value)
+        self.a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.a = None
+            lib().kmc_host_pool_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def host_pool_owns(a: np.ndarray) -> bool:
+    return bool(lib().kmc_host_pool_owns(a.ctypes.data, a.nbytes))
+
+
 def synth_points_host(n: int, seed: int) -> np.ndarray:
     out = np.empty((n, 4), dtype=np.float32)
     rc = lib().kmc_synth_points_host(out.ctypes.data, n, seed)
@@ -392,6 +430,10 @@ class Context:
     def set_frame_queues(self, queues: int):
         """queues > 1: device-resident deskew_f32 calls go round-robin over that many HIP streams and may overlap (see kmc_hip.h)."""
         self._check(lib().kmc_hip_set_frame_queues(self._h, int(queues)), "kmc_hip_set_frame_queues")
+
+    def set_frame_queue_order(self, after_producers: bool = True):
+        """False: only the first frame after a join waits for the context's stream (all inputs produced up front)."""
+        self._check(lib().kmc_hip_set_frame_queue_order(self._h, 1 if after_producers else 0), "kmc_hip_set_frame_queue_order")
 
     def frame_queue_join(self):
         self._check(lib().kmc_hip_frame_queue_join(self._h), "kmc_hip_frame_queue_join")

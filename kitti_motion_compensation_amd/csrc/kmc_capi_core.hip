@@ -2,6 +2,8 @@
 // definitions of the helpers every other translation unit of libkmc_hip.so shares (kmc_internal.hip.h).
 #include "kmc_internal.hip.h"
 
+#include <cstdlib>
+
 namespace kmc_impl {
 
 int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n) {
@@ -71,17 +73,21 @@ int fq_stream(kmc_ctx* c, hipStream_t* out) {
     *out = c->stream;
     return KMC_OK;
   }
-  if (!c->fq_forked) {  // the frames must not start before what the caller has already issued on `stream` (their producers)
-    KMC_HIP_TRY(c, hipEventRecord(c->fq_fork, c->stream));
-    for (int q = 0; q < c->fq_count; ++q) {
-      KMC_HIP_TRY(c, hipStreamWaitEvent(c->fq[q], c->fq_fork, 0));
-      c->fq_used[q] = false;
-    }
+  if (!c->fq_forked) {
+    for (int q = 0; q < c->fq_count; ++q) c->fq_used[q] = false;
     c->fq_forked = true;
     c->fq_next = 0;
   }
   const int q = c->fq_next;
   c->fq_next = (q + 1) % c->fq_count;
+  // EVERY queued frame is ordered behind what the caller has issued on `stream` up to this call -- its producers (with
+  // the fork recorded only for the first frame after a join, the usual loop "produce frame k on the stream, deskew it" raced from
+  // the second frame on).  One event record and one device-side wait per frame; frames still overlap each other.  A caller whose
+  // frames are all produced before the first call may switch this off (kmc_hip_set_frame_queue_order).
+  if (c->fq_ordered || !c->fq_used[q]) {
+    KMC_HIP_TRY(c, hipEventRecord(c->fq_fork, c->stream));
+    KMC_HIP_TRY(c, hipStreamWaitEvent(c->fq[q], c->fq_fork, 0));
+  }
   c->fq_used[q] = true;
   *out = c->fq[q];
   return KMC_OK;
@@ -159,8 +165,8 @@ int slot_end(kmc_ctx* c, int slot_id) {
 }
 // coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point.
 // All positions are VIRTUAL: `head` dead points precede the batch (frame 0 owns them), n_virtual = n + head.
-void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n_virtual, uint32_t head, uint2* h_coarse) {
-  const uint64_t chunk = 1ull << kChunkShift;
+void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n_virtual, uint32_t head, uint2* h_coarse, uint32_t chunk_shift) {
+  const uint64_t chunk = 1ull << chunk_shift;
   const uint64_t n_chunks = (n_virtual + chunk - 1) / chunk;
   auto end_of = [&](uint32_t f) { return offsets[f + 1] + head; };  // virtual end offset of frame f
   uint32_t f = 0;
@@ -223,6 +229,8 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   for (auto& ev : c->group_consumed)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocPortable | hipHostMallocMapped);
+  if (e == hipSuccess) *c->h_flag = 0;
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fq_fork, hipEventDisableTiming);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -230,6 +238,7 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
     return KMC_ERR_NO_DEVICE;
   }
   c->stream = c->own_stream;
+  if (const char* e = std::getenv("KMC_NO_INLINE_TABLES")) c->no_inline_tables = std::atoi(e) != 0;
   *out = c;
   return KMC_OK;
 }
@@ -269,6 +278,7 @@ void kmc_hip_destroy(kmc_ctx* c) {
     if (ev) (void)hipEventDestroy(ev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->d_counter) (void)hipFree(c->d_counter);
+  if (c->h_flag) (void)hipHostFree(c->h_flag);
   hipEvent_t evs[] = {c->ev_k0, c->ev_k1, c->ev_c0, c->ev_c1, c->ev_t0, c->ev_t1};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
@@ -330,6 +340,13 @@ int kmc_hip_set_frame_queues(kmc_ctx* c, int queues) {
   }
   c->fq_count = queues;
   c->fq_next = 0;
+  return KMC_OK;
+}
+
+int kmc_hip_set_frame_queue_order(kmc_ctx* c, int after_producers) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_ENTER(c);
+  c->fq_ordered = after_producers != 0;
   return KMC_OK;
 }
 

@@ -4,6 +4,10 @@
 #include "kmc_internal.hip.h"
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <system_error>
 #include <thread>
 
 namespace {
@@ -42,9 +46,9 @@ template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
                      uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64) {
   if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, BatchInline{});
   else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64);
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, BatchInline{});
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
@@ -55,6 +59,17 @@ void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, c
     case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
     default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
   }
+}
+// tables in the kernel arguments (default launch geometry only: one point per lane)
+template <int TIER>
+void launch_batch_inline(hipStream_t s, int grid, const v4f* in, v4f* out, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head,
+                         uint32_t chunk_shift, const BatchInline& inl) {
+  if (idx)
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, true, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
+                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, inl);
+  else
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
+                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, inl);
 }
 }  // namespace
 
@@ -92,6 +107,7 @@ int check_frame_args(const float* xyzi_in, float* xyzi_out, uint64_t n, const km
 // memory block their caller, hence the second thread).  The device scratch holds the whole frame, so chunks never wait for a
 // buffer.
 constexpr uint64_t kF64PipelineMinPoints = 1ull << 20;
+constexpr uint64_t kMappedMinPoints = 2048;  // below this a kernel over the link is all latency; the staged route's small copies are as good
 constexpr uint64_t kF64ChunkPoints = 1ull << 20;
 
 int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
@@ -112,26 +128,40 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
   hipStream_t s_up = c->pipe[0], s_run = c->pipe[1], s_down = c->pipe[2];
   KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), s_run));
 
-  std::atomic<uint64_t> launched{0};   // chunks whose kernel-done event has been recorded
-  std::atomic<bool> abort_flag{false};
+  // chunks whose kernel-done event has been recorded; the downloader sleeps on the condition variable between them
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t launched = 0;
+  bool abort_flag = false;
   hipError_t down_error = hipSuccess;
-  std::thread downloader([&] {
-    hipError_t e = hipSetDevice(c->device);
-    for (uint64_t k = 0; k < n_chunks && e == hipSuccess; ++k) {
-      while (launched.load(std::memory_order_acquire) <= k) {
-        if (abort_flag.load(std::memory_order_acquire)) return;
-        std::this_thread::yield();
+  if (c->timing) {  // the pipeline lives on its own three streams: bracket it with events on the kernel stream
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_c0, s_run));
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_k0, s_run));
+  }
+  std::thread downloader;
+  try {
+    downloader = std::thread([&] {
+      hipError_t e = hipSetDevice(c->device);
+      for (uint64_t k = 0; k < n_chunks && e == hipSuccess; ++k) {
+        {
+          std::unique_lock<std::mutex> lock(mu);
+          cv.wait(lock, [&] { return launched > k || abort_flag; });
+          if (abort_flag) return;
+        }
+        const uint64_t off = k * kF64ChunkPoints, m = std::min<uint64_t>(kF64ChunkPoints, n - off);
+        e = hipStreamWaitEvent(s_down, c->ev_pool[2 * k + 1], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(ox + off, cols[5] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess) e = hipMemcpyAsync(oy + off, cols[6] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess) e = hipMemcpyAsync(oz + off, cols[7] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess && down_w) e = hipMemcpyAsync(ow + off, cols[8] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
       }
-      const uint64_t off = k * kF64ChunkPoints, m = std::min<uint64_t>(kF64ChunkPoints, n - off);
-      e = hipStreamWaitEvent(s_down, c->ev_pool[2 * k + 1], 0);
-      if (e == hipSuccess) e = hipMemcpyAsync(ox + off, cols[5] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
-      if (e == hipSuccess) e = hipMemcpyAsync(oy + off, cols[6] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
-      if (e == hipSuccess) e = hipMemcpyAsync(oz + off, cols[7] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
-      if (e == hipSuccess && down_w) e = hipMemcpyAsync(ow + off, cols[8] + off, m * sizeof(double), hipMemcpyDeviceToHost, s_down);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(s_down);
-    down_error = e;
-  });
+      if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+      down_error = e;
+    });
+  } catch (const std::system_error&) {
+    // no exception may cross the C ABI: the caller falls back to the un-pipelined route
+    return KMC_ERR_ALLOC;
+  }
   hipError_t up_error = hipSuccess;
   for (uint64_t k = 0; k < n_chunks && up_error == hipSuccess; ++k) {
     const uint64_t off = k * kF64ChunkPoints, m = std::min<uint64_t>(kF64ChunkPoints, n - off);
@@ -145,14 +175,28 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
     if (e == hipSuccess) {
       const int grid = grid_for(c, (m + 127) / 128);
       hipLaunchKernelGGL(deskew_f64cols<0>, dim3(grid), dim3(64), 0, s_run, cols[0] + off, cols[1] + off, cols[2] + off, w ? cols[3] + off : nullptr,
-                         cols[4] + off, m, f, cols[5] + off, cols[6] + off, cols[7] + off, down_w ? cols[8] + off : nullptr, c->d_counter);
+                         cols[4] + off, m, f, cols[5] + off, cols[6] + off, cols[7] + off, down_w ? cols[8] + off : nullptr, c->d_counter, (uint32_t*)nullptr);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(c->ev_pool[2 * k + 1], s_run);
-    if (e == hipSuccess) launched.store(k + 1, std::memory_order_release);
+    if (e == hipSuccess) {
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        launched = k + 1;
+      }
+      cv.notify_one();
+    }
     up_error = e;
   }
-  if (up_error != hipSuccess) abort_flag.store(true, std::memory_order_release);
+  if (up_error != hipSuccess) {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      abort_flag = true;
+    }
+    cv.notify_one();
+  } else if (c->timing) {
+    up_error = hipEventRecord(c->ev_k1, s_run);  // behind the last chunk's kernel
+  }
   downloader.join();
   if (up_error != hipSuccess) return fail_hip(c, up_error, "f64 host pipeline (upload / launch)");
   if (down_error != hipSuccess) return fail_hip(c, down_error, "f64 host pipeline (download)");
@@ -161,6 +205,14 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
   KMC_HIP_TRY(c, hipStreamSynchronize(s_run));
   KMC_HIP_TRY(c, hipStreamSynchronize(s_up));
   if (st) { st->n_launches = (uint32_t)n_chunks; st->n_out_of_range = bad; }
+  if (c->timing) {  // kernel_ms: first upload wait to last kernel on the kernel stream; total_ms: until the last byte is back in host memory
+    KMC_HIP_TRY(c, hipEventRecord(c->ev_c1, s_run));  // every stream has been synchronized above: this is "now"
+    KMC_HIP_TRY(c, hipEventSynchronize(c->ev_c1));
+    if (st) {
+      KMC_HIP_TRY(c, hipEventElapsedTime(&st->kernel_ms, c->ev_k0, c->ev_k1));
+      KMC_HIP_TRY(c, hipEventElapsedTime(&st->total_ms, c->ev_c0, c->ev_c1));
+    }
+  }
   return bad ? KMC_ERR_TIME_OUT_OF_RANGE : KMC_OK;
 }
 }  // namespace
@@ -171,7 +223,19 @@ extern "C" {
 int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params,
                        int mem_kind, kmc_stats* st) {
   if (!c) return KMC_ERR_INVALID_ARG;
-  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE && mem_kind != KMC_MEM_HOST_MAPPED) return KMC_ERR_INVALID_ARG;
+  if (mem_kind == KMC_MEM_HOST_MAPPED) {
+    // page-locked, device-addressable host buffers: the device route on the caller's pointers (the kernel streams over the link in
+    // both directions at once), then a wait -- the results are in host memory when the call returns
+    const int rc_dev = kmc_hip_deskew_f32(c, xyzi_in, xyzi_out, n, params, KMC_MEM_DEVICE, st);
+    if (rc_dev != KMC_OK) return rc_dev;
+    {
+      const int rc_j = fq_join(c);
+      if (rc_j != KMC_OK) return rc_j;
+    }
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+  }
   {
     const int rc_args = check_frame_args(xyzi_in, xyzi_out, n, params, mem_kind);
     if (rc_args != KMC_OK) return rc_args;
@@ -309,6 +373,49 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const uint64_t nv = n + head;                       // virtual size; every offset below is shifted by `head` too
   const uint64_t tile = (uint64_t)kLaunchBlock * ppt;
   const uint64_t n_tiles = (nv + tile - 1) / tile;
+
+  // Small batches of device-resident frames: the tables travel in the kernel arguments.  Nothing to upload, nothing for the host to
+  // wait for -- the call only enqueues one launch on the context's stream (and can therefore be captured into a HIP graph).
+  if (mem_kind == KMC_MEM_DEVICE && n_frames <= (uint32_t)kInlineBatchFrames && ppt == 1 && c->blocks_per_cu == 0 && !c->no_inline_tables) {
+    uint32_t shift = kChunkShift;
+    while (((nv + (1ull << shift) - 1) >> shift) > (uint64_t)kInlineBatchChunks) ++shift;
+    if (shift <= 31) {
+      BatchInline inl;
+      std::memset(&inl, 0, sizeof(inl));
+      for (uint32_t f = 0; f < n_frames; ++f) {
+        fill_rec(params[f], &inl.recs[f]);
+        fill_recd(params[f], &inl.recs64[f]);
+        inl.recs[f].end_lo = (uint32_t)((offsets[f + 1] + head) & 0xFFFFFFFFull);
+        inl.recs[f].end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
+      }
+      build_coarse(offsets, n_frames, nv, head, inl.coarse, shift);
+      CallTimer tmi(c);
+      if (tmi.begin_call() || tmi.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+      const int grid = grid_for(c, n_tiles);
+      const v4f* vin = (const v4f*)xyzi_in - head;
+      v4f* vout = (v4f*)xyzi_out - head;
+      uint32_t* vidx = frame_idx_out ? frame_idx_out - head : nullptr;
+      switch (tier) {
+        case kSeries3: launch_batch_inline<kSeries3>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl); break;
+        case kSeries5: launch_batch_inline<kSeries5>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl); break;
+        case kWide: launch_batch_inline<kWide>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl); break;
+        default: launch_batch_inline<kTrig>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl); break;
+      }
+      KMC_HIP_TRY(c, hipGetLastError());
+      if (tmi.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+      if (st) st->n_launches = 1;
+      return tmi.end_call(st);
+    }
+  }
+  // A table upload cannot be part of a stream capture (the slot is reused by later calls, and the host waits for the copy)
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      c->last_error = "kmc_hip_deskew_batch_f32: only batches of at most 16 device-resident frames can be captured into a HIP graph";
+      return KMC_ERR_INVALID_ARG;
+    }
+    (void)hipGetLastError();
+  }
   const uint64_t chunk = 1ull << kChunkShift;
   const uint64_t n_chunks = (nv + chunk - 1) / chunk;
   const uint64_t n_coarse = n_chunks + 1;
@@ -389,12 +496,12 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
                            double* oy, double* oz, double* ow, int mem_kind, kmc_stats* st) {
   if (!c || !params) return KMC_ERR_INVALID_ARG;
   if (n && (!x || !y || !z || !stamps || !ox || !oy || !oz)) return KMC_ERR_INVALID_ARG;
-  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE && mem_kind != KMC_MEM_HOST_MAPPED) return KMC_ERR_INVALID_ARG;
   if (!(stamp_start < stamp_end)) return KMC_ERR_DEGENERATE;
   if (!params_ok(params)) return KMC_ERR_INVALID_ARG;
   if (!(params->x_req >= 0.0 && params->x_req <= 1.0)) return KMC_ERR_TIME_OUT_OF_RANGE;
   if (st) std::memset(st, 0, sizeof(*st));
-  if (st) { st->n_points = n; st->variant = 3; }
+  if (st) { st->n_points = n; st->variant = 5; }
   if (n == 0) return KMC_OK;
   KMC_ENTER(c);
 
@@ -412,16 +519,26 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   f.t_start = stamp_start;
   f.t_end = stamp_end;
   f.dur = stamp_end - stamp_start;
-  f.halvings = (f.phi2 <= 0.25) ? 0 : 3;  // |s| <= 1 inside the scan
+  f.halvings = halvings_for(f.phi2);  // |s| <= 1 inside the scan
   f.pad = 0;
 
   const double *dx = x, *dy = y, *dz = z, *dw = w, *ds = stamps;
   double *dox = ox, *doy = oy, *doz = oz, *dow = ow;
   const size_t col = n * sizeof(double);
+  // Host containers made of the page-locked pool (the C++ drop-in's Pointcloud / VectorXd are): the kernel works on them in place.
+  // ONE launch -- the 40 B per point coming up and the 24-32 B going down share the full-duplex link -- instead of three staged copies
+  // with ~20 us of fixed cost each (123 k-point frame: 224-239 us staged, see profiles/NOTES.md for the in-place figure).
+  if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && host_pool_owns(x, col) && host_pool_owns(y, col) && host_pool_owns(z, col) &&
+      (!w || host_pool_owns(w, col)) && host_pool_owns(stamps, col) && host_pool_owns(ox, col) && host_pool_owns(oy, col) &&
+      host_pool_owns(oz, col) && (!ow || host_pool_owns(ow, col)))
+    mem_kind = KMC_MEM_HOST_MAPPED;
   // (Recognising a homogeneous column of ones on the host and skipping its two transfers was measured and dropped: scanning
   // and refilling it costs what moving it over PCIe costs -- 12 + 9 us against 37 us saved at 123 k points, and it serialises
   // with the pageable copies; tools/f64_route_probe.hip.)
-  if (mem_kind == KMC_MEM_HOST && n >= kF64PipelineMinPoints) return deskew_f64cols_host_pipelined(c, x, y, z, w, stamps, n, f, ox, oy, oz, ow, st);
+  if (mem_kind == KMC_MEM_HOST && n >= kF64PipelineMinPoints) {
+    const int rc_pipe = deskew_f64cols_host_pipelined(c, x, y, z, w, stamps, n, f, ox, oy, oz, ow, st);
+    if (rc_pipe != KMC_ERR_ALLOC) return rc_pipe;  // KMC_ERR_ALLOC: the helper thread could not be started -> the plain route below
+  }
   if (mem_kind == KMC_MEM_HOST) {
     int rc = ensure_tmp(c, 9 * col);
     if (rc != KMC_OK) return rc;
@@ -446,13 +563,12 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   CallTimer tm(c);
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+  *c->h_flag = 0;  // the previous call has synchronized: nothing on the device still writes it
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-  hipLaunchKernelGGL(deskew_f64cols<0>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter);
+  hipLaunchKernelGGL(deskew_f64cols<0>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  unsigned long long bad = 0;
-  KMC_HIP_TRY(c, hipMemcpyAsync(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
   if (mem_kind == KMC_MEM_HOST) {
     const bool down_w = ow != nullptr;
     if (oy == ox + n && oz == oy + n && (!down_w || ow == oz + n)) {  // one column-major block again
@@ -465,6 +581,10 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
     }
   }
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the out-of-range verdict is part of the call's result
+  unsigned long long bad = 0;
+  if (*(volatile uint32_t*)c->h_flag != 0) {  // cold: some stamp was out of range -> fetch the exact count
+    KMC_HIP_TRY(c, hipMemcpy(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost));
+  }
   if (st) { st->n_launches = 1; st->n_out_of_range = bad; }
   int rc = tm.end_call(st);
   if (rc != KMC_OK) return rc;
@@ -474,12 +594,14 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
 int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, uint64_t n, double scan_start, double scan_end,
                                   double* stamps_out, int mem_kind) {
   if (!c || (n && (!x || !y || !stamps_out))) return KMC_ERR_INVALID_ARG;
-  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
+  if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE && mem_kind != KMC_MEM_HOST_MAPPED) return KMC_ERR_INVALID_ARG;
   if (n == 0) return KMC_OK;
   KMC_ENTER(c);
   const size_t col = n * sizeof(double);
   const double *dx = x, *dy = y;
   double* dout = stamps_out;
+  if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && host_pool_owns(x, col) && host_pool_owns(y, col) && host_pool_owns(stamps_out, col))
+    mem_kind = KMC_MEM_HOST_MAPPED;  // page-locked containers: in place, see kmc_hip_deskew_f64cols
   if (mem_kind == KMC_MEM_HOST) {
     int rc = ensure_tmp(c, 3 * col);
     if (rc != KMC_OK) return rc;
@@ -495,10 +617,8 @@ int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, 
   const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
   hipLaunchKernelGGL(pseudo_timestamps_f64<0>, dim3(grid), dim3(64), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
   KMC_HIP_TRY(c, hipGetLastError());
-  if (mem_kind == KMC_MEM_HOST) {
-    KMC_HIP_TRY(c, hipMemcpyAsync(stamps_out, dout, col, hipMemcpyDeviceToHost, c->stream));
-    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  }
+  if (mem_kind == KMC_MEM_HOST) KMC_HIP_TRY(c, hipMemcpyAsync(stamps_out, dout, col, hipMemcpyDeviceToHost, c->stream));
+  if (mem_kind != KMC_MEM_DEVICE) KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the results are in host memory when the call returns
   return KMC_OK;
 }
 }  // extern "C"

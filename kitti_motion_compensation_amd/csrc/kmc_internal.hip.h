@@ -37,8 +37,10 @@ struct kmc_ctx {
   int blocks_per_cu = 0;  // 0 = default
   int ppt = 0;            // 0 = default
   int force_tier = -1;
+  bool no_inline_tables = false;  // testing / A-B hook (KMC_NO_INLINE_TABLES=1): small batches go through the device tables too
   // out-of-range counter (f64 path)
   unsigned long long* d_counter = nullptr;
+  uint32_t* h_flag = nullptr;  // page-locked word the f64 kernels raise when a stamp is out of range (read by the host after the sync: no D2H copy on the good path)
   // batch tables: a ring of slots, each one device buffer + one pinned staging buffer holding
   // [BatchRec x n_frames | coarse x (n_chunks + 1)], uploaded with ONE copy on a side stream so that the per-step host
   // preparation and the table H2D overlap the previous step's kernel.  The compute stream sees no event between two
@@ -82,6 +84,7 @@ struct kmc_ctx {
   int fq_count = 1;                  // 1 = off: every launch on `stream`
   int fq_next = 0;
   bool fq_forked = false;            // frames have been issued on the queues since the last join
+  bool fq_ordered = true;            // every queued frame waits for what `stream` holds at its call (kmc_hip_set_frame_queue_order)
   hipStream_t fq[kMaxFrameQueues] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t fq_done[kMaxFrameQueues] = {nullptr, nullptr, nullptr, nullptr};
   bool fq_used[kMaxFrameQueues] = {false, false, false, false};
@@ -109,6 +112,16 @@ inline int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
     hipError_t _e = (expr);                           \
     if (_e != hipSuccess) return fail_hip(ctx, _e, #expr); \
   } while (0)
+
+// f64 kernels: the 8-term series is evaluated at t / 2^h and doubled back h times; it needs t / 2^h <= 0.5 (truncation < 1e-19).
+// h from the frame's |phi| (|s| <= 1 inside a scan / a segment): 0 for every vehicle, whatever it takes for a caller-supplied
+// twist (a fixed 3 lost accuracy beyond ~4 rad).  Wave-uniform loop count in the kernel.
+inline int halvings_for(double phi2) {
+  const double phi = std::sqrt(phi2);
+  if (!(phi > 0.5)) return 0;
+  const int h = (int)std::ceil(std::log2(phi / 0.5));
+  return h < 0 ? 0 : (h > 60 ? 60 : h);
+}
 
 // the cheapest tier valid up to theta_max = max over the frames of |phi| * max|s| (NaN -> the any-angle tier)
 inline int tier_of_theta(double theta_max) {
@@ -195,6 +208,7 @@ inline int ppt_of(const kmc_ctx* c) {
   return (p == 1 || p == 2 || p == 4 || p == 8) ? p : kDefaultPpt;
 }
 
+bool host_pool_owns(const void* ptr, size_t bytes);  // inside a live block of the page-locked host pool (kmc_capi_hostpool.hip)
 int ensure_tmp(kmc_ctx* c, size_t bytes);  // grow-only device scratch of the host-buffer paths
 int ensure_pipeline(kmc_ctx* c);           // streams, events and device slots of the three-stage host pipeline
 int ensure_pipe_streams(kmc_ctx* c);       // only its three streams
@@ -230,7 +244,7 @@ struct CallTimer {
 
 // coarse[c] = {frame that owns point c * chunk (empty frames skipped), split}; coarse[n_chunks].x = frame of the last point.
 // All positions are VIRTUAL: `head` dead points precede the batch (frame 0 owns them), n_virtual = n + head.
-void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n_virtual, uint32_t head, uint2* h_coarse);
+void build_coarse(const uint64_t* offsets, uint32_t n_frames, uint64_t n_virtual, uint32_t head, uint2* h_coarse, uint32_t chunk_shift = kChunkShift);
 
 }  // namespace kmc_impl
 

@@ -190,7 +190,7 @@ __device__ __forceinline__ FrameRec to_frame(const BatchRec& r) {
 }
 
 constexpr int kLdsFrames = 16;   // records staged in LDS for a tile that straddles frame boundaries
-constexpr int kChunkShift = 14;  // coarse frame table: one entry per 16384 points
+constexpr int kChunkShift = 14;  // coarse frame table: one entry per 16384 points (device tables; inline tables choose their own shift)
 constexpr uint32_t kSplitNone = 0xFFFFFFFEu;    // no frame boundary inside the chunk
 constexpr uint32_t kSplitSearch = 0xFFFFFFFFu;  // two or more boundaries (tiny or empty frames): search
 
@@ -211,16 +211,64 @@ constexpr uint32_t kSplitSearch = 0xFFFFFFFFu;  // two or more boundaries (tiny 
 //      (integer compares on the end offsets: the per-point "timestamp index", bit-exact by construction) and gathers its
 //      record from LDS; a wave whose lanes all landed in one frame broadcasts the index through readfirstlane and stays on
 //      the uniform path.
-template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock>
+//
+// INLINE (round 3): a batch of at most kInlineBatchFrames frames carries its tables IN THE KERNEL ARGUMENTS -- records, their f64
+// twins and a coarse table of at most kInlineBatchChunks entries (the chunk size grows with the batch: `chunk_shift`).  No table
+// slot, no upload, no host wait: the call only enqueues a launch, so it is as asynchronous as kmc_hip_deskew_f32 and can be
+// captured into a HIP graph; a 16-frame batch no longer pays the 4.5 us the host spent waiting for its table copy.  `inl` is never
+// named in the body (the compiler would preload 3.5 KB of it into SGPRs): everything reads it through the kernel-argument segment.
+constexpr int kInlineBatchFrames = 16;
+constexpr int kInlineBatchChunks = 64;
+struct BatchInline {
+  BatchRec recs[kInlineBatchFrames];
+  FrameRecD recs64[kInlineBatchFrames];
+  uint2 coarse[kInlineBatchChunks + 1];
+};
+static_assert(sizeof(BatchInline) <= 3800, "the batch tables must leave room for the other arguments in the 4 KB kernel-argument segment");
+using brec_cp = const BatchRec __attribute__((address_space(4)))*;
+using uint2_cp = const uint2 __attribute__((address_space(4)))*;
+// (loads through builtin vector types: the implicit copy constructors of the structs cannot bind a constant-address-space reference)
+using v2u = uint32_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ BatchRec load_rec(brec_cp r) {
+  const v4u __attribute__((address_space(4)))* w = (const v4u __attribute__((address_space(4)))*)r;
+  const v4u a[4] = {w[0], w[1], w[2], w[3]};
+  BatchRec out;
+  __builtin_memcpy(&out, a, sizeof(out));
+  return out;
+}
+__device__ __forceinline__ uint64_t rec_end_at(brec_cp r) {
+  const v4u __attribute__((address_space(4)))* w = (const v4u __attribute__((address_space(4)))*)r;
+  return ((uint64_t)w[3].w << 32) | w[2].w;  // end_hi, end_lo: the last words of the third and fourth 16-byte groups
+}
+static_assert(offsetof(BatchRec, end_lo) == 44 && offsetof(BatchRec, end_hi) == 60, "rec_end_at reads the end offset by position");
+__device__ __forceinline__ uint2 load_coarse(uint2_cp c) {
+  const v2u e = *(const v2u __attribute__((address_space(4)))*)c;
+  return make_uint2(e.x, e.y);
+}
+
+template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock, bool INLINE = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 ? 8 : 4, 8))) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
-                                                         const BatchRec* __restrict__ recs,
-                                                         const uint2* __restrict__ coarse, uint32_t n_frames,
+                                                         const BatchRec* __restrict__ recs_g,
+                                                         const uint2* __restrict__ coarse_g, uint32_t n_frames,
                                                          uint64_t n, uint32_t* __restrict__ frame_idx_out, uint32_t head,
-                                                         const FrameRecD* __restrict__ recs64) {
+                                                         const FrameRecD* __restrict__ recs64, uint32_t chunk_shift, BatchInline inl) {
   // `recs64[f]`: frame f's constants in f64 for the near-origin guard's redo (kmc_device_math); cold
   // `head`: dead leading indices, see deskew_frame_f32 (the host has shifted the pointers and every offset by it)
+  // `chunk_shift`: log2 of the coarse table's chunk size (kChunkShift for device tables)
   static_assert(BLOCK >= kLdsFrames * 4, "the LDS staging uses one lane per 16 bytes of the record table");
   constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
+  brec_cp recs;      // tables are written by the host before the launch: constant for the kernel, uniform reads are scalar loads
+  uint2_cp coarse;
+  if constexpr (INLINE) {
+    struct ArgLayout { const v4f* in; v4f* out; const BatchRec* recs_g; const uint2* coarse_g; uint32_t n_frames; uint64_t n; uint32_t* frame_idx_out; uint32_t head; const FrameRecD* recs64; uint32_t chunk_shift; BatchInline inl; };
+    const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    recs = (brec_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, recs));
+    coarse = (uint2_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, coarse));
+    recs64 = (const FrameRecD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, recs64));
+  } else {
+    recs = (brec_cp)(uintptr_t)recs_g;
+    coarse = (uint2_cp)(uintptr_t)coarse_g;
+  }
   __shared__ BatchRec lds_recs[kLdsFrames];
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + kTile - 1) / kTile;
@@ -236,21 +284,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
       for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * BLOCK + tid);
     }
     // frame of the tile's first point (uniform -> SALU + scalar loads)
-    const uint64_t c = base >> kChunkShift;
-    const uint2 entry = coarse[c];  // one s_load_dwordx2
+    const uint64_t c = base >> chunk_shift;
+    const uint2 entry = load_coarse(coarse + c);  // one s_load_dwordx2
     uint32_t f0;
     if (entry.y != kSplitSearch) {
-      f0 = entry.x + ((uint32_t)(base - (c << kChunkShift)) >= entry.y ? 1u : 0u);
+      f0 = entry.x + ((uint32_t)(base - (c << chunk_shift)) >= entry.y ? 1u : 0u);
     } else {
-      uint32_t lo = entry.x, hi = coarse[c + 1].x;
+      uint32_t lo = entry.x, hi = load_coarse(coarse + c + 1).x;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (rec_end(recs[mid]) > base) hi = mid;
+        if (rec_end_at(recs + mid) > base) hi = mid;
         else lo = mid + 1;
       }
       f0 = lo;
     }
-    const BatchRec r0 = recs[f0];
+    const BatchRec r0 = load_rec(recs + f0);
     // near-origin guard (kmc_device_math): lanes whose f32 result lost significance are flagged here, skipped by the regular
     // stores and redone in f64 at the end of the tile -- ONE cold site for both paths below
     uint32_t redo_mask = 0;
@@ -279,7 +327,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
       if (tid < kLdsFrames * 4) {  // 16 records x 4 x 16 B: one ds_write_b128 per lane
         const uint32_t fr = f0 + (tid >> 2);
         if (fr < n_frames)
-          reinterpret_cast<v4f*>(lds_recs)[tid] = reinterpret_cast<const v4f*>(recs)[(uint64_t)f0 * 4 + tid];
+          reinterpret_cast<v4f*>(lds_recs)[tid] = ((const v4f __attribute__((address_space(4)))*)recs)[(uint64_t)f0 * 4 + tid];
       }
       __syncthreads();
 #pragma unroll
@@ -291,7 +339,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
         if (live) {
           while (true) {
             const uint32_t k = fi - f0;
-            const uint64_t e = (k < kLdsFrames) ? rec_end(lds_recs[k]) : rec_end(recs[fi]);
+            const uint64_t e = (k < kLdsFrames) ? rec_end(lds_recs[k]) : rec_end_at(recs + fi);
             if (i < e || fi + 1 >= n_frames) break;
             ++fi;
           }
@@ -303,10 +351,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
         BatchRec r;
         if (wave_uniform) {
           const uint32_t k0 = fi0 - f0;
-          r = (k0 < kLdsFrames) ? lds_recs[k0] : recs[fi0];  // uniform address: LDS broadcast / scalar load
+          if (k0 < kLdsFrames) r = lds_recs[k0];  // uniform address: LDS broadcast / scalar load
+          else r = load_rec(recs + fi0);
         } else {
           const uint32_t k = fi - f0;
-          r = (k < kLdsFrames) ? lds_recs[k] : recs[fi];     // per-lane gather
+          if (k < kLdsFrames) r = lds_recs[k];  // per-lane gather
+          else r = load_rec(recs + fi);
         }
         if (live) {
           const FrameRec f = to_frame(r);
@@ -360,7 +410,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
                                                      const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
                                                      double* __restrict__ ox, double* __restrict__ oy,
                                                      double* __restrict__ oz, double* __restrict__ ow,
-                                                     unsigned long long* __restrict__ n_bad) {
+                                                     unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag) {
+  // `bad_flag`: a page-locked host word raised together with the count, so that the host learns "nothing was out of range" from
+  // its own memory after the stream sync instead of through a device-to-host copy (~20 us of fixed cost per call)
   constexpr uint64_t kTile = 128;  // points per wave
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + kTile - 1) / kTile;
@@ -402,7 +454,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
     if (bad_lanes) {  // rare: count through a wave reduction, one atomic per wave
       uint32_t total = bad_count;
       for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-      if (tid == 0) atomicAdd(n_bad, (unsigned long long)total);
+      if (tid == 0) {
+        atomicAdd(n_bad, (unsigned long long)total);
+        if (bad_flag) __hip_atomic_store(bad_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -767,7 +822,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
                                                           double t_first, double t_last, double* __restrict__ ox,
                                                           double* __restrict__ oy, double* __restrict__ oz,
                                                           double* __restrict__ ow, uint32_t* __restrict__ bracket_out,
-                                                          unsigned long long* __restrict__ n_bad) {
+                                                          unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag) {
   constexpr uint64_t kTile = 128;
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + kTile - 1) / kTile;
@@ -812,7 +867,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
     if (__ballot(bad_count != 0)) {
       uint32_t total = bad_count;
       for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-      if (tid == 0) atomicAdd(n_bad, (unsigned long long)total);
+      if (tid == 0) {
+        atomicAdd(n_bad, (unsigned long long)total);
+        if (bad_flag) __hip_atomic_store(bad_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }

@@ -496,6 +496,52 @@ def test_f64cols_out_of_range_stamps_are_reported(ctx, kitti):
     assert rc_o == orc.ERR_TIME_OUT_OF_RANGE and nbad_o == 3
 
 
+def test_f64cols_in_place_on_page_locked_containers_same_bits(ctx, kitti):
+    """Round 3: when every column handed to kmc_hip_deskew_f64cols(KMC_MEM_HOST) lies in the C-ABI's page-locked pool -- what the
+    C++ drop-in's Pointcloud / VectorXd are made of -- the kernel works on the caller's memory in place (one launch, no staging
+    copies).  Same kernel, same bits as the staged route on ordinary numpy arrays; out-of-range stamps are still counted (through
+    the page-locked flag word instead of a device-to-host copy); foreign pointers keep the staged route."""
+    xyzi, P1 = kitti
+    n = xyzi.shape[0]
+    A, B = _poses(P1, TRAJECTORIES["gentle_turn"])
+    params = _params(A, B)
+    cloud = np.concatenate([xyzi[:, :3].astype(np.float64), np.ones((n, 1))], axis=1)
+    stamps = orc.pseudo_timestamps(cloud, T0, T1)
+    cols = [np.ascontiguousarray(cloud[:, j]) for j in range(4)]
+    staged = [np.empty(n) for _ in range(4)]
+    rc, st = ctx.deskew_f64cols(cols[0], cols[1], cols[2], cols[3], stamps, T0, T1, params, *staged)
+    assert rc == capi.OK and st.variant == 5 and not capi.host_pool_owns(cols[0])
+    pin = capi.PooledArray((4, n))      # one column-major N x 4 block, like Eigen::MatrixX4d
+    pst = capi.PooledArray((n,))
+    pout = capi.PooledArray((4, n))
+    try:
+        pin.a[:] = np.stack(cols)
+        pst.a[:] = stamps
+        pout.a[:] = -7.0
+        assert capi.host_pool_owns(pin.a) and capi.host_pool_owns(pout.a[2])
+        rc, st = ctx.deskew_f64cols(pin.a[0], pin.a[1], pin.a[2], pin.a[3], pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], pout.a[3])
+        assert rc == capi.OK and st.n_out_of_range == 0 and st.n_launches == 1
+        for j in range(4):
+            assert np.array_equal(pout.a[j].view(np.uint64), staged[j].view(np.uint64)), j
+        want = orc.motion_compensate_frame(cloud, stamps, T0, A, T1, B, TREQ)[2]
+        assert util.rel_point_error(pout.a[:3].T, want[:, :3]).max() <= 5e-9
+        # the reference's assert (trajectory_interpolation.cpp:32) on the in-place route
+        pst.a[[5, n // 2]] = [T0 - 1e-6, T1 + 1.0]
+        rc, st = ctx.deskew_f64cols(pin.a[0], pin.a[1], pin.a[2], pin.a[3], pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], pout.a[3],
+                                    raise_on_range=False)
+        assert rc == capi.ERR_TIME_OUT_OF_RANGE and st.n_out_of_range == 2 and np.isnan(pout.a[0][[5, n // 2]]).all()
+        pst.a[:] = stamps
+        rc, st = ctx.deskew_f64cols(pin.a[0], pin.a[1], pin.a[2], pin.a[3], pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], pout.a[3])
+        assert rc == capi.OK and st.n_out_of_range == 0, "the flag word must be cleared between calls"
+        # pseudo stamps in place
+        ctx.pseudo_timestamps_f64(pin.a[0], pin.a[1], T0, T1, pst.a)
+        ref = np.empty(n)
+        ctx.pseudo_timestamps_f64(cols[0], cols[1], T0, T1, ref)
+        assert np.array_equal(pst.a.view(np.uint64), ref.view(np.uint64))
+    finally:
+        pin.close(); pst.close(); pout.close()
+
+
 def test_f64cols_host_route_large_frame_is_pipelined_and_identical(torch_mod, ctx):
     """Host buffers of >= 2^20 points take the duplex chunk pipeline (upload of chunk k+1, kernel, download of chunk k in
     parallel, a helper thread for the downloads): same bits as the device-resident call on the same data, a column of ones is
@@ -839,6 +885,89 @@ def test_single_frame_entry_point_is_graph_capturable(ctx, torch_mod):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(d_out.view(torch.int32), ref.view(torch.int32))
+    finally:
+        ctx.set_stream(None)
+
+
+def test_small_batches_travel_in_kernel_arguments_same_bits(torch_mod, ctx, monkeypatch):
+    """Round 3: batches of at most 16 device-resident frames carry their tables in the kernel arguments (no table upload, no host
+    wait).  Same kernel body, same records -> the SAME bits and the same per-point frame indices as the device-table route,
+    which a second context created with KMC_NO_INLINE_TABLES=1 still takes -- for ragged, empty, tile-straddling and huge frames
+    (the inline coarse table grows its chunk size with the batch) and for every tier."""
+    torch = torch_mod
+    rng = np.random.default_rng(77)
+    monkeypatch.setenv("KMC_NO_INLINE_TABLES", "1")
+    table_ctx = capi.Context(0)
+    monkeypatch.delenv("KMC_NO_INLINE_TABLES")
+    try:
+        for c in (ctx, table_ctx):
+            c.set_stream(torch.cuda.current_stream().cuda_stream)
+        pool = torch.empty((6_000_000, 4), dtype=torch.float32, device="cuda")
+        ctx.synth_points(pool, pool.shape[0], 4242)
+        for case in range(40):
+            nf = int(rng.integers(1, 17))
+            kind = rng.integers(0, 5, size=nf)
+            sizes = np.where(kind == 0, 0, np.where(kind == 1, rng.integers(1, 200, size=nf), np.where(kind == 2, 64 * rng.integers(1, 300, size=nf),
+                             np.where(kind == 3, rng.integers(1000, 40_000, size=nf), rng.integers(100_000, 370_000, size=nf)))))
+            offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+            n = int(offsets[-1])
+            if n == 0:
+                continue
+            yaw = [0.03, 0.6, 2.0, 5.0][case % 4]  # series3 / series5 / wide / any-angle
+            params = [capi.FrameParams.make([1.0 + 0.1 * f, 0.02, -0.01, 0.001 * f, -0.002, yaw * (1 - 0.02 * f)], float(rng.uniform(0, 1))) for f in range(nf)]
+            shift = int(rng.integers(0, 64))  # any 16-byte offset of the sub-range
+            outs, idxs, sts = [], [], []
+            for c in (ctx, table_ctx):
+                d_out = torch.full((n + 128, 4), 7.0, dtype=torch.float32, device="cuda")
+                d_idx = torch.full((n + 128,), -1, dtype=torch.int32, device="cuda")
+                sts.append(c.deskew_batch_f32(pool[shift:shift + n], d_out[shift:shift + n], offsets, params, d_idx[shift:shift + n]))
+                outs.append(d_out)
+                idxs.append(d_idx)
+            torch.cuda.synchronize()
+            assert sts[0].variant == sts[1].variant == case % 4
+            assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), case
+            assert torch.equal(idxs[0], idxs[1]), case
+            want = (np.searchsorted(offsets, np.arange(n, dtype=np.uint64), side="right") - 1).astype(np.int32)
+            assert np.array_equal(idxs[0][shift:shift + n].cpu().numpy(), want), case
+            assert bool((outs[0][:shift] == 7.0).all()) and bool((outs[0][shift + n:] == 7.0).all()), case
+    finally:
+        table_ctx.close()
+
+
+def test_batched_entry_point_is_graph_capturable(ctx, torch_mod):
+    """A batch of at most 16 device-resident frames only enqueues ONE launch on the caller's stream (its tables are kernel arguments):
+    it can be captured into a HIP graph and replayed; the replay writes the same bits.  A larger batch needs a table upload and
+    says so instead of silently recording a launch that would read a recycled table."""
+    torch = torch_mod
+    nf, per = 16, 50_000
+    pts = capi.synth_points_host(nf * per, 987)
+    d_in = torch.from_numpy(pts).cuda()
+    d_out = torch.zeros_like(d_in)
+    d_idx = torch.zeros((nf * per,), dtype=torch.int32, device="cuda")
+    params = capi.params_array([capi.FrameParams.make([1.0 + 0.01 * f, 0.02, 0.0, 0.001, 0.0, 0.03], 0.25) for f in range(nf)])
+    offsets = np.arange(nf + 1, dtype=np.uint64) * per
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.deskew_batch_f32(d_in, d_out, offsets, params, d_idx)
+    torch.cuda.synchronize()
+    ref, ref_idx = d_out.clone(), d_idx.clone()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.stream(side):
+            ctx.set_stream(side.cuda_stream)
+            ctx.deskew_batch_f32(d_in, d_out, offsets, params, d_idx)
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                ctx.deskew_batch_f32(d_in, d_out, offsets, params, d_idx)
+                offs17 = np.arange(18, dtype=np.uint64) * 1000
+                with pytest.raises(capi.KmcError) as ei:
+                    ctx.deskew_batch_f32(d_in[:17000], d_out[:17000], offs17, [params[0]] * 17, None)
+                assert ei.value.status == capi.ERR_INVALID_ARG
+        d_out.zero_()
+        d_idx.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(d_out.view(torch.int32), ref.view(torch.int32)) and torch.equal(d_idx, ref_idx)
     finally:
         ctx.set_stream(None)
 

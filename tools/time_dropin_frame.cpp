@@ -1,5 +1,7 @@
 // time_dropin_frame.cpp -- latency of the literal drop-in call kmc::MotionCompensateFrame(Frame const&, Time) on the shipped KITTI
-// frame (f64 Eigen-layout cloud in pageable host memory, result by value), and of the f32 KITTI-layout call next to it.
+// frame (f64 Eigen-layout cloud in the drop-in's own containers, result by value), and of the f32 KITTI-layout call next to it.
+// The containers come from the C-ABI's page-locked pool (round 3), so the kernel works on them in place; KMC_HOST_POOL=0 in the
+// environment restores ordinary memory and the staged three-copy route for comparison.
 //   time_dropin_frame <golden_dir> [iterations=200]
 #include <chrono>
 #include <cstdio>
@@ -9,6 +11,7 @@
 
 #include "kitti_motion_compensation/data_io.hpp"
 #include "kitti_motion_compensation/motion_compensation.hpp"
+#include "kmc_hip.h"
 
 using namespace kmc;
 
@@ -40,6 +43,8 @@ int main(int argc, char** argv) {
   for (int i = 0; i < iters; ++i)
     hip::MotionCompensateKittiCloud(raw.data(), n, frame.T_start, frame.T_end, scan.stamp_start, scan.stamp_end, scan.stamp_middle, out.data());
   double const us32 = std::chrono::duration<double, std::micro>(clk::now() - t0).count() / iters;
+  bool const pooled = kmc_host_pool_owns(frame.scan.cloud.data(), sizeof(double)) != 0;
+  std::printf("route: %s\n", pooled ? "containers in the page-locked pool -> ONE kernel in place over the link" : "ordinary host memory -> staged copies (KMC_HOST_POOL=0 or no pool)");
   std::printf("%zu points: MotionCompensateFrame(Frame, Time) [f64, result by value] %.1f us/frame = %.1f M points/s;  "
               "hip::MotionCompensateKittiCloud [f32 KITTI layout] %.1f us/frame = %.1f M points/s  (checksum %.6f)\n",
               n, us64, n / us64, us32, n / us32, checksum + out[0]);
