@@ -16,6 +16,15 @@ frames x 8 000, rank r owning the contiguous frame range sharding.frame_range(80
 each rank's range, and reports it as the "configs3" object of the same JSON line (the headline stays configs[1] at every N,
 so the N = 1 line of a scaling sweep is the BENCH line).
 
+At N = 1 the same line also carries the secondary configurations as driver-observed legs, each with its time,
+GB/s, fraction of the 8 TB/s peak, kernel name and an oracle spot check outside the timing:
+  configs1_literal  BASELINE.json configs[1] literally: ONE 1 M-point frame per kmc_hip_deskew_f32 call -- in order on one stream,
+                    and over the context's four frame queues;
+  configs2_drive    configs[2]'s shape: a drive of 108 frames of ~121 k points in ONE batched launch, steady state;
+  nknot3            north_star's three bracketing poses used directly: 10 M-point frames through kmc_hip_deskew_traj_f32;
+  f64cols           the reference's own layout (Eigen column-major f64 + per-point stamps), 16 M points, 72 B per point.
+At N > 1 the line reports the slowest and the fastest rank's own rate next to the aggregate.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -115,6 +124,8 @@ def cpu_baseline(xyzi_sample, frame_meta, n_frames_sample, gpu_out_frame0):
                   "(reference op sequence incl. per-point Log/Exp), f64, 1 thread like the reference",
         "all_cores": {"cores": cores, "logical_cpus_visible": os.cpu_count(), "faithful_Mpts_s": round(b2, 3),
                       "hoisted_closed_form_Mpts_s": round(b3, 3)},
+        "note": "a plain-C restatement at -O3 -ffp-contract=off: probably FASTER than the Eigen build it stands in for (SURVEY.md 3.2 estimates "
+                "0.2-0.5 Mpts/s for the reference; Eigen + OpenCV are not in this image, so the reference itself cannot be timed: kind = port)",
     }, parity
 
 
@@ -134,7 +145,7 @@ def live_traffic(frames_per_step, points_per_frame, yaw_per_frame, calibration):
     for counter, factor in (("FETCH_SIZE", calibration["fetch_correction_factor"]), ("WRITE_SIZE", calibration["write_correction_factor"])):
         out = tempfile.mkdtemp(prefix="kmc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--no-configs3", "--frames-per-step", str(frames_per_step),
+               "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--no-configs3", "--no-legs", "--frames-per-step", str(frames_per_step),
                "--points-per-frame", str(points_per_frame), "--yaw-per-frame", str(yaw_per_frame)]
         env = dict(os.environ)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "KMC_BENCH_FORCE_DIST"):
@@ -213,7 +224,7 @@ def run_configs3(capi, sharding, torch, ctx, dist, rank, world, dev, timed_frame
             (t_s, t_m, t_e), oxs = work[f][1], work[f][2]
             oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
             rc, A, Bp = orc.make_frame_poses(oo[0], oo[1], oo[2], t_s, t_e)
-            ref = orc.deskew_xyzi_f32(pts, t_s, A, t_e, Bp, t_m, mode=orc.FAITHFUL)
+            ref = orc.deskew_xyzi_f32(pts, t_s, A, t_e, Bp, t_m, mode=orc.FAITHFUL, threads=max(1, orc.default_threads() // world))  # the ranks share the host's cores
             assert rc == orc.OK and ref["rc"] == orc.OK
             err = np.linalg.norm(got[:, :3] - ref["xyz_f64"], axis=1) / np.maximum(np.linalg.norm(ref["xyz_f64"], axis=1), 1e-3)
             assert np.array_equal(got[:, 3].view(np.uint32), pts[:, 3].view(np.uint32)), "configs3: intensity not bit-identical"
@@ -221,6 +232,189 @@ def run_configs3(capi, sharding, torch, ctx, dist, rank, world, dev, timed_frame
         assert worst <= 1e-5, f"configs3 parity violated on rank {rank}: {worst:.3e}"
         res["parity_err"] = worst
     return res
+
+
+def _frac(gbps):
+    return round(gbps / HBM_PEAK_GBPS, 4)
+
+
+def run_secondary_legs(capi, torch, ctx, dev, check):
+    """N = 1 only: the secondary configurations as legs of the ONE bench line.  Every leg: device-resident inputs generated before its
+    timed region, HIP events on the launch stream around it (kmc_hip_timer_begin / _end), rotating buffers beyond the 256 MiB
+    Infinity Cache, and -- outside the timing -- an oracle spot check of what the GPU wrote."""
+    out = {}
+    orc = None
+    if check:
+        from oracle import oracle as orc
+
+    def timed(fn, iters, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ctx.timer_begin()
+        for _ in range(iters):
+            fn()
+        return ctx.timer_end() / iters  # ms per call
+
+    def rel_err(got, ref):
+        return float((np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-3)).max())
+
+    # ---- configs1_literal: one 1 M-point frame per call ---------------------------------------------------------------------
+    n = 1_000_000
+    work = make_workload(capi, 1, 0)[0]
+    prm, (t0, tm, t1), oxs = work
+    bufs = []
+    for k in range(24):  # 24 x (16 + 16) MB = 768 MB: every frame comes from HBM
+        a = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        ctx.synth_points(a, n, SEED + 0xC1000000 + k)
+        bufs.append((a, torch.empty_like(a)))
+    state = {"k": 0}
+
+    def one_frame():
+        a, b = bufs[state["k"] % len(bufs)]
+        state["k"] += 1
+        ctx.deskew_f32(a, b, prm)
+
+    # the frames are handed to the C-ABI 480 at a time (kmc_hip_deskew_frames_f32) so that the C loop, not Python's ~8 us per
+    # ctypes call, sets the pace; the same entry point with one queue is the strictly-in-order stream of launches
+    pack = ctx.prepare_frames([bufs[k % len(bufs)] for k in range(480)], [prm] * 480)
+    ctx.set_frame_queues(1)
+    ms_order = timed(lambda: ctx.deskew_frames_f32(pack), 6, 2) / 480
+    ctx.set_frame_queues(4)
+    ms_q4 = timed(lambda: ctx.deskew_frames_f32(pack), 6, 2) / 480
+    ms_q4_calls = timed(one_frame, 960, 48)  # one kmc_hip_deskew_f32 call per frame from Python, queues on (host-bound: ~8 us per ctypes call)
+    ctx.set_frame_queues(1)
+    leg = {
+        "workload": "configs[1] literally: one synthetic 1 M-point frame per kmc_hip_deskew_f32 call, 24 rotating buffer pairs (768 MB)",
+        "kernel": "kmc_dev::deskew_frame_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64>",
+        "in_order": {"us_per_frame": round(ms_order * 1e3, 3), "Mpts_s": round(n / ms_order / 1e3, 1), "GBps": round(32 * n / ms_order / 1e6, 1),
+                     "frac": _frac(32 * n / ms_order / 1e6), "note": "one stream (kmc_hip_set_frame_queues(ctx, 1)): the chip drains between two launches"},
+        "four_frame_queues": {"us_per_frame": round(ms_q4 * 1e3, 3), "Mpts_s": round(n / ms_q4 / 1e3, 1), "GBps": round(32 * n / ms_q4 / 1e6, 1),
+                              "frac": _frac(32 * n / ms_q4 / 1e6),
+                              "note": "kmc_hip_deskew_frames_f32, 480 frames per call over 4 HIP streams of the context (one fork from the context's stream per call, one join)"},
+        "four_frame_queues_one_call_per_frame_from_python": {"us_per_frame": round(ms_q4_calls * 1e3, 3), "GBps": round(32 * n / ms_q4_calls / 1e6, 1),
+                                                             "note": "kmc_hip_deskew_f32 per frame through ctypes: the host's ~8 us per call is the limit, not the device"},
+    }
+    if check:
+        pts, got = bufs[0][0][:100_000].cpu().numpy(), bufs[0][1][:100_000].cpu().numpy()
+        oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
+        rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
+        ref = orc.deskew_xyzi_f32(pts, t0, A, t1, B, tm, mode=orc.FAITHFUL)
+        assert rc == orc.OK and ref["rc"] == orc.OK
+        leg["parity"] = {"max_rel_err": rel_err(got[:, :3], ref["xyz_f64"]), "bar": 1e-5, "points": 100_000}
+        assert leg["parity"]["max_rel_err"] <= 1e-5, leg
+    out["configs1_literal"] = leg
+    del bufs, pack
+
+    # ---- configs2_drive: 108 frames of ~121 k points, one batched launch ---------------------------------------------------------
+    rng = np.random.default_rng(SEED + 2)
+    sizes = np.clip(rng.normal(121_000, 3_000, size=108), 90_000, 140_000).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    ntot = int(offs[-1])
+    dwork = make_workload(capi, 108, 0, yaw_per_frame=0.03)  # a turning drive: every frame its own poses through the whole host pre-step
+    dparams = capi.params_array([w[0] for w in dwork])
+    sets = []
+    for k in range(3):
+        a = torch.empty((ntot, 4), dtype=torch.float32, device=dev)
+        ctx.synth_points(a, ntot, SEED + 0xC2000000 + k)
+        sets.append((a, torch.empty_like(a)))
+    state["k"] = 0
+
+    def drive():
+        a, b = sets[state["k"] % 3]
+        state["k"] += 1
+        ctx.deskew_batch_f32(a, b, offs, dparams, None)
+
+    ms = min(timed(drive, 300, 300 if r == 0 else 0) for r in range(3))
+    leg = {"workload": f"configs[2] shape: a drive of 108 frames ~N(121 k, 3 k) points ({ntot} points) in ONE batched launch, 3 rotating buffer sets, best of 3 x 300 launches",
+           "kernel": "kmc_dev::deskew_batch_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64>",
+           "us_per_drive": round(ms * 1e3, 2), "Mpts_s": round(ntot / ms / 1e3, 1), "GBps": round(32 * ntot / ms / 1e6, 1), "frac": _frac(32 * ntot / ms / 1e6)}
+    if check:
+        f = 57
+        s0, s1 = int(offs[f]), int(offs[f + 1])
+        a, b = sets[(state["k"] - 1) % 3]
+        pts, got = a[s0:s1].cpu().numpy(), b[s0:s1].cpu().numpy()
+        (t0, tm, t1), oxs = dwork[f][1], dwork[f][2]
+        oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
+        rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
+        ref = orc.deskew_xyzi_f32(pts, t0, A, t1, B, tm, mode=orc.FAITHFUL)
+        assert rc == orc.OK and ref["rc"] == orc.OK
+        leg["parity"] = {"max_rel_err": rel_err(got[:, :3], ref["xyz_f64"]), "bar": 1e-5, "points": int(s1 - s0), "frame": f}
+        assert leg["parity"]["max_rel_err"] <= 1e-5, leg
+    out["configs2_drive"] = leg
+    del sets
+
+    # ---- nknot3: three bracketing poses used directly, 10 M-point frames ---------------------------------------------------------
+    n = 10_000_000
+    Tz = 47072.0
+    knot_t = [Tz + 0.05, Tz + 0.15, Tz + 0.25]
+    P = []
+    for k in range(3):
+        M = np.eye(4)[:3].copy()
+        c, s_ = np.cos(0.03 * k), np.sin(0.03 * k)
+        M[:2, :2] = [[c, -s_], [s_, c]]
+        M[:, 3] = [1.3 * k, 0.02 * k * k, 0.0]
+        P.append(M)
+    P = np.stack(P)
+    bufs = []
+    for k in range(3):
+        a = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        ctx.synth_points(a, n, SEED + 0xC4000000 + k)
+        bufs.append((a, torch.empty_like(a)))
+    state["k"] = 0
+
+    def traj():
+        a, b = bufs[state["k"] % 3]
+        state["k"] += 1
+        ctx.deskew_traj_f32(a, b, knot_t, P, Tz + 0.10, Tz + 0.20, Tz + 0.15, None)
+
+    ms = timed(traj, 120, 12)
+    leg = {"workload": "north_star's three bracketing poses used directly (piecewise geodesic, 2 segments): one synthetic 10 M-point frame per kmc_hip_deskew_traj_f32 call, 3 rotating buffer pairs",
+           "kernel": "kmc_dev::deskew_traj_f32<series3, nt loads + nt|sc1 stores, inline records> (no LDS: records through scalar loads)",
+           "us_per_frame": round(ms * 1e3, 2), "Mpts_s": round(n / ms / 1e3, 1), "GBps": round(32 * n / ms / 1e6, 1), "frac": _frac(32 * n / ms / 1e6)}
+    if check:
+        sel = slice(4_950_000, 5_050_000)  # around mid-scan: both segments
+        a, b = bufs[(state["k"] - 1) % 3]
+        pts, got = a[sel].cpu().numpy(), b[sel].cpu().numpy()
+        poses = [orc.Affine.from_Rt(M[:, :3], M[:, 3]) for M in P]
+        ref = orc.deskew_xyzi_f32_traj(pts, Tz + 0.10, Tz + 0.20, knot_t, poses, Tz + 0.15)
+        assert ref["rc"] == orc.OK
+        leg["parity"] = {"max_rel_err": rel_err(got[:, :3], ref["xyz_f64"]), "bar": 1e-5, "points": 100_000,
+                         "segments_seen": sorted(set(ref["bracket_by_time"].tolist()))}
+        assert leg["parity"]["max_rel_err"] <= 1e-5, leg
+    out["nknot3"] = leg
+    del bufs
+
+    # ---- f64cols: the reference's own layout, device resident ----------------------------------------------------------------------
+    n = 16_000_000
+    turn = capi.FrameParams.make([1.3, 0.05, -0.02, 0.002, -0.004, 0.03], 0.5)
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED)
+    cols = [torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 80 - 40 for _ in range(3)]
+    w = torch.ones(n, dtype=torch.float64, device=dev)
+    stamps = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 0.1 + 100.0
+    outs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)]
+    ctx.enable_timing(True)  # per-call kernel time: the call itself ends with a stream sync (the out-of-range verdict is part of its result)
+    for _ in range(3):
+        ctx.deskew_f64cols(cols[0], cols[1], cols[2], w, stamps, 100.0, 100.1, turn, *outs)
+    ms = float(np.median([ctx.deskew_f64cols(cols[0], cols[1], cols[2], w, stamps, 100.0, 100.1, turn, *outs)[1].kernel_ms for _ in range(20)]))
+    ctx.enable_timing(False)
+    leg = {"workload": "the reference's layout: four f64 columns (Eigen::MatrixX4d, column-major) + f64 per-point stamps, 16 M points, device resident; 40 B read + 32 B written per point",
+           "kernel": "kmc_dev::deskew_f64cols (one wave per workgroup, two points per lane)", "bytes_per_point": 72,
+           "us_per_call": round(ms * 1e3, 2), "Mpts_s": round(n / ms / 1e3, 1), "GBps": round(72 * n / ms / 1e6, 1), "frac": _frac(72 * n / ms / 1e6)}
+    if check:
+        m = 50_000
+        cl = np.stack([c[:m].cpu().numpy() for c in cols] + [np.ones(m)], axis=1)
+        st = stamps[:m].cpu().numpy()
+        A = orc.se3_exp([0.0] * 6)
+        B = orc.se3_exp(list(turn.twist))
+        rc, nbad, want = orc.motion_compensate_frame(cl, st, 100.0, A, 100.1, B, 100.05)
+        got = np.stack([o[:m].cpu().numpy() for o in outs[:3]], axis=1)
+        assert rc == orc.OK
+        leg["parity"] = {"max_rel_err": rel_err(got, want[:, :3]), "bar": 1e-11, "points": m}
+        assert leg["parity"]["max_rel_err"] <= 1e-11, leg
+    out["f64cols"] = leg
+    return out
 
 
 def main():
@@ -241,6 +435,7 @@ def main():
     ap.add_argument("--no-configs3", action="store_true", help="skip the configs[3] leg (10 M-point frames, frame-sharded)")
     ap.add_argument("--configs3-frames", type=int, default=960, help="timed frames per rank of the configs[3] leg")
     ap.add_argument("--configs3-frames-per-launch", type=int, default=C3_FRAMES_PER_LAUNCH)
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (configs1_literal, configs2_drive, nknot3, f64cols; N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
     ap.add_argument("--rotate", type=int, default=1, help="number of in/out buffer pairs cycled through by the steps")
@@ -345,10 +540,19 @@ def main():
         c3 = run_configs3(capi, sharding, torch, ctx, dist, rank, world, dev, args.configs3_frames, args.configs3_frames_per_launch,
                           check=not args.no_cpu_baseline)
 
-    # the job's ONLY collective (RCCL when N > 1): one all_gather of every rank's counters; SUM of points, MAX of times
-    sums, maxes = sharding.reduce_counters(
+    # ---- secondary legs (N = 1: the BENCH line), each with its own timed region and oracle spot check ----
+    legs = None
+    if world == 1 and dist is None and headline and not args.no_legs:
+        torch.cuda.empty_cache()
+        legs = run_secondary_legs(capi, torch, ctx, dev, check=not args.no_cpu_baseline)
+
+    # the job's ONLY data collective (RCCL when N > 1): one all_gather of every rank's counters; SUM of points, MAX of times.
+    # (The four dist.barrier() calls around the two timed regions are collectives too -- one-element all-reduces on the nccl
+    # backend -- and are what the timing contract asks for.)
+    sums, maxes, rows = sharding.reduce_counters(
         dist, reduce_dev, [float(n * args.steps), c3["points"] if c3 else 0.0],
-        [wall, ev_ms * 1e-3, c3["wall"] if c3 else 0.0, c3["ev_s"] if c3 else 0.0, c3["parity_err"] if c3 else 0.0])
+        [wall, ev_ms * 1e-3, c3["wall"] if c3 else 0.0, c3["ev_s"] if c3 else 0.0, c3["parity_err"] if c3 else 0.0,
+         torch.cuda.max_memory_allocated(dev) / 2**30], with_rows=True)
     pts_total, t_max = sums[0], maxes[0]
 
     if rank == 0:
@@ -391,7 +595,7 @@ def main():
                              f"NOT the headline -- configs[3]-shaped stream: synthetic {POINTS_PER_FRAME}-point frames, yaw {args.yaw_per_frame} rad per frame; ")
                             + f"{F} distinct frames per step in one batched launch (per GPU), device-resident",
                 "points_per_frame": POINTS_PER_FRAME, "frames_per_step_per_gpu": F, "points_per_step_per_gpu": n,
-                "parallelism": f"frame-sharded x{world} (no data-path collective)",
+                "parallelism": f"frame-sharded x{world} (no data-path collective; one all_gather of the counters + the contract's four barriers)",
                 "kernel": "kmc_dev::deskew_batch_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64>, one 64-point tile (one wave) per workgroup", "device": info["name"], "arch": info["arch"],
             },
             "roofline": {
@@ -401,6 +605,16 @@ def main():
                 "kernel_ms_avg_is": "HIP-event time of the timed region on the launch stream / steps (one launch per step)",
             },
         }
+        out["peak_device_GiB_per_rank"] = round(maxes[5], 2)  # torch's allocator high-water mark, MAX over the ranks (8 ranks of the default run: ~8 x 15.4 GiB of the 288)
+        if world > 1:  # a straggler is invisible in SUM / MAX: every rank's own rate (its points / its own wall time of the timed region)
+            rates = [r[0] / r[2] / 1e6 for r in rows]  # row = [points, c3 points | wall, ev_s, c3 wall, c3 ev_s, c3 parity]
+            out["per_rank"] = {"Mpts_s_min": round(min(rates), 1), "Mpts_s_max": round(max(rates), 1), "Mpts_s": [round(v, 1) for v in rates],
+                               "slowest_rank": int(np.argmin(rates)), "note": "each rank's points / its own wall time between the two barriers"}
+            if c3:
+                rates3 = [r[1] / r[4] / 1e6 for r in rows]  # c3 points / c3 wall
+                out["per_rank"]["configs3_Mpts_s_min"] = round(min(rates3), 1)
+                out["per_rank"]["configs3_Mpts_s_max"] = round(max(rates3), 1)
+                out["per_rank"]["configs3_Mpts_s"] = [round(v, 1) for v in rates3]
         if c3:
             t3 = maxes[2]
             out["configs3"] = {
@@ -418,6 +632,10 @@ def main():
                 "parity_first_last_frame_per_rank": ({"max_rel_err": maxes[4], "bar": 1e-5, "oracle": "FAITHFUL, whole 10 M-point frames"}
                                                      if not args.no_cpu_baseline else None),
             }
+        if legs:
+            out.update(legs)
+        out["config"]["kitti_root"] = ("present (not used by the synthetic headline; tests/test_configs_at_size.py and tools/measure_configs.py run the real drives)"
+                                        if os.environ.get("KITTI_ROOT") and os.path.isdir(os.environ["KITTI_ROOT"]) else "absent: every workload is a synthetic twin")
         if cpu_sample is not None:
             k_cpu, sample, gpu_frame0 = cpu_sample
             out["cpu_baseline"], out["parity_spot_check"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k_cpu, gpu_frame0)

@@ -209,7 +209,18 @@ class VectorXd {
   detail::Storage d_;
 };
 
+class MatrixX4d;
+namespace detail {
+void set_homogeneous(MatrixX4d& m, bool value);  // library-internal: the library has just written the column itself
+}
+
 // N x 4, column-major (Eigen::MatrixX4d).  Homogeneous points: the last column is 1 (data_types.hpp:13-14).
+//
+// The matrix remembers whether its last column is KNOWN to be all ones (every cloud the reference loads is, data_io.cpp:130, and
+// MotionCompensateFrame passes the column through, motion_compensation.cpp:13): a Pointcloud with that knowledge lets the device
+// skip the column -- 16 of the 72 bytes a point costs on the link.  The knowledge is established only by detect_homogeneous()
+// (which looks at every element) or by the library for clouds it has produced itself, it is copied with the matrix, and ANY
+// non-const access (operator(), row(), col(), data()) drops it, so it can never be stale.
 class MatrixX4d {
  public:
   class RowRef {
@@ -237,19 +248,34 @@ class MatrixX4d {
   }
   Index rows() const { return n_; }
   Index cols() const { return 4; }
-  double& operator()(Index i, Index j) { return d_[static_cast<std::size_t>(j * n_ + i)]; }
+  double& operator()(Index i, Index j) { homogeneous_ = false; return d_[static_cast<std::size_t>(j * n_ + i)]; }
   double operator()(Index i, Index j) const { return d_[static_cast<std::size_t>(j * n_ + i)]; }
-  RowRef row(Index i) { return RowRef(d_.data(), n_, i); }
+  RowRef row(Index i) { homogeneous_ = false; return RowRef(d_.data(), n_, i); }
   Vector4d row(Index i) const { return {(*this)(i, 0), (*this)(i, 1), (*this)(i, 2), (*this)(i, 3)}; }
-  double* col(Index j) { return d_.data() + j * n_; }
+  double* col(Index j) { homogeneous_ = false; return d_.data() + j * n_; }
   double const* col(Index j) const { return d_.data() + j * n_; }
-  double* data() { return d_.data(); }
+  double* data() { homogeneous_ = false; return d_.data(); }
   double const* data() const { return d_.data(); }
+  // true only if the last column is known to be all ones (see above)
+  bool is_homogeneous() const { return homogeneous_; }
+  // looks at every element of the last column; remembers and returns whether all of them are exactly 1.0
+  bool detect_homogeneous() {
+    double const* w = d_.data() + 3 * n_;
+    bool ones = true;
+    for (Index i = 0; i < n_ && ones; ++i) ones = w[i] == 1.0;
+    homogeneous_ = ones;
+    return ones;
+  }
 
  private:
+  friend void detail::set_homogeneous(MatrixX4d& m, bool value);
   Index n_ = 0;
   detail::Storage d_;
+  bool homogeneous_ = false;
 };
+namespace detail {
+inline void set_homogeneous(MatrixX4d& m, bool value) { m.homogeneous_ = value; }
+}
 using Pointcloud = MatrixX4d;
 
 struct Oxts {  // data_types.hpp:35-49

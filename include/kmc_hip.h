@@ -201,8 +201,10 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip, tools/fq_probe.hip).
  *   - queues = 1 (default): every call on the context's stream, strictly in order (the behaviour of ABI version 1).
  *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls -- and kmc_hip_deskew_traj_f32(KMC_MEM_DEVICE) calls with
- *     at most four knots -- are NOT ordered with each other.  EVERY queued frame waits (device-side) for what has been issued on
- *     the context's stream up to its call -- its producers --, so the usual loop "produce frame k on the stream, deskew it" is safe;
+ *     at most four knots -- are NOT ordered with each other.  EVERY queued frame is ordered behind what has been issued on
+ *     the context's stream up to its call -- its producers --, so the usual loop "produce frame k on the stream, deskew it" is safe
+ *     (the library looks at the stream at every call: an idle stream needs no wait, a busy one gets an event record + a device-side
+ *     wait, which costs about as much as the overlap gains -- hand frames that are ready to kmc_hip_deskew_frames_f32 instead);
  *     what is NOT ordered is later work on the context's stream against frames still in flight: a producer that OVERWRITES a buffer
  *     a queued frame reads or writes must follow a join.  kmc_hip_frame_queue_join() makes the context's stream wait for every
  *     frame issued so far (device-side, the host does not block).  Every other entry point, kmc_hip_synchronize(),
@@ -214,8 +216,10 @@ int kmc_hip_set_frame_queues(kmc_ctx* ctx, int queues);
 int kmc_hip_set_frame_queue_order(kmc_ctx* ctx, int after_producers);
 int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
- * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues (four for this call if they are off) and joined:
- * the call as a whole is ordered on the context's stream like any other.  Same per-point results as kmc_hip_deskew_f32. */
+ * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues -- the count the caller chose with
+ * kmc_hip_set_frame_queues (1 = strictly in order on the context's stream), four for this call if it never chose -- and joined: the
+ * call as a whole is ordered on the context's stream like any other, all its frames behind everything issued before it (ONE fork for
+ * the whole call: every input was handed over before the call).  Same per-point results as kmc_hip_deskew_f32. */
 int kmc_hip_deskew_frames_f32(kmc_ctx* ctx, const float* const* xyzi_in, float* const* xyzi_out, const uint64_t* n_points,
                               const kmc_frame_params* params, uint32_t n_frames, kmc_stats* out_stats);
 

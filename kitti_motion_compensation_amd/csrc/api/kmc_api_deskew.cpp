@@ -2,6 +2,7 @@
 //
 // Everything per-point goes through the C-ABI (libkmc_hip.so).  No CPU fallback: without a HIP device the first call
 // throws std::runtime_error.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -133,16 +134,23 @@ Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time) 
   if (frame.scan.timestamps.size() != n) throw std::invalid_argument("kmc::MotionCompensateFrame: timestamps.size() != cloud.rows()");
   kmc_frame_params const p = detail::frame_params(frame.T_start, frame.T_end, frame.scan.stamp_start, frame.scan.stamp_end, requested_time,
                                                   "kmc::MotionCompensateFrame");
-  Pointcloud out{MatrixX4d::Uninitialized(n)};  // every element is written by the download below
+  Pointcloud out{MatrixX4d::Uninitialized(n)};  // every element is written below
   if (n == 0) return out;
   kmc_ctx* c = detail::thread_context();
   kmc_stats st;
   Pointcloud const& in = frame.scan.cloud;
-  int const rc = kmc_hip_deskew_f64cols(c, in.col(0), in.col(1), in.col(2), in.col(3), frame.scan.timestamps.data(), static_cast<std::uint64_t>(n),
-                                        frame.scan.stamp_start, frame.scan.stamp_end, &p, out.col(0), out.col(1), out.col(2), out.col(3),
-                                        KMC_MEM_HOST, &st);
+  // A cloud whose homogeneous column is KNOWN to be all ones (every cloud the loaders produce, data_io.cpp:130): the device neither
+  // reads the column nor writes it back -- Affine3d * (x, y, z, 1) needs no w, and the output's column is filled with ones here,
+  // on the host, which costs a tenth of what the two transfers cost on the link.
+  bool const ones = in.is_homogeneous();
+  double* const ox = out.col(0);
+  if (ones) std::fill(ox + 3 * n, ox + 4 * n, 1.0);
+  int const rc = kmc_hip_deskew_f64cols(c, in.col(0), in.col(1), in.col(2), ones ? nullptr : in.col(3), frame.scan.timestamps.data(),
+                                        static_cast<std::uint64_t>(n), frame.scan.stamp_start, frame.scan.stamp_end, &p, ox, ox + n, ox + 2 * n,
+                                        ones ? nullptr : ox + 3 * n, KMC_MEM_HOST, &st);
   if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::MotionCompensateFrame");
   if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_f64cols", c);
+  detail::set_homogeneous(out, ones);
   return out;
 }
 

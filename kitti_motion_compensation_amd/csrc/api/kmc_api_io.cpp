@@ -133,6 +133,7 @@ std::tuple<Pointcloud, VectorXd> KittiPclLoader::LoadPointcloud(Path const& file
     cloud(i, 3) = 1.0;  // homogeneous component
     intensities(i) = raw[4 * i + 3];
   }
+  detail::set_homogeneous(cloud, true);  // the loop above has just written the ones
   return {cloud, intensities};
 }
 

@@ -127,6 +127,7 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
   const bool down_w = ow != nullptr;
   hipStream_t s_up = c->pipe[0], s_run = c->pipe[1], s_down = c->pipe[2];
   KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), s_run));
+  c->counter_dirty = true;
 
   // chunks whose kernel-done event has been recorded; the downloader sleeps on the condition variable between them
   std::mutex mu;
@@ -319,12 +320,17 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
   KMC_ENTER(c);
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  // the context's setting if frame queues are on, else four for this call: that is the point of handing over several frames
+  // the context's setting if the caller has chosen one (kmc_hip_set_frame_queues, 1 = strictly in order), else four for this
+  // call: that is the point of handing over several frames
   const int saved = c->fq_count;
-  if (saved < 2) {
+  const bool saved_explicit = c->fq_explicit, saved_ordered = c->fq_ordered;
+  if (!saved_explicit) {
     const int rc_set = kmc_hip_set_frame_queues(c, kmc_ctx::kMaxFrameQueues);
     if (rc_set != KMC_OK) return rc_set;
   }
+  // every frame of THIS call was handed over before the call: one fork from the context's stream at its start orders all of them
+  // behind their producers, no per-frame event
+  c->fq_ordered = false;
   uint64_t total = 0;
   int tier_max = 0, rc = KMC_OK;
   for (uint32_t f = 0; f < n_frames && rc == KMC_OK; ++f) {
@@ -337,6 +343,8 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
   }
   const int rc_join = fq_join(c);  // `stream` waits for every frame: the call as a whole is ordered like any other
   c->fq_count = saved;
+  c->fq_explicit = saved_explicit;
+  c->fq_ordered = saved_ordered;
   if (rc != KMC_OK) return rc;
   if (rc_join != KMC_OK) return rc_join;
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
@@ -562,11 +570,18 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   }
   CallTimer tm(c);
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+  if (c->counter_dirty) KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+  c->counter_dirty = true;
   *c->h_flag = 0;  // the previous call has synchronized: nothing on the device still writes it
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-  hipLaunchKernelGGL(deskew_f64cols<0>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
+  if (mem_kind == KMC_MEM_HOST_MAPPED) {
+    // over the link: a few hundred persistent waves, each with its next tile's loads in flight while it stores the current one
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 127) / 128, (uint64_t)c->mapped_waves));
+    hipLaunchKernelGGL((deskew_f64cols<0, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
+  } else {
+    const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
+    hipLaunchKernelGGL((deskew_f64cols<0, false>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
+  }
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {
@@ -584,6 +599,8 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
   unsigned long long bad = 0;
   if (*(volatile uint32_t*)c->h_flag != 0) {  // cold: some stamp was out of range -> fetch the exact count
     KMC_HIP_TRY(c, hipMemcpy(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost));
+  } else {
+    c->counter_dirty = false;  // nobody touched the counter
   }
   if (st) { st->n_launches = 1; st->n_out_of_range = bad; }
   int rc = tm.end_call(st);

@@ -444,7 +444,8 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   rc = upload_traj(c, segs, kMaxSegments * sizeof(TrajSeg32), th.n_seg * sizeof(TrajSeg64));
   if (rc != KMC_OK) return rc;
-  KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+  if (c->counter_dirty) KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+  c->counter_dirty = true;
   *c->h_flag = 0;
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
@@ -466,6 +467,7 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   }
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (*(volatile uint32_t*)c->h_flag != 0) KMC_HIP_TRY(c, hipMemcpy(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost));  // cold
+  else c->counter_dirty = false;  // nobody touched the counter
   if (st) { st->n_launches = 1; st->n_out_of_range = bad; }
   rc = tm.end_call(st);
   if (rc != KMC_OK) return rc;

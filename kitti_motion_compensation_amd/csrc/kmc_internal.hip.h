@@ -40,6 +40,8 @@ struct kmc_ctx {
   bool no_inline_tables = false;  // testing / A-B hook (KMC_NO_INLINE_TABLES=1): small batches go through the device tables too
   // out-of-range counter (f64 path)
   unsigned long long* d_counter = nullptr;
+  bool counter_dirty = true;   // d_counter may be non-zero: the f64 entry points clear it only then (a memset per call costs ~5 us)
+  int mapped_waves = 128;      // persistent one-wave workgroups of the f64 kernel when it works on page-locked host memory (KMC_MAPPED_WAVES)
   uint32_t* h_flag = nullptr;  // page-locked word the f64 kernels raise when a stamp is out of range (read by the host after the sync: no D2H copy on the good path)
   // batch tables: a ring of slots, each one device buffer + one pinned staging buffer holding
   // [BatchRec x n_frames | coarse x (n_chunks + 1)], uploaded with ONE copy on a side stream so that the per-step host
@@ -82,6 +84,7 @@ struct kmc_ctx {
   // (hardware queues) so that consecutive, independent frames overlap instead of draining the chip between two launches
   static constexpr int kMaxFrameQueues = 4;
   int fq_count = 1;                  // 1 = off: every launch on `stream`
+  bool fq_explicit = false;          // the caller has chosen the count (kmc_hip_set_frame_queues), even if it chose 1
   int fq_next = 0;
   bool fq_forked = false;            // frames have been issued on the queues since the last join
   bool fq_ordered = true;            // every queued frame waits for what `stream` holds at its call (kmc_hip_set_frame_queue_order)

@@ -404,41 +404,84 @@ __device__ __forceinline__ void deskew_one_f64(double px, double py, double pz, 
 // At most 4 waves per SIMD on purpose: every wave streams nine columns, and with the 7 waves its 52 VGPRs would allow the
 // kernel is 2-3 % slower (189-196 us against 183-186 us per 16 M points, A/B on one box) -- more concurrent streams, more
 // DRAM page conflicts.
-template <int kInstance = 0>  // a template only so that the header can be included by several translation units
+// `bad_flag`: a page-locked host word raised together with the count, so that the host learns "nothing was out of range" from
+// its own memory after the stream sync instead of through a device-to-host copy (~20 us of fixed cost per call).
+struct F64Tile {  // the five input columns of one 128-point tile, two consecutive points per lane
+  v2d_u ts, vx, vy, vz, vw;
+};
+__device__ __forceinline__ F64Tile f64_tile_load(const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+                                                 const double* __restrict__ w, const double* __restrict__ stamps, uint64_t i) {
+  F64Tile t;
+  t.ts = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(stamps + i));
+  t.vx = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(x + i));
+  t.vy = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(y + i));
+  t.vz = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(z + i));
+  t.vw = (v2d_u){1.0, 1.0};
+  if (w) t.vw = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(w + i));
+  return t;
+}
+__device__ __forceinline__ uint32_t f64_tile_finish(const F64Tile& t, const FrameRec64& f, double* __restrict__ ox, double* __restrict__ oy,
+                                                    double* __restrict__ oz, double* __restrict__ ow, uint64_t i) {
+  v2d_u rx, ry, rz;
+  bool ok0, ok1;
+  double a, b, c;
+  deskew_one_f64(t.vx.x, t.vy.x, t.vz.x, t.vw.x, t.ts.x, f, a, b, c, ok0);
+  rx.x = a; ry.x = b; rz.x = c;
+  deskew_one_f64(t.vx.y, t.vy.y, t.vz.y, t.vw.y, t.ts.y, f, a, b, c, ok1);
+  rx.y = a; ry.y = b; rz.y = c;
+  __builtin_nontemporal_store(rx, reinterpret_cast<v2d_u*>(ox + i));
+  __builtin_nontemporal_store(ry, reinterpret_cast<v2d_u*>(oy + i));
+  __builtin_nontemporal_store(rz, reinterpret_cast<v2d_u*>(oz + i));
+  if (ow) __builtin_nontemporal_store(t.vw, reinterpret_cast<v2d_u*>(ow + i));
+  return (ok0 ? 0u : 1u) + (ok1 ? 0u : 1u);
+}
+__device__ __forceinline__ void f64_report_bad(uint32_t bad_count, uint32_t tid, unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag) {
+  if (__ballot(bad_count != 0)) {  // rare: count through a wave reduction, one atomic per wave
+    uint32_t total = bad_count;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (tid == 0) {
+      atomicAdd(n_bad, (unsigned long long)total);
+      if (bad_flag) __hip_atomic_store(bad_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// STREAMED = false: one tile per workgroup turn (device-resident columns: HBM-bound, the hardware dispatcher streams the tiles).
+// STREAMED = true: the columns are PAGE-LOCKED HOST memory and the kernel works on them over the link (KMC_MEM_HOST_MAPPED).  A few
+// hundred persistent waves each walk many tiles with the NEXT tile's loads issued before the current tile is computed and stored,
+// so that uploads and downloads overlap in time: launched like the device kernel (every wave loads its tile, then stores it, all
+// ~1000 waves of a KITTI frame at once) the link is used one direction after the other -- 148 us per 123 k-point frame against
+// ~110 us pipelined (profiles/NOTES.md).
+template <int kInstance = 0, bool STREAMED = false>  // kInstance: a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                      const double* __restrict__ z, const double* __restrict__ w,
                                                      const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
                                                      double* __restrict__ ox, double* __restrict__ oy,
                                                      double* __restrict__ oz, double* __restrict__ ow,
                                                      unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag) {
-  // `bad_flag`: a page-locked host word raised together with the count, so that the host learns "nothing was out of range" from
-  // its own memory after the stream sync instead of through a device-to-host copy (~20 us of fixed cost per call)
   constexpr uint64_t kTile = 128;  // points per wave
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + kTile - 1) / kTile;
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  const uint64_t n_full = n / kTile;  // tiles without a ragged end
+  if constexpr (STREAMED) {
+    uint64_t t = blockIdx.x;
+    F64Tile cur;
+    if (t < n_full) cur = f64_tile_load(x, y, z, w, stamps, t * kTile + 2 * (uint64_t)tid);
+    while (t < n_full) {
+      const uint64_t next = t + gridDim.x;
+      F64Tile nxt = cur;
+      if (next < n_full) nxt = f64_tile_load(x, y, z, w, stamps, next * kTile + 2 * (uint64_t)tid);  // in flight while `cur` is finished
+      f64_report_bad(f64_tile_finish(cur, f, ox, oy, oz, ow, t * kTile + 2 * (uint64_t)tid), tid, n_bad, bad_flag);
+      cur = nxt;
+      t = next;
+    }
+  }
+  for (uint64_t t = STREAMED ? n_full + blockIdx.x : blockIdx.x; t < n_tiles; t += gridDim.x) {  // STREAMED: only the ragged last tile is left
     const uint64_t i = t * kTile + 2 * (uint64_t)tid;
-    unsigned long long bad_lanes;
     uint32_t bad_count;
     if (i + 1 < n) {
-      const v2d_u ts = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(stamps + i));
-      const v2d_u vx = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(x + i));
-      const v2d_u vy = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(y + i));
-      const v2d_u vz = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(z + i));
-      v2d_u vw = {1.0, 1.0};
-      if (w) vw = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(w + i));
-      v2d_u rx, ry, rz;
-      bool ok0, ok1;
-      double a, b, c;
-      deskew_one_f64(vx.x, vy.x, vz.x, vw.x, ts.x, f, a, b, c, ok0);
-      rx.x = a; ry.x = b; rz.x = c;
-      deskew_one_f64(vx.y, vy.y, vz.y, vw.y, ts.y, f, a, b, c, ok1);
-      rx.y = a; ry.y = b; rz.y = c;
-      __builtin_nontemporal_store(rx, reinterpret_cast<v2d_u*>(ox + i));
-      __builtin_nontemporal_store(ry, reinterpret_cast<v2d_u*>(oy + i));
-      __builtin_nontemporal_store(rz, reinterpret_cast<v2d_u*>(oz + i));
-      if (ow) __builtin_nontemporal_store(vw, reinterpret_cast<v2d_u*>(ow + i));
-      bad_count = (ok0 ? 0u : 1u) + (ok1 ? 0u : 1u);
+      const F64Tile tl = f64_tile_load(x, y, z, w, stamps, i);
+      bad_count = f64_tile_finish(tl, f, ox, oy, oz, ow, i);
     } else if (i < n) {  // the odd last point
       const double pw = w ? w[i] : 1.0;
       double a, b, c;
@@ -450,15 +493,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
     } else {
       bad_count = 0;
     }
-    bad_lanes = __ballot(bad_count != 0);
-    if (bad_lanes) {  // rare: count through a wave reduction, one atomic per wave
-      uint32_t total = bad_count;
-      for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-      if (tid == 0) {
-        atomicAdd(n_bad, (unsigned long long)total);
-        if (bad_flag) __hip_atomic_store(bad_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
+    f64_report_bad(bad_count, tid, n_bad, bad_flag);
   }
 }
 

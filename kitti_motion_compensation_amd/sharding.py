@@ -1,9 +1,10 @@
 """Frame-range sharding for the one-process-per-GPU launch.
 
 The deskew path shards trivially: points within a frame are independent and frames are independent given their own
-(T_start, T_end).  A drive is split into CONTIGUOUS frame ranges, one per rank; no point data ever crosses GPUs and the
-only collective of a job is ONE all_gather of the throughput counters (RCCL on the GPU box, gloo in the CPU
-tests).  Plumbing only -- no compute here.
+(T_start, T_end).  A drive is split into CONTIGUOUS frame ranges, one per rank; no point data ever crosses GPUs.  The
+collectives of a job: ONE all_gather of the throughput counters (RCCL on the GPU box, gloo in the CPU tests) -- plus, in
+bench.py, the four barriers the timing contract asks for around its two timed regions (on the nccl backend a barrier is a
+one-element all-reduce).  Plumbing only -- no compute here.
 """
 from __future__ import annotations
 
@@ -77,23 +78,34 @@ def make_batches(frame_sizes: Sequence[int], begin: int, end: int, max_points: i
         i = j
 
 
-def reduce_counters(dist, device, sums: Sequence[float], maxes: Sequence[float]):
-    """The job's ONLY collective: every rank contributes one small vector, ONE all_gather (RCCL on the GPU box, gloo on CPU;
-    ~100 bytes per rank: latency-bound, link bandwidth is irrelevant); SUM over the first block, MAX over the second, computed
-    identically on every rank.  `dist` is torch.distributed or None for a single process.  -> (sums, maxes) as float lists."""
-    sums = [float(v) for v in sums]
-    maxes = [float(v) for v in maxes]
+def gather_counters(dist, device, values: Sequence[float]):
+    """ONE all_gather of a small vector per rank (RCCL on the GPU box, gloo on CPU; ~100 bytes per rank: latency-bound, link
+    bandwidth is irrelevant).  -> rows[r] = rank r's vector, identical on every rank.  `dist` is torch.distributed or None for a
+    single process."""
+    values = [float(v) for v in values]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return sums, maxes
+        return [values]
     import torch
 
     world = dist.get_world_size()
-    mine = torch.tensor(sums + maxes, dtype=torch.float64, device=device)
+    mine = torch.tensor(values, dtype=torch.float64, device=device)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
-    everyone = torch.stack(parts).cpu()
+    return torch.stack(parts).cpu().tolist()
+
+
+def reduce_counters(dist, device, sums: Sequence[float], maxes: Sequence[float], with_rows: bool = False):
+    """The job's ONLY data collective: every rank contributes one small vector, ONE all_gather (gather_counters); SUM over the first
+    block, MAX over the second, computed identically on every rank.  -> (sums, maxes) as float lists; with_rows=True also returns
+    the per-rank rows (sums block followed by maxes block), from which a caller can report per-rank minima / maxima -- a
+    straggler is invisible in SUM / MAX alone."""
+    sums = [float(v) for v in sums]
+    maxes = [float(v) for v in maxes]
+    rows = gather_counters(dist, device, sums + maxes)
     k = len(sums)
-    return everyone[:, :k].sum(dim=0).tolist(), everyone[:, k:].max(dim=0).values.tolist()
+    tot = [sum(r[i] for r in rows) for i in range(k)]
+    mx = [max(r[k + i] for r in rows) for i in range(len(maxes))]
+    return (tot, mx, rows) if with_rows else (tot, mx)
 
 
 def reduce_throughput(dist, device, points: float, seconds: float, kernel_seconds: float = 0.0):

@@ -414,6 +414,34 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
     ASSERT_FLOAT_EQ(scan.timestamps(0), 47072.336);
     ASSERT_FLOAT_EQ(scan.timestamps(123396), 47072.332);
   }
+  CASE("homogeneous column known to be ones: skipped on the link, same cloud");
+  {
+    // the loaders' clouds carry the knowledge (data_io.cpp:130 writes the ones); any write access drops it; detect re-establishes it
+    LidarScan scan{LoadLidarScan(data_folder, 0)};
+    ASSERT_TRUE(scan.cloud.is_homogeneous());
+    Affine3d T_end;
+    T_end.rotate(AngleAxisd{0.03, Vector3d{0, 0, 1}});
+    T_end.translation() = Vector3d{1.3, 0.05, -0.02};
+    Frame const known{Affine3d::Identity(), T_end, scan};  // the Frame's copy keeps the knowledge
+    ASSERT_TRUE(known.scan.cloud.is_homogeneous());
+    LidarScan touched{scan};
+    touched.cloud(7, 0) = touched.cloud(7, 0);  // a write access, whatever it writes
+    ASSERT_TRUE(!touched.cloud.is_homogeneous());
+    Frame const unknown{Affine3d::Identity(), T_end, touched};
+    Pointcloud const a{MotionCompensateFrame(known, scan.stamp_middle)};
+    Pointcloud const b{MotionCompensateFrame(unknown, scan.stamp_middle)};
+    ASSERT_TRUE(a.is_homogeneous() && !b.is_homogeneous());
+    bool same = true;
+    for (Index i = 0; i < a.rows() && same; ++i)
+      for (Index j = 0; j < 4; ++j) same = same && std::memcmp(&a.data()[j * a.rows() + i], &b.data()[j * b.rows() + i], sizeof(double)) == 0;
+    ASSERT_TRUE(same);
+    ASSERT_TRUE(touched.cloud.detect_homogeneous());
+    touched.cloud(11, 3) = 2.0;  // a projective weight that is NOT one travels like in the reference: Affine3d * Vector4d scales the translation
+    ASSERT_TRUE(!touched.cloud.detect_homogeneous());
+    Frame const weighted{Affine3d::Identity(), T_end, touched};
+    Pointcloud const w{MotionCompensateFrame(weighted, scan.stamp_middle)};
+    ASSERT_TRUE(w(11, 3) == 2.0 && w(10, 3) == 1.0 && w(10, 0) == a(10, 0) && w(11, 0) != a(11, 0));
+  }
   CASE("f32 KITTI-layout path == f64 Eigen-layout path (to f32 rounding) on the shipped frame");
   {
     LidarScan const scan{LoadLidarScan(data_folder, 0)};

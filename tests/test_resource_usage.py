@@ -1,0 +1,73 @@
+"""Compiler evidence, guarded: the register / scratch / occupancy figures DESIGN.md quotes are not prose -- this
+test re-runs hipcc's kernel-resource-usage analysis on the shipped translation units (cross-compiling gfx950 needs no GPU) and
+holds every kernel to its budget, so that a compiler update or an innocent edit cannot silently cost a wave slot:
+
+  * every shipped f32 deskew kernel in the default geometry (one point per lane): no scratch, <= 64 VGPRs, 8 waves per SIMD --
+    these kernels need every wave slot (occupancy sweep, profiles/r02_tune_occ_ppt.csv);
+  * the N-knot kernels use no LDS since round 3 (records travel through scalar loads);
+  * the f64 Eigen-layout kernels: no scratch, 4 waves per SIMD on purpose (nine streams per wave);
+  * nothing anywhere spills to scratch.
+The committed summary profiles/r03_resource_usage.txt must list the same kernels (it is regenerated with
+`make -C kitti_motion_compensation_amd/csrc resource-usage 2>&1 | python tools/summarize_resource_usage.py`)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import summarize_resource_usage as sru  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def usage():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "kitti_motion_compensation_amd", "csrc"), "resource-usage"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = sru.parse(r.stdout + r.stderr)
+    names = sru.demangle([x["mangled"] for x in rows])
+    out = {}
+    for x, n in zip(rows, names):
+        out[n.replace("void ", "").replace("kmc_dev::", "").split("(")[0]] = {k: int(v) for k, v in x.items() if k != "mangled"}
+    assert len(out) > 80
+    return out
+
+
+def test_nothing_spills_to_scratch(usage):
+    bad = {k: v["scratch"] for k, v in usage.items() if v["scratch"] != 0}
+    assert not bad, bad
+
+
+def test_f32_kernels_keep_eight_waves_per_simd(usage):
+    hot = {k: v for k, v in usage.items() if k.startswith(("deskew_frame_f32<", "deskew_batch_f32<", "deskew_traj_f32<", "deskew_traj_batch_f32<"))}
+    default_geometry = {k: v for k, v in hot.items() if not k.startswith(("deskew_frame_f32<", "deskew_batch_f32<")) or k.split("<")[1].split(",")[1].strip() == "1"}
+    assert len(default_geometry) >= 4 + 16 + 16 + 8
+    for k, v in default_geometry.items():
+        assert v["occupancy"] == 8 and v["vgprs"] <= 64 and v["agprs"] == 0, (k, v)
+    # the headline kernel by name
+    bench = usage["deskew_batch_f32<0, 1, 7, false, 64, false>"]
+    assert bench["vgprs"] <= 62 and bench["sgprs"] <= 78 and bench["sgpr_spills"] == 0 and bench["lds"] == 1024, bench
+    # kernel-argument tables: same body, no extra registers
+    inline = usage["deskew_batch_f32<0, 1, 7, false, 64, true>"]
+    assert inline["vgprs"] <= bench["vgprs"] + 2 and inline["occupancy"] == 8, inline
+
+
+def test_nknot_kernels_use_no_lds(usage):
+    for k, v in usage.items():
+        if k.startswith(("deskew_traj_f32<", "deskew_traj_batch_f32<")):
+            assert v["lds"] == 0, (k, v)
+
+
+def test_f64_kernels_as_documented(usage):
+    for k in ("deskew_f64cols<0, false>", "deskew_f64cols<0, true>", "deskew_traj_f64cols<0>"):
+        assert usage[k]["occupancy"] == 4 and usage[k]["scratch"] == 0, (k, usage[k])
+    assert usage["deskew_f64cols<0, false>"]["vgprs"] <= 64
+
+
+def test_committed_summary_lists_the_same_kernels(usage):
+    path = os.path.join(ROOT, "profiles", "r03_resource_usage.txt")
+    with open(path) as f:
+        committed = {ln.split(" | ")[0]: ln.strip().split(" | ")[1:] for ln in f if ln.strip() and not ln.startswith("#")}
+    assert set(committed) == set(usage), (sorted(set(committed) ^ set(usage))[:5], "regenerate profiles/r03_resource_usage.txt")
+    stale = [k for k, v in usage.items() if [str(v[x]) for x in ("vgprs", "agprs", "sgprs", "sgpr_spills", "scratch", "occupancy", "lds")] != committed[k]]
+    assert not stale, (stale[:5], "the committed figures differ from what hipcc produces now: regenerate profiles/r03_resource_usage.txt")

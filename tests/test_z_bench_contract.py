@@ -42,6 +42,17 @@ def test_bench_prints_one_contract_line():
     assert c3["rank_frame_ranges"] == [[0, 8000]] and c3["timed_frames_per_rank"] == 24
     assert c3["value"] > 50_000 and c3["unit"] == "Mpts/s"
     assert c3["parity_first_last_frame_per_rank"]["max_rel_err"] <= 1e-5
+    # the secondary configurations as legs of the same line (round 3): time, GB/s, fraction of peak, kernel, oracle spot check
+    lit = d["configs1_literal"]
+    for k in ("in_order", "four_frame_queues"):
+        assert lit[k]["us_per_frame"] > 0 and 0.2 < lit[k]["frac"] < 1.0, (k, lit[k])
+    assert lit["four_frame_queues"]["us_per_frame"] < lit["in_order"]["us_per_frame"]  # overlapping frames beats draining the chip
+    assert lit["parity"]["max_rel_err"] <= 1e-5
+    for leg, bar in (("configs2_drive", 1e-5), ("nknot3", 1e-5), ("f64cols", 1e-11)):
+        assert d[leg]["GBps"] > 3000 and abs(d[leg]["frac"] - d[leg]["GBps"] / 8000.0) < 1e-3 and "kernel" in d[leg], (leg, d[leg])
+        assert d[leg]["parity"]["max_rel_err"] <= bar and d[leg]["parity"]["bar"] == bar, (leg, d[leg]["parity"])
+    assert d["nknot3"]["parity"]["segments_seen"] == [0, 1]
+    assert "absent" in d["config"]["kitti_root"] or "present" in d["config"]["kitti_root"]
 
 
 @pytest.mark.gpu
@@ -82,6 +93,38 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     assert abs(c3["value"] - 2 * 16 * 10_000_000 / (c3["ms_per_frame"] * 16 * 1e-3) / 1e6) / c3["value"] < 0.02
     assert 20_000 < c3["value"] < 260_000
     assert c3["parity_first_last_frame_per_rank"]["max_rel_err"] <= 1e-5
+    # every rank's own rate is in the line (a straggler is invisible in SUM / MAX); no secondary legs at N > 1
+    pr = d["per_rank"]
+    assert len(pr["Mpts_s"]) == 2 and pr["Mpts_s_min"] <= pr["Mpts_s_max"] and len(pr["configs3_Mpts_s"]) == 2
+    assert "configs1_literal" not in d
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """The driver's 8-GPU launch line, dry: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8`
+    with all eight ranks placed on the only GPU of the test box and the counters reduced over gloo (KMC_BENCH_DEVICE /
+    KMC_BENCH_BACKEND are test knobs; unset = RCCL, one rank per GPU), with reduced frame counts.  What the first real SCALE run
+    must not fail on: rendezvous, rank r owning frames [1000 r, 1000 (r + 1)) of the 8 000-frame stream, every rank's own parity
+    check (its oracle capped at cores / world threads), the one all_gather, the per-rank rates, and the memory: the default
+    run holds max(256 x 1 M, 2 x 24 x 10 M) points x 32 B = 15.4 GB per rank."""
+    env = dict(os.environ, KMC_BENCH_BACKEND="gloo", KMC_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29587", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
+           "--frames-per-step", "16", "--configs3-frames", "24", "--configs3-frames-per-launch", "12"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "x8" in d["config"]["parallelism"]
+    c3 = d["configs3"]
+    assert c3["rank_frame_ranges"] == [[1000 * r, 1000 * (r + 1)] for r in range(8)] and c3["timed_frames_per_rank"] == 24
+    assert c3["parity_first_last_frame_per_rank"]["max_rel_err"] <= 1e-5  # MAX over the eight ranks' own checks
+    pr = d["per_rank"]
+    assert len(pr["Mpts_s"]) == 8 and len(pr["configs3_Mpts_s"]) == 8 and all(v > 0 for v in pr["Mpts_s"] + pr["configs3_Mpts_s"])
+    assert abs(d["value"] - 8 * 16 * 1_000_000 * 4 / (d["ms_per_step"] * 4 * 1e-3) / 1e6) / d["value"] < 0.02
+    # eight ranks' buffers lived on ONE device here; the default run's 15.4 GB per rank is one rank per 288 GB device
+    assert 8 * d["peak_device_GiB_per_rank"] < 250
 
 
 @pytest.mark.gpu
@@ -94,7 +137,7 @@ def test_bench_live_traffic_matches_the_algorithmic_bytes():
         pytest.skip("rocprofv3 not installed")
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames-per-step", "64",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
+                        "--no-cpu-baseline", "--no-legs"], capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     rf = d["roofline"]
