@@ -145,7 +145,7 @@ def live_traffic(frames_per_step, points_per_frame, yaw_per_frame, calibration):
     for counter, factor in (("FETCH_SIZE", calibration["fetch_correction_factor"]), ("WRITE_SIZE", calibration["write_correction_factor"])):
         out = tempfile.mkdtemp(prefix="kmc_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--no-configs3", "--no-legs", "--frames-per-step", str(frames_per_step),
+               "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--no-configs3", "--no-legs", "--sustained-seconds", "0", "--frames-per-step", str(frames_per_step),
                "--points-per-frame", str(points_per_frame), "--yaw-per-frame", str(yaw_per_frame)]
         env = dict(os.environ)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "KMC_BENCH_FORCE_DIST"):
@@ -435,6 +435,8 @@ def main():
     ap.add_argument("--no-configs3", action="store_true", help="skip the configs[3] leg (10 M-point frames, frame-sharded)")
     ap.add_argument("--configs3-frames", type=int, default=960, help="timed frames per rank of the configs[3] leg")
     ap.add_argument("--configs3-frames-per-launch", type=int, default=C3_FRAMES_PER_LAUNCH)
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="N = 1: repeat the headline launch for this long after the timed region and report the rate per ~0.1 s window (0 = skip)")
+    ap.add_argument("--legs-only", action="store_true", help="run ONLY the secondary legs and print their JSON (for a profiler pass whose kernel rows then belong to the legs alone)")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (configs1_literal, configs2_drive, nknot3, f64cols; N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
@@ -482,6 +484,11 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
     info = ctx.device_info()
+    if args.legs_only:
+        assert world == 1 and dist is None, "--legs-only is an N = 1 profiling aid"
+        print(json.dumps(run_secondary_legs(capi, torch, ctx, dev, check=not args.no_cpu_baseline)), flush=True)
+        ctx.close()
+        return
 
     # ---- workload: generated on the device (identical generator on the host for the oracle), resident in HBM ----
     R = max(1, args.rotate)
@@ -525,6 +532,24 @@ def main():
     if dist:
         dist.barrier()
     wall = time.perf_counter() - t_begin
+
+    # ---- sustained leg (N = 1): the headline launch repeated for a wall-clock budget, in windows, so that the driver's run holds
+    # more than a few milliseconds of evidence: mean / min / max / std over the windows ----
+    sustained = None
+    if world == 1 and dist is None and headline and args.sustained_seconds > 0:
+        window = max(1, int(round(0.1 / max(ev_ms / args.steps * 1e-3, 1e-6))))  # ~0.1 s of launches per window
+        rates, t_stop = [], time.perf_counter() + args.sustained_seconds
+        while time.perf_counter() < t_stop:
+            ctx.timer_begin()
+            for _ in range(window):
+                step()
+            rates.append(n * window / (ctx.timer_end() * 1e-3) / 1e6)
+        r = np.array(rates)
+        sustained = {"seconds": args.sustained_seconds, "windows": int(r.size), "launches_per_window": window, "launches": int(r.size) * window,
+                     "Mpts_s_mean": round(float(r.mean()), 1), "Mpts_s_min": round(float(r.min()), 1), "Mpts_s_max": round(float(r.max()), 1),
+                     "Mpts_s_std": round(float(r.std()), 1), "GBps_mean": round(float(r.mean()) * BYTES_PER_POINT / 1e3, 1),
+                     "frac_mean": round(float(r.mean()) * BYTES_PER_POINT / 1e3 / HBM_PEAK_GBPS, 4),
+                     "note": "the headline's step (one 256 M-point batched launch) back to back, HIP events per window on the launch stream"}
 
     # the sample the cpu_baseline leg needs, before the configs[3] leg reuses the buffers
     cpu_sample = None
@@ -632,6 +657,8 @@ def main():
                 "parity_first_last_frame_per_rank": ({"max_rel_err": maxes[4], "bar": 1e-5, "oracle": "FAITHFUL, whole 10 M-point frames"}
                                                      if not args.no_cpu_baseline else None),
             }
+        if sustained:
+            out["sustained"] = sustained
         if legs:
             out.update(legs)
         out["config"]["kitti_root"] = ("present (not used by the synthetic headline; tests/test_configs_at_size.py and tools/measure_configs.py run the real drives)"

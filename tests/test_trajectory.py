@@ -150,6 +150,54 @@ def test_three_bracketing_poses_vs_oracle_and_bit_exact_indices(ctx, kitti):
 
 
 @pytest.mark.gpu
+def test_bracket_decision_around_the_knots_is_the_exact_one(ctx, kitti):
+    """Round 3 decides a point's bracket from the scan fraction the deskew computes anyway and falls back to the exact trig-free
+    half-plane test only for waves that hold a lane within 1e-4 turn of a knot (or a coordinate that is not a normal number).
+    The claim "outside the margin the two decisions are the same" is put under load here: hundreds of thousands of points placed
+    at angular distances from 1e-9 to 3e-3 turn on BOTH sides of every knot -- inside the margin, on its edge, outside it --, at
+    radii from 1e-30 to 1e30 m, through the single-frame kernel (2, 3, 4 and 7 knots: kernel-argument records, the preloaded knot
+    path and the knot loop): every bracket index equals the oracle's (which only knows the exact test), bit for bit."""
+    xyzi, P1 = kitti
+    rng = np.random.default_rng(31)
+    steps = [[0.7, 0.02, -0.01, 0.001, -0.002, 0.018], [0.66, 0.02, 0.0, -0.001, 0.001, 0.02], [0.71, -0.01, 0.01, 0.0, 0.002, 0.022],
+             [0.69, 0.0, 0.0, 0.001, 0.0, 0.019], [0.7, 0.01, 0.0, 0.0, 0.001, 0.02], [0.68, 0.0, 0.01, 0.001, 0.0, 0.021]]
+    for n_knots in (2, 3, 4, 7):
+        # knots: the first / last just outside the scan, the interior ones at "ugly" fractions plus the exact quarter turns
+        interior = {3: [0.5003], 4: [0.25, 0.75], 7: [0.1234, 0.25, 0.5, 0.6180339, 0.9]}.get(n_knots, [])
+        fr = np.array([-0.04] + interior + [1.04])
+        times = list(T0 + fr * (T1 - T0))
+        poses = _chain(P1, steps[:n_knots - 1])
+        pts = []
+        for c in interior:
+            d = np.concatenate([10.0 ** rng.uniform(-9, -2.5, size=40_000), [0.0, 1e-4, 0.99e-4, 1.01e-4, 5e-5]])
+            d = d * rng.choice([-1.0, 1.0], size=d.size)
+            frac = np.clip(c + d, 1e-9, 1 - 1e-9)
+            az = np.pi - 2 * np.pi * frac                        # timestamp_mocking.cpp:46 inverted
+            r = 10.0 ** rng.choice([0.0, 1.0, 1.7, -3.0, 6.0, -30.0, 30.0], size=d.size, p=[0.3, 0.3, 0.3, 0.04, 0.04, 0.01, 0.01])
+            pts.append(np.stack([r * np.cos(az), r * np.sin(az), rng.normal(0, 1, d.size), rng.uniform(0, 1, d.size)], axis=1))
+        cloud = np.ascontiguousarray(np.concatenate(pts + [xyzi[:5000]]).astype(np.float32))
+        cloud = cloud[rng.permutation(cloud.shape[0])]           # knot neighbours scattered over the waves, not sorted by angle
+        out = np.empty_like(cloud)
+        br = np.empty(cloud.shape[0], dtype=np.uint32)
+        ctx.deskew_traj_f32(cloud, out, times, _rt(poses), T0, T1, TREQ, br)
+        want = orc.bracket_indices_f32(cloud, times, T0, T1)
+        bad = np.flatnonzero(br != want)
+        assert bad.size == 0, (n_knots, bad.size, cloud[bad[:3]], br[bad[:3]], want[bad[:3]])
+        assert len(set(want.tolist())) == n_knots - 1            # every bracket really occurs
+        import torch
+
+        d_in = torch.from_numpy(cloud).cuda()                    # device-resident: records in the kernel arguments up to four knots
+        d_out = torch.empty_like(d_in)
+        d_br = torch.zeros(cloud.shape[0], dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.deskew_traj_f32(d_in, d_out, times, _rt(poses), T0, T1, TREQ, d_br)
+        torch.cuda.synchronize()
+        ctx.set_stream(None)
+        assert np.array_equal(d_br.cpu().numpy().astype(np.uint32), want), n_knots
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), out.view(np.uint32)), n_knots
+
+
+@pytest.mark.gpu
 def test_short_trajectories_ride_in_the_kernel_arguments(kitti):
     """Up to four knots (three segments) on device-resident points: the segment records are kernel arguments -- no table slot, no
     upload, no host wait -- and the call may go over the frame queues like kmc_hip_deskew_f32.  Longer trajectories, and host

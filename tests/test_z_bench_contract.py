@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-                        "--frames-per-step", "176", "--cpu-sample-frames", "1", "--configs3-frames", "24", "--configs3-frames-per-launch", "8", "--no-live-traffic"],
+                        "--frames-per-step", "176", "--cpu-sample-frames", "1", "--configs3-frames", "24", "--configs3-frames-per-launch", "8", "--no-live-traffic",
+                        "--sustained-seconds", "1.5"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -42,6 +43,8 @@ def test_bench_prints_one_contract_line():
     assert c3["rank_frame_ranges"] == [[0, 8000]] and c3["timed_frames_per_rank"] == 24
     assert c3["value"] > 50_000 and c3["unit"] == "Mpts/s"
     assert c3["parity_first_last_frame_per_rank"]["max_rel_err"] <= 1e-5
+    su = d["sustained"]  # the headline launch back to back for a wall-clock budget, in ~0.1 s windows
+    assert su["windows"] >= 5 and su["Mpts_s_min"] <= su["Mpts_s_mean"] <= su["Mpts_s_max"] and su["Mpts_s_mean"] > 50_000
     # the secondary configurations as legs of the same line (round 3): time, GB/s, fraction of peak, kernel, oracle spot check
     lit = d["configs1_literal"]
     for k in ("in_order", "four_frame_queues"):
@@ -137,7 +140,7 @@ def test_bench_live_traffic_matches_the_algorithmic_bytes():
         pytest.skip("rocprofv3 not installed")
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames-per-step", "64",
-                        "--no-cpu-baseline", "--no-legs"], capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
+                        "--no-cpu-baseline", "--no-legs", "--sustained-seconds", "0"], capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     rf = d["roofline"]

@@ -36,6 +36,17 @@ def main():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(src, "kt", "bench_kernel_stats.csv"), os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
+    for extra_src, extra_dst in (("kt_legs/legs_kernel_stats.csv", f"{tag}_legs_kernel_stats.csv"), ("tune_r3.csv", f"{tag}_tune_traj.csv"),
+                                 ("legs_kt.log", f"{tag}_legs_profiled_run.json")):
+        if os.path.exists(os.path.join(src, extra_src)):
+            if extra_src.endswith(".log"):  # the legs' own JSON line of the profiled run (HIP-event figures next to the profiler's)
+                with open(os.path.join(src, extra_src)) as fh:
+                    lines = [ln for ln in fh.read().splitlines() if ln.startswith("{")]
+                if lines:
+                    with open(os.path.join(out, extra_dst), "w") as fh:
+                        fh.write(lines[-1] + "\n")
+            else:
+                shutil.copy(os.path.join(src, extra_src), os.path.join(out, extra_dst))
 
     # calibration on the copy kernel: 64 Mi points x 16 B each way
     cal_f = counters(os.path.join(src, "cal_fetch", "tune_counter_collection.csv"), "FETCH_SIZE")
