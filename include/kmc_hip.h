@@ -242,6 +242,17 @@ int kmc_hip_deskew_f64cols(kmc_ctx* ctx, const double* x, const double* y, const
                            const kmc_frame_params* params, double* ox, double* oy, double* oz, double* ow,
                            int mem_kind, kmc_stats* out_stats);
 
+/* The same call in two halves, for a caller with host work to overlap (the C++ drop-in fills the output's homogeneous column while
+ * the kernel runs).  _begin checks the arguments and ISSUES the work; with device-addressable buffers (KMC_MEM_DEVICE,
+ * KMC_MEM_HOST_MAPPED, or KMC_MEM_HOST pointers that all lie in the page-locked pool) it returns without waiting, with staged host
+ * buffers it completes the call.  _end waits and returns what kmc_hip_deskew_f64cols would have returned (KMC_ERR_TIME_OUT_OF_RANGE
+ * included) and its stats.  Exactly one _end per successful _begin, and no other call on the context in between; the buffers belong
+ * to the library until _end returns. */
+int kmc_hip_deskew_f64cols_begin(kmc_ctx* ctx, const double* x, const double* y, const double* z, const double* w,
+                                 const double* stamps, uint64_t n, double stamp_start, double stamp_end,
+                                 const kmc_frame_params* params, double* ox, double* oy, double* oz, double* ow, int mem_kind);
+int kmc_hip_deskew_f64cols_end(kmc_ctx* ctx, kmc_stats* out_stats);
+
 /* ---- N-knot trajectories: the 3-argument MotionCompensateFrame(Frame, Trajectory, Time) of BASELINE.json's north_star ----
  * The reference interpolates along ONE geodesic between the two scan poses.  These entry points generalise that to a
  * piecewise SE(3) geodesic through n_knots time-stamped poses (e.g. the three bracketing OXTS poses directly):

@@ -149,6 +149,11 @@ SIGNATURES = {
         [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, C.POINTER(FrameParams), _vp, _vp, _vp, _vp,
          C.c_int, C.POINTER(Stats)],
     ),
+    "kmc_hip_deskew_f64cols_begin": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_double, C.c_double, C.POINTER(FrameParams), _vp, _vp, _vp, _vp, C.c_int],
+    ),
+    "kmc_hip_deskew_f64cols_end": (C.c_int, [_vp, C.POINTER(Stats)]),
     "kmc_hip_deskew_traj_f32": (
         C.c_int,
         [_vp, _vp, _vp, C.c_uint64, _dp, _dp, C.c_uint32, C.c_double, C.c_double, C.c_double, _vp, C.c_int, C.POINTER(Stats)],
@@ -481,6 +486,21 @@ class Context:
         if rc == ERR_TIME_OUT_OF_RANGE and not raise_on_range:
             return rc, st
         self._check(rc, "kmc_hip_deskew_f64cols")
+        return rc, st
+
+    def deskew_f64cols_begin(self, x, y, z, w, stamps, stamp_start, stamp_end, params: FrameParams, ox, oy, oz, ow=None):
+        """kmc_hip_deskew_f64cols_begin: issues the call (returns at once for device-addressable buffers); pair with deskew_f64cols_end."""
+        rc = lib().kmc_hip_deskew_f64cols_begin(self._h, _ptr(x, np.float64), _ptr(y, np.float64), _ptr(z, np.float64), _ptr(w, np.float64),
+                                                _ptr(stamps, np.float64), int(x.shape[0]), stamp_start, stamp_end, C.byref(params),
+                                                _ptr(ox, np.float64), _ptr(oy, np.float64), _ptr(oz, np.float64), _ptr(ow, np.float64), _mem_kind(x))
+        self._check(rc, "kmc_hip_deskew_f64cols_begin")
+
+    def deskew_f64cols_end(self, raise_on_range=True):
+        st = Stats()
+        rc = lib().kmc_hip_deskew_f64cols_end(self._h, C.byref(st))
+        if rc == ERR_TIME_OUT_OF_RANGE and not raise_on_range:
+            return rc, st
+        self._check(rc, "kmc_hip_deskew_f64cols_end")
         return rc, st
 
     def deskew_traj_f32(self, xyzi_in, xyzi_out, knot_times, knot_poses, stamp_start, stamp_end, requested_time,

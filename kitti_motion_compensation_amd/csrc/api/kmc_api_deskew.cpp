@@ -144,10 +144,13 @@ Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time) 
   // on the host, which costs a tenth of what the two transfers cost on the link.
   bool const ones = in.is_homogeneous();
   double* const ox = out.col(0);
-  if (ones) std::fill(ox + 3 * n, ox + 4 * n, 1.0);
-  int const rc = kmc_hip_deskew_f64cols(c, in.col(0), in.col(1), in.col(2), ones ? nullptr : in.col(3), frame.scan.timestamps.data(),
+  int rc = kmc_hip_deskew_f64cols_begin(c, in.col(0), in.col(1), in.col(2), ones ? nullptr : in.col(3), frame.scan.timestamps.data(),
                                         static_cast<std::uint64_t>(n), frame.scan.stamp_start, frame.scan.stamp_end, &p, ox, ox + n, ox + 2 * n,
-                                        ones ? nullptr : ox + 3 * n, KMC_MEM_HOST, &st);
+                                        ones ? nullptr : ox + 3 * n, KMC_MEM_HOST);
+  if (rc == KMC_OK) {
+    if (ones) std::fill(ox + 3 * n, ox + 4 * n, 1.0);  // while the kernel works on the other three columns
+    rc = kmc_hip_deskew_f64cols_end(c, &st);
+  }
   if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::MotionCompensateFrame");
   if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_f64cols", c);
   detail::set_homogeneous(out, ones);

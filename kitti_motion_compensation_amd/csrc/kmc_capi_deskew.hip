@@ -499,10 +499,14 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
 }
 
 // ---- f64 Eigen-layout path ------------------------------------------------------------------------
-int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
-                           uint64_t n, double stamp_start, double stamp_end, const kmc_frame_params* params, double* ox,
-                           double* oy, double* oz, double* ow, int mem_kind, kmc_stats* st) {
+// `defer`: kmc_hip_deskew_f64cols_begin -- when the buffers are device-addressable the work is only ISSUED here and
+// f64cols_finish() (kmc_hip_deskew_f64cols_end) waits for it; staged host buffers complete here and leave their verdict for _end.
+static int f64cols_finish(kmc_ctx* c, kmc_stats* st);
+static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
+                         uint64_t n, double stamp_start, double stamp_end, const kmc_frame_params* params, double* ox,
+                         double* oy, double* oz, double* ow, int mem_kind, kmc_stats* st, bool defer) {
   if (!c || !params) return KMC_ERR_INVALID_ARG;
+  if (c->f64_pending) return KMC_ERR_INVALID_ARG;  // a _begin without its _end
   if (n && (!x || !y || !z || !stamps || !ox || !oy || !oz)) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE && mem_kind != KMC_MEM_HOST_MAPPED) return KMC_ERR_INVALID_ARG;
   if (!(stamp_start < stamp_end)) return KMC_ERR_DEGENERATE;
@@ -595,17 +599,69 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
       if (down_w) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
     }
   }
-  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the out-of-range verdict is part of the call's result
+  c->f64_stats = kmc_stats{};
+  c->f64_stats.n_points = n;
+  c->f64_stats.variant = 5;
+  c->f64_stats.n_launches = 1;
+  c->f64_pending = 1;  // issued, not waited for
+  if (defer && mem_kind != KMC_MEM_HOST) return KMC_OK;
+  return f64cols_finish(c, st);
+}
+
+static int f64cols_finish(kmc_ctx* c, kmc_stats* st) {
+  if (c->f64_pending == 2) {  // a staged route that completed inside _begin
+    c->f64_pending = 0;
+    if (st) *st = c->f64_stats;
+    return c->f64_result;
+  }
+  if (c->f64_pending != 1) return KMC_ERR_INVALID_ARG;
+  c->f64_pending = 0;
+  // The out-of-range verdict is part of the call's result: wait.  A short busy wait first -- the in-place kernel of a KITTI frame takes
+  // ~100 us and an interrupt-driven wake-up adds several microseconds to a call whose whole budget is ~130.
+  hipError_t q = hipErrorNotReady;
+  for (int spin = 0; spin < 20000 && (q = hipStreamQuery(c->stream)) == hipErrorNotReady; ++spin) {
+  }
+  if (q != hipSuccess) {
+    (void)hipGetLastError();
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   unsigned long long bad = 0;
   if (*(volatile uint32_t*)c->h_flag != 0) {  // cold: some stamp was out of range -> fetch the exact count
     KMC_HIP_TRY(c, hipMemcpy(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost));
   } else {
     c->counter_dirty = false;  // nobody touched the counter
   }
-  if (st) { st->n_launches = 1; st->n_out_of_range = bad; }
-  int rc = tm.end_call(st);
+  c->f64_stats.n_out_of_range = bad;
+  CallTimer tm(c);
+  const int rc = tm.end_call(&c->f64_stats);
+  if (st) *st = c->f64_stats;
   if (rc != KMC_OK) return rc;
   return bad ? KMC_ERR_TIME_OUT_OF_RANGE : KMC_OK;
+}
+
+int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
+                           uint64_t n, double stamp_start, double stamp_end, const kmc_frame_params* params, double* ox,
+                           double* oy, double* oz, double* ow, int mem_kind, kmc_stats* st) {
+  return f64cols_issue(c, x, y, z, w, stamps, n, stamp_start, stamp_end, params, ox, oy, oz, ow, mem_kind, st, false);
+}
+
+int kmc_hip_deskew_f64cols_begin(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
+                                 uint64_t n, double stamp_start, double stamp_end, const kmc_frame_params* params, double* ox,
+                                 double* oy, double* oz, double* ow, int mem_kind) {
+  kmc_stats st;
+  const int rc = f64cols_issue(c, x, y, z, w, stamps, n, stamp_start, stamp_end, params, ox, oy, oz, ow, mem_kind, &st, true);
+  if (!c || c->f64_pending == 1) return rc;  // issued (KMC_OK), or rejected before anything was issued
+  // completed inside this call (n == 0, staged host buffers, an argument error): keep the verdict for _end
+  c->f64_stats = st;
+  c->f64_result = rc;
+  c->f64_pending = 2;
+  return (rc == KMC_ERR_TIME_OUT_OF_RANGE) ? KMC_OK : rc == KMC_OK ? KMC_OK : (c->f64_pending = 0, rc);
+}
+
+int kmc_hip_deskew_f64cols_end(kmc_ctx* c, kmc_stats* st) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
+  return f64cols_finish(c, st);
 }
 
 int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, uint64_t n, double scan_start, double scan_end,

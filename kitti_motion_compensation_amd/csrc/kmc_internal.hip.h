@@ -40,6 +40,9 @@ struct kmc_ctx {
   bool no_inline_tables = false;  // testing / A-B hook (KMC_NO_INLINE_TABLES=1): small batches go through the device tables too
   // out-of-range counter (f64 path)
   unsigned long long* d_counter = nullptr;
+  int f64_pending = 0;         // kmc_hip_deskew_f64cols_begin / _end: 0 = none, 1 = issued and not waited for, 2 = completed inside _begin
+  int f64_result = 0;
+  kmc_stats f64_stats = {};
   bool counter_dirty = true;   // d_counter may be non-zero: the f64 entry points clear it only then (a memset per call costs ~5 us)
   int mapped_waves = 128;      // persistent one-wave workgroups of the f64 kernel when it works on page-locked host memory (KMC_MAPPED_WAVES)
   uint32_t* h_flag = nullptr;  // page-locked word the f64 kernels raise when a stamp is out of range (read by the host after the sync: no D2H copy on the good path)

@@ -533,6 +533,25 @@ def test_f64cols_in_place_on_page_locked_containers_same_bits(ctx, kitti):
         pst.a[:] = stamps
         rc, st = ctx.deskew_f64cols(pin.a[0], pin.a[1], pin.a[2], pin.a[3], pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], pout.a[3])
         assert rc == capi.OK and st.n_out_of_range == 0, "the flag word must be cleared between calls"
+        # the call in two halves (what the C++ drop-in uses to fill the homogeneous column while the kernel runs): same bits, the
+        # verdict arrives with _end; a second _begin before the _end is refused; staged buffers complete inside _begin
+        pout.a[:] = -7.0
+        ctx.deskew_f64cols_begin(pin.a[0], pin.a[1], pin.a[2], None, pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], None)
+        with pytest.raises(capi.KmcError):
+            ctx.deskew_f64cols_begin(pin.a[0], pin.a[1], pin.a[2], None, pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], None)
+        rc, st = ctx.deskew_f64cols_end()
+        assert rc == capi.OK and st.n_points == n and st.n_out_of_range == 0
+        for j in range(3):
+            assert np.array_equal(pout.a[j].view(np.uint64), staged[j].view(np.uint64)), j
+        assert (pout.a[3] == -7.0).all(), "no w column asked for: the output's column is the caller's"
+        with pytest.raises(capi.KmcError):
+            ctx.deskew_f64cols_end()  # nothing pending
+        bad_stamps = stamps.copy()
+        bad_stamps[9] = T1 + 5.0
+        halves = [np.empty(n) for _ in range(4)]
+        ctx.deskew_f64cols_begin(cols[0], cols[1], cols[2], cols[3], bad_stamps, T0, T1, params, *halves)  # ordinary memory: staged
+        rc, st = ctx.deskew_f64cols_end(raise_on_range=False)
+        assert rc == capi.ERR_TIME_OUT_OF_RANGE and st.n_out_of_range == 1 and np.isnan(halves[0][9])
         # pseudo stamps in place
         ctx.pseudo_timestamps_f64(pin.a[0], pin.a[1], T0, T1, pst.a)
         ref = np.empty(n)
