@@ -19,8 +19,8 @@ Affine3d OxtsToPose(Oxts const& odometry, double const scale = 1.0);        // :
 class KittiPclLoader {
  public:
   std::tuple<Pointcloud, VectorXd> LoadPointcloud(Path const& file);  // data_io.cpp:101-138
-  // raw f32 AoS x,y,z,intensity exactly as on disk -- the layout the f32 kernel consumes
-  static std::vector<float> LoadRaw(Path const& file);
+  // raw f32 AoS x,y,z,intensity exactly as on disk -- the layout the f32 kernel consumes (page-locked when a HIP device is there)
+  static KittiCloudF32 LoadRaw(Path const& file);
 };
 
 LidarScan LoadLidarScan(Path const folder, std::size_t const frame_id);  // :142-166

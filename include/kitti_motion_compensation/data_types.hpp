@@ -189,6 +189,10 @@ struct PoolAllocator {
 using Storage = std::vector<double, PoolAllocator<double>>;
 }  // namespace detail
 
+// A KITTI cloud as it is on disk -- float x, y, z, intensity per point (data_io.cpp:101-138) -- in page-locked memory when a HIP device is
+// there: kmc::hip::MotionCompensateKittiCloud then works on it in place over the link instead of staging copies.
+using KittiCloudF32 = std::vector<float, detail::PoolAllocator<float>>;
+
 class VectorXd {
  public:
   VectorXd() = default;

@@ -57,9 +57,10 @@ typedef enum kmc_mem_kind {
   KMC_MEM_HOST_MAPPED = 2 /* page-locked host memory the device can address (kmc_host_pool_alloc, kmc_hip_host_alloc, hipHostMalloc):
                              the kernel reads and writes it IN PLACE over the link -- one launch, upload and download overlapped, no
                              staging copies -- and the call returns when the results are in host memory.  Accepted by
-                             kmc_hip_deskew_f32, kmc_hip_deskew_f64cols, kmc_hip_deskew_traj_f64cols and kmc_hip_pseudo_timestamps_f64;
-                             the f64 entry points also take this route by themselves when every KMC_MEM_HOST pointer they are given
-                             lies in a block of the pool below (which is what the C++ drop-in's containers are made of). */
+                             kmc_hip_deskew_f32, kmc_hip_deskew_batch_f32, kmc_hip_deskew_f64cols, kmc_hip_deskew_traj_f64cols and
+                             kmc_hip_pseudo_timestamps_f64; kmc_hip_deskew_f32 and the f64 entry points also take this route by
+                             themselves when every KMC_MEM_HOST pointer they are given lies in a block of the pool below (which is
+                             what the C++ drop-in's containers and KittiPclLoader::LoadRaw's clouds are made of). */
 } kmc_mem_kind;
 
 typedef struct kmc_ctx kmc_ctx; /* opaque */

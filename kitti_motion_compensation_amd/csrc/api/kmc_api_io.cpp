@@ -110,19 +110,19 @@ Oxts LoadOxts(Path const folder, std::size_t const frame_id) {  // :37-66
   return LoadOxtsWithStamp(folder, frame_id, LoadTimeStamp(folder / Path("oxts/timestamps.txt"), frame_id));
 }
 
-std::vector<float> KittiPclLoader::LoadRaw(Path const& file) {
+KittiCloudF32 KittiPclLoader::LoadRaw(Path const& file) {
   std::ifstream is{file, std::ios::in | std::ios::binary | std::ios::ate};
   if (!is.is_open()) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + file.string());  // :104
   std::int64_t const bytes{static_cast<std::int64_t>(is.tellg())};
   if (bytes == -1 || (bytes % 4) != 0) throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + file.string());  // :109
-  std::vector<float> data(static_cast<std::size_t>(bytes) / 16 * 4);  // whole points only (16 bytes each), :112
+  KittiCloudF32 data(static_cast<std::size_t>(bytes) / 16 * 4);  // whole points only (16 bytes each), :112
   is.seekg(0, std::ios::beg);
   is.read(reinterpret_cast<char*>(data.data()), static_cast<std::streamsize>(data.size() * sizeof(float)));
   return data;
 }
 
 std::tuple<Pointcloud, VectorXd> KittiPclLoader::LoadPointcloud(Path const& file) {  // :101-138
-  std::vector<float> const raw = LoadRaw(file);
+  KittiCloudF32 const raw = LoadRaw(file);
   Index const n = static_cast<Index>(raw.size() / 4);
   Pointcloud cloud{MatrixX4d(n, 4)};
   VectorXd intensities(n);
@@ -188,12 +188,12 @@ void CopyOverUncompensatedFirstAndLastFrame(Path const run_folder) {  // :19-39
   Path const velodyne{run_folder / Path{"velodyne_points"}};
   Path const out_dir{velodyne / Path("data_motion_compensated")};
   std::size_t const n_frames{NumberOfFilesInDirectory(velodyne / Path("data"))};
-  std::vector<float> const first = KittiPclLoader::LoadRaw(velodyne / Path("data/" + IdToZeroPaddedString(0) + ".bin"));
+  KittiCloudF32 const first = KittiPclLoader::LoadRaw(velodyne / Path("data/" + IdToZeroPaddedString(0) + ".bin"));
   WriteRaw(out_dir, 0, first.data(), first.size() / 4);
   std::size_t const last_id{n_frames - 1};
   char const* fix = std::getenv("KMC_FIX_LAST_FRAME_COPY");
   if (fix && fix[0] == '1') {
-    std::vector<float> const last = KittiPclLoader::LoadRaw(velodyne / Path("data/" + IdToZeroPaddedString(last_id) + ".bin"));
+    KittiCloudF32 const last = KittiPclLoader::LoadRaw(velodyne / Path("data/" + IdToZeroPaddedString(last_id) + ".bin"));
     WriteRaw(out_dir, last_id, last.data(), last.size() / 4);
   } else {
     WriteRaw(out_dir, last_id, first.data(), first.size() / 4);  // what the reference writes (handlers.cpp:36-38)

@@ -225,17 +225,50 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
                        int mem_kind, kmc_stats* st) {
   if (!c) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE && mem_kind != KMC_MEM_HOST_MAPPED) return KMC_ERR_INVALID_ARG;
+  // host buffers that both lie in the page-locked pool take the in-place route by themselves
+  if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && xyzi_in && xyzi_out && !((((uintptr_t)xyzi_in) | ((uintptr_t)xyzi_out)) & 15u) &&
+      host_pool_owns(xyzi_in, n * sizeof(v4f)) && host_pool_owns(xyzi_out, n * sizeof(v4f)))
+    mem_kind = KMC_MEM_HOST_MAPPED;
   if (mem_kind == KMC_MEM_HOST_MAPPED) {
-    // page-locked, device-addressable host buffers: the device route on the caller's pointers (the kernel streams over the link in
-    // both directions at once), then a wait -- the results are in host memory when the call returns
-    const int rc_dev = kmc_hip_deskew_f32(c, xyzi_in, xyzi_out, n, params, KMC_MEM_DEVICE, st);
-    if (rc_dev != KMC_OK) return rc_dev;
+    // page-locked, device-addressable host buffers: ONE kernel works on the caller's memory over the link -- persistent waves with the
+    // next tile's load in flight while the current one is stored, so that upload and download overlap -- then a wait: the results are
+    // in host memory when the call returns
     {
-      const int rc_j = fq_join(c);
-      if (rc_j != KMC_OK) return rc_j;
+      const int rc_args = check_frame_args(xyzi_in, xyzi_out, n, params, KMC_MEM_DEVICE);
+      if (rc_args != KMC_OK) return rc_args;
     }
-    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return KMC_OK;
+    if (st) std::memset(st, 0, sizeof(*st));
+    KMC_ENTER(c);
+    const int tier = pick_tier(c, params, 1);
+    FrameRec f;
+    std::memset(&f, 0, sizeof(f));
+    fill_rec(*params, &f);
+    f.pre2 = guard_pre2(*params);
+    FrameRecD d;
+    fill_recd(*params, &d);
+    if (st) { st->n_points = n; st->variant = (uint32_t)tier; st->n_launches = n ? 1 : 0; }
+    if (n == 0) return KMC_OK;
+    CallTimer tm(c);
+    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 63) / 64, (uint64_t)c->mapped_waves * 2));  // 16 B per lane here, 80 in the f64 kernel
+    const v4f* vin = (const v4f*)xyzi_in;
+    v4f* vout = (v4f*)xyzi_out;
+    switch (tier) {
+      case kSeries3: hipLaunchKernelGGL((deskew_frame_streamed_f32<kSeries3>), dim3(grid), dim3(64), 0, c->stream, vin, vout, n, f, d); break;
+      case kSeries5: hipLaunchKernelGGL((deskew_frame_streamed_f32<kSeries5>), dim3(grid), dim3(64), 0, c->stream, vin, vout, n, f, d); break;
+      case kWide: hipLaunchKernelGGL((deskew_frame_streamed_f32<kWide>), dim3(grid), dim3(64), 0, c->stream, vin, vout, n, f, d); break;
+      default: hipLaunchKernelGGL((deskew_frame_streamed_f32<kTrig>), dim3(grid), dim3(64), 0, c->stream, vin, vout, n, f, d); break;
+    }
+    KMC_HIP_TRY(c, hipGetLastError());
+    if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 20000 && (q = hipStreamQuery(c->stream)) == hipErrorNotReady; ++spin) {
+    }
+    if (q != hipSuccess) {
+      (void)hipGetLastError();
+      KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return tm.end_call(st);
   }
   {
     const int rc_args = check_frame_args(xyzi_in, xyzi_out, n, params, mem_kind);
@@ -356,6 +389,14 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
 int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets, uint32_t n_frames,
                              const kmc_frame_params* params, uint32_t* frame_idx_out, int mem_kind, kmc_stats* st) {
   if (!c || !offsets || (n_frames && !params)) return KMC_ERR_INVALID_ARG;
+  if (mem_kind == KMC_MEM_HOST_MAPPED) {
+    // page-locked, device-addressable host buffers: the device route on the caller's pointers (the tiles of a batch are spread over
+    // thousands of waves in flight, reads and writes mix by themselves), then a wait -- the results are in host memory on return
+    const int rc_dev = kmc_hip_deskew_batch_f32(c, xyzi_in, xyzi_out, offsets, n_frames, params, frame_idx_out, KMC_MEM_DEVICE, st);
+    if (rc_dev != KMC_OK) return rc_dev;
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+  }
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE) return KMC_ERR_INVALID_ARG;
   if (st) std::memset(st, 0, sizeof(*st));
   if (offsets[0] != 0) return KMC_ERR_INVALID_ARG;

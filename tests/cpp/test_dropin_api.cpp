@@ -355,7 +355,10 @@ static void ProjectOnHost(double x, double y, double z, Affine3d const& tf, viz:
 }
 
 // ---- gpu cases ---------------------------------------------------------------------------------------------------------
-static std::vector<float> read_bin(Path const& f) { return KittiPclLoader::LoadRaw(f); }
+static std::vector<float> read_bin(Path const& f) {  // ordinary memory on purpose: the tests below also cover the staged route
+  KittiCloudF32 const raw{KittiPclLoader::LoadRaw(f)};
+  return std::vector<float>(raw.begin(), raw.end());
+}
 
 static void gpu_cases(std::string const& golden, std::string const& tmp) {
   Path const data_folder{golden + "/kitti_2011_09_26_drive_0005"};

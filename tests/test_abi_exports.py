@@ -85,3 +85,33 @@ def test_python_plumbing_rejects_strided_or_mistyped_buffers():
         capi._ptr(np.zeros((4, 4), dtype=np.float64), np.float32)
     assert capi._ptr(np.zeros((4, 4), dtype=np.float32), np.float32) != 0
     assert capi._ptr(None) is None
+
+
+def test_host_pool_declines_without_a_device_and_never_claims_foreign_memory():
+    """The page-locked pool behind the drop-in's containers (kmc_host_pool_*): without a HIP device (this CPU box; or KMC_HOST_POOL=0)
+    kmc_host_pool_alloc fails with KMC_ERR_NO_DEVICE so that the containers fall back to ordinary memory -- an allocation is not a
+    computation, there is still no CPU fallback for the deskew --, and the pool never claims a pointer it did not hand out."""
+    import ctypes as C
+
+    import numpy as np
+
+    from kitti_motion_compensation_amd import capi
+
+    L = capi.lib()
+    a = np.zeros(1 << 16)
+    assert L.kmc_host_pool_owns(a.ctypes.data, a.nbytes) == 0
+    assert L.kmc_host_pool_free(a.ctypes.data) == 0 and L.kmc_host_pool_free(None) == 0
+    p = C.c_void_p()
+    rc = L.kmc_host_pool_alloc(1 << 20, C.byref(p))
+    try:
+        import torch
+
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        assert rc == capi.OK and p.value and L.kmc_host_pool_owns(p, 1 << 20) == 1 and L.kmc_host_pool_owns(p, (1 << 21) + 1) == 0
+        assert L.kmc_host_pool_free(p) == 1 and L.kmc_host_pool_owns(p, 16) == 0 and L.kmc_host_pool_trim() >= 1
+    else:
+        assert rc == capi.ERR_NO_DEVICE and not p.value and L.kmc_host_pool_trim() == 0
+    assert L.kmc_host_pool_alloc(0, C.byref(p)) in (capi.OK, capi.ERR_NO_DEVICE)

@@ -561,6 +561,36 @@ def test_f64cols_in_place_on_page_locked_containers_same_bits(ctx, kitti):
         pin.close(); pst.close(); pout.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 2047, 2048, 2049, 123_397, 1_000_003])
+def test_f32_in_place_on_page_locked_buffers_same_bits(torch_mod, ctx, kitti, n):
+    """KITTI-layout clouds in the C-ABI's page-locked pool (what KittiPclLoader::LoadRaw returns): kmc_hip_deskew_f32(KMC_MEM_HOST)
+    recognises them and runs ONE kernel in place over the link (persistent waves, next tile's load in flight while the current one
+    is stored).  Same arithmetic, near-origin guard included: the same bits as the device-resident kernel, for every tier, ragged
+    sizes, and nothing written past the end.  (Below 2048 points the staged route is taken: same bits as well.)"""
+    torch = torch_mod
+    xyzi, P1 = kitti
+    pts = capi.synth_points_host(n, 77) if n > xyzi.shape[0] else np.ascontiguousarray(xyzi[:n])
+    pin, pout = capi.PooledArray((n + 16, 4), np.float32), capi.PooledArray((n + 16, 4), np.float32)
+    try:
+        pin.a[:n] = pts
+        for name in ("gentle_turn", "spin", "tumble"):
+            params = _params(*_poses(P1, TRAJECTORIES[name]))
+            want, st_dev = _run_device(torch, ctx, pts, params)
+            pout.a[:] = -7.0
+            st = ctx.deskew_f32(pin.a[:n], pout.a[:n], params)
+            assert st.variant == st_dev.variant and st.n_points == n
+            assert np.array_equal(pout.a[:n].view(np.uint32), want.view(np.uint32)), name
+            assert (pout.a[n:] == -7.0).all(), "wrote past the end"
+        # a caller-supplied twist beyond pi (any-angle tier) and a point built on the near-origin cancellation
+        raw = capi.FrameParams.make([2.0, 0.1, 0.0, 0.3, -0.2, 5.0], 0.5)
+        pin.a[0] = [-1.0e-3, 0.0, 0.0, 0.25]  # frac = 1.0 -> s = 0.5: ends up a millimetre from where the translation takes it
+        want, _ = _run_device(torch, ctx, np.ascontiguousarray(pin.a[:n]), raw)
+        ctx.deskew_f32(pin.a[:n], pout.a[:n], raw)
+        assert np.array_equal(pout.a[:n].view(np.uint32), want.view(np.uint32))
+    finally:
+        pin.close(); pout.close()
+
+
 def test_f64cols_host_route_large_frame_is_pipelined_and_identical(torch_mod, ctx):
     """Host buffers of >= 2^20 points take the duplex chunk pipeline (upload of chunk k+1, kernel, download of chunk k in
     parallel, a helper thread for the downloads): same bits as the device-resident call on the same data, a column of ones is

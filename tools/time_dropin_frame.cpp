@@ -34,8 +34,8 @@ int main(int argc, char** argv) {
   for (int i = 0; i < iters; ++i) checksum += MotionCompensateFrame(frame, scan.stamp_middle)(0, 0);
   double const us64 = std::chrono::duration<double, std::micro>(clk::now() - t0).count() / iters;
 
-  std::vector<float> const raw = KittiPclLoader::LoadRaw(run / "velodyne_points/data/0000000000.bin");
-  std::vector<float> out(raw.size());
+  KittiCloudF32 const raw = KittiPclLoader::LoadRaw(run / "velodyne_points/data/0000000000.bin");  // page-locked when the pool is on
+  KittiCloudF32 out(raw.size());
   std::size_t const n = raw.size() / 4;
   for (int i = 0; i < 10; ++i)
     hip::MotionCompensateKittiCloud(raw.data(), n, frame.T_start, frame.T_end, scan.stamp_start, scan.stamp_end, scan.stamp_middle, out.data());
