@@ -46,9 +46,9 @@ template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
                      uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64) {
   if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, BatchInline{});
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, BatchNoInline{});
   else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, BatchInline{});
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, BatchNoInline{});
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,

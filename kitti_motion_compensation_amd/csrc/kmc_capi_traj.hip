@@ -394,6 +394,7 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   if (rc != KMC_OK) return rc;
   if (st) { st->n_points = n; st->variant = 5; }
   if (n == 0) return KMC_OK;
+  if (c->f64_pending) return KMC_ERR_INVALID_ARG;  // between kmc_hip_deskew_f64cols_begin and its _end: the range flag word is in use
   KMC_ENTER(c);
   TrajSeg64 segs[kMaxSegments];
   std::memset(segs, 0, sizeof(segs));

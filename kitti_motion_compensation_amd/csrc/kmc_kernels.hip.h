@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kmc_device_math.hip.h"
 #include "kmc_synth.h"
 
@@ -282,12 +284,15 @@ __device__ __forceinline__ uint2 load_coarse(uint2_cp c) {
   return make_uint2(e.x, e.y);
 }
 
+struct BatchNoInline { uint32_t unused; };  // what the device-table instantiations carry instead of 3.5 KB of unused tables
+template <bool INLINE> using BatchInlineArg = typename std::conditional<INLINE, BatchInline, BatchNoInline>::type;
+
 template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock, bool INLINE = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 ? 8 : 4, 8))) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
                                                          const BatchRec* __restrict__ recs_g,
                                                          const uint2* __restrict__ coarse_g, uint32_t n_frames,
                                                          uint64_t n, uint32_t* __restrict__ frame_idx_out, uint32_t head,
-                                                         const FrameRecD* __restrict__ recs64, uint32_t chunk_shift, BatchInline inl) {
+                                                         const FrameRecD* __restrict__ recs64, uint32_t chunk_shift, BatchInlineArg<INLINE> inl) {
   // `recs64[f]`: frame f's constants in f64 for the near-origin guard's redo (kmc_device_math); cold
   // `head`: dead leading indices, see deskew_frame_f32 (the host has shifted the pointers and every offset by it)
   // `chunk_shift`: log2 of the coarse table's chunk size (kChunkShift for device tables)

@@ -366,7 +366,7 @@ static Variant batch_variant(const char* label) {
     const uint64_t tiles = (n + (uint64_t)BLOCK * PPT - 1) / ((uint64_t)BLOCK * PPT);
     const uint64_t cap = bpc <= 0 ? tiles : (uint64_t)g_cus * bpc * (kBlock / (BLOCK < kBlock ? BLOCK : kBlock));
     hipLaunchKernelGGL((deskew_batch_f32<kSeries3, PPT, NT, false, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s,
-                       in, out, bt.d_recs, bt.d_coarse, bt.n_frames, n, (uint32_t*)nullptr, 0u, (const FrameRecD*)bt.d_recd, (uint32_t)kChunkShift, BatchInline{});
+                       in, out, bt.d_recs, bt.d_coarse, bt.n_frames, n, (uint32_t*)nullptr, 0u, (const FrameRecD*)bt.d_recd, (uint32_t)kChunkShift, BatchNoInline{});
   };
   return v;
 }
