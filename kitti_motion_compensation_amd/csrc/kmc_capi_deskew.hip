@@ -44,20 +44,20 @@ void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f*
 
 template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
-                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64) {
+                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64, const float* pre2s) {
   if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, BatchNoInline{});
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
   else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, BatchNoInline{});
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
-                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64) {
+                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64, const float* pre2s) {
   switch (ppt) {
-    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
-    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
-    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
-    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64); break;
+    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s); break;
+    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s); break;
+    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s); break;
+    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s); break;
   }
 }
 // tables in the kernel arguments (default launch geometry only: one point per lane)
@@ -66,10 +66,10 @@ void launch_batch_inline(hipStream_t s, int grid, const v4f* in, v4f* out, uint3
                          uint32_t chunk_shift, const BatchInline& inl) {
   if (idx)
     hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, true, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
-                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, inl);
+                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
   else
     hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
-                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, inl);
+                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
 }
 }  // namespace
 
@@ -434,6 +434,7 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
       for (uint32_t f = 0; f < n_frames; ++f) {
         fill_rec(params[f], &inl.recs[f]);
         fill_recd(params[f], &inl.recs64[f]);
+        inl.pre2[f] = guard_pre2(params[f]);
         inl.recs[f].end_lo = (uint32_t)((offsets[f + 1] + head) & 0xFFFFFFFFull);
         inl.recs[f].end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
       }
@@ -469,10 +470,11 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const uint64_t n_chunks = (nv + chunk - 1) / chunk;
   const uint64_t n_coarse = n_chunks + 1;
 
-  // slot layout: [BatchRec x F | FrameRecD x F (f64 twins for the near-origin guard) | coarse x (n_chunks + 1)]
+  // slot layout: [BatchRec x F | FrameRecD x F (f64 twins for the near-origin guard) | coarse x (n_chunks + 1) | pre2 x F (guard thresholds)]
   const size_t recs_bytes = ((size_t)n_frames * sizeof(BatchRec) + 255) & ~(size_t)255;
   const size_t recd_bytes = ((size_t)n_frames * sizeof(FrameRecD) + 255) & ~(size_t)255;
-  const size_t need = recs_bytes + recd_bytes + (size_t)n_coarse * sizeof(uint2);
+  const size_t coarse_bytes = ((size_t)n_coarse * sizeof(uint2) + 255) & ~(size_t)255;
+  const size_t need = recs_bytes + recd_bytes + coarse_bytes + (size_t)n_frames * sizeof(float);
   int slot_id = 0;
   {
     const int rc_slot = slot_begin(c, need, &slot_id);
@@ -485,10 +487,13 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const BatchRec* d_recs = reinterpret_cast<const BatchRec*>(sl.d_buf);
   const FrameRecD* d_recd = reinterpret_cast<const FrameRecD*>(sl.d_buf + recs_bytes);
   const uint2* d_coarse = reinterpret_cast<const uint2*>(sl.d_buf + recs_bytes + recd_bytes);
+  float* h_pre2 = reinterpret_cast<float*>(sl.h_buf + recs_bytes + recd_bytes + coarse_bytes);
+  const float* d_pre2 = reinterpret_cast<const float*>(sl.d_buf + recs_bytes + recd_bytes + coarse_bytes);
   for (uint32_t f = 0; f < n_frames; ++f) {
     BatchRec* r = &h_recs[f];
     fill_rec(params[f], r);
     fill_recd(params[f], &h_recd[f]);
+    h_pre2[f] = guard_pre2(params[f]);
     r->end_lo = (uint32_t)((offsets[f + 1] + head) & 0xFFFFFFFFull);
     r->end_hi = (uint32_t)((offsets[f + 1] + head) >> 32);
   }
@@ -519,10 +524,10 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const int grid = grid_for(c, n_tiles);
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
   switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
-    case kWide: launch_batch_t<kWide>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
-    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd); break;
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2); break;
+    case kWide: launch_batch_t<kWide>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
   {

@@ -65,8 +65,11 @@ __device__ __forceinline__ float azimuth_turns(float x, float y) {
   const float ay = __builtin_fabsf(y);
   const float mx = __builtin_fmaxf(ax, ay);
   const float mn = __builtin_fminf(ax, ay);
-  float q = mn * __builtin_amdgcn_rcpf(mx);
-  const bool tame = (mx >= 1.17549435e-38f) & (mx <= 8.5e37f);  // false for NaN
+  const float rmx = __builtin_amdgcn_rcpf(mx);
+  float q = mn * rmx;
+  // the reciprocal is a normal number exactly when mx is in [2^-126, 2^126]: a zero or denormal mx gives infinity, an infinite or
+  // huge one zero or a (flushed) denormal, NaN stays NaN -- ONE class test instead of two compares
+  const bool tame = __builtin_amdgcn_classf(rmx, 0x100);
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(!tame) != 0, 0)) {  // cold; only the odd lanes take the other quotient, so a
                                                                         // point's result never depends on its neighbours
     float qi = mn / mx;              // IEEE divide (handles denormals); 0/0 -> NaN fixed below

@@ -222,7 +222,7 @@ __device__ __forceinline__ FrameRec to_frame(const BatchRec& r) {
   FrameRec f;
   f.phi_x = r.phi_x; f.phi_y = r.phi_y; f.phi_z = r.phi_z; f.phi2 = r.phi2;
   f.rho_x = r.rho_x; f.rho_y = r.rho_y; f.rho_z = r.rho_z; f.s0 = r.s0;
-  f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pre2 = kGuardPre * rho_norm2(r.rho_x, r.rho_y, r.rho_z);  // no room in the 64-byte record
+  f.c1_x = r.c1_x; f.c1_y = r.c1_y; f.c1_z = r.c1_z; f.pre2 = kGuardPre * rho_norm2(r.rho_x, r.rho_y, r.rho_z);  // no room in the 64-byte record: the uniform fast path overrides it with the table's
   f.c2_x = r.c2_x; f.c2_y = r.c2_y; f.c2_z = r.c2_z; f.pad1 = 0.f;
   return f;
 }
@@ -261,6 +261,7 @@ struct BatchInline {
   BatchRec recs[kInlineBatchFrames];
   FrameRecD recs64[kInlineBatchFrames];
   uint2 coarse[kInlineBatchChunks + 1];
+  float pre2[kInlineBatchFrames];  // first-stage thresholds of the near-origin guard, see `pre2s` below
 };
 static_assert(sizeof(BatchInline) <= 3800, "the batch tables must leave room for the other arguments in the 4 KB kernel-argument segment");
 using brec_cp = const BatchRec __attribute__((address_space(4)))*;
@@ -292,23 +293,30 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
                                                          const BatchRec* __restrict__ recs_g,
                                                          const uint2* __restrict__ coarse_g, uint32_t n_frames,
                                                          uint64_t n, uint32_t* __restrict__ frame_idx_out, uint32_t head,
-                                                         const FrameRecD* __restrict__ recs64, uint32_t chunk_shift, BatchInlineArg<INLINE> inl) {
+                                                         const FrameRecD* __restrict__ recs64, uint32_t chunk_shift,
+                                                         const float* __restrict__ pre2s_g, BatchInlineArg<INLINE> inl) {
   // `recs64[f]`: frame f's constants in f64 for the near-origin guard's redo (kmc_device_math); cold
+  // `pre2s[f]`: kGuardPre * |rho_f|^2, the guard's first-stage threshold.  The 64-byte record has no room for it, and computing it from
+  // the record costs every wave four VALU instructions on wave-uniform values (there is no scalar float unit): one more 4-byte
+  // scalar load next to the record instead -- these kernels keep their SIMDs ~60 % busy, VALU instructions are not free
   // `head`: dead leading indices, see deskew_frame_f32 (the host has shifted the pointers and every offset by it)
   // `chunk_shift`: log2 of the coarse table's chunk size (kChunkShift for device tables)
   static_assert(BLOCK >= kLdsFrames * 4, "the LDS staging uses one lane per 16 bytes of the record table");
   constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
   brec_cp recs;      // tables are written by the host before the launch: constant for the kernel, uniform reads are scalar loads
   uint2_cp coarse;
+  const float __attribute__((address_space(4)))* pre2s;
   if constexpr (INLINE) {
-    struct ArgLayout { const v4f* in; v4f* out; const BatchRec* recs_g; const uint2* coarse_g; uint32_t n_frames; uint64_t n; uint32_t* frame_idx_out; uint32_t head; const FrameRecD* recs64; uint32_t chunk_shift; BatchInline inl; };
+    struct ArgLayout { const v4f* in; v4f* out; const BatchRec* recs_g; const uint2* coarse_g; uint32_t n_frames; uint64_t n; uint32_t* frame_idx_out; uint32_t head; const FrameRecD* recs64; uint32_t chunk_shift; const float* pre2s_g; BatchInline inl; };
     const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     recs = (brec_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, recs));
     coarse = (uint2_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, coarse));
     recs64 = (const FrameRecD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, recs64));
+    pre2s = (const float __attribute__((address_space(4)))*)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, pre2));
   } else {
     recs = (brec_cp)(uintptr_t)recs_g;
     coarse = (uint2_cp)(uintptr_t)coarse_g;
+    pre2s = (const float __attribute__((address_space(4)))*)(uintptr_t)pre2s_g;
   }
   __shared__ BatchRec lds_recs[kLdsFrames];
   const uint32_t tid = threadIdx.x;
@@ -340,12 +348,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
       f0 = lo;
     }
     const BatchRec r0 = load_rec(recs + f0);
+    const float pre2_0 = pre2s[f0];
     // near-origin guard (kmc_device_math): lanes whose f32 result lost significance are flagged here, skipped by the regular
     // stores and redone in f64 at the end of the tile -- ONE cold site for both paths below
     uint32_t redo_mask = 0;
     uint32_t fi_of[PPT];
     if (full && rec_end(r0) >= tile_end) {
-      const FrameRec f = to_frame(r0);
+      FrameRec f = to_frame(r0);
+      f.pre2 = pre2_0;  // (to_frame's own value -- computed from the record -- is only needed where lanes gather their records)
       const __amdgpu_buffer_rsrc_t rout = tile_rsrc(tout, kTile * sizeof(v4f));
 #pragma unroll
       for (int u = 0; u < PPT; ++u) {

@@ -314,6 +314,7 @@ struct BatchTables {
   BatchRec* d_recs = nullptr;
   FrameRecD* d_recd = nullptr;
   uint2* d_coarse = nullptr;
+  float* d_pre2 = nullptr;
   uint32_t n_frames = 0;
 };
 static BatchTables g_bt_big, g_bt_small;
@@ -337,6 +338,9 @@ static void build_tables(BatchTables* bt, uint64_t n, uint64_t pts_per_frame) {
     std::vector<FrameRecD> recd(nf, make_recd());
     CK(hipMalloc((void**)&bt->d_recd, nf * sizeof(FrameRecD)));
     CK(hipMemcpy(bt->d_recd, recd.data(), nf * sizeof(FrameRecD), hipMemcpyHostToDevice));
+    std::vector<float> pre2(nf, kGuardPre * (f.rho_x * f.rho_x + f.rho_y * f.rho_y + f.rho_z * f.rho_z));
+    CK(hipMalloc((void**)&bt->d_pre2, nf * sizeof(float)));
+    CK(hipMemcpy(bt->d_pre2, pre2.data(), nf * sizeof(float), hipMemcpyHostToDevice));
   }
   {
     const uint64_t chunk = 1ull << kChunkShift, nc = (n + chunk - 1) / chunk;
@@ -366,7 +370,7 @@ static Variant batch_variant(const char* label) {
     const uint64_t tiles = (n + (uint64_t)BLOCK * PPT - 1) / ((uint64_t)BLOCK * PPT);
     const uint64_t cap = bpc <= 0 ? tiles : (uint64_t)g_cus * bpc * (kBlock / (BLOCK < kBlock ? BLOCK : kBlock));
     hipLaunchKernelGGL((deskew_batch_f32<kSeries3, PPT, NT, false, BLOCK>), dim3((unsigned)std::min(tiles, cap)), dim3(BLOCK), 0, s,
-                       in, out, bt.d_recs, bt.d_coarse, bt.n_frames, n, (uint32_t*)nullptr, 0u, (const FrameRecD*)bt.d_recd, (uint32_t)kChunkShift, BatchNoInline{});
+                       in, out, bt.d_recs, bt.d_coarse, bt.n_frames, n, (uint32_t*)nullptr, 0u, (const FrameRecD*)bt.d_recd, (uint32_t)kChunkShift, bt.d_pre2, BatchNoInline{});
   };
   return v;
 }
