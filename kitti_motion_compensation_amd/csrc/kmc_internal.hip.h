@@ -5,6 +5,7 @@
 //   kmc_capi_traj.hip     N-knot trajectory entry points and their f64 host pre-step
 //   kmc_capi_project.hip  LiDAR -> image projection (row N4)
 //   kmc_capi_synth.hip    synthetic workload generator
+//   kmc_capi_hostpool.hip process-wide pool of page-locked, device-addressable host memory (what the in-place routes work on)
 // There is no CPU fallback anywhere: every hot-path entry point needs a live kmc_ctx, and kmc_hip_create() fails without a
 // HIP device.
 #pragma once

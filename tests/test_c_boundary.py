@@ -37,6 +37,7 @@ def test_plain_c_client_deskews_the_kitti_frame(exe, tmp_path, golden_dir):
     twist = [1.3, 0.05, -0.02, 0.002, -0.004, 0.03]
     r = subprocess.run([exe, src, dst] + [repr(v) for v in twist], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "1 launch(es)" in r.stdout and "in place on page-locked buffers" in r.stdout  # pool buffers: ONE kernel over the link, no staging
     xyzi = np.fromfile(src, dtype=np.float32).reshape(-1, 4)
     got = np.fromfile(dst, dtype=np.float32).reshape(-1, 4)
     P1 = orc.Affine.identity()
