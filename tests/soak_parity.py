@@ -310,6 +310,66 @@ def f64_round(ctx, rng, acc):
     acc["f64_max_rel_err"] = max(acc["f64_max_rel_err"], float(err.max()))
 
 
+def inplace_round(ctx, table_ctx, rng, acc, torch):
+    """Round 3's routes against the ones they stand next to, bit for bit: (a) the KITTI f32 layout on page-locked pool buffers (ONE
+    streamed kernel in place over the link) against the device-resident kernel; (b) the f64 Eigen layout on pool containers, with and
+    without the homogeneous column, whole call and begin / end halves, against the staged route; (c) a batch of at most 16 frames
+    (tables in the kernel arguments) against a context that sends small batches through device tables (KMC_NO_INLINE_TABLES=1)."""
+    n = int(rng.choice([1, 64, 2047, 2048, 2049, 5000, 123_397, 400_003, 1_048_576 + 3]))
+    pts = random_points(rng, n)
+    twist = random_twist(rng)
+    params = params_from_twist(twist, float(rng.random()))
+    ok = True
+    # (a)
+    pin, pout = capi.PooledArray((n, 4), np.float32), capi.PooledArray((n + 8, 4), np.float32)
+    pin.a[:] = pts
+    pout.a[:] = 7.0
+    ctx.deskew_f32(pin.a, pout.a[:n], params)
+    d_in = torch.from_numpy(pts).cuda()
+    d_out = torch.empty_like(d_in)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.deskew_f32(d_in, d_out, params)
+    torch.cuda.synchronize()
+    ctx.set_stream(None)
+    ok = ok and np.array_equal(pout.a[:n].view(np.uint32), d_out.cpu().numpy().view(np.uint32)) and bool((pout.a[n:] == 7.0).all())
+    pin.close(); pout.close()
+    # (b)
+    m = min(n, 300_000)
+    cols = [np.ascontiguousarray(pts[:m, k].astype(np.float64)) for k in range(3)] + [np.ones(m)]
+    stamps = np.ascontiguousarray(T0 + rng.random(m) * (T1 - T0))
+    staged = [np.empty(m) for _ in range(4)]
+    ctx.deskew_f64cols(cols[0], cols[1], cols[2], cols[3], stamps, T0, T1, params, *staged)
+    qin, qst, qout = capi.PooledArray((4, m)), capi.PooledArray((m,)), capi.PooledArray((4, m))
+    qin.a[:] = np.stack(cols)
+    qst.a[:] = stamps
+    qout.a[:] = -3.0
+    ctx.deskew_f64cols(qin.a[0], qin.a[1], qin.a[2], qin.a[3], qst.a, T0, T1, params, qout.a[0], qout.a[1], qout.a[2], qout.a[3])
+    ok = ok and all(np.array_equal(qout.a[j].view(np.uint64), staged[j].view(np.uint64)) for j in range(4))
+    qout.a[:] = -3.0
+    ctx.deskew_f64cols_begin(qin.a[0], qin.a[1], qin.a[2], None, qst.a, T0, T1, params, qout.a[0], qout.a[1], qout.a[2], None)
+    rc, st = ctx.deskew_f64cols_end()
+    ok = ok and rc == capi.OK and all(np.array_equal(qout.a[j].view(np.uint64), staged[j].view(np.uint64)) for j in range(3)) and bool((qout.a[3] == -3.0).all())
+    qin.close(); qst.close(); qout.close()
+    # (c)
+    nf = int(rng.integers(1, 17))
+    cuts = np.sort(rng.integers(0, n + 1, nf - 1)) if nf > 1 else np.array([], dtype=np.int64)
+    offsets = np.concatenate([[0], cuts, [n]]).astype(np.uint64)
+    plist = [params_from_twist(random_twist(rng), float(rng.random())) for _ in range(nf)]
+    outs, idxs = [], []
+    for c in (ctx, table_ctx):
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        o = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")
+        ix = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
+        c.deskew_batch_f32(d_in, o[:n], offsets, plist, ix[:n])
+        torch.cuda.synchronize()
+        c.set_stream(None)
+        outs.append(o)
+        idxs.append(ix)
+    ok = ok and bool(torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))) and bool(torch.equal(idxs[0], idxs[1]))
+    acc["inplace_points"] += 2 * n + 2 * m + 2 * n
+    acc["inplace_failures"] += 0 if ok else 1
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -317,6 +377,9 @@ def main():
     last_checkpoint = time.time()
     rng = np.random.default_rng(seed)
     ctx = capi.Context(0)
+    os.environ["KMC_NO_INLINE_TABLES"] = "1"
+    table_ctx = capi.Context(0)  # small batches through device tables: the A/B partner of the kernel-argument route
+    del os.environ["KMC_NO_INLINE_TABLES"]
     calib = util.load_kitti_calibration(os.path.join(ROOT, "tests", "golden"))
     acc = dict(seed=seed, seconds=budget, rounds=0, deskew_points=0, deskew_intensity_mismatch=0, batch_points=0, batch_index_mismatch=0, projection_points=0, projection_drawn=0,
                projection_int_mismatch=0, oracle_threads=orc.num_threads())
@@ -328,9 +391,10 @@ def main():
 
     acc.update(subrange_points=0, subrange_failures=0, f64_points=0, f64_max_rel_err=0.0, near_origin_rounds=0,
                near_origin_single_vs_batch_mismatch=0, near_origin_single_vs_batch_points=0,
-               traj_points=0, traj_index_mismatch=0, traj_intensity_mismatch=0, traj_device_vs_host_mismatch=0, half_turn_frames_redrawn=0)
+               traj_points=0, traj_index_mismatch=0, traj_intensity_mismatch=0, traj_device_vs_host_mismatch=0, half_turn_frames_redrawn=0,
+               inplace_points=0, inplace_failures=0)
     while time.time() < t_end:
-        r = acc["rounds"] % 7
+        r = acc["rounds"] % 8
         if r == 0:
             deskew_round(ctx, rng, acc)
         elif r == 1:
@@ -343,6 +407,8 @@ def main():
             near_origin_round(ctx, rng, acc)
         elif r == 5:
             f64_round(ctx, rng, acc)
+        elif r == 6:
+            inplace_round(ctx, table_ctx, rng, acc, torch)
         else:
             traj_round(ctx, rng, acc, torch)
         acc["rounds"] += 1
@@ -357,7 +423,7 @@ def main():
                      and acc["batch_index_mismatch"] == 0 and acc["projection_int_mismatch"] == 0
                      and acc["near_origin_single_vs_batch_mismatch"] == 0
                      and acc["traj_max_rel_err_literal"] <= 1e-5 and acc["traj_max_err_over_scale"] <= 2e-6 and acc["traj_index_mismatch"] == 0
-                     and acc["traj_intensity_mismatch"] == 0 and acc["traj_device_vs_host_mismatch"] == 0)
+                     and acc["traj_intensity_mismatch"] == 0 and acc["traj_device_vs_host_mismatch"] == 0 and acc["inplace_failures"] == 0)
     print(json.dumps(acc))
     sys.exit(0 if acc["ok"] else 1)
 
