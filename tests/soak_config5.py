@@ -6,7 +6,7 @@ in batches of <= 64 M points through the batched kernel, device-resident, for a 
 oracle (HOISTED, all cores) -- the soak's last output is what is checked at the end, so a kernel that drifted, or a table slot that
 was recycled too early somewhere in the run, does not go unnoticed.
 
-    python tools/soak_config5.py [seconds=60]      -> one JSON object per rank
+    python tests/soak_config5.py [seconds=60]      -> one JSON object per rank
 
 Test infrastructure: imports the oracle as the checker (outside every timed region)."""
 import json

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential soak: HIP path vs CPU oracle, for a wall-clock budget, over random sizes / twists / batch
 layouts / camera rigs.  Test infrastructure (it drives the oracle); prints one JSON summary.
-  python tools/soak_parity.py [seconds=300] [seed=1] [checkpoint.json] > gpurun_out/soak.json
-(tools/soak_parity.py is a launcher; the code lives under tests/ because it drives the oracle, which only test code may do.)
+  python tests/soak_parity.py [seconds=300] [seed=1] [checkpoint.json] > gpurun_out/soak.json
+(The code lives under tests/ because it drives the oracle, which only test code may do.)
 With a checkpoint path the running totals are rewritten there once a minute, so a run that is cut short (gpurun caps a call at
 3600 s) still leaves its evidence."""
 import json

@@ -1,4 +1,4 @@
-"""Workload builders shared by the -m gpu tests, tools/soak_config5.py and tools/measure_configs.py (test infrastructure:
+"""Workload builders shared by the -m gpu tests, tests/soak_config5.py and tools/measure_configs.py (test infrastructure:
 this module drives the ORACLE as the checker, so it lives under tests/).
 
   * five_drives(): BASELINE.json configs[4] -- five concurrent KITTI drives 0001/0005/0091/0104/0117 with their real frame
