@@ -52,15 +52,17 @@ extern "C" {
 #define KMC_ERR_DEGENERATE (-6)        /* stamp_start >= stamp_end, or a singular pose */
 
 typedef enum kmc_mem_kind {
-  KMC_MEM_HOST = 0,  /* pageable or pinned host memory: the library stages H2D / D2H (PCIe-bound) */
+  KMC_MEM_HOST = 0,  /* any host memory.  Pageable: the library stages H2D / D2H (PCIe-bound).  Page-locked and addressed by the device
+                        at its host address (the pool below, hipHostMalloc, torch's pin_memory()): recognised (one runtime lookup per
+                        buffer) and handled like KMC_MEM_HOST_MAPPED; KMC_HOST_DETECT_PINNED=0 limits that to pool memory */
   KMC_MEM_DEVICE = 1, /* device memory of the ctx's GPU: zero-copy, the roofline path */
   KMC_MEM_HOST_MAPPED = 2 /* page-locked host memory the device can address (kmc_host_pool_alloc, kmc_hip_host_alloc, hipHostMalloc):
                              the kernel reads and writes it IN PLACE over the link -- one launch, upload and download overlapped, no
                              staging copies -- and the call returns when the results are in host memory.  Accepted by
                              kmc_hip_deskew_f32, kmc_hip_deskew_batch_f32, kmc_hip_deskew_f64cols, kmc_hip_deskew_traj_f64cols and
-                             kmc_hip_pseudo_timestamps_f64; kmc_hip_deskew_f32 and the f64 entry points also take this route by
-                             themselves when every KMC_MEM_HOST pointer they are given lies in a block of the pool below (which is
-                             what the C++ drop-in's containers and KittiPclLoader::LoadRaw's clouds are made of). */
+                             kmc_hip_pseudo_timestamps_f64; the same entry points take this route by themselves when every KMC_MEM_HOST
+                             pointer they are given is page-locked (the pool below is what the C++ drop-in's containers and
+                             KittiPclLoader::LoadRaw's clouds are made of). */
 } kmc_mem_kind;
 
 typedef struct kmc_ctx kmc_ctx; /* opaque */
@@ -245,7 +247,7 @@ int kmc_hip_deskew_f64cols(kmc_ctx* ctx, const double* x, const double* y, const
 
 /* The same call in two halves, for a caller with host work to overlap (the C++ drop-in fills the output's homogeneous column while
  * the kernel runs).  _begin checks the arguments and ISSUES the work; with device-addressable buffers (KMC_MEM_DEVICE,
- * KMC_MEM_HOST_MAPPED, or KMC_MEM_HOST pointers that all lie in the page-locked pool) it returns without waiting, with staged host
+ * KMC_MEM_HOST_MAPPED, or KMC_MEM_HOST pointers that are all page-locked) it returns without waiting, with staged host
  * buffers it completes the call.  _end waits and returns what kmc_hip_deskew_f64cols would have returned (KMC_ERR_TIME_OUT_OF_RANGE
  * included) and its stats.  Exactly one _end per successful _begin, and no other call on the context in between; the buffers belong
  * to the library until _end returns. */

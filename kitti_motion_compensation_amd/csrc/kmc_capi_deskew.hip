@@ -227,7 +227,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE && mem_kind != KMC_MEM_HOST_MAPPED) return KMC_ERR_INVALID_ARG;
   // host buffers that both lie in the page-locked pool take the in-place route by themselves
   if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && xyzi_in && xyzi_out && !((((uintptr_t)xyzi_in) | ((uintptr_t)xyzi_out)) & 15u) &&
-      host_pool_owns(xyzi_in, n * sizeof(v4f)) && host_pool_owns(xyzi_out, n * sizeof(v4f)))
+      host_in_place_ok(xyzi_in, n * sizeof(v4f)) && host_in_place_ok(xyzi_out, n * sizeof(v4f)))
     mem_kind = KMC_MEM_HOST_MAPPED;
   if (mem_kind == KMC_MEM_HOST_MAPPED) {
     // page-locked, device-addressable host buffers: ONE kernel works on the caller's memory over the link -- persistent waves with the
@@ -389,6 +389,10 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
 int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets, uint32_t n_frames,
                              const kmc_frame_params* params, uint32_t* frame_idx_out, int mem_kind, kmc_stats* st) {
   if (!c || !offsets || (n_frames && !params)) return KMC_ERR_INVALID_ARG;
+  if (mem_kind == KMC_MEM_HOST && n_frames && xyzi_in && xyzi_out && offsets[n_frames] >= kMappedMinPoints &&
+      host_in_place_ok(xyzi_in, offsets[n_frames] * sizeof(v4f)) && host_in_place_ok(xyzi_out, offsets[n_frames] * sizeof(v4f)) &&
+      (!frame_idx_out || host_in_place_ok(frame_idx_out, offsets[n_frames] * sizeof(uint32_t))))
+    mem_kind = KMC_MEM_HOST_MAPPED;  // the caller's buffers are page-locked: no staging copies
   if (mem_kind == KMC_MEM_HOST_MAPPED) {
     // page-locked, device-addressable host buffers: the device route on the caller's pointers (the tiles of a batch are spread over
     // thousands of waves in flight, reads and writes mix by themselves), then a wait -- the results are in host memory on return
@@ -586,9 +590,9 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
   // Host containers made of the page-locked pool (the C++ drop-in's Pointcloud / VectorXd are): the kernel works on them in place.
   // ONE launch -- the 40 B per point coming up and the 24-32 B going down share the full-duplex link -- instead of three staged copies
   // with ~20 us of fixed cost each (123 k-point frame: 224-239 us staged, see profiles/NOTES.md for the in-place figure).
-  if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && host_pool_owns(x, col) && host_pool_owns(y, col) && host_pool_owns(z, col) &&
-      (!w || host_pool_owns(w, col)) && host_pool_owns(stamps, col) && host_pool_owns(ox, col) && host_pool_owns(oy, col) &&
-      host_pool_owns(oz, col) && (!ow || host_pool_owns(ow, col)))
+  if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && host_in_place_ok(x, col) && host_in_place_ok(y, col) && host_in_place_ok(z, col) &&
+      (!w || host_in_place_ok(w, col)) && host_in_place_ok(stamps, col) && host_in_place_ok(ox, col) && host_in_place_ok(oy, col) &&
+      host_in_place_ok(oz, col) && (!ow || host_in_place_ok(ow, col)))
     mem_kind = KMC_MEM_HOST_MAPPED;
   // (Recognising a homogeneous column of ones on the host and skipping its two transfers was measured and dropped: scanning
   // and refilling it costs what moving it over PCIe costs -- 12 + 9 us against 37 us saved at 123 k points, and it serialises
@@ -719,7 +723,7 @@ int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, 
   const size_t col = n * sizeof(double);
   const double *dx = x, *dy = y;
   double* dout = stamps_out;
-  if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && host_pool_owns(x, col) && host_pool_owns(y, col) && host_pool_owns(stamps_out, col))
+  if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && host_in_place_ok(x, col) && host_in_place_ok(y, col) && host_in_place_ok(stamps_out, col))
     mem_kind = KMC_MEM_HOST_MAPPED;  // page-locked containers: in place, see kmc_hip_deskew_f64cols
   if (mem_kind == KMC_MEM_HOST) {
     int rc = ensure_tmp(c, 3 * col);

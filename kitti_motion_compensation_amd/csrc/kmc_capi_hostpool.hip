@@ -14,6 +14,7 @@
 #include "kmc_internal.hip.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 
@@ -70,6 +71,36 @@ bool host_pool_owns(const void* ptr, size_t bytes) {
   if (it == p.blocks.begin()) return false;
   --it;
   return it->second.in_use && (uintptr_t)ptr + bytes <= it->first + it->second.bytes;
+}
+
+// Page-locked memory the CALLER allocated (hipHostMalloc, torch's pin_memory(), a registered range whose device address equals its
+// host address) is as good as the pool's: the kernels can work on it in place.  One runtime lookup per end of the range; pageable
+// memory answers "unregistered" (or an error, in older runtimes) and the call takes the staged route.  KMC_HOST_DETECT_PINNED=0
+// restricts the in-place routes to pool memory and explicit KMC_MEM_HOST_MAPPED.
+static bool device_addressable_host_byte(const void* p) {
+  hipPointerAttribute_t a;
+  std::memset(&a, 0, sizeof(a));
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost && a.devicePointer == p;
+}
+
+bool host_in_place_ok(const void* ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return false;
+  if (host_pool_owns(ptr, bytes)) return true;
+  static const bool detect = [] {
+    const char* e = std::getenv("KMC_HOST_DETECT_PINNED");
+    return !(e && std::atoi(e) == 0);
+  }();
+  if (!detect) return false;
+  {
+    Pool& p = pool();
+    std::lock_guard<std::mutex> lock(p.m);
+    if (!usable(p)) return false;  // no HIP device: nothing to ask
+  }
+  return device_addressable_host_byte(ptr) && device_addressable_host_byte((const char*)ptr + bytes - 1);
 }
 }  // namespace kmc_impl
 

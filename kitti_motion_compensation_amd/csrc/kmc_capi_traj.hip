@@ -416,9 +416,9 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   uint32_t* d_idx = bracket_idx_out;
   const size_t col = n * sizeof(double);
   // containers made of the page-locked pool: the kernel works on them in place (see kmc_hip_deskew_f64cols)
-  if (mem_kind == KMC_MEM_HOST && n >= 2048 && host_pool_owns(x, col) && host_pool_owns(y, col) && host_pool_owns(z, col) && (!w || host_pool_owns(w, col)) &&
-      host_pool_owns(stamps, col) && host_pool_owns(ox, col) && host_pool_owns(oy, col) && host_pool_owns(oz, col) && (!ow || host_pool_owns(ow, col)) &&
-      (!bracket_idx_out || host_pool_owns(bracket_idx_out, n * sizeof(uint32_t))))
+  if (mem_kind == KMC_MEM_HOST && n >= 2048 && host_in_place_ok(x, col) && host_in_place_ok(y, col) && host_in_place_ok(z, col) && (!w || host_in_place_ok(w, col)) &&
+      host_in_place_ok(stamps, col) && host_in_place_ok(ox, col) && host_in_place_ok(oy, col) && host_in_place_ok(oz, col) && (!ow || host_in_place_ok(ow, col)) &&
+      (!bracket_idx_out || host_in_place_ok(bracket_idx_out, n * sizeof(uint32_t))))
     mem_kind = KMC_MEM_HOST_MAPPED;
   if (mem_kind == KMC_MEM_HOST) {
     rc = ensure_tmp(c, 9 * col + (bracket_idx_out ? n * sizeof(uint32_t) : 0));

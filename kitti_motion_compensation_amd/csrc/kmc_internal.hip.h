@@ -216,6 +216,7 @@ inline int ppt_of(const kmc_ctx* c) {
 }
 
 bool host_pool_owns(const void* ptr, size_t bytes);  // inside a live block of the page-locked host pool (kmc_capi_hostpool.hip)
+bool host_in_place_ok(const void* ptr, size_t bytes);  // pool memory, or the caller's own page-locked memory that the device addresses at the same address
 int ensure_tmp(kmc_ctx* c, size_t bytes);  // grow-only device scratch of the host-buffer paths
 int ensure_pipeline(kmc_ctx* c);           // streams, events and device slots of the three-stage host pipeline
 int ensure_pipe_streams(kmc_ctx* c);       // only its three streams

@@ -148,7 +148,9 @@ def test_host_pipeline_many_chunks_matches_device_path(torch_mod, ctx, kitti):
     assert np.array_equal(out.view(np.uint32), dev.view(np.uint32))
     pinned_in = torch.from_numpy(xyzi).pin_memory()
     pinned_out = torch.empty_like(pinned_in).pin_memory()
-    ctx.deskew_f32(pinned_in.numpy(), pinned_out.numpy(), params)
+    # the caller's OWN page-locked memory (not the library's pool): recognised, one kernel works on it in place over the link
+    st_pinned = ctx.deskew_f32(pinned_in.numpy(), pinned_out.numpy(), params)
+    assert st_pinned.n_launches == 1 and not capi.host_pool_owns(pinned_in.numpy())
     assert np.array_equal(pinned_out.numpy().view(np.uint32), dev.view(np.uint32))
     sel = np.arange(0, n, 1013)
     _check(out[sel], xyzi[sel], _oracle(xyzi[sel], P1, P2, mode=orc.HOISTED))
