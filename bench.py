@@ -247,14 +247,15 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     if check:
         from oracle import oracle as orc
 
-    def timed(fn, iters, warm):
+    def timed(fn, iters, warm, on=None):
+        on = on or ctx
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
-        ctx.timer_begin()
+        on.timer_begin()
         for _ in range(iters):
             fn()
-        return ctx.timer_end() / iters  # ms per call
+        return on.timer_end() / iters  # ms per call
 
     def rel_err(got, ref):
         return float((np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-3)).max())
@@ -278,17 +279,37 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     # the frames are handed to the C-ABI 480 at a time (kmc_hip_deskew_frames_f32) so that the C loop, not Python's ~8 us per
     # ctypes call, sets the pace; the same entry point with one queue is the strictly-in-order stream of launches
     pack = ctx.prepare_frames([bufs[k % len(bufs)] for k in range(480)], [prm] * 480)
+    # (these legs run on the contexts' OWN streams, like a C caller's would: torch's current stream here is HIP's legacy default
+    # stream, whose implicit synchronisation with other streams the library does not second-guess -- no any-order launches there)
+    caller_stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    ctx.set_stream(None)
     ctx.set_frame_queues(1)
+    ao_before = ctx.any_order_launches()
     ms_order = timed(lambda: ctx.deskew_frames_f32(pack), 6, 2) / 480
+    ao_share = (ctx.any_order_launches() - ao_before) / (8 * 480)
+    # the same stream of launches from a context that keeps the barrier bit on every dispatch (KMC_ANY_ORDER=0 is read at creation)
+    os.environ["KMC_ANY_ORDER"] = "0"
+    drained_ctx = capi.Context(dev.index or 0)
+    del os.environ["KMC_ANY_ORDER"]
+    drained_ctx.set_frame_queues(1)
+    ms_drained = timed(lambda: drained_ctx.deskew_frames_f32(pack), 6, 2, on=drained_ctx) / 480
+    drained_ctx.close()
     ctx.set_frame_queues(4)
     ms_q4 = timed(lambda: ctx.deskew_frames_f32(pack), 6, 2) / 480
     ms_q4_calls = timed(one_frame, 960, 48)  # one kmc_hip_deskew_f32 call per frame from Python, queues on (host-bound: ~8 us per ctypes call)
     ctx.set_frame_queues(1)
+    ctx.synchronize()
+    ctx.set_stream(caller_stream)
     leg = {
         "workload": "configs[1] literally: one synthetic 1 M-point frame per kmc_hip_deskew_f32 call, 24 rotating buffer pairs (768 MB)",
         "kernel": "kmc_dev::deskew_frame_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64>",
         "in_order": {"us_per_frame": round(ms_order * 1e3, 3), "Mpts_s": round(n / ms_order / 1e3, 1), "GBps": round(32 * n / ms_order / 1e6, 1),
-                     "frac": _frac(32 * n / ms_order / 1e6), "note": "one stream (kmc_hip_set_frame_queues(ctx, 1)): the chip drains between two launches"},
+                     "frac": _frac(32 * n / ms_order / 1e6), "dispatched_without_barrier_bit": round(ao_share, 3),
+                     "note": "one stream (kmc_hip_set_frame_queues(ctx, 1)); frames of the call that share no buffer with one in flight are dispatched "
+                             "without the barrier bit (hipExtAnyOrderLaunch), so the chip does not drain between them"},
+        "in_order_drained": {"us_per_frame": round(ms_drained * 1e3, 3), "GBps": round(32 * n / ms_drained / 1e6, 1), "frac": _frac(32 * n / ms_drained / 1e6),
+                             "note": "the same launches from a context created with KMC_ANY_ORDER=0: every dispatch waits for the last wave of the one before it"},
         "four_frame_queues": {"us_per_frame": round(ms_q4 * 1e3, 3), "Mpts_s": round(n / ms_q4 / 1e3, 1), "GBps": round(32 * n / ms_q4 / 1e6, 1),
                               "frac": _frac(32 * n / ms_q4 / 1e6),
                               "note": "kmc_hip_deskew_frames_f32, 480 frames per call over 4 HIP streams of the context (one fork from the context's stream per call, one join)"},

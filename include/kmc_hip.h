@@ -202,7 +202,15 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * (motion_compensation.cpp:22-25 reads nothing a previous frame wrote), so they may overlap: with frame queues on,
  * device-resident kmc_hip_deskew_f32 calls are issued round-robin over `queues` HIP streams (hardware queues) of the context --
  * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip, tools/fq_probe.hip).
- *   - queues = 1 (default): every call on the context's stream, strictly in order (the behaviour of ABI version 1).
+ *   - queues = 1 (default): every call on the context's stream, in order.  Since ABI version 3 "in order" no longer means "drained":
+ *     a device-resident frame whose buffers overlap none of the frames launched since the last ordinary launch is dispatched WITHOUT
+ *     the barrier bit (hipExtAnyOrderLaunch) and starts while the frame before it is still running -- the results of every frame,
+ *     and everything the context or the caller puts on the stream afterwards (copies, events, other kernels: ordinary packets, which
+ *     wait for all of them), are the same as before.  This needs no queues and no events; it applies (a) on the context's own
+ *     stream, (b) on a caller's stream after kmc_hip_set_frame_queue_order(ctx, 0), (c) between the frames of one
+ *     kmc_hip_deskew_frames_f32 call; at most 32 frames go out between two ordinary launches; KMC_ANY_ORDER=0 switches it off.
+ *     Measured (tools/anyorder_probe.hip, bench.py's configs1_literal leg): 7.0 -> 6.3 us per 1 M-point frame; never on HIP's legacy
+ *     default stream (handle NULL) and never while the stream captures a graph.
  *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls -- and kmc_hip_deskew_traj_f32(KMC_MEM_DEVICE) calls with
  *     at most four knots -- are NOT ordered with each other.  EVERY queued frame is ordered behind what has been issued on
  *     the context's stream up to its call -- its producers --, so the usual loop "produce frame k on the stream, deskew it" is safe
@@ -218,6 +226,8 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
 int kmc_hip_set_frame_queues(kmc_ctx* ctx, int queues);
 int kmc_hip_set_frame_queue_order(kmc_ctx* ctx, int after_producers);
 int kmc_hip_frame_queue_join(kmc_ctx* ctx);
+/* How many frames of this context have been dispatched without the barrier bit so far (a counter for tests and tuning). */
+uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
  * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues -- the count the caller chose with
  * kmc_hip_set_frame_queues (1 = strictly in order on the context's stream), four for this call if it never chose -- and joined: the

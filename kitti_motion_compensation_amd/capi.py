@@ -138,6 +138,7 @@ SIGNATURES = {
     "kmc_hip_deskew_f32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(FrameParams), C.c_int, C.POINTER(Stats)]),
     "kmc_hip_set_frame_queues": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_frame_queue_join": (C.c_int, [_vp]),
+    "kmc_hip_any_order_launches": (C.c_uint64, [_vp]),
     "kmc_hip_set_frame_queue_order": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_deskew_frames_f32": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(FrameParams), C.c_uint32, C.POINTER(Stats)]),
     "kmc_hip_deskew_batch_f32": (
@@ -442,6 +443,10 @@ class Context:
 
     def frame_queue_join(self):
         self._check(lib().kmc_hip_frame_queue_join(self._h), "kmc_hip_frame_queue_join")
+
+    def any_order_launches(self) -> int:
+        """Frames dispatched without the barrier bit so far (see kmc_hip_set_frame_queues in kmc_hip.h)."""
+        return int(lib().kmc_hip_any_order_launches(self._h))
 
     def prepare_frames(self, pairs, params_list):
         """pairs: [(device_in, device_out), ...] of (n_f, 4) float32 device tensors.  -> opaque argument pack for deskew_frames_f32

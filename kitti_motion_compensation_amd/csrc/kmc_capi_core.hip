@@ -104,6 +104,7 @@ int fq_stream(kmc_ctx* c, hipStream_t* out) {
 }
 
 int fq_join(kmc_ctx* c) {
+  c->ao_valid = false;  // whoever joins is about to put ordinary work on the stream: the any-order window ends here
   if (!c->fq_forked) return KMC_OK;
   for (int q = 0; q < c->fq_count; ++q) {
     if (!c->fq_used[q]) continue;
@@ -112,6 +113,37 @@ int fq_join(kmc_ctx* c) {
   }
   c->fq_forked = false;
   return KMC_OK;
+}
+
+// May this frame start before the launches ahead of it on the context's stream have finished?  Yes if
+//   - nothing the library does not know about can sit between the previous frame launch and this one: the stream is the context's
+//     own, or the caller has said that its frames are produced before the first call (kmc_hip_set_frame_queue_order(ctx, 0)), or both
+//     frames belong to one kmc_hip_deskew_frames_f32 call (`same_call`);
+//   - the window describes everything in flight behind the last ordered launch (every other entry point ends it);
+//   - the frame's buffers overlap none of the window's (write against reads and writes, read against writes).
+// Either way the frame is entered into the window; an ordered launch starts a new one.
+bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call) {
+  const kmc_ctx::AoRange r = {(uintptr_t)in, (uintptr_t)in + bytes}, w = {(uintptr_t)out, (uintptr_t)out + bytes};
+  bool any_order = c->ao_enabled && c->ao_valid && c->stream != nullptr && c->ao_count < kmc_ctx::kAoWindow &&
+                   (same_call || c->stream == c->own_stream || !c->fq_ordered);
+  for (int k = 0; any_order && k < c->ao_count; ++k) {
+    const kmc_ctx::AoRange &pr = c->ao_reads[k], &pw = c->ao_writes[k];
+    if ((w.lo < pr.hi && pr.lo < w.hi) || (w.lo < pw.hi && pw.lo < w.hi) || (r.lo < pw.hi && pw.lo < r.hi)) any_order = false;
+  }
+  if (any_order && c->stream != c->own_stream) {  // a caller's stream may be capturing a graph: plain launches there
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      any_order = false;
+    }
+  }
+  if (!any_order) c->ao_count = 0;
+  c->ao_reads[c->ao_count] = r;
+  c->ao_writes[c->ao_count] = w;
+  ++c->ao_count;
+  c->ao_valid = c->ao_enabled;
+  c->ao_launches += any_order ? 1 : 0;
+  return any_order;
 }
 
 int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
@@ -249,6 +281,7 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   }
   c->stream = c->own_stream;
   if (const char* e = std::getenv("KMC_NO_INLINE_TABLES")) c->no_inline_tables = std::atoi(e) != 0;
+  if (const char* e = std::getenv("KMC_ANY_ORDER")) c->ao_enabled = std::atoi(e) != 0;
   if (const char* e = std::getenv("KMC_MAPPED_WAVES")) c->mapped_waves = std::max(1, std::min(65536, std::atoi(e)));
   *out = c;
   return KMC_OK;
@@ -367,6 +400,8 @@ int kmc_hip_frame_queue_join(kmc_ctx* c) {
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   return fq_join(c);
 }
+
+uint64_t kmc_hip_any_order_launches(kmc_ctx* c) { return c ? c->ao_launches : 0; }
 
 int kmc_hip_enable_timing(kmc_ctx* c, int enabled) {
   if (!c) return KMC_ERR_INVALID_ARG;

@@ -3,6 +3,8 @@
 // f64 -> device-precision frame records, launch geometry, optional host staging; all per-point work is in kmc_kernels.hip.h.
 #include "kmc_internal.hip.h"
 
+#include <hip/hip_ext.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -13,21 +15,27 @@
 namespace {
 
 // ---- template dispatch ---------------------------------------------------------------------------
+// any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao_valid
 template <int TIER, int PPT>
-void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d) {
-  hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head, d);
+void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d, bool any_order) {
+  if (any_order)
+    hipExtLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, nullptr, nullptr,
+                          (uint32_t)hipExtAnyOrderLaunch, in, out, n, f, head, d);
+  else
+    hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head, d);
 }
 template <int TIER>
-void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d) {
+void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d, bool any_order) {
   switch (ppt) {
-    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head, d); break;
-    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head, d); break;
-    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head, d); break;
-    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head, d); break;
+    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head, d, any_order); break;
+    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head, d, any_order); break;
+    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head, d, any_order); break;
+    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head, d, any_order); break;
   }
 }
 // in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of()
-void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0) {
+void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0,
+                  bool any_order = false) {
   const int ppt = ppt_of(c);
   in -= head;
   out -= head;
@@ -35,10 +43,10 @@ void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f*
   const uint64_t n_tiles = (n + (uint64_t)kLaunchBlock * ppt - 1) / ((uint64_t)kLaunchBlock * ppt);
   const int grid = grid_for(c, n_tiles);
   switch (tier) {
-    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head, d); break;
-    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head, d); break;
-    case kWide: launch_frame_t<kWide>(ppt, s, grid, in, out, n, f, head, d); break;
-    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head, d); break;
+    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head, d, any_order); break;
+    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head, d, any_order); break;
+    case kWide: launch_frame_t<kWide>(ppt, s, grid, in, out, n, f, head, d, any_order); break;
+    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head, d, any_order); break;
   }
 }
 
@@ -76,7 +84,8 @@ void launch_batch_inline(hipStream_t s, int grid, const v4f* in, v4f* out, uint3
 // ---- helpers of the single-frame entry points ----
 namespace {
 // one device-resident frame on stream `s` (arguments already validated)
-int issue_frame(kmc_ctx* c, hipStream_t s, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params, int* tier_out) {
+int issue_frame(kmc_ctx* c, hipStream_t s, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params, int* tier_out,
+                bool any_order = false) {
   const int tier = pick_tier(c, params, 1);
   FrameRec f;
   std::memset(&f, 0, sizeof(f));
@@ -86,7 +95,7 @@ int issue_frame(kmc_ctx* c, hipStream_t s, const float* xyzi_in, float* xyzi_out
   fill_recd(*params, &d);
   if (tier_out) *tier_out = tier;
   if (n == 0) return KMC_OK;
-  launch_frame(c, s, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, KMC_MEM_DEVICE));
+  launch_frame(c, s, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, KMC_MEM_DEVICE), any_order);
   KMC_HIP_TRY(c, hipGetLastError());
   return KMC_OK;
 }
@@ -281,16 +290,22 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     // frame queues on (kmc_hip_set_frame_queues) and no per-call timing: the frame goes to the next queue and is NOT ordered
     // with the frames before it -- they are independent -- until the next join
     hipStream_t s = c->stream;
+    bool any_order = false;
     if (c->fq_count > 1 && !c->timing) {
+      c->ao_valid = false;
       const int rc_q = fq_stream(c, &s);
       if (rc_q != KMC_OK) return rc_q;
     } else {
-      const int rc_j = fq_join(c);
-      if (rc_j != KMC_OK) return rc_j;
+      if (c->fq_forked || c->timing) {  // joins, event records: ordinary work on the stream, the any-order window ends
+        const int rc_j = fq_join(c);
+        if (rc_j != KMC_OK) return rc_j;
+      }
+      // in order on the context's stream -- but a frame that shares no buffer with the frames still in flight need not wait for them
+      if (n) any_order = ao_admit(c, xyzi_in, xyzi_out, n * sizeof(v4f), false);
     }
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     int tier = 0;
-    const int rc_issue = issue_frame(c, s, xyzi_in, xyzi_out, n, params, &tier);
+    const int rc_issue = issue_frame(c, s, xyzi_in, xyzi_out, n, params, &tier, any_order);
     if (rc_issue != KMC_OK) return rc_issue;
     if (st) { st->n_points = n; st->variant = (uint32_t)tier; st->n_launches = n ? 1 : 0; }
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
@@ -370,7 +385,9 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
     hipStream_t s;
     rc = fq_stream(c, &s);
     int tier = 0;
-    if (rc == KMC_OK) rc = issue_frame(c, s, xyzi_in[f], xyzi_out[f], n_points[f], &params[f], &tier);
+    // one queue = the context's stream, in order: frames of this call that share no buffer still need not wait for each other
+    const bool any_order = rc == KMC_OK && c->fq_count <= 1 && n_points[f] && ao_admit(c, xyzi_in[f], xyzi_out[f], n_points[f] * sizeof(v4f), f > 0);
+    if (rc == KMC_OK) rc = issue_frame(c, s, xyzi_in[f], xyzi_out[f], n_points[f], &params[f], &tier, any_order);
     tier_max = std::max(tier_max, tier);
     total += n_points[f];
   }

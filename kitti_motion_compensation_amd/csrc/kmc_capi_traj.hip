@@ -2,6 +2,8 @@
 // north_star): f64 host pre-step per trajectory, single-frame, batched and f64 Eigen-layout entry points.
 #include "kmc_internal.hip.h"
 
+#include <hip/hip_ext.h>
+
 namespace {
 
 // ---- N-knot trajectory: host pre-step (f64) -------------------------------------------------------------------------
@@ -167,10 +169,13 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   const bool inline_records = mem_kind == KMC_MEM_DEVICE && th.n_seg <= (uint32_t)kInlineSegments;
   const bool queued = inline_records && c->fq_count > 1 && !c->timing;  // goes to a frame queue: not ordered with the frames before it
-  if (!queued) {
+  // in order on the context's stream, but -- like kmc_hip_deskew_f32 -- not behind frames it shares no buffer with (kmc_ctx::ao_valid)
+  const bool window = inline_records && !queued && !c->timing && !c->fq_forked && !bracket_idx_out && n;
+  if (!queued && !window) {
     rc = fq_join(c);
     if (rc != KMC_OK) return rc;
   }
+  if (queued) c->ao_valid = false;
   const int tier = traj_tier(c, th, stamp_start, stamp_end);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
@@ -178,7 +183,8 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
 #define KMC_LAUNCH_TRAJ(T, INL, STREAM, SEGS, SEGS64, ...)                                                                          \
   do {                                                                                                                              \
-    if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
+    if (any_order) hipExtLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL>), dim3(grid), dim3(64), 0, STREAM, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
+    else if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
     else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__);      \
   } while (0)
 #define KMC_LAUNCH_TRAJ_TIER(INL, STREAM, SEGS, SEGS64, ...)                                        \
@@ -204,6 +210,7 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
     const v4f* d_in = (const v4f*)xyzi_in;
     v4f* d_out = (v4f*)xyzi_out;
     uint32_t* d_idx = bracket_idx_out;
+    const bool any_order = window && ao_admit(c, xyzi_in, xyzi_out, n * sizeof(v4f), false);
     CallTimer tm(c);
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     const uint32_t head = head_of(xyzi_out, mem_kind);
@@ -249,6 +256,7 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   const TrajSeg32* d_segs = (const TrajSeg32*)c->slots[slot_id].d_buf;
   const TrajSegD* d_segs64 = (const TrajSegD*)(c->slots[slot_id].d_buf + kMaxSegments * sizeof(TrajSeg32));
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
+  constexpr bool any_order = false;  // the table route: ordinary launches
   KMC_LAUNCH_TRAJ_TIER(false, c->stream, d_segs, d_segs64, TrajInline{})
 #undef KMC_LAUNCH_TRAJ_TIER
 #undef KMC_LAUNCH_TRAJ

@@ -97,6 +97,18 @@ struct kmc_ctx {
   bool fq_used[kMaxFrameQueues] = {false, false, false, false};
   hipEvent_t fq_fork = nullptr;      // "everything issued on `stream` so far", which the queues wait for
   hipStream_t fq_spacer[8] = {};     // idle streams created before the queues (hardware-queue mapping, see kmc_hip_set_frame_queues)
+  // independent frames on ONE stream without the drain between them: a device-resident single-frame launch whose buffers overlap
+  // nothing that was launched since (and including) the last ORDERED launch goes out with hipExtAnyOrderLaunch -- the dispatch packet
+  // carries no barrier bit, the frame starts while the frame before it is still running.  Everything else the context puts on
+  // its stream is an ordinary (barrier) packet and waits for all of them (tools/anyorder_probe.hip measures both facts).  Only on the
+  // context's OWN stream: a caller's stream may hold producers the library does not see.
+  struct AoRange { uintptr_t lo, hi; };
+  static constexpr int kAoWindow = 32;   // frames between two ordered launches at most
+  bool ao_enabled = true;                // KMC_ANY_ORDER=0 turns it off
+  bool ao_valid = false;                 // the window describes EVERYTHING in flight on `stream` after the last ordered launch (it included)
+  int ao_count = 0;
+  uint64_t ao_launches = 0;              // frames that went out without the barrier bit so far (kmc_hip_any_order_launches)
+  AoRange ao_reads[kAoWindow], ao_writes[kAoWindow];
 };
 
 namespace kmc_impl {
@@ -147,6 +159,7 @@ int fq_join(kmc_ctx* c);
 // what every entry point that issues work on `stream` starts with
 #define KMC_ENTER(ctx)                                      \
   do {                                                      \
+    (ctx)->ao_valid = false;                                \
     KMC_HIP_TRY(ctx, hipSetDevice((ctx)->device));          \
     const int rc_join_ = fq_join(ctx);                      \
     if (rc_join_ != KMC_OK) return rc_join_;                \
@@ -215,6 +228,7 @@ inline int ppt_of(const kmc_ctx* c) {
   return (p == 1 || p == 2 || p == 4 || p == 8) ? p : kDefaultPpt;
 }
 
+bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call);  // may this frame be dispatched without the barrier bit?  (kmc_capi_core.hip)
 bool host_pool_owns(const void* ptr, size_t bytes);  // inside a live block of the page-locked host pool (kmc_capi_hostpool.hip)
 bool host_in_place_ok(const void* ptr, size_t bytes);  // pool memory, or the caller's own page-locked memory that the device addresses at the same address
 int ensure_tmp(kmc_ctx* c, size_t bytes);  // grow-only device scratch of the host-buffer paths

@@ -1188,3 +1188,125 @@ def test_switching_streams_drains_the_context(torch_mod, ctx):
             assert torch.equal(out_b[f * 64:(f + 1) * 64].view(torch.int32), want.view(torch.int32)), f
     finally:
         own.close()
+
+
+def test_any_order_frames_same_bits_and_hazards_kept(torch_mod, monkeypatch):
+    """In order on ONE stream, but not drained: a device-resident frame that shares no buffer with the frames launched since the last
+    ordinary launch is dispatched without the barrier bit (kmc_hip.h, kmc_hip_set_frame_queues).  Same bits as a context with
+    KMC_ANY_ORDER=0; frames that DO share a buffer with one in flight (chains, an overwritten input, the same buffer twice) stay
+    ordered; copies / consumers issued afterwards see every frame's result."""
+    torch = torch_mod
+    n, nf = 300_007, 40
+    params = [capi.FrameParams.make([1.3, 0.05 * (f % 3), -0.02, 0.002, -0.004, 0.03 + 0.001 * f], (f % 5) / 4.0) for f in range(nf)]
+    monkeypatch.setenv("KMC_ANY_ORDER", "0")
+    plain = capi.Context(0)
+    monkeypatch.delenv("KMC_ANY_ORDER")
+    fast = capi.Context(0)  # both on their OWN streams: inputs are synchronised by hand
+    try:
+        ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for _ in range(nf)]
+        for f in range(nf):
+            plain.synth_points(ins[f], n, 4100 + f)
+        plain.synchronize()
+        want = [torch.empty_like(x) for x in ins]
+        for f in range(nf):
+            plain.deskew_f32(ins[f], want[f], params[f])
+        plain.synchronize()
+        assert plain.any_order_launches() == 0
+        # (1) independent frames: one ordinary launch opens a window, at most 31 frames follow it without the barrier bit
+        outs = [torch.zeros_like(x) for x in ins]
+        torch.cuda.synchronize()
+        for f in range(nf):
+            fast.deskew_f32(ins[f], outs[f], params[f])
+        assert fast.any_order_launches() == nf - 2, fast.any_order_launches()
+        fast.synchronize()
+        for f in range(nf):
+            assert torch.equal(outs[f].view(torch.int32), want[f].view(torch.int32)), f
+        # (2) a chain: every frame reads what the one before it wrote -> none of them may overtake
+        before = fast.any_order_launches()
+        chain_ref = [ins[0]]
+        for f in range(6):
+            o = torch.empty_like(ins[0])
+            plain.deskew_f32(chain_ref[-1], o, params[f])
+            plain.synchronize()
+            chain_ref.append(o)
+        chain = [ins[0]] + [torch.zeros_like(ins[0]) for _ in range(6)]
+        torch.cuda.synchronize()
+        for f in range(6):
+            fast.deskew_f32(chain[f], chain[f + 1], params[f])
+        assert fast.any_order_launches() == before
+        fast.synchronize()
+        assert torch.equal(chain[6].view(torch.int32), chain_ref[6].view(torch.int32))
+        # (3) write-after-read: B overwrites the buffer A reads; the same buffer in place twice; a partial overlap
+        big = 4_000_000
+        x = torch.empty((big, 4), dtype=torch.float32, device="cuda")
+        plain.synth_points(x, big, 77)
+        plain.synchronize()
+        x0 = x.clone()
+        a_ref, ip_ref = torch.empty_like(x), x0.clone()
+        torch.cuda.synchronize()  # torch's clones run on ITS stream; the contexts' own streams are not ordered with it
+        plain.deskew_f32(x0, a_ref, params[1])
+        plain.deskew_f32(ip_ref, ip_ref, params[2])
+        plain.deskew_f32(ip_ref, ip_ref, params[3])
+        plain.synchronize()
+        a_out, other = torch.zeros_like(x), ins[5]
+        torch.cuda.synchronize()
+        before = fast.any_order_launches()
+        fast.deskew_f32(x, a_out, params[1])               # A reads x
+        fast.deskew_f32(other, x[:n], params[5])             # B writes the head of x: must wait for A
+        assert fast.any_order_launches() == before
+        fast.synchronize()
+        assert torch.equal(a_out.view(torch.int32), a_ref.view(torch.int32))
+        assert torch.equal(x[:n].view(torch.int32), want[5].view(torch.int32))
+        y = x0.clone()
+        torch.cuda.synchronize()
+        before = fast.any_order_launches()
+        fast.deskew_f32(y, y, params[2])
+        fast.deskew_f32(y, y, params[3])
+        assert fast.any_order_launches() == before
+        fast.synchronize()
+        assert torch.equal(y.view(torch.int32), ip_ref.view(torch.int32))
+        # (4) whatever follows on the stream waits for every frame of the window: a batched call right behind 8 any-order frames
+        mid = [torch.zeros_like(ins[0]) for _ in range(8)]
+        torch.cuda.synchronize()
+        before = fast.any_order_launches()
+        for f in range(8):
+            fast.deskew_f32(ins[f], mid[f], params[f])
+        assert fast.any_order_launches() == before + 7
+        # (the eight outputs are separate tensors: gather them with the library itself, an ordinary launch per tensor)
+        ident = capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5)
+        again = [torch.zeros_like(ins[0]) for _ in range(8)]
+        for f in range(8):
+            fast.deskew_batch_f32(mid[f], again[f], np.array([0, n], dtype=np.uint64), [ident], None)
+        fast.synchronize()
+        for f in range(8):
+            assert torch.equal(again[f].view(torch.int32), want[f].view(torch.int32)), f
+        # (5) a caller's stream: frames of ONE kmc_hip_deskew_frames_f32 call with one queue; separate calls only after the caller has
+        # said that nothing is produced in between
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            fast.set_stream(side.cuda_stream)
+            fast.set_frame_queues(1)
+            outs2 = [torch.zeros_like(x) for x in ins]
+            pack = fast.prepare_frames(list(zip(ins, outs2)), params)
+            before = fast.any_order_launches()
+            st = fast.deskew_frames_f32(pack)
+            assert st.n_launches == nf and fast.any_order_launches() == before + nf - 2
+            got = torch.stack(outs2)  # consumer on the same stream, no sync in between
+            assert torch.equal(got.view(torch.int32), torch.stack(want).view(torch.int32))
+            outs3 = [torch.zeros_like(x) for x in ins[:8]]
+            before = fast.any_order_launches()
+            for f in range(8):
+                fast.deskew_f32(ins[f], outs3[f], params[f])
+            assert fast.any_order_launches() == before  # producers may sit between two calls on a caller's stream
+            fast.set_frame_queue_order(False)
+            for f in range(8):
+                fast.deskew_f32(ins[f], outs3[f], params[f])  # writes outs3 again: conflicts with the frames above -> first ordered
+            assert fast.any_order_launches() == before + 7
+            got = torch.stack(outs3)
+            assert torch.equal(got.view(torch.int32), torch.stack(want[:8]).view(torch.int32))
+            fast.set_frame_queue_order(True)
+        side.synchronize()
+        fast.set_stream(None)
+    finally:
+        plain.close()
+        fast.close()

@@ -448,3 +448,58 @@ def test_batched_trajectories_argument_checks(ctx, kitti):
     assert e.value.status == capi.ERR_INVALID_ARG
     st = ctx.deskew_traj_batch_f32(pts, out, [0], [])   # no frames: nothing to do
     assert st.n_points == 0
+
+
+@pytest.mark.gpu
+def test_nknot_frames_without_the_barrier_bit_same_bits(kitti, monkeypatch):
+    """Short trajectories on device-resident points travel in the kernel arguments; on the context's own stream such frames are
+    dispatched without the barrier bit when they share no buffer with the frames in flight (kmc_hip.h, kmc_hip_set_frame_queues).
+    Same bits as a context created with KMC_ANY_ORDER=0; a frame that reads what the frame before it wrote stays ordered; two-pose
+    and N-knot frames share one window."""
+    import torch
+
+    xyzi, P1 = kitti
+    times, poses = _oxts_like_trajectory(P1)
+    n, nf = xyzi.shape[0], 12
+    monkeypatch.setenv("KMC_ANY_ORDER", "0")
+    plain = capi.Context(0)
+    monkeypatch.delenv("KMC_ANY_ORDER")
+    fast = capi.Context(0)
+    try:
+        rng = np.random.default_rng(9)
+        ins = [torch.from_numpy(np.ascontiguousarray(xyzi[rng.permutation(n)])).cuda() for _ in range(nf)]
+        treq = [T0 + (T1 - T0) * (f + 0.5) / nf for f in range(nf)]
+        want = [torch.empty_like(x) for x in ins]
+        for f in range(nf):
+            plain.deskew_traj_f32(ins[f], want[f], times, _rt(poses), T0, T1, treq[f], None, n=n)
+        plain.synchronize()
+        assert plain.any_order_launches() == 0
+        outs = [torch.zeros_like(x) for x in ins]
+        torch.cuda.synchronize()
+        for f in range(nf):
+            fast.deskew_traj_f32(ins[f], outs[f], times, _rt(poses), T0, T1, treq[f], None, n=n)
+        assert fast.any_order_launches() == nf - 1
+        fast.synchronize()
+        for f in range(nf):
+            assert torch.equal(outs[f].view(torch.int32), want[f].view(torch.int32)), f
+        # a chain through both kinds of frame: N-knot -> two-pose -> N-knot, each reading the output of the one before
+        prm = capi.FrameParams.make([1.3, 0.02, -0.01, 0.001, -0.002, 0.03], 0.5)
+        ref = [ins[0], torch.empty_like(ins[0]), torch.empty_like(ins[0]), torch.empty_like(ins[0])]
+        plain.deskew_traj_f32(ref[0], ref[1], times, _rt(poses), T0, T1, treq[3], None, n=n)
+        plain.deskew_f32(ref[1], ref[2], prm)
+        plain.deskew_traj_f32(ref[2], ref[3], times, _rt(poses), T0, T1, treq[7], None, n=n)
+        plain.synchronize()
+        got = [ins[0], torch.zeros_like(ins[0]), torch.zeros_like(ins[0]), torch.zeros_like(ins[0])]
+        torch.cuda.synchronize()
+        before = fast.any_order_launches()
+        fast.deskew_traj_f32(got[0], got[1], times, _rt(poses), T0, T1, treq[3], None, n=n)
+        fast.deskew_f32(got[1], got[2], prm)
+        fast.deskew_traj_f32(got[2], got[3], times, _rt(poses), T0, T1, treq[7], None, n=n)
+        assert fast.any_order_launches() == before
+        fast.deskew_f32(ins[4], outs[4], prm)  # independent of the chain: may overtake it
+        assert fast.any_order_launches() == before + 1
+        fast.synchronize()
+        assert torch.equal(got[3].view(torch.int32), ref[3].view(torch.int32))
+    finally:
+        plain.close()
+        fast.close()
