@@ -10,6 +10,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -186,6 +187,48 @@ int main(int argc, char** argv) {
     }
     CHECK(hipDeviceSynchronize());
   }
+  // ---- (ix) the same stream of frames with the HOST out of the picture: a 20 ms kernel holds the queue(s) while the host enqueues
+  // every frame, events right behind the blocker and behind the last frame time the device alone ----
+  double dev_us[3] = {0, 0, 0};  // [one stream ordinary, one stream any-order, four streams ordinary]
+  {
+    hipStream_t q[4];
+    for (auto& x : q) CHECK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    hipEvent_t e0, e1, eq[4], gate;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventCreateWithFlags(&gate, hipEventDisableTiming));
+    for (auto& x : eq) CHECK(hipEventCreateWithFlags(&x, hipEventDisableTiming));
+    uint32_t* spin_flag = nullptr;
+    CHECK(hipMalloc(&spin_flag, 4));
+    for (int mode = 0; mode < 3; ++mode) {
+      double best = 1e30;
+      for (int r = 0; r < 3; ++r) {
+        CHECK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, spin_flag, (uint64_t)2000000);  // 20 ms
+        CHECK(hipEventRecord(e0, s));
+        if (mode == 2) {
+          CHECK(hipEventRecord(gate, s));
+          for (auto& x : q) CHECK(hipStreamWaitEvent(x, gate, 0));
+        }
+        for (int f = 0; f < frames; ++f) {
+          if (mode == 0) hipLaunchKernelGGL(stream_kernel, grid, block, 0, s, in + (size_t)f * n, out + (size_t)f * n, n, 1.5f);
+          if (mode == 1) hipExtLaunchKernelGGL(stream_kernel, grid, block, 0, s, nullptr, nullptr, f ? hipExtAnyOrderLaunch : 0u, in + (size_t)f * n, out + (size_t)f * n, n, 1.5f);
+          if (mode == 2) hipLaunchKernelGGL(stream_kernel, grid, block, 0, q[f & 3], in + (size_t)f * n, out + (size_t)f * n, n, 1.5f);
+        }
+        if (mode == 2)
+          for (int k = 0; k < 4; ++k) {
+            CHECK(hipEventRecord(eq[k], q[k]));
+            CHECK(hipStreamWaitEvent(s, eq[k], 0));
+          }
+        CHECK(hipEventRecord(e1, s));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, (double)ms * 1e3 / frames);
+      }
+      dev_us[mode] = best;
+    }
+  }
   // ---- (vii) two spinning kernels of one workgroup each: 10 ms + 10 ms, or 10 ms side by side? ----
   double pair_us[3] = {0, 0, 0};  // [ordinary, ordinary], [any, any], [ordinary, any, any] (last two)
   {
@@ -240,8 +283,10 @@ int main(int argc, char** argv) {
       if (mode == 3) bad_both_ordinary = v;
     }
   }
+  std::printf("{\"device_side_us_per_frame_host_not_in_the_loop\": {\"one_stream\": %.3f, \"one_stream_any_order\": %.3f, \"four_streams\": %.3f},\n ", dev_us[0],
+              dev_us[1], dev_us[2]);
   std::printf(
-      "{\"two_10ms_kernels_us\": {\"ordinary_ordinary\": %.0f, \"any_any\": %.0f, \"ordinary_then_any_any\": %.0f}, "
+      "\"two_10ms_kernels_us\": {\"ordinary_ordinary\": %.0f, \"any_any\": %.0f, \"ordinary_then_any_any\": %.0f}, "
       "\"plain_stores_of_an_any_order_kernel\": {\"missed_by_an_ordinary_kernel_behind_it\": %llu, \"missed_by_an_any_order_kernel_behind_it\": %llu, "
       "\"missed_by_the_host_after_stream_sync\": %llu, \"control_both_ordinary\": %llu},\n ",
       pair_us[0], pair_us[1], pair_us[2], bad_ordinary_reader, bad_anyorder_reader, bad_host, bad_both_ordinary);
