@@ -281,6 +281,7 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   }
   c->stream = c->own_stream;
   if (const char* e = std::getenv("KMC_NO_INLINE_TABLES")) c->no_inline_tables = std::atoi(e) != 0;
+  if (const char* e = std::getenv("KMC_TILE_LOOP")) c->tile_loop = std::atoi(e) != 0;
   if (const char* e = std::getenv("KMC_ANY_ORDER")) c->ao_enabled = std::atoi(e) != 0;
   if (const char* e = std::getenv("KMC_MAPPED_WAVES")) c->mapped_waves = std::max(1, std::min(65536, std::atoi(e)));
   *out = c;

@@ -17,7 +17,17 @@ namespace {
 // ---- template dispatch ---------------------------------------------------------------------------
 // any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao_valid
 template <int TIER, int PPT>
-void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d, bool any_order) {
+void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d, bool any_order, bool one_pass) {
+  if constexpr (PPT == 1) {  // the default geometry: one workgroup per tile -> the kernel without its tile loop
+    if (one_pass) {
+      if (any_order)
+        hipExtLaunchKernelGGL((deskew_frame_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, nullptr, nullptr,
+                              (uint32_t)hipExtAnyOrderLaunch, in, out, n, f, head, d);
+      else
+        hipLaunchKernelGGL((deskew_frame_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head, d);
+      return;
+    }
+  }
   if (any_order)
     hipExtLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, nullptr, nullptr,
                           (uint32_t)hipExtAnyOrderLaunch, in, out, n, f, head, d);
@@ -25,12 +35,12 @@ void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t 
     hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head, d);
 }
 template <int TIER>
-void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d, bool any_order) {
+void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d, bool any_order, bool one_pass) {
   switch (ppt) {
-    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head, d, any_order); break;
-    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head, d, any_order); break;
-    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head, d, any_order); break;
-    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head, d, any_order); break;
+    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head, d, any_order, one_pass); break;
+    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head, d, any_order, one_pass); break;
+    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head, d, any_order, one_pass); break;
+    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head, d, any_order, one_pass); break;
   }
 }
 // in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of()
@@ -42,17 +52,27 @@ void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f*
   n += head;
   const uint64_t n_tiles = (n + (uint64_t)kLaunchBlock * ppt - 1) / ((uint64_t)kLaunchBlock * ppt);
   const int grid = grid_for(c, n_tiles);
+  const bool one_pass = one_pass_for(c, grid, n_tiles);
   switch (tier) {
-    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head, d, any_order); break;
-    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head, d, any_order); break;
-    case kWide: launch_frame_t<kWide>(ppt, s, grid, in, out, n, f, head, d, any_order); break;
-    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head, d, any_order); break;
+    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head, d, any_order, one_pass); break;
+    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head, d, any_order, one_pass); break;
+    case kWide: launch_frame_t<kWide>(ppt, s, grid, in, out, n, f, head, d, any_order, one_pass); break;
+    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head, d, any_order, one_pass); break;
   }
 }
 
 template <int TIER, int PPT>
 void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
-                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64, const float* pre2s) {
+                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64, const float* pre2s, bool one_pass) {
+  if constexpr (PPT == 1) {  // the default geometry: one workgroup per tile -> the kernel without its tile loop
+    if (one_pass) {
+      if (idx)
+        hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, true, kLaunchBlock, false, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
+      else
+        hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, false, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
+      return;
+    }
+  }
   if (idx)
     hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
   else
@@ -60,20 +80,26 @@ void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const Bat
 }
 template <int TIER>
 void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
-                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64, const float* pre2s) {
+                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64, const float* pre2s, bool one_pass) {
   switch (ppt) {
-    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s); break;
-    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s); break;
-    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s); break;
-    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s); break;
+    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s, one_pass); break;
+    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s, one_pass); break;
+    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s, one_pass); break;
+    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s, one_pass); break;
   }
 }
 // tables in the kernel arguments (default launch geometry only: one point per lane)
 template <int TIER>
 void launch_batch_inline(hipStream_t s, int grid, const v4f* in, v4f* out, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head,
-                         uint32_t chunk_shift, const BatchInline& inl) {
-  if (idx)
+                         uint32_t chunk_shift, const BatchInline& inl, bool one_pass) {
+  if (idx && one_pass)
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, true, kLaunchBlock, true, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
+                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
+  else if (idx)
     hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, true, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
+                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
+  else if (one_pass)
+    hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
                        (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
   else
     hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
@@ -463,14 +489,15 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
       CallTimer tmi(c);
       if (tmi.begin_call() || tmi.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
       const int grid = grid_for(c, n_tiles);
+      const bool one_pass = one_pass_for(c, grid, n_tiles);
       const v4f* vin = (const v4f*)xyzi_in - head;
       v4f* vout = (v4f*)xyzi_out - head;
       uint32_t* vidx = frame_idx_out ? frame_idx_out - head : nullptr;
       switch (tier) {
-        case kSeries3: launch_batch_inline<kSeries3>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl); break;
-        case kSeries5: launch_batch_inline<kSeries5>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl); break;
-        case kWide: launch_batch_inline<kWide>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl); break;
-        default: launch_batch_inline<kTrig>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl); break;
+        case kSeries3: launch_batch_inline<kSeries3>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass); break;
+        case kSeries5: launch_batch_inline<kSeries5>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass); break;
+        case kWide: launch_batch_inline<kWide>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass); break;
+        default: launch_batch_inline<kTrig>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass); break;
       }
       KMC_HIP_TRY(c, hipGetLastError());
       if (tmi.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
@@ -543,12 +570,13 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
     KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, n * sizeof(v4f), hipMemcpyHostToDevice, c->stream));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, n_tiles);
+  const bool one_pass = one_pass_for(c, grid, n_tiles) && ppt == 1;
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
   switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2); break;
-    case kWide: launch_batch_t<kWide>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2); break;
-    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2); break;
+    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass); break;
+    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass); break;
+    case kWide: launch_batch_t<kWide>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass); break;
+    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass); break;
   }
   KMC_HIP_TRY(c, hipGetLastError());
   {

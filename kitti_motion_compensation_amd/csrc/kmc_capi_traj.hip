@@ -183,8 +183,11 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
 #define KMC_LAUNCH_TRAJ(T, INL, STREAM, SEGS, SEGS64, ...)                                                                          \
   do {                                                                                                                              \
-    if (any_order) hipExtLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL>), dim3(grid), dim3(64), 0, STREAM, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
+    if (any_order && one_pass) hipExtLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL, true>), dim3(grid), dim3(64), 0, STREAM, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
+    else if (any_order) hipExtLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL>), dim3(grid), dim3(64), 0, STREAM, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
+    else if (d_idx && one_pass) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true, INL, true>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
     else if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
+    else if (one_pass) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL, true>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
     else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__);      \
   } while (0)
 #define KMC_LAUNCH_TRAJ_TIER(INL, STREAM, SEGS, SEGS64, ...)                                        \
@@ -216,6 +219,7 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
     const uint32_t head = head_of(xyzi_out, mem_kind);
     const uint64_t nv = n + head;
     const int grid = grid_for(c, (nv + 63) / 64);
+    const bool one_pass = one_pass_for(c, grid, (nv + 63) / 64);
     uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
     KMC_LAUNCH_TRAJ_TIER(true, s, (const TrajSeg32*)nullptr, (const TrajSegD*)nullptr, inl)
     KMC_HIP_TRY(c, hipGetLastError());
@@ -253,6 +257,7 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   const uint32_t head = head_of(xyzi_out, mem_kind);
   const uint64_t nv = n + head;
   const int grid = grid_for(c, (nv + 63) / 64);
+  const bool one_pass = one_pass_for(c, grid, (nv + 63) / 64);
   const TrajSeg32* d_segs = (const TrajSeg32*)c->slots[slot_id].d_buf;
   const TrajSegD* d_segs64 = (const TrajSegD*)(c->slots[slot_id].d_buf + kMaxSegments * sizeof(TrajSeg32));
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
@@ -361,13 +366,16 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   if (mem_kind == KMC_MEM_HOST) KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, pts, hipMemcpyHostToDevice, c->stream));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, (nv + 63) / 64);
+  const bool one_pass = one_pass_for(c, grid, (nv + 63) / 64);  // one workgroup per tile: the kernel without its tile loop
   const bool idx = d_fidx || d_bidx;
   uint32_t* v_fidx = d_fidx ? d_fidx - head : nullptr;
   uint32_t* v_bidx = d_bidx ? d_bidx - head : nullptr;
 #define KMC_LAUNCH_TRAJ_BATCH(T)                                                                                                   \
   do {                                                                                                                             \
-    if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
-    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);     \
+    if (idx && one_pass) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
+    else if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
+    else if (one_pass) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
+    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);     \
   } while (0)
   switch (tier) {
     case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;

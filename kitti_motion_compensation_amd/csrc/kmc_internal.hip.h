@@ -38,6 +38,7 @@ struct kmc_ctx {
   int blocks_per_cu = 0;  // 0 = default
   int ppt = 0;            // 0 = default
   int force_tier = -1;
+  bool tile_loop = false;         // testing / A-B hook (KMC_TILE_LOOP=1): the kernels' tile-loop instantiations even with one workgroup per tile
   bool no_inline_tables = false;  // testing / A-B hook (KMC_NO_INLINE_TABLES=1): small batches go through the device tables too
   // out-of-range counter (f64 path)
   unsigned long long* d_counter = nullptr;
@@ -222,6 +223,9 @@ inline int grid_for(const kmc_ctx* c, uint64_t n_tiles, uint32_t threads_per_blo
   const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu * (kBlock / kLaunchBlock) : hw;
   return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, std::min(cap, hw)));
 }
+
+// one workgroup per tile: the kernels' ONE_PASS instantiations (no tile loop); KMC_TILE_LOOP=1 keeps the loop variants (A/B hook)
+inline bool one_pass_for(const kmc_ctx* c, int grid, uint64_t n_tiles) { return !c->tile_loop && (uint64_t)grid == n_tiles; }
 
 inline int ppt_of(const kmc_ctx* c) {
   const int p = c->ppt > 0 ? c->ppt : kDefaultPpt;

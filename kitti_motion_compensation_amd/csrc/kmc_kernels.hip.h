@@ -69,7 +69,9 @@ __device__ __forceinline__ void tile_store(__amdgpu_buffer_rsrc_t r, uint32_t by
 // ------------------------------------------------------------------------------------------------
 // single-frame kernel: constants by value (kernarg segment -> s_load -> SGPRs)
 // ------------------------------------------------------------------------------------------------
-template <int TIER, int PPT, int NT, bool OCML_ATAN, int BLOCK = kBlock>
+// ONE_PASS: the launch holds one workgroup per tile (the default geometry) -- the kernel without its tile loop: nothing is carried
+// around a back edge, the register allocator needs a third fewer registers and the wave a few scalar instructions less
+template <int TIER, int PPT, int NT, bool OCML_ATAN, int BLOCK = kBlock, bool ONE_PASS = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 ? 8 : 4, 8))) void deskew_frame_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
                                                          uint64_t n, FrameRec f, uint32_t head, FrameRecD d) {
   // `d`: the frame's constants in f64, read only by a wave that contains a lane the near-origin guard redoes (kmc_device_math).
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
       const uint64_t i = (uint64_t)u * BLOCK + tid;
       if (i >= head && i < n) one_point(i);
     }
+    if constexpr (ONE_PASS) return;
     t_begin += gridDim.x;
   }
   if constexpr ((NT & (kStoreSc1 | kBufLoad)) != 0) {
@@ -131,9 +134,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
         for (int u = 0; u < PPT; ++u)
           redo_lanes(((redo_mask >> u) & 1u) != 0, p[u], d_rec, [&](v4f v) { tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), v); });
       }
+      if constexpr (ONE_PASS) break;
     }
     return;
   }
+  static_assert(!ONE_PASS || (NT & (kStoreSc1 | kBufLoad)) != 0, "ONE_PASS is for the descriptor variants (the default policy)");
   const uint64_t n_full = n / kTile;  // tiles that need no bounds checks
   for (uint64_t t = t_begin; t < n_full; t += gridDim.x) {
     const v4f* __restrict__ tin = in + t * kTile;
@@ -288,7 +293,7 @@ __device__ __forceinline__ uint2 load_coarse(uint2_cp c) {
 struct BatchNoInline { uint32_t unused; };  // what the device-table instantiations carry instead of 3.5 KB of unused tables
 template <bool INLINE> using BatchInlineArg = typename std::conditional<INLINE, BatchInline, BatchNoInline>::type;
 
-template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock, bool INLINE = false>
+template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock, bool INLINE = false, bool ONE_PASS = false>  // ONE_PASS: one workgroup per tile, no tile loop
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 ? 8 : 4, 8))) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
                                                          const BatchRec* __restrict__ recs_g,
                                                          const uint2* __restrict__ coarse_g, uint32_t n_frames,
@@ -428,6 +433,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
         redo_lanes(((redo_mask >> u) & 1u) != 0, p[u], recs64, fi_of[u],
                    [&](v4f v) { tile_store<NT>(rfix, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), v); });
     }
+    if constexpr (ONE_PASS) break;
   }
 }
 
@@ -726,7 +732,7 @@ struct TrajInline {
   TrajSeg32 s[kInlineSegments];
   TrajSegD d[kInlineSegments];
 };
-template <int TIER, int NT, bool WRITE_IDX, bool INLINE = false>
+template <int TIER, int NT, bool WRITE_IDX, bool INLINE = false, bool ONE_PASS = false>  // ONE_PASS: see deskew_traj_batch_f32
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                      const TrajSeg32* __restrict__ segs, uint32_t n_seg,
                                                      uint32_t* __restrict__ bracket_out, uint32_t head,
@@ -767,6 +773,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       if (alive) __builtin_nontemporal_store(k, bracket_out + i);
     }
     traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
+    if constexpr (ONE_PASS) break;
   }
 }
 
@@ -787,7 +794,9 @@ struct alignas(32) TrajFrameRec {
 static_assert(sizeof(TrajFrameRec) == 32, "TrajFrameRec must stay one 32-byte record");
 __device__ __forceinline__ uint64_t rec_end(const TrajFrameRec& r) { return ((uint64_t)r.end_hi << 32) | r.end_lo; }
 
-template <int TIER, int NT, bool WRITE_IDX>
+// ONE_PASS: the grid holds one workgroup per tile (the default geometry): no tile loop -- the loop-carried copies of the twelve
+// kernel arguments cost ~40 SGPR spill instructions per wave (round 3, profiles/NOTES.md)
+template <int TIER, int NT, bool WRITE_IDX, bool ONE_PASS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                            const TrajFrameRec* __restrict__ frecs,
                                                            const TrajSeg32* __restrict__ segs,
@@ -871,6 +880,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       }
     }
     traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
+    if constexpr (ONE_PASS) break;
   }
 }
 

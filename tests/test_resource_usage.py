@@ -44,12 +44,18 @@ def test_f32_kernels_keep_eight_waves_per_simd(usage):
     assert len(default_geometry) >= 4 + 16 + 16 + 8
     for k, v in default_geometry.items():
         assert v["occupancy"] == 8 and v["vgprs"] <= 64 and v["agprs"] == 0, (k, v)
-    # the headline kernel by name
-    bench = usage["deskew_batch_f32<0, 1, 7, false, 64, false>"]
-    assert bench["vgprs"] <= 62 and bench["sgprs"] <= 78 and bench["sgpr_spills"] == 0 and bench["lds"] == 1024, bench
+    # the headline kernel by name: the one-workgroup-per-tile instantiation (no tile loop) that the default geometry launches, and its
+    # tile-loop twin (KMC_TILE_LOOP=1, capped grids)
+    bench = usage["deskew_batch_f32<0, 1, 7, false, 64, false, true>"]
+    assert bench["vgprs"] <= 48 and bench["sgprs"] <= 56 and bench["sgpr_spills"] == 0 and bench["lds"] == 1024, bench
+    loop = usage["deskew_batch_f32<0, 1, 7, false, 64, false, false>"]
+    assert loop["vgprs"] <= 62 and loop["sgprs"] <= 78 and loop["sgpr_spills"] == 0 and loop["lds"] == 1024, loop
     # kernel-argument tables: same body, no extra registers
-    inline = usage["deskew_batch_f32<0, 1, 7, false, 64, true>"]
+    inline = usage["deskew_batch_f32<0, 1, 7, false, 64, true, true>"]
     assert inline["vgprs"] <= bench["vgprs"] + 2 and inline["occupancy"] == 8, inline
+    # the batched N-knot kernel: without the loop-carried copies of its twelve arguments it no longer lives on spills
+    for idx in ("false", "true"):
+        assert usage[f"deskew_traj_batch_f32<0, 7, {idx}, true>"]["sgpr_spills"] <= 8 < usage[f"deskew_traj_batch_f32<0, 7, {idx}, false>"]["sgpr_spills"]
 
 
 def test_nknot_kernels_use_no_lds(usage):
