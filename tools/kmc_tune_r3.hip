@@ -183,7 +183,7 @@ static FrameRec make_rec(double yaw) {
   return f;
 }
 
-template <int TIER>
+template <int TIER, bool ONE_PASS = false>
 static Variant frame_variant(const char* label, double yaw) {
   Variant v;
   v.name = label;
@@ -191,12 +191,12 @@ static Variant frame_variant(const char* label, double yaw) {
   v.launch = [f](hipStream_t s, const v4f* in, v4f* out, uint64_t n) {
     FrameRecD d;
     std::memset(&d, 0, sizeof(d));
-    hipLaunchKernelGGL((deskew_frame_f32<TIER, 1, kPolicyDefault, false, 64>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in, out, n, f, 0u, d);
+    hipLaunchKernelGGL((deskew_frame_f32<TIER, 1, kPolicyDefault, false, 64, ONE_PASS>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in, out, n, f, 0u, d);
   };
   return v;
 }
 
-enum TrajKind { kR2, kR3 };
+enum TrajKind { kR2, kR3, kR3OnePass };  // kR3OnePass: round 3's kernel without its tile loop (what the library launches by default)
 template <int KIND, bool INL>
 static Variant traj_variant(const char* label, const TrajSet& ts) {
   Variant v;
@@ -207,6 +207,7 @@ static Variant traj_variant(const char* label, const TrajSet& ts) {
     const TrajSegD* segs64 = INL ? nullptr : ts.d_segs64;
     if constexpr (KIND == kR2) hipLaunchKernelGGL((r2_deskew_traj_f32<kSeries3, kPolicyDefault, false, INL>), grid, block, 0, s, in, out, n, segs, ts.n_seg, (uint32_t*)nullptr, 0u, segs64, ts.inl);
     if constexpr (KIND == kR3) hipLaunchKernelGGL((deskew_traj_f32<kSeries3, kPolicyDefault, false, INL>), grid, block, 0, s, in, out, n, segs, ts.n_seg, (uint32_t*)nullptr, 0u, segs64, ts.inl);
+    if constexpr (KIND == kR3OnePass) hipLaunchKernelGGL((deskew_traj_f32<kSeries3, kPolicyDefault, false, INL, true>), grid, block, 0, s, in, out, n, segs, ts.n_seg, (uint32_t*)nullptr, 0u, segs64, ts.inl);
   };
   return v;
 }
@@ -238,6 +239,11 @@ int main(int argc, char** argv) {
   const TrajSet t2 = build_traj(2), t3 = build_traj(3), t6 = build_traj(6);
   std::vector<Variant> vs;
   vs.push_back(frame_variant<kSeries3>("frame_s3", -0.1));
+  {
+    Variant v = frame_variant<kSeries3, true>("frame_s3_one_pass", -0.1);
+    v.check_against = 0;
+    vs.push_back(v);
+  }
   vs.push_back(frame_variant<kWide>("frame_wide", -2.9));
   vs.push_back(frame_variant<kTrig>("frame_trig_r3", -6.0));
   vs.push_back(frame_variant<kTrigOcml>("frame_trig_ocml_r2", -6.0));
@@ -246,9 +252,11 @@ int main(int argc, char** argv) {
     vs.push_back(traj_variant<kR2, false>((std::string("traj") + tag + "_r2_lds_table").c_str(), ts));
     auto add = [&](Variant v) { v.check_against = ref; vs.push_back(v); };
     add(traj_variant<kR3, false>((std::string("traj") + tag + "_r3_scalar_table").c_str(), ts));
+    add(traj_variant<kR3OnePass, false>((std::string("traj") + tag + "_r3_scalar_table_one_pass").c_str(), ts));
     if (inline_ok) {
       add(traj_variant<kR2, true>((std::string("traj") + tag + "_r2_lds_inline").c_str(), ts));
       add(traj_variant<kR3, true>((std::string("traj") + tag + "_r3_scalar_inline").c_str(), ts));
+      add(traj_variant<kR3OnePass, true>((std::string("traj") + tag + "_r3_scalar_inline_one_pass").c_str(), ts));
     }
   };
   add_traj("2", t2, true);
