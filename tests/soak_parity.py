@@ -370,6 +370,73 @@ def inplace_round(ctx, table_ctx, rng, acc, torch):
     acc["inplace_failures"] += 0 if ok else 1
 
 
+def stream_round(ctx, plain_ctx, rng, acc, torch):
+    """A random PROGRAM of device-resident single-frame calls on the context's own stream, issued back to back: every call reads one
+    buffer of a small pool and writes another (or the same one, or a sub-range of one), so that consecutive calls are independent,
+    chained, write-after-read or write-after-write at random; two-pose and short N-knot frames, now and then another entry point in
+    between.  The library may dispatch a frame without the barrier bit only when it shares no buffer with the frames in flight;
+    whatever it decides, the final content of EVERY buffer must equal, bit for bit, what a context with KMC_ANY_ORDER=0 produces when
+    each call is waited for before the next one.  One output is also held against the oracle."""
+    n = int(rng.choice([64, 4097, 50_000, 123_397, 300_000]))
+    nbuf = int(rng.integers(3, 9))
+    ncall = int(rng.integers(4, 49))
+    base = [torch.from_numpy(random_points(rng, n)).cuda() for _ in range(nbuf)]
+    prog, first = [], None
+    for _ in range(ncall):
+        src, dst = int(rng.integers(0, nbuf)), int(rng.integers(0, nbuf))
+        lo = 0 if rng.random() < 0.7 else 16 * int(rng.integers(0, max(1, n // 32)))
+        m = n - lo if rng.random() < 0.7 else int(rng.integers(1, n - lo + 1))
+        kind = "frame" if rng.random() < 0.75 else ("traj" if rng.random() < 0.8 else "batch")
+        if kind == "traj":
+            times, poses, t_req = random_trajectory(rng)
+            while len(times) > 4:  # records in the kernel arguments (the route that may skip the barrier): up to four knots
+                times, poses, t_req = random_trajectory(rng)
+            arg = (times, np.stack([_rt(T) for T in poses]), t_req)
+        else:
+            tw = random_twist(rng) * (0.2 if rng.random() < 0.8 else 1.0)  # chains of large motions would leave the scanner's range
+            xr = float(rng.random())
+            arg = params_from_twist(tw, xr)
+            if not prog:
+                first = (tw, xr)
+        prog.append((kind, src, dst, lo, m, arg))
+
+    def run(c, bufs, wait):
+        for kind, src, dst, lo, m, arg in prog:
+            a, b = bufs[src][lo:lo + m], bufs[dst][lo:lo + m]
+            if kind == "frame":
+                c.deskew_f32(a, b, arg)
+            elif kind == "traj":
+                c.deskew_traj_f32(a, b, arg[0], arg[1], T0, T1, arg[2], None, n=m)
+            else:
+                c.deskew_batch_f32(a, b, np.array([0, m], dtype=np.uint64), [arg], None)
+            if wait:
+                c.synchronize()
+        c.synchronize()
+
+    want = [x.clone() for x in base]
+    got = [x.clone() for x in base]
+    torch.cuda.synchronize()
+    run(plain_ctx, want, True)
+    before = ctx.any_order_launches()
+    run(ctx, got, False)
+    acc["stream_any_order_launches"] += ctx.any_order_launches() - before
+    ok = all(bool(torch.equal(g.view(torch.int32), w.view(torch.int32))) for g, w in zip(got, want))
+    # the first call of the program against the oracle (its input is still the pristine buffer in `base`)
+    kind, src, dst, lo, m, arg = prog[0]
+    if kind != "traj":
+        pts = base[src][lo:lo + m].cpu().numpy()
+        one = torch.empty((m, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.deskew_f32(base[src][lo:lo + m], one, arg)
+        ctx.synchronize()
+        tw, xr = first
+        ref = orc.deskew_xyzi_f32(pts, T0, orc.se3_exp([0] * 6), T1, orc.se3_exp(list(tw)), T0 + xr * (T1 - T0), mode=orc.HOISTED)
+        check_cloud(acc, "deskew", pts, one.cpu().numpy(), ref["xyz_f64"], dict(twist=[float(v) for v in tw], x_req=xr, stream_round=True))
+    acc["stream_points"] += sum(c[4] for c in prog)
+    acc["stream_calls"] += ncall
+    acc["stream_failures"] += 0 if ok else 1
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -380,6 +447,9 @@ def main():
     os.environ["KMC_NO_INLINE_TABLES"] = "1"
     table_ctx = capi.Context(0)  # small batches through device tables: the A/B partner of the kernel-argument route
     del os.environ["KMC_NO_INLINE_TABLES"]
+    os.environ["KMC_ANY_ORDER"] = "0"
+    plain_ctx = capi.Context(0)  # every dispatch with its barrier bit: the reference of stream_round
+    del os.environ["KMC_ANY_ORDER"]
     calib = util.load_kitti_calibration(os.path.join(ROOT, "tests", "golden"))
     acc = dict(seed=seed, seconds=budget, rounds=0, deskew_points=0, deskew_intensity_mismatch=0, batch_points=0, batch_index_mismatch=0, projection_points=0, projection_drawn=0,
                projection_int_mismatch=0, oracle_threads=orc.num_threads())
@@ -392,9 +462,9 @@ def main():
     acc.update(subrange_points=0, subrange_failures=0, f64_points=0, f64_max_rel_err=0.0, near_origin_rounds=0,
                near_origin_single_vs_batch_mismatch=0, near_origin_single_vs_batch_points=0,
                traj_points=0, traj_index_mismatch=0, traj_intensity_mismatch=0, traj_device_vs_host_mismatch=0, half_turn_frames_redrawn=0,
-               inplace_points=0, inplace_failures=0)
+               inplace_points=0, inplace_failures=0, stream_points=0, stream_calls=0, stream_failures=0, stream_any_order_launches=0)
     while time.time() < t_end:
-        r = acc["rounds"] % 8
+        r = acc["rounds"] % 9
         if r == 0:
             deskew_round(ctx, rng, acc)
         elif r == 1:
@@ -409,6 +479,8 @@ def main():
             f64_round(ctx, rng, acc)
         elif r == 6:
             inplace_round(ctx, table_ctx, rng, acc, torch)
+        elif r == 8:
+            stream_round(ctx, plain_ctx, rng, acc, torch)
         else:
             traj_round(ctx, rng, acc, torch)
         acc["rounds"] += 1
@@ -423,7 +495,7 @@ def main():
                      and acc["batch_index_mismatch"] == 0 and acc["projection_int_mismatch"] == 0
                      and acc["near_origin_single_vs_batch_mismatch"] == 0
                      and acc["traj_max_rel_err_literal"] <= 1e-5 and acc["traj_max_err_over_scale"] <= 2e-6 and acc["traj_index_mismatch"] == 0
-                     and acc["traj_intensity_mismatch"] == 0 and acc["traj_device_vs_host_mismatch"] == 0 and acc["inplace_failures"] == 0)
+                     and acc["traj_intensity_mismatch"] == 0 and acc["traj_device_vs_host_mismatch"] == 0 and acc["inplace_failures"] == 0 and acc["stream_failures"] == 0)
     print(json.dumps(acc))
     sys.exit(0 if acc["ok"] else 1)
 
