@@ -389,14 +389,21 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         state["k"] += 1
         ctx.deskew_traj_f32(a, b, knot_t, P, Tz + 0.10, Tz + 0.20, Tz + 0.15, None)
 
+    torch.cuda.synchronize()
+    ctx.set_stream(None)  # the context's own stream, like configs1_literal
+    ao_before = ctx.any_order_launches()
     ms = timed(traj, 120, 12)
+    ao_share = (ctx.any_order_launches() - ao_before) / 132
     ctx.set_frame_queues(4)  # short trajectories carry their records in the kernel arguments: the calls may overlap like two-pose frames
     ms_q4 = timed(traj, 120, 12)
     ctx.set_frame_queues(1)
+    ctx.synchronize()
+    ctx.set_stream(caller_stream)
     leg = {"workload": "north_star's three bracketing poses used directly (piecewise geodesic, 2 segments): one synthetic 10 M-point frame per kmc_hip_deskew_traj_f32 call, 3 rotating buffer pairs",
            "kernel": "kmc_dev::deskew_traj_f32<series3, nt loads + nt|sc1 stores, inline records> (no LDS: records through scalar loads)",
            "us_per_frame": round(ms * 1e3, 2), "Mpts_s": round(n / ms / 1e3, 1), "GBps": round(32 * n / ms / 1e6, 1), "frac": _frac(32 * n / ms / 1e6),
-           "note": "call to call on one stream: the kernel itself (rocprofv3 row in profiles/) plus the ~5 us drain / launch gap between two frames",
+           "dispatched_without_barrier_bit": round(ao_share, 3),
+           "note": "call to call on one stream: the kernel itself (rocprofv3 row in profiles/) plus the drain / launch gap between two frames (three rotating buffer pairs: two of three frames go out without the barrier bit)",
            "four_frame_queues": {"us_per_frame": round(ms_q4 * 1e3, 2), "GBps": round(32 * n / ms_q4 / 1e6, 1), "frac": _frac(32 * n / ms_q4 / 1e6)}}
     if check:
         sel = slice(4_950_000, 5_050_000)  # around mid-scan: both segments
