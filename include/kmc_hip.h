@@ -230,7 +230,8 @@ int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
  * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues -- the count the caller chose with
- * kmc_hip_set_frame_queues (1 = strictly in order on the context's stream), four for this call if it never chose -- and joined: the
+ * kmc_hip_set_frame_queues (1 = in order on the context's stream); if it never chose: four for a list of at least 64 frames of
+ * 400 k points or more on average (the fork and the join cost ~45 us of barrier packets), else one -- and joined: the
  * call as a whole is ordered on the context's stream like any other, all its frames behind everything issued before it (ONE fork for
  * the whole call: every input was handed over before the call).  Same per-point results as kmc_hip_deskew_f32. */
 int kmc_hip_deskew_frames_f32(kmc_ctx* ctx, const float* const* xyzi_in, float* const* xyzi_out, const uint64_t* n_points,

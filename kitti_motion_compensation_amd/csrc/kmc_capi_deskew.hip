@@ -394,12 +394,17 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
   KMC_ENTER(c);
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  // the context's setting if the caller has chosen one (kmc_hip_set_frame_queues, 1 = strictly in order), else four for this
-  // call: that is the point of handing over several frames
+  // the context's setting if the caller has chosen one (kmc_hip_set_frame_queues, 1 = in order on the context's stream), else what
+  // is faster for this call: the fork to four queues and the join behind them cost ~45 us of barrier packets, which a list of 1 M-point
+  // frames earns back from ~64 frames on (tools/measure_join_cost.py: 96 frames 5.6 against 6.2 us per frame, 32 frames 6.5 against
+  // 6.2); shorter lists and small frames stay on the one stream, where frames that share no buffer go out without the barrier bit
   const int saved = c->fq_count;
   const bool saved_explicit = c->fq_explicit, saved_ordered = c->fq_ordered;
   if (!saved_explicit) {
-    const int rc_set = kmc_hip_set_frame_queues(c, kmc_ctx::kMaxFrameQueues);
+    uint64_t all_points = 0;
+    for (uint32_t f = 0; f < n_frames; ++f) all_points += n_points[f];
+    const bool worth_queues = n_frames >= 64 && all_points >= (uint64_t)n_frames * 400000ull;
+    const int rc_set = kmc_hip_set_frame_queues(c, worth_queues ? kmc_ctx::kMaxFrameQueues : 1);
     if (rc_set != KMC_OK) return rc_set;
   }
   // every frame of THIS call was handed over before the call: one fork from the context's stream at its start orders all of them
@@ -679,7 +684,10 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
     hipLaunchKernelGGL((deskew_f64cols<0, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
   } else {
     const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-    hipLaunchKernelGGL((deskew_f64cols<0, false>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
+    if (one_pass_for(c, grid, (n + 127) / 128))
+      hipLaunchKernelGGL((deskew_f64cols<0, false, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
+    else
+      hipLaunchKernelGGL((deskew_f64cols<0, false>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
   }
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");

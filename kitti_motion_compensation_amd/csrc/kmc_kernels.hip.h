@@ -509,7 +509,7 @@ __device__ __forceinline__ void f64_report_bad(uint32_t bad_count, uint32_t tid,
 // so that uploads and downloads overlap in time: launched like the device kernel (every wave loads its tile, then stores it, all
 // ~1000 waves of a KITTI frame at once) the link is used one direction after the other -- 148 us per 123 k-point frame against
 // ~110 us pipelined (profiles/NOTES.md).
-template <int kInstance = 0, bool STREAMED = false>  // kInstance: a template only so that the header can be included by several translation units
+template <int kInstance = 0, bool STREAMED = false, bool ONE_PASS = false>  // kInstance: a template only so that the header can be included by several translation units; ONE_PASS: no tile loop (one workgroup per tile)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                      const double* __restrict__ z, const double* __restrict__ w,
                                                      const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
       bad_count = 0;
     }
     f64_report_bad(bad_count, tid, n_bad, bad_flag);
+    if constexpr (ONE_PASS && !STREAMED) break;
   }
 }
 
