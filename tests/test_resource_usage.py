@@ -65,9 +65,9 @@ def test_nknot_kernels_use_no_lds(usage):
 
 
 def test_f64_kernels_as_documented(usage):
-    for k in ("deskew_f64cols<0, false>", "deskew_f64cols<0, true>", "deskew_traj_f64cols<0>"):
+    for k in ("deskew_f64cols<0, false, false>", "deskew_f64cols<0, false, true>", "deskew_f64cols<0, true, false>", "deskew_traj_f64cols<0>"):
         assert usage[k]["occupancy"] == 4 and usage[k]["scratch"] == 0, (k, usage[k])
-    assert usage["deskew_f64cols<0, false>"]["vgprs"] <= 64
+    assert usage["deskew_f64cols<0, false, false>"]["vgprs"] <= 64 and usage["deskew_f64cols<0, false, true>"]["sgpr_spills"] == 0
 
 
 def test_committed_summary_lists_the_same_kernels(usage):
