@@ -81,10 +81,14 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, (n + 63) / 64);
+  const bool one_pass = one_pass_for(c, grid, (n + 63) / 64);
   const int kind = rig_kind(rig);
 #define KMC_LAUNCH_PROJECT(T)                                                                                                     \
   do {                                                                                                                            \
-    if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL((project_f32<T, kRigSharedIntrinsics>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
+    if (one_pass && kind == kRigSharedIntrinsics) hipLaunchKernelGGL((project_f32<T, kRigSharedIntrinsics, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
+    else if (one_pass && kind == kRigPinhole) hipLaunchKernelGGL((project_f32<T, kRigPinhole, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
+    else if (one_pass) hipLaunchKernelGGL((project_f32<T, kRigGeneral, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
+    else if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL((project_f32<T, kRigSharedIntrinsics>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
     else if (kind == kRigPinhole) hipLaunchKernelGGL((project_f32<T, kRigPinhole>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
     else hipLaunchKernelGGL((project_f32<T, kRigGeneral>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd);       \
   } while (0)
@@ -143,7 +147,11 @@ int kmc_hip_project_f64cols(kmc_ctx* c, const double* x, const double* y, const 
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, (n + 63) / 64);
   const int kind = rig_kind(rig);
-  if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL(project_f64cols<kRigSharedIntrinsics>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
+  if (one_pass_for(c, grid, (n + 63) / 64)) {
+    if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL((project_f64cols<kRigSharedIntrinsics, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
+    else if (kind == kRigPinhole) hipLaunchKernelGGL((project_f64cols<kRigPinhole, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
+    else hipLaunchKernelGGL((project_f64cols<kRigGeneral, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
+  } else if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL(project_f64cols<kRigSharedIntrinsics>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
   else if (kind == kRigPinhole) hipLaunchKernelGGL(project_f64cols<kRigPinhole>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
   else hipLaunchKernelGGL(project_f64cols<kRigGeneral>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
   KMC_HIP_TRY(c, hipGetLastError());

@@ -1028,7 +1028,7 @@ __device__ __forceinline__ void store_uv_tile(v2i* __restrict__ uv, uint64_t til
   tile_store<kPolicyDefault>(r, 1024u + tid * 16u, __builtin_bit_cast(v4f, hi));
 }
 
-template <int TIER, int RIG>
+template <int TIER, int RIG, bool ONE_PASS = false>  // ONE_PASS: one workgroup per tile, no tile loop (see deskew_frame_f32)
 __global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, uint64_t n, CameraRigRec g, FrameRec f,
                                                   v4f* __restrict__ cloud_out, v2i* __restrict__ uv,
                                                   uint32_t* __restrict__ bgrv, FrameRecD d) {
@@ -1060,10 +1060,11 @@ __global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, ui
     const bool drawn = project_point<RIG>((double)p.x, (double)p.y, (double)p.z, g_rec, px, col);
     store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
     if (live) __builtin_nontemporal_store(col, bgrv + i);
+    if constexpr (ONE_PASS) break;
   }
 }
 
-template <int RIG>
+template <int RIG, bool ONE_PASS = false>
 __global__ __launch_bounds__(64) void project_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                       const double* __restrict__ z, uint64_t n, CameraRigRec g,
                                                       v2i* __restrict__ uv, uint32_t* __restrict__ bgrv) {
@@ -1083,6 +1084,7 @@ __global__ __launch_bounds__(64) void project_f64cols(const double* __restrict__
                                                  __builtin_nontemporal_load(z + j), g_rec, px, col);
     store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
     if (live) __builtin_nontemporal_store(col, bgrv + i);
+    if constexpr (ONE_PASS) break;
   }
 }
 
