@@ -791,7 +791,10 @@ int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, 
     dx = base; dy = base + n; dout = base + 2 * n;
   }
   const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-  hipLaunchKernelGGL(pseudo_timestamps_f64<0>, dim3(grid), dim3(64), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
+  if (one_pass_for(c, grid, (n + 127) / 128))
+    hipLaunchKernelGGL((pseudo_timestamps_f64<0, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
+  else
+    hipLaunchKernelGGL((pseudo_timestamps_f64<0, false>), dim3(grid), dim3(64), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
   KMC_HIP_TRY(c, hipGetLastError());
   if (mem_kind == KMC_MEM_HOST) KMC_HIP_TRY(c, hipMemcpyAsync(stamps_out, dout, col, hipMemcpyDeviceToHost, c->stream));
   if (mem_kind != KMC_MEM_DEVICE) KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the results are in host memory when the call returns

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
 // GetPseudoTimeStamps (timestamp_mocking.cpp:46-63) in f64
 // (one wave per workgroup, two consecutive points per lane, 16-byte column accesses -- see deskew_f64cols below)
 typedef double v2d_col __attribute__((ext_vector_type(2), aligned(8)));
-template <int kInstance = 0>  // a template only so that the header can be included by several translation units
+template <int kInstance = 0, bool ONE_PASS = false>  // a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(64) void pseudo_timestamps_f64(const double* __restrict__ x, const double* __restrict__ y,
                                                             uint64_t n, double start, double end,
                                                             double* __restrict__ stamps) {
@@ -580,6 +580,7 @@ __global__ __launch_bounds__(64) void pseudo_timestamps_f64(const double* __rest
     } else if (i < n) {
       stamps[i] = start + (((kPi - atan2(y[i], x[i])) / (2.0 * kPi)) * dur);
     }
+    if constexpr (ONE_PASS) break;
   }
 }
 
