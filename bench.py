@@ -277,7 +277,7 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         ctx.deskew_f32(a, b, prm)
 
     # the frames are handed to the C-ABI 480 at a time (kmc_hip_deskew_frames_f32) so that the C loop, not Python's ~8 us per
-    # ctypes call, sets the pace; the same entry point with one queue is the strictly-in-order stream of launches
+    # ctypes call, sets the pace; the same entry point with one queue is the in-order stream of launches on ONE stream
     pack = ctx.prepare_frames([bufs[k % len(bufs)] for k in range(480)], [prm] * 480)
     # (these legs run on the contexts' OWN streams, like a C caller's would: torch's current stream here is HIP's legacy default
     # stream, whose implicit synchronisation with other streams the library does not second-guess -- no any-order launches there)

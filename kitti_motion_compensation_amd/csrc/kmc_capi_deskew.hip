@@ -14,36 +14,19 @@
 
 namespace {
 
-// ---- template dispatch ---------------------------------------------------------------------------
-// any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao_valid
-template <int TIER, int PPT>
-void launch_frame_tp(hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d, bool any_order, bool one_pass) {
-  if constexpr (PPT == 1) {  // the default geometry: one workgroup per tile -> the kernel without its tile loop
-    if (one_pass) {
-      if (any_order)
-        hipExtLaunchKernelGGL((deskew_frame_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, nullptr, nullptr,
-                              (uint32_t)hipExtAnyOrderLaunch, in, out, n, f, head, d);
-      else
-        hipLaunchKernelGGL((deskew_frame_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head, d);
-      return;
-    }
-  }
-  if (any_order)
-    hipExtLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, nullptr, nullptr,
-                          (uint32_t)hipExtAnyOrderLaunch, in, out, n, f, head, d);
-  else
-    hipLaunchKernelGGL((deskew_frame_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, n, f, head, d);
-}
-template <int TIER>
-void launch_frame_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, uint32_t head, const FrameRecD& d, bool any_order, bool one_pass) {
+// ---- template dispatch: the run-time choices of a call (tier, points per lane, index output, tile loop or not, barrier bit) become
+// template arguments through with_tier / with_ppt / with_bool, every launch goes through launch_on (kmc_internal.hip.h) ----
+template <typename F>
+void with_ppt(int ppt, F&& f) {
   switch (ppt) {
-    case 1: launch_frame_tp<TIER, 1>(s, grid, in, out, n, f, head, d, any_order, one_pass); break;
-    case 2: launch_frame_tp<TIER, 2>(s, grid, in, out, n, f, head, d, any_order, one_pass); break;
-    case 8: launch_frame_tp<TIER, 8>(s, grid, in, out, n, f, head, d, any_order, one_pass); break;
-    default: launch_frame_tp<TIER, 4>(s, grid, in, out, n, f, head, d, any_order, one_pass); break;
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    default: f(std::integral_constant<int, 4>{}); break;
   }
 }
-// in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of()
+// in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of().
+// any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao_valid
 void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0,
                   bool any_order = false) {
   const int ppt = ppt_of(c);
@@ -53,57 +36,44 @@ void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f*
   const uint64_t n_tiles = (n + (uint64_t)kLaunchBlock * ppt - 1) / ((uint64_t)kLaunchBlock * ppt);
   const int grid = grid_for(c, n_tiles);
   const bool one_pass = one_pass_for(c, grid, n_tiles);
-  switch (tier) {
-    case kSeries3: launch_frame_t<kSeries3>(ppt, s, grid, in, out, n, f, head, d, any_order, one_pass); break;
-    case kSeries5: launch_frame_t<kSeries5>(ppt, s, grid, in, out, n, f, head, d, any_order, one_pass); break;
-    case kWide: launch_frame_t<kWide>(ppt, s, grid, in, out, n, f, head, d, any_order, one_pass); break;
-    default: launch_frame_t<kTrig>(ppt, s, grid, in, out, n, f, head, d, any_order, one_pass); break;
-  }
+  with_tier(tier, [&](auto T) {
+    with_ppt(ppt, [&](auto P) {
+      with_bool(one_pass, [&](auto OP) {
+        // the loop-free instantiations exist for the default geometry (one point per lane) only
+        constexpr bool kOnePass = decltype(OP)::value && decltype(P)::value == 1;
+        launch_on(deskew_frame_f32<decltype(T)::value, decltype(P)::value, kPolicyDefault, false, kLaunchBlock, kOnePass>, grid, kLaunchBlock, s, any_order, in, out, n, f,
+                  head, d);
+      });
+    });
+  });
 }
 
-template <int TIER, int PPT>
-void launch_batch_tp(hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles,
-                     uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64, const float* pre2s, bool one_pass) {
-  if constexpr (PPT == 1) {  // the default geometry: one workgroup per tile -> the kernel without its tile loop
-    if (one_pass) {
-      if (idx)
-        hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, true, kLaunchBlock, false, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
-      else
-        hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, false, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
-      return;
-    }
-  }
-  if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, true, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
-  else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, PPT, kPolicyDefault, false, kLaunchBlock>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
+// batch of frames, tables in device memory
+void launch_batch(int tier, int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx,
+                  uint32_t head, const FrameRecD* recs64, const float* pre2s, bool one_pass) {
+  with_tier(tier, [&](auto T) {
+    with_ppt(ppt, [&](auto P) {
+      with_bool(idx != nullptr, [&](auto IDX) {
+        with_bool(one_pass, [&](auto OP) {
+          constexpr bool kOnePass = decltype(OP)::value && decltype(P)::value == 1;
+          launch_on(deskew_batch_f32<decltype(T)::value, decltype(P)::value, kPolicyDefault, decltype(IDX)::value, kLaunchBlock, false, kOnePass>, grid, kLaunchBlock, s,
+                    false, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
+        });
+      });
+    });
+  });
 }
-template <int TIER>
-void launch_batch_t(int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs,
-                    const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, const FrameRecD* recs64, const float* pre2s, bool one_pass) {
-  switch (ppt) {
-    case 1: launch_batch_tp<TIER, 1>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s, one_pass); break;
-    case 2: launch_batch_tp<TIER, 2>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s, one_pass); break;
-    case 8: launch_batch_tp<TIER, 8>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s, one_pass); break;
-    default: launch_batch_tp<TIER, 4>(s, grid, in, out, recs, tiles, nf, n, idx, head, recs64, pre2s, one_pass); break;
-  }
-}
-// tables in the kernel arguments (default launch geometry only: one point per lane)
-template <int TIER>
-void launch_batch_inline(hipStream_t s, int grid, const v4f* in, v4f* out, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head,
-                         uint32_t chunk_shift, const BatchInline& inl, bool one_pass) {
-  if (idx && one_pass)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, true, kLaunchBlock, true, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
-                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
-  else if (idx)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, true, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
-                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
-  else if (one_pass)
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
-                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
-  else
-    hipLaunchKernelGGL((deskew_batch_f32<TIER, 1, kPolicyDefault, false, kLaunchBlock, true>), dim3(grid), dim3(kLaunchBlock), 0, s, in, out, (const BatchRec*)nullptr,
-                       (const uint2*)nullptr, nf, n, idx, head, (const FrameRecD*)nullptr, chunk_shift, (const float*)nullptr, inl);
+// batch of at most 16 frames, tables in the kernel arguments (default launch geometry only: one point per lane)
+void launch_batch_inline(int tier, hipStream_t s, int grid, const v4f* in, v4f* out, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, uint32_t chunk_shift,
+                         const BatchInline& inl, bool one_pass) {
+  with_tier(tier, [&](auto T) {
+    with_bool(idx != nullptr, [&](auto IDX) {
+      with_bool(one_pass, [&](auto OP) {
+        launch_on(deskew_batch_f32<decltype(T)::value, 1, kPolicyDefault, decltype(IDX)::value, kLaunchBlock, true, decltype(OP)::value>, grid, kLaunchBlock, s, false, in,
+                  out, nullptr, nullptr, nf, n, idx, head, nullptr, chunk_shift, nullptr, inl);
+      });
+    });
+  });
 }
 }  // namespace
 
@@ -288,12 +258,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 63) / 64, (uint64_t)c->mapped_waves * 2));  // 16 B per lane here, 80 in the f64 kernel
     const v4f* vin = (const v4f*)xyzi_in;
     v4f* vout = (v4f*)xyzi_out;
-    switch (tier) {
-      case kSeries3: hipLaunchKernelGGL((deskew_frame_streamed_f32<kSeries3>), dim3(grid), dim3(64), 0, c->stream, vin, vout, n, f, d); break;
-      case kSeries5: hipLaunchKernelGGL((deskew_frame_streamed_f32<kSeries5>), dim3(grid), dim3(64), 0, c->stream, vin, vout, n, f, d); break;
-      case kWide: hipLaunchKernelGGL((deskew_frame_streamed_f32<kWide>), dim3(grid), dim3(64), 0, c->stream, vin, vout, n, f, d); break;
-      default: hipLaunchKernelGGL((deskew_frame_streamed_f32<kTrig>), dim3(grid), dim3(64), 0, c->stream, vin, vout, n, f, d); break;
-    }
+    with_tier(tier, [&](auto T) { launch_on(deskew_frame_streamed_f32<decltype(T)::value>, grid, 64, c->stream, false, vin, vout, n, f, d); });
     KMC_HIP_TRY(c, hipGetLastError());
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     hipError_t q = hipErrorNotReady;
@@ -498,12 +463,7 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
       const v4f* vin = (const v4f*)xyzi_in - head;
       v4f* vout = (v4f*)xyzi_out - head;
       uint32_t* vidx = frame_idx_out ? frame_idx_out - head : nullptr;
-      switch (tier) {
-        case kSeries3: launch_batch_inline<kSeries3>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass); break;
-        case kSeries5: launch_batch_inline<kSeries5>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass); break;
-        case kWide: launch_batch_inline<kWide>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass); break;
-        default: launch_batch_inline<kTrig>(c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass); break;
-      }
+      launch_batch_inline(tier, c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass);
       KMC_HIP_TRY(c, hipGetLastError());
       if (tmi.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
       if (st) st->n_launches = 1;
@@ -577,12 +537,7 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   const int grid = grid_for(c, n_tiles);
   const bool one_pass = one_pass_for(c, grid, n_tiles) && ppt == 1;
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
-  switch (tier) {
-    case kSeries3: launch_batch_t<kSeries3>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass); break;
-    case kSeries5: launch_batch_t<kSeries5>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass); break;
-    case kWide: launch_batch_t<kWide>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass); break;
-    default: launch_batch_t<kTrig>(ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass); break;
-  }
+  launch_batch(tier, ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass);
   KMC_HIP_TRY(c, hipGetLastError());
   {
     const int rc_end = slot_end(c, slot_id);
@@ -684,10 +639,9 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
     hipLaunchKernelGGL((deskew_f64cols<0, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
   } else {
     const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-    if (one_pass_for(c, grid, (n + 127) / 128))
-      hipLaunchKernelGGL((deskew_f64cols<0, false, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
-    else
-      hipLaunchKernelGGL((deskew_f64cols<0, false>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
+    with_bool(one_pass_for(c, grid, (n + 127) / 128), [&](auto OP) {
+      launch_on(deskew_f64cols<0, false, decltype(OP)::value>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
+    });
   }
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
@@ -791,10 +745,9 @@ int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, 
     dx = base; dy = base + n; dout = base + 2 * n;
   }
   const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-  if (one_pass_for(c, grid, (n + 127) / 128))
-    hipLaunchKernelGGL((pseudo_timestamps_f64<0, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
-  else
-    hipLaunchKernelGGL((pseudo_timestamps_f64<0, false>), dim3(grid), dim3(64), 0, c->stream, dx, dy, n, scan_start, scan_end, dout);
+  with_bool(one_pass_for(c, grid, (n + 127) / 128), [&](auto OP) {
+    launch_on(pseudo_timestamps_f64<0, decltype(OP)::value>, grid, 64, c->stream, false, dx, dy, n, scan_start, scan_end, dout);
+  });
   KMC_HIP_TRY(c, hipGetLastError());
   if (mem_kind == KMC_MEM_HOST) KMC_HIP_TRY(c, hipMemcpyAsync(stamps_out, dout, col, hipMemcpyDeviceToHost, c->stream));
   if (mem_kind != KMC_MEM_DEVICE) KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the results are in host memory when the call returns

@@ -83,23 +83,20 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   const int grid = grid_for(c, (n + 63) / 64);
   const bool one_pass = one_pass_for(c, grid, (n + 63) / 64);
   const int kind = rig_kind(rig);
-#define KMC_LAUNCH_PROJECT(T)                                                                                                     \
-  do {                                                                                                                            \
-    if (one_pass && kind == kRigSharedIntrinsics) hipLaunchKernelGGL((project_f32<T, kRigSharedIntrinsics, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
-    else if (one_pass && kind == kRigPinhole) hipLaunchKernelGGL((project_f32<T, kRigPinhole, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
-    else if (one_pass) hipLaunchKernelGGL((project_f32<T, kRigGeneral, true>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
-    else if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL((project_f32<T, kRigSharedIntrinsics>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
-    else if (kind == kRigPinhole) hipLaunchKernelGGL((project_f32<T, kRigPinhole>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd); \
-    else hipLaunchKernelGGL((project_f32<T, kRigGeneral>), dim3(grid), dim3(64), 0, c->stream, d_in, n, g, f, d_cloud, d_uv, d_col, fd);       \
-  } while (0)
-  switch (tier) {
-    case kSeries3: KMC_LAUNCH_PROJECT(kSeries3); break;
-    case kSeries5: KMC_LAUNCH_PROJECT(kSeries5); break;
-    case kWide: KMC_LAUNCH_PROJECT(kWide); break;
-    case kTrig: KMC_LAUNCH_PROJECT(kTrig); break;
-    default: KMC_LAUNCH_PROJECT(-1); break;
-  }
-#undef KMC_LAUNCH_PROJECT
+  auto with_rig = [&](auto&& fn) {
+    if (kind == kRigSharedIntrinsics) fn(std::integral_constant<int, kRigSharedIntrinsics>{});
+    else if (kind == kRigPinhole) fn(std::integral_constant<int, kRigPinhole>{});
+    else fn(std::integral_constant<int, kRigGeneral>{});
+  };
+  auto launch_tier = [&](auto T) {  // T = -1: projection only, no deskew
+    with_rig([&](auto RIG) {
+      with_bool(one_pass, [&](auto OP) {
+        launch_on(project_f32<decltype(T)::value, decltype(RIG)::value, decltype(OP)::value>, grid, 64, c->stream, false, d_in, n, g, f, d_cloud, d_uv, d_col, fd);
+      });
+    });
+  };
+  if (tier >= kSeries3 && tier <= kTrig) with_tier(tier, launch_tier);
+  else launch_tier(std::integral_constant<int, -1>{});
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {
@@ -147,13 +144,15 @@ int kmc_hip_project_f64cols(kmc_ctx* c, const double* x, const double* y, const 
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   const int grid = grid_for(c, (n + 63) / 64);
   const int kind = rig_kind(rig);
-  if (one_pass_for(c, grid, (n + 63) / 64)) {
-    if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL((project_f64cols<kRigSharedIntrinsics, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
-    else if (kind == kRigPinhole) hipLaunchKernelGGL((project_f64cols<kRigPinhole, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
-    else hipLaunchKernelGGL((project_f64cols<kRigGeneral, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
-  } else if (kind == kRigSharedIntrinsics) hipLaunchKernelGGL(project_f64cols<kRigSharedIntrinsics>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
-  else if (kind == kRigPinhole) hipLaunchKernelGGL(project_f64cols<kRigPinhole>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
-  else hipLaunchKernelGGL(project_f64cols<kRigGeneral>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, n, g, d_uv, d_col);
+  {
+    const bool one_pass = one_pass_for(c, grid, (n + 63) / 64);
+    auto launch_rig = [&](auto RIG) {
+      with_bool(one_pass, [&](auto OP) { launch_on(project_f64cols<decltype(RIG)::value, decltype(OP)::value>, grid, 64, c->stream, false, dx, dy, dz, n, g, d_uv, d_col); });
+    };
+    if (kind == kRigSharedIntrinsics) launch_rig(std::integral_constant<int, kRigSharedIntrinsics>{});
+    else if (kind == kRigPinhole) launch_rig(std::integral_constant<int, kRigPinhole>{});
+    else launch_rig(std::integral_constant<int, kRigGeneral>{});
+  }
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {

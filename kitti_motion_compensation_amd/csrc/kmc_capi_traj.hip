@@ -181,22 +181,24 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (n == 0) return KMC_OK;
 
   static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
-#define KMC_LAUNCH_TRAJ(T, INL, STREAM, SEGS, SEGS64, ...)                                                                          \
-  do {                                                                                                                              \
-    if (any_order && one_pass) hipExtLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL, true>), dim3(grid), dim3(64), 0, STREAM, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
-    else if (any_order) hipExtLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL>), dim3(grid), dim3(64), 0, STREAM, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
-    else if (d_idx && one_pass) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true, INL, true>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
-    else if (d_idx) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, true, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
-    else if (one_pass) hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL, true>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__); \
-    else hipLaunchKernelGGL((deskew_traj_f32<T, kPolicyDefault, false, INL>), dim3(grid), dim3(64), 0, STREAM, d_in - head, d_out - head, nv, SEGS, th.n_seg, v_idx, head, SEGS64, __VA_ARGS__);      \
-  } while (0)
-#define KMC_LAUNCH_TRAJ_TIER(INL, STREAM, SEGS, SEGS64, ...)                                        \
-  switch (tier) {                                                                                   \
-    case kSeries3: KMC_LAUNCH_TRAJ(kSeries3, INL, STREAM, SEGS, SEGS64, __VA_ARGS__); break;        \
-    case kSeries5: KMC_LAUNCH_TRAJ(kSeries5, INL, STREAM, SEGS, SEGS64, __VA_ARGS__); break;        \
-    case kWide: KMC_LAUNCH_TRAJ(kWide, INL, STREAM, SEGS, SEGS64, __VA_ARGS__); break;              \
-    default: KMC_LAUNCH_TRAJ(kTrig, INL, STREAM, SEGS, SEGS64, __VA_ARGS__); break;                 \
-  }
+  // one launch site for both routes: tier, index output, record source (kernel arguments / device table), tile loop or not and the
+  // barrier bit are run-time choices of this call, template arguments of the kernel
+  auto launch_traj = [&](auto INL, hipStream_t stream, bool any_order, const v4f* d_in, v4f* d_out, uint32_t* d_idx, const TrajSeg32* segs, const TrajSegD* segs64,
+                         const TrajInline& inl) {
+    const uint32_t head = head_of(xyzi_out, mem_kind);
+    const uint64_t nv = n + head;
+    const int grid = grid_for(c, (nv + 63) / 64);
+    const bool one_pass = one_pass_for(c, grid, (nv + 63) / 64);
+    uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
+    with_tier(tier, [&](auto T) {
+      with_bool(d_idx != nullptr, [&](auto IDX) {
+        with_bool(one_pass, [&](auto OP) {
+          launch_on(deskew_traj_f32<decltype(T)::value, kPolicyDefault, decltype(IDX)::value, decltype(INL)::value, decltype(OP)::value>, grid, 64, stream, any_order,
+                    d_in - head, d_out - head, nv, segs, th.n_seg, v_idx, head, segs64, inl);
+        });
+      });
+    });
+  };
 
   if (inline_records) {
     // A short trajectory on device-resident points -- north_star's "three bracketing poses" -- carries its segment records in the
@@ -216,12 +218,7 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
     const bool any_order = window && ao_admit(c, xyzi_in, xyzi_out, n * sizeof(v4f), false);
     CallTimer tm(c);
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    const uint32_t head = head_of(xyzi_out, mem_kind);
-    const uint64_t nv = n + head;
-    const int grid = grid_for(c, (nv + 63) / 64);
-    const bool one_pass = one_pass_for(c, grid, (nv + 63) / 64);
-    uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
-    KMC_LAUNCH_TRAJ_TIER(true, s, (const TrajSeg32*)nullptr, (const TrajSegD*)nullptr, inl)
+    launch_traj(std::true_type{}, s, any_order, d_in, d_out, d_idx, nullptr, nullptr, inl);
     KMC_HIP_TRY(c, hipGetLastError());
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     if (st) st->n_launches = 1;
@@ -254,17 +251,9 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   CallTimer tm(c);
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const uint32_t head = head_of(xyzi_out, mem_kind);
-  const uint64_t nv = n + head;
-  const int grid = grid_for(c, (nv + 63) / 64);
-  const bool one_pass = one_pass_for(c, grid, (nv + 63) / 64);
   const TrajSeg32* d_segs = (const TrajSeg32*)c->slots[slot_id].d_buf;
   const TrajSegD* d_segs64 = (const TrajSegD*)(c->slots[slot_id].d_buf + kMaxSegments * sizeof(TrajSeg32));
-  uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
-  constexpr bool any_order = false;  // the table route: ordinary launches
-  KMC_LAUNCH_TRAJ_TIER(false, c->stream, d_segs, d_segs64, TrajInline{})
-#undef KMC_LAUNCH_TRAJ_TIER
-#undef KMC_LAUNCH_TRAJ
+  launch_traj(std::false_type{}, c->stream, false, d_in, d_out, d_idx, d_segs, d_segs64, TrajInline{});  // the table route: ordinary launches
   KMC_HIP_TRY(c, hipGetLastError());
   rc = slot_end(c, slot_id);
   if (rc != KMC_OK) return rc;
@@ -370,20 +359,14 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   const bool idx = d_fidx || d_bidx;
   uint32_t* v_fidx = d_fidx ? d_fidx - head : nullptr;
   uint32_t* v_bidx = d_bidx ? d_bidx - head : nullptr;
-#define KMC_LAUNCH_TRAJ_BATCH(T)                                                                                                   \
-  do {                                                                                                                             \
-    if (idx && one_pass) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
-    else if (idx) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, true, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
-    else if (one_pass) hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false, true>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd); \
-    else hipLaunchKernelGGL((deskew_traj_batch_f32<T, kPolicyDefault, false, false>), dim3(grid), dim3(64), 0, c->stream, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);     \
-  } while (0)
-  switch (tier) {
-    case kSeries3: KMC_LAUNCH_TRAJ_BATCH(kSeries3); break;
-    case kSeries5: KMC_LAUNCH_TRAJ_BATCH(kSeries5); break;
-    case kWide: KMC_LAUNCH_TRAJ_BATCH(kWide); break;
-    default: KMC_LAUNCH_TRAJ_BATCH(kTrig); break;
-  }
-#undef KMC_LAUNCH_TRAJ_BATCH
+  with_tier(tier, [&](auto T) {
+    with_bool(idx, [&](auto IDX) {
+      with_bool(one_pass, [&](auto OP) {
+        launch_on(deskew_traj_batch_f32<decltype(T)::value, kPolicyDefault, decltype(IDX)::value, decltype(OP)::value>, grid, 64, c->stream, false, d_in - head, d_out - head, nv,
+                  d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);
+      });
+    });
+  });
   KMC_HIP_TRY(c, hipGetLastError());
   rc = slot_end(c, slot_id);
   if (rc != KMC_OK) return rc;

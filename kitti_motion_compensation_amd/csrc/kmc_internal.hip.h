@@ -12,6 +12,7 @@
 
 #include "../../include/kmc_hip.h"
 
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -20,6 +21,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "kmc_host_math.hpp"
@@ -222,6 +224,31 @@ inline int grid_for(const kmc_ctx* c, uint64_t n_tiles, uint32_t threads_per_blo
   const uint64_t hw = 0xFFFFFFFFull / threads_per_block;
   const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu * (kBlock / kLaunchBlock) : hw;
   return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, std::min(cap, hw)));
+}
+
+// ---- launch plumbing: run-time choices -> template arguments, and the one place that knows the two launch calls ----
+template <typename F>
+inline void with_bool(bool b, F&& f) {
+  if (b) f(std::true_type{});
+  else f(std::false_type{});
+}
+template <typename F>
+inline void with_tier(int tier, F&& f) {
+  switch (tier) {
+    case kSeries3: f(std::integral_constant<int, kSeries3>{}); break;
+    case kSeries5: f(std::integral_constant<int, kSeries5>{}); break;
+    case kWide: f(std::integral_constant<int, kWide>{}); break;
+    default: f(std::integral_constant<int, kTrig>{}); break;
+  }
+}
+// `any_order`: dispatch without the AQL barrier bit (hipExtAnyOrderLaunch), see kmc_ctx::ao_valid
+template <typename... KArgs, typename... Args>
+inline void launch_on(void (*kernel)(KArgs...), int grid, int block, hipStream_t s, bool any_order, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+  if (any_order)
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, static_cast<KArgs>(args)...);
+  else
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, static_cast<KArgs>(args)...);
 }
 
 // one workgroup per tile: the kernels' ONE_PASS instantiations (no tile loop); KMC_TILE_LOOP=1 keeps the loop variants (A/B hook)
