@@ -204,7 +204,8 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip, tools/fq_probe.hip).
  *   - queues = 1 (default): every call on the context's stream, in order.  Since ABI version 3 "in order" no longer means "drained":
  *     a device-resident frame whose buffers overlap none of the frames launched since the last ordinary launch is dispatched WITHOUT
- *     the barrier bit (hipExtAnyOrderLaunch) and starts while the frame before it is still running -- the results of every frame,
+ *     the barrier bit (hipExtAnyOrderLaunch): the packet processor does not wait for the completion and the cache release of the
+ *     frame before it (it does not run whole kernels of one queue side by side either: four queues stay ahead) -- the results of every frame,
  *     and everything the context or the caller puts on the stream afterwards (copies, events, other kernels: ordinary packets, which
  *     wait for all of them), are the same as before.  This needs no queues and no events; it applies (a) on the context's own
  *     stream, (b) on a caller's stream after kmc_hip_set_frame_queue_order(ctx, 0), (c) between the frames of one
