@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define KMC_ABI_VERSION 3
+#define KMC_ABI_VERSION 4
 
 /* ---- status codes ---- */
 #define KMC_OK 0
@@ -99,6 +99,10 @@ typedef struct kmc_device_info {
   int wavefront_size;
   uint64_t hbm_bytes;
   int clock_khz;
+  int any_order_dispatch; /* barrier-free dispatch of independent frames (see kmc_hip_set_frame_queues): 1 = verified on this device at
+                             kmc_hip_create and in use; 0 = switched off (KMC_ANY_ORDER=0); -1 = the run-time probe saw an ordinary packet
+                             overtake a barrier-free one (off); -2 = the flag has no effect on this runtime (off); -3 = the probe could
+                             not run (off) */
 } kmc_device_info;
 
 /* ------------------------------------------------------------------------------------------------
@@ -209,7 +213,11 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  *     and everything the context or the caller puts on the stream afterwards (copies, events, other kernels: ordinary packets, which
  *     wait for all of them), are the same as before.  This needs no queues and no events; it applies (a) on the context's own
  *     stream, (b) on a caller's stream after kmc_hip_set_frame_queue_order(ctx, 0), (c) between the frames of one
- *     kmc_hip_deskew_frames_f32 call; at most 32 frames go out between two ordinary launches; KMC_ANY_ORDER=0 switches it off.
+ *     kmc_hip_deskew_frames_f32 call; at most 32 frames go out between two ordinary launches.  CONTRACT: the flag is documented as
+ *     unsupported on gfx9, so the library does not take it on trust -- kmc_hip_create runs a probe (< 1 ms, once per device and process)
+ *     that must SEE, on this device and runtime, (1) an ordinary kernel, a copy and an event behind barrier-free packets wait for all of
+ *     them and (2) a barrier-free packet really start next to the kernel before it; only then is the feature on
+ *     (kmc_device_info.any_order_dispatch == 1), otherwise every launch is an ordinary one.  KMC_ANY_ORDER=0 switches it off unprobed.
  *     Measured (tools/anyorder_probe.hip, bench.py's configs1_literal leg): 7.0 -> 6.3 us per 1 M-point frame; never on HIP's legacy
  *     default stream (handle NULL) and never while the stream captures a graph.
  *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls -- and kmc_hip_deskew_traj_f32(KMC_MEM_DEVICE) calls with
@@ -261,8 +269,12 @@ int kmc_hip_deskew_f64cols(kmc_ctx* ctx, const double* x, const double* y, const
  * the kernel runs).  _begin checks the arguments and ISSUES the work; with device-addressable buffers (KMC_MEM_DEVICE,
  * KMC_MEM_HOST_MAPPED, or KMC_MEM_HOST pointers that are all page-locked) it returns without waiting, with staged host
  * buffers it completes the call.  _end waits and returns what kmc_hip_deskew_f64cols would have returned (KMC_ERR_TIME_OUT_OF_RANGE
- * included) and its stats.  Exactly one _end per successful _begin, and no other call on the context in between; the buffers belong
- * to the library until _end returns. */
+ * included) and its stats.  The buffers belong to the library until _end returns, and no other call on the context in between --
+ * except further _begin calls on device-addressable buffers: they queue up behind each other on the context's stream (K frames
+ * back to back without a host wait between them) and ONE _end then waits for all of them and returns their combined verdict and
+ * stats (points and launches summed, out-of-range stamps counted over all of them).  A _begin that cannot queue (staged host
+ * buffers behind queued work, or behind a staged verdict that has not been collected) fails with KMC_ERR_INVALID_ARG and leaves the
+ * queued work as it was. */
 int kmc_hip_deskew_f64cols_begin(kmc_ctx* ctx, const double* x, const double* y, const double* z, const double* w,
                                  const double* stamps, uint64_t n, double stamp_start, double stamp_end,
                                  const kmc_frame_params* params, double* ox, double* oy, double* oz, double* ow, int mem_kind);

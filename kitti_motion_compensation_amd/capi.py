@@ -70,6 +70,7 @@ class DeviceInfo(C.Structure):
         ("wavefront_size", C.c_int),
         ("hbm_bytes", C.c_uint64),
         ("clock_khz", C.c_int),
+        ("any_order_dispatch", C.c_int),
     ]
 
 
@@ -412,7 +413,7 @@ class Context:
         d = DeviceInfo()
         self._check(lib().kmc_hip_device_info(self._h, C.byref(d)), "kmc_hip_device_info")
         return dict(name=d.name.decode(), arch=d.arch.decode(), device_id=d.device_id, compute_units=d.compute_units,
-                    wavefront_size=d.wavefront_size, hbm_bytes=d.hbm_bytes, clock_khz=d.clock_khz)
+                    wavefront_size=d.wavefront_size, hbm_bytes=d.hbm_bytes, clock_khz=d.clock_khz, any_order_dispatch=d.any_order_dispatch)
 
     def timer_begin(self):
         self._check(lib().kmc_hip_timer_begin(self._h), "kmc_hip_timer_begin")

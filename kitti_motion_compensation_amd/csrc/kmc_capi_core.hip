@@ -3,6 +3,7 @@
 #include "kmc_internal.hip.h"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace kmc_impl {
 
@@ -146,6 +147,88 @@ bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool 
   return any_order;
 }
 
+// ---- barrier-free dispatch: checked at run time before it is used ------------------------------------
+// hipExtAnyOrderLaunch is documented "not supported on GFX9xx"; on MI355X / ROCm 7.2 it does clear the AQL barrier bit
+// (profiles/r03_anyorder_aql_headers.txt).  The library relies on two facts and verifies BOTH on the device it is about to use, once per
+// device and process (< 1 ms), before ao_enabled may become true:
+//   (1) ORDER: an ordinary packet behind barrier-free packets -- a kernel launch, a device-to-host copy, an event record -- waits for
+//       EVERY packet before it, barrier-free ones included.  A (ordinary, spins ~120 us, then raises flag 0), B (barrier-free, stamps the
+//       clock), B2 (barrier-free, spins ~40 us, then raises flag 1), C (ordinary, reads both flags), a D2H copy of the flags, an event:
+//       C and the copy must both have seen both flags raised.  If not, consumers of a frame could read it too early: feature OFF.
+//   (2) OVERLAP: B's time stamp lies before A's end, i.e. the packet processor really started B while A was running.  If not, the
+//       flag is a no-op on this runtime: feature OFF (nothing to gain; the ordinary launch is the documented one).
+// Verdict (kmc_device_info.any_order_dispatch): 1 = verified, on;  0 = switched off (KMC_ANY_ORDER=0);  -1 = order violated;
+// -2 = no overlap observed;  -3 = the probe could not run (a HIP error).
+__global__ void ao_probe_spin(uint32_t* flag, uint64_t ticks, unsigned long long* t_end) {
+  const uint64_t t0 = wall_clock64();  // 100 MHz constant clock
+  while (wall_clock64() - t0 < ticks) {
+  }
+  if (threadIdx.x == 0) {
+    if (t_end) *t_end = wall_clock64();
+    __hip_atomic_store(flag, 0x4B4D43u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__global__ void ao_probe_stamp(unsigned long long* t_seen) {
+  if (threadIdx.x == 0) *t_seen = wall_clock64();
+}
+__global__ void ao_probe_read(const uint32_t* flags, uint32_t* seen) {
+  if (threadIdx.x < 2) seen[threadIdx.x] = __hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static int ao_probe_run(kmc_ctx* c) {
+  struct Words { uint32_t flags[2]; uint32_t seen[2]; unsigned long long t_end_a, t_seen_b; };
+  Words* d = nullptr;
+  Words* h = nullptr;  // [0]: what the D2H copy behind the packets saw, [1]: the final state
+  int verdict = -3;
+  hipStream_t s = c->own_stream;
+  hipEvent_t ev = nullptr;
+  do {
+    if (hipMalloc((void**)&d, sizeof(Words)) != hipSuccess) break;
+    if (hipHostMalloc((void**)&h, 2 * sizeof(Words), hipHostMallocDefault) != hipSuccess) break;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
+    std::memset(h, 0, 2 * sizeof(Words));
+    if (hipMemsetAsync(d, 0, sizeof(Words), s) != hipSuccess) break;
+    hipLaunchKernelGGL(ao_probe_spin, dim3(1), dim3(64), 0, s, &d->flags[0], (uint64_t)12000, &d->t_end_a);                   // A: ordinary
+    hipExtLaunchKernelGGL(ao_probe_stamp, dim3(1), dim3(64), 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, &d->t_seen_b);  // B
+    hipExtLaunchKernelGGL(ao_probe_spin, dim3(1), dim3(64), 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, &d->flags[1], (uint64_t)4000,
+                          (unsigned long long*)nullptr);                                                                          // B2
+    hipLaunchKernelGGL(ao_probe_read, dim3(1), dim3(64), 0, s, (const uint32_t*)d->flags, d->seen);                            // C: ordinary
+    if (hipGetLastError() != hipSuccess) break;
+    if (hipMemcpyAsync(&h[0], d, sizeof(Words), hipMemcpyDeviceToHost, s) != hipSuccess) break;  // a copy behind them
+    if (hipEventRecord(ev, s) != hipSuccess) break;
+    if (hipEventSynchronize(ev) != hipSuccess) break;
+    const bool copy_waited = h[0].flags[0] == 0x4B4D43u && h[0].flags[1] == 0x4B4D43u;  // read right after the EVENT: it waited too
+    if (hipStreamSynchronize(s) != hipSuccess) break;
+    if (hipMemcpy(&h[1], d, sizeof(Words), hipMemcpyDeviceToHost) != hipSuccess) break;
+    const bool kernel_waited = h[1].seen[0] == 0x4B4D43u && h[1].seen[1] == 0x4B4D43u;
+    const bool overlapped = h[1].t_seen_b != 0 && h[1].t_seen_b < h[1].t_end_a;
+    verdict = !(copy_waited && kernel_waited) ? -1 : (overlapped ? 1 : -2);
+  } while (false);
+  (void)hipGetLastError();
+  if (ev) (void)hipEventDestroy(ev);
+  if (h) (void)hipHostFree(h);
+  if (d) (void)hipFree(d);
+  return verdict;
+}
+
+// one probe per device and process; KMC_ANY_ORDER=0 switches the feature off without probing.  KMC_ANY_ORDER_PROBE=fail is a TEST hook:
+// the probe's verdict is replaced by "order violated" so that the gate itself can be exercised on a runtime where the probe passes.
+int ao_verdict_for(kmc_ctx* c) {
+  if (const char* e = std::getenv("KMC_ANY_ORDER"))
+    if (std::atoi(e) == 0) return 0;
+  if (const char* e = std::getenv("KMC_ANY_ORDER_PROBE"))
+    if (std::strcmp(e, "fail") == 0) return -1;
+  static std::mutex mu;
+  static int cached[64];
+  static bool have[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  const int d = c->device;
+  if (d >= 0 && d < 64 && have[d]) return cached[d];
+  const int v = ao_probe_run(c);
+  if (d >= 0 && d < 64) { cached[d] = v; have[d] = true; }
+  return v;
+}
+
 int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
   const int slot_id = c->next_slot;
   const int group_id = slot_id / kmc_ctx::kSlotsPerGroup;
@@ -282,7 +365,8 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   c->stream = c->own_stream;
   if (const char* e = std::getenv("KMC_NO_INLINE_TABLES")) c->no_inline_tables = std::atoi(e) != 0;
   if (const char* e = std::getenv("KMC_TILE_LOOP")) c->tile_loop = std::atoi(e) != 0;
-  if (const char* e = std::getenv("KMC_ANY_ORDER")) c->ao_enabled = std::atoi(e) != 0;
+  c->ao_verdict = ao_verdict_for(c);  // barrier-free dispatch only where this device and runtime were SEEN to honour what it relies on
+  c->ao_enabled = c->ao_verdict == 1;
   if (const char* e = std::getenv("KMC_MAPPED_WAVES")) c->mapped_waves = std::max(1, std::min(65536, std::atoi(e)));
   *out = c;
   return KMC_OK;
@@ -422,6 +506,7 @@ int kmc_hip_device_info(kmc_ctx* c, kmc_device_info* out) {
   out->wavefront_size = c->prop.warpSize;
   out->hbm_bytes = c->prop.totalGlobalMem;
   out->clock_khz = c->prop.clockRate;
+  out->any_order_dispatch = c->ao_verdict;
   return KMC_OK;
 }
 

@@ -25,6 +25,19 @@ void with_ppt(int ppt, F&& f) {
     default: f(std::integral_constant<int, 4>{}); break;
   }
 }
+// The in-place routes end with "the results are in host memory".  A short busy wait first -- the kernel of a KITTI frame takes
+// ~100 us and an interrupt-driven wake-up adds several microseconds -- and then ALWAYS a hipStreamSynchronize: a successful
+// hipStreamQuery says the stream is idle, but only the synchronize carries the runtime's system-scope release / acquire (and is the
+// point at which HIP promises visibility for non-coherent pinned allocations, which host_in_place_ok() may have recognised); on an
+// idle stream it returns at once.
+int wait_results_in_host_memory(kmc_ctx* c) {
+  hipError_t q = hipErrorNotReady;
+  for (int spin = 0; spin < 20000 && (q = hipStreamQuery(c->stream)) == hipErrorNotReady; ++spin) {
+  }
+  if (q != hipSuccess) (void)hipGetLastError();
+  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return KMC_OK;
+}
 // in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of().
 // any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao_valid
 void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0,
@@ -261,12 +274,9 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     with_tier(tier, [&](auto T) { launch_on(deskew_frame_streamed_f32<decltype(T)::value>, grid, 64, c->stream, false, vin, vout, n, f, d); });
     KMC_HIP_TRY(c, hipGetLastError());
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    hipError_t q = hipErrorNotReady;
-    for (int spin = 0; spin < 20000 && (q = hipStreamQuery(c->stream)) == hipErrorNotReady; ++spin) {
-    }
-    if (q != hipSuccess) {
-      (void)hipGetLastError();
-      KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    {
+      const int rc_wait = wait_results_in_host_memory(c);
+      if (rc_wait != KMC_OK) return rc_wait;
     }
     return tm.end_call(st);
   }
@@ -347,54 +357,120 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   return tm.end_call(st);
 }
 
-// ---- hot path: a stream of separate frames --------------------------------------------------------
+// ---- hot path: a list of separate frames, ONE launch ------------------------------------------------
+namespace {
+// Do two DIFFERENT frames of the list touch the same memory with at least one of them writing it?  (in == out of one frame is fine.)
+// Sorted sweep over the 2 F intervals; lists whose buffers come in ascending, disjoint order -- the usual case -- are recognised in O(F).
+bool list_has_hazard(const float* const* in, float* const* out, const uint64_t* n_points, uint32_t n_frames) {
+  struct Iv { uintptr_t lo, hi; uint32_t frame; bool write; };
+  std::vector<Iv> iv;
+  iv.reserve(2 * (size_t)n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    if (!n_points[f]) continue;
+    const uintptr_t bytes = (uintptr_t)n_points[f] * sizeof(v4f);
+    iv.push_back({(uintptr_t)in[f], (uintptr_t)in[f] + bytes, f, false});
+    iv.push_back({(uintptr_t)out[f], (uintptr_t)out[f] + bytes, f, true});
+  }
+  if (!std::is_sorted(iv.begin(), iv.end(), [](const Iv& a, const Iv& b) { return a.lo < b.lo; }))
+    std::sort(iv.begin(), iv.end(), [](const Iv& a, const Iv& b) { return a.lo < b.lo; });
+  for (size_t i = 0; i < iv.size(); ++i)
+    for (size_t j = i + 1; j < iv.size() && iv[j].lo < iv[i].hi; ++j)
+      if (iv[i].frame != iv[j].frame && (iv[i].write || iv[j].write)) return true;
+  return false;
+}
+}  // namespace
+
 int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* const* xyzi_out, const uint64_t* n_points,
                               const kmc_frame_params* params, uint32_t n_frames, kmc_stats* st) {
   if (!c || (n_frames && (!xyzi_in || !xyzi_out || !n_points || !params))) return KMC_ERR_INVALID_ARG;
   if (st) std::memset(st, 0, sizeof(*st));
+  uint64_t total = 0, n_max = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
     const int rc_args = check_frame_args(xyzi_in[f], xyzi_out[f], n_points[f], &params[f], KMC_MEM_DEVICE);
     if (rc_args != KMC_OK) return rc_args;
+    total += n_points[f];
+    n_max = std::max<uint64_t>(n_max, n_points[f] + head_of(xyzi_out[f], KMC_MEM_DEVICE));
   }
   KMC_ENTER(c);
+  const int tier = pick_tier(c, params, n_frames);  // one launch runs its widest frame's tier, like a batch
+  if (st) { st->n_points = total; st->variant = (uint32_t)tier; }
+  if (total == 0) return KMC_OK;
   CallTimer tm(c);
-  if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  // the context's setting if the caller has chosen one (kmc_hip_set_frame_queues, 1 = in order on the context's stream), else what
-  // is faster for this call: the fork to four queues and the join behind them cost ~45 us of barrier packets, which a list of 1 M-point
-  // frames earns back from ~64 frames on (tools/measure_join_cost.py: 96 frames 5.6 against 6.2 us per frame, 32 frames 6.5 against
-  // 6.2); shorter lists and small frames stay on the one stream, where frames that share no buffer go out without the barrier bit
-  const int saved = c->fq_count;
-  const bool saved_explicit = c->fq_explicit, saved_ordered = c->fq_ordered;
-  if (!saved_explicit) {
-    uint64_t all_points = 0;
-    for (uint32_t f = 0; f < n_frames; ++f) all_points += n_points[f];
-    const bool worth_queues = n_frames >= 64 && all_points >= (uint64_t)n_frames * 400000ull;
-    const int rc_set = kmc_hip_set_frame_queues(c, worth_queues ? kmc_ctx::kMaxFrameQueues : 1);
-    if (rc_set != KMC_OK) return rc_set;
+  // Frames that depend on each other (one's output is another's input, or two write the same buffer) cannot share a launch: such a list
+  // goes out frame by frame, in order, as ordinary launches on the context's stream -- what separate kmc_hip_deskew_f32 calls would do.
+  // So does a list the 2-D grid cannot hold (more than 65 535 frames, or beyond 2^32 work-items).
+  const uint64_t tiles_x = (n_max + 63) / 64;
+  const bool fits = n_frames <= 65535u && tiles_x * 64 * (uint64_t)n_frames < (1ull << 32);
+  if (!fits || c->blocks_per_cu != 0 || list_has_hazard(xyzi_in, xyzi_out, n_points, n_frames)) {
+    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      const int rc = issue_frame(c, c->stream, xyzi_in[f], xyzi_out[f], n_points[f], &params[f], nullptr, false);
+      if (rc != KMC_OK) return rc;
+    }
+    if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    if (st) st->n_launches = n_frames;
+    return tm.end_call(st);
   }
-  // every frame of THIS call was handed over before the call: one fork from the context's stream at its start orders all of them
-  // behind their producers, no per-frame event
-  c->fq_ordered = false;
-  uint64_t total = 0;
-  int tier_max = 0, rc = KMC_OK;
-  for (uint32_t f = 0; f < n_frames && rc == KMC_OK; ++f) {
-    hipStream_t s;
-    rc = fq_stream(c, &s);
-    int tier = 0;
-    // one queue = the context's stream, in order: frames of this call that share no buffer still need not wait for each other
-    const bool any_order = rc == KMC_OK && c->fq_count <= 1 && n_points[f] && ao_admit(c, xyzi_in[f], xyzi_out[f], n_points[f] * sizeof(v4f), f > 0);
-    if (rc == KMC_OK) rc = issue_frame(c, s, xyzi_in[f], xyzi_out[f], n_points[f], &params[f], &tier, any_order);
-    tier_max = std::max(tier_max, tier);
-    total += n_points[f];
+  auto fill = [&](uint32_t f, ListRec* r, FrameRecD* d) {
+    std::memset(r, 0, sizeof(*r));
+    fill_rec(params[f], &r->f);
+    r->f.pre2 = guard_pre2(params[f]);
+    fill_recd(params[f], d);
+    const uint32_t head = n_points[f] ? head_of(xyzi_out[f], KMC_MEM_DEVICE) : 0u;
+    r->in = (const v4f*)xyzi_in[f] - head;
+    r->out = (v4f*)xyzi_out[f] - head;
+    r->n = n_points[f] ? n_points[f] + head : 0;
+    r->head = head;
+  };
+  const dim3 grid((uint32_t)tiles_x, n_frames, 1);
+  if (n_frames <= (uint32_t)kInlineListFrames) {  // the records travel in the kernel arguments: the call only enqueues a launch
+    ListInline inl;
+    std::memset(&inl, 0, sizeof(inl));
+    for (uint32_t f = 0; f < n_frames; ++f) fill(f, &inl.recs[f], &inl.recs64[f]);
+    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    with_tier(tier, [&](auto T) {
+      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kPolicyDefault, true>), grid, dim3(64), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, inl);
+    });
+    KMC_HIP_TRY(c, hipGetLastError());
+  } else {
+    {  // a table upload cannot be part of a stream capture (the slot is reused by later calls, and the host waits for the copy)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        c->last_error = "kmc_hip_deskew_frames_f32: only lists of at most 16 frames can be captured into a HIP graph";
+        return KMC_ERR_INVALID_ARG;
+      }
+      (void)hipGetLastError();
+    }
+    // slot layout: [ListRec x F | FrameRecD x F], one upload on the side stream, awaited on the host (like a batch's tables)
+    const size_t recs_bytes = ((size_t)n_frames * sizeof(ListRec) + 255) & ~(size_t)255;
+    const size_t need = recs_bytes + (size_t)n_frames * sizeof(FrameRecD);
+    int slot_id = 0;
+    {
+      const int rc_slot = slot_begin(c, need, &slot_id);
+      if (rc_slot != KMC_OK) return rc_slot;
+    }
+    kmc_ctx::TableSlot& sl = c->slots[slot_id];
+    ListRec* h_recs = reinterpret_cast<ListRec*>(sl.h_buf);
+    FrameRecD* h_recd = reinterpret_cast<FrameRecD*>(sl.h_buf + recs_bytes);
+    for (uint32_t f = 0; f < n_frames; ++f) fill(f, &h_recs[f], &h_recd[f]);
+    {
+      const int rc_up = slot_upload(c, slot_id, need);
+      if (rc_up != KMC_OK) return rc_up;
+    }
+    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    const ListRec* d_recs = reinterpret_cast<const ListRec*>(sl.d_buf);
+    const FrameRecD* d_recd = reinterpret_cast<const FrameRecD*>(sl.d_buf + recs_bytes);
+    with_tier(tier, [&](auto T) {
+      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kPolicyDefault, false>), grid, dim3(64), 0, c->stream, d_recs, d_recd, ListNoInline{});
+    });
+    KMC_HIP_TRY(c, hipGetLastError());
+    {
+      const int rc_end = slot_end(c, slot_id);
+      if (rc_end != KMC_OK) return rc_end;
+    }
   }
-  const int rc_join = fq_join(c);  // `stream` waits for every frame: the call as a whole is ordered like any other
-  c->fq_count = saved;
-  c->fq_explicit = saved_explicit;
-  c->fq_ordered = saved_ordered;
-  if (rc != KMC_OK) return rc;
-  if (rc_join != KMC_OK) return rc_join;
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  if (st) { st->n_points = total; st->variant = (uint32_t)tier_max; st->n_launches = n_frames; }
+  if (st) st->n_launches = 1;
   return tm.end_call(st);
 }
 
@@ -402,7 +478,10 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
 int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, const uint64_t* offsets, uint32_t n_frames,
                              const kmc_frame_params* params, uint32_t* frame_idx_out, int mem_kind, kmc_stats* st) {
   if (!c || !offsets || (n_frames && !params)) return KMC_ERR_INVALID_ARG;
+  // (a page-locked buffer that is only 4-byte aligned stays on the staged route, which copies it: the kernels' 16-byte accesses need
+  // 16-byte alignment, the copies do not -- ADVICE r03)
   if (mem_kind == KMC_MEM_HOST && n_frames && xyzi_in && xyzi_out && offsets[n_frames] >= kMappedMinPoints &&
+      !((((uintptr_t)xyzi_in) | ((uintptr_t)xyzi_out)) & 15u) && (!frame_idx_out || !(((uintptr_t)frame_idx_out) & 3u)) &&
       host_in_place_ok(xyzi_in, offsets[n_frames] * sizeof(v4f)) && host_in_place_ok(xyzi_out, offsets[n_frames] * sizeof(v4f)) &&
       (!frame_idx_out || host_in_place_ok(frame_idx_out, offsets[n_frames] * sizeof(uint32_t))))
     mem_kind = KMC_MEM_HOST_MAPPED;  // the caller's buffers are page-locked: no staging copies
@@ -561,7 +640,9 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
                          uint64_t n, double stamp_start, double stamp_end, const kmc_frame_params* params, double* ox,
                          double* oy, double* oz, double* ow, int mem_kind, kmc_stats* st, bool defer) {
   if (!c || !params) return KMC_ERR_INVALID_ARG;
-  if (c->f64_pending) return KMC_ERR_INVALID_ARG;  // a _begin without its _end
+  // a staged verdict waits for its _end, or a plain call arrives while _begin calls are queued
+  if (c->f64_pending == 2 || (c->f64_pending == 1 && !defer)) return KMC_ERR_INVALID_ARG;
+  const bool queued = c->f64_pending == 1;  // behind earlier _begin calls: the counter, the flag word and the stats accumulate until _end
   if (n && (!x || !y || !z || !stamps || !ox || !oy || !oz)) return KMC_ERR_INVALID_ARG;
   if (mem_kind != KMC_MEM_HOST && mem_kind != KMC_MEM_DEVICE && mem_kind != KMC_MEM_HOST_MAPPED) return KMC_ERR_INVALID_ARG;
   if (!(stamp_start < stamp_end)) return KMC_ERR_DEGENERATE;
@@ -602,6 +683,7 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
   // (Recognising a homogeneous column of ones on the host and skipping its two transfers was measured and dropped: scanning
   // and refilling it costs what moving it over PCIe costs -- 12 + 9 us against 37 us saved at 123 k points, and it serialises
   // with the pageable copies; tools/f64_route_probe.hip.)
+  if (queued && mem_kind == KMC_MEM_HOST) return KMC_ERR_INVALID_ARG;  // staged buffers complete inside the call: not behind queued work
   if (mem_kind == KMC_MEM_HOST && n >= kF64PipelineMinPoints) {
     const int rc_pipe = deskew_f64cols_host_pipelined(c, x, y, z, w, stamps, n, f, ox, oy, oz, ow, st);
     if (rc_pipe != KMC_ERR_ALLOC) return rc_pipe;  // KMC_ERR_ALLOC: the helper thread could not be started -> the plain route below
@@ -628,11 +710,13 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
     dox = cols[5]; doy = cols[6]; doz = cols[7]; dow = ow ? cols[8] : nullptr;
   }
   CallTimer tm(c);
-  if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  if (c->counter_dirty) KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
-  c->counter_dirty = true;
-  *c->h_flag = 0;  // the previous call has synchronized: nothing on the device still writes it
-  if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  if (!queued) {
+    if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    if (c->counter_dirty) KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
+    c->counter_dirty = true;
+    *c->h_flag = 0;  // the previous call has synchronized: nothing on the device still writes it
+    if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  }
   if (mem_kind == KMC_MEM_HOST_MAPPED) {
     // over the link: a few hundred persistent waves, each with its next tile's loads in flight while it stores the current one
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 127) / 128, (uint64_t)c->mapped_waves));
@@ -656,10 +740,10 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
       if (down_w) KMC_HIP_TRY(c, hipMemcpyAsync(ow, dow, col, hipMemcpyDeviceToHost, c->stream));
     }
   }
-  c->f64_stats = kmc_stats{};
-  c->f64_stats.n_points = n;
+  if (!queued) c->f64_stats = kmc_stats{};
+  c->f64_stats.n_points += n;
   c->f64_stats.variant = 5;
-  c->f64_stats.n_launches = 1;
+  c->f64_stats.n_launches += 1;
   c->f64_pending = 1;  // issued, not waited for
   if (defer && mem_kind != KMC_MEM_HOST) return KMC_OK;
   return f64cols_finish(c, st);
@@ -675,12 +759,9 @@ static int f64cols_finish(kmc_ctx* c, kmc_stats* st) {
   c->f64_pending = 0;
   // The out-of-range verdict is part of the call's result: wait.  A short busy wait first -- the in-place kernel of a KITTI frame takes
   // ~100 us and an interrupt-driven wake-up adds several microseconds to a call whose whole budget is ~130.
-  hipError_t q = hipErrorNotReady;
-  for (int spin = 0; spin < 20000 && (q = hipStreamQuery(c->stream)) == hipErrorNotReady; ++spin) {
-  }
-  if (q != hipSuccess) {
-    (void)hipGetLastError();
-    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  {
+    const int rc_wait = wait_results_in_host_memory(c);
+    if (rc_wait != KMC_OK) return rc_wait;
   }
   unsigned long long bad = 0;
   if (*(volatile uint32_t*)c->h_flag != 0) {  // cold: some stamp was out of range -> fetch the exact count
@@ -705,14 +786,21 @@ int kmc_hip_deskew_f64cols(kmc_ctx* c, const double* x, const double* y, const d
 int kmc_hip_deskew_f64cols_begin(kmc_ctx* c, const double* x, const double* y, const double* z, const double* w, const double* stamps,
                                  uint64_t n, double stamp_start, double stamp_end, const kmc_frame_params* params, double* ox,
                                  double* oy, double* oz, double* ow, int mem_kind) {
-  kmc_stats st;
+  if (!c) return KMC_ERR_INVALID_ARG;
+  const int was_pending = c->f64_pending;
+  kmc_stats st = {};
   const int rc = f64cols_issue(c, x, y, z, w, stamps, n, stamp_start, stamp_end, params, ox, oy, oz, ow, mem_kind, &st, true);
-  if (!c || c->f64_pending == 1) return rc;  // issued (KMC_OK), or rejected before anything was issued
-  // completed inside this call (n == 0, staged host buffers, an argument error): keep the verdict for _end
+  if (c->f64_pending == 1 && rc == KMC_OK) return rc;  // issued (behind the earlier _begin calls, if any); n == 0 behind queued work
+  if (was_pending != 0) return rc;  // rejected, or failed, with earlier work still waiting for its _end: that state is not touched
+  if (rc != KMC_OK && rc != KMC_ERR_TIME_OUT_OF_RANGE) {  // an argument / runtime error: nothing to _end
+    c->f64_pending = 0;
+    return rc;
+  }
+  // completed inside this call (n == 0, staged host buffers): keep the verdict for _end
   c->f64_stats = st;
   c->f64_result = rc;
   c->f64_pending = 2;
-  return (rc == KMC_ERR_TIME_OUT_OF_RANGE) ? KMC_OK : rc == KMC_OK ? KMC_OK : (c->f64_pending = 0, rc);
+  return KMC_OK;
 }
 
 int kmc_hip_deskew_f64cols_end(kmc_ctx* c, kmc_stats* st) {

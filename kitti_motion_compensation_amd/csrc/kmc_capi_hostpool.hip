@@ -13,6 +13,7 @@
 //   - thread-safe; blocks are never returned to the system at process exit (the HIP runtime may already be gone by then).
 #include "kmc_internal.hip.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -28,6 +29,13 @@ struct Pool {
   size_t cached_bytes = 0, max_cached = (size_t)2048 << 20;
   int state = 0;  // 0 = untested, 1 = usable, -1 = no device / disabled
 };
+
+// Set by an atexit handler registered the first time the pool is found usable -- i.e. AFTER the HIP runtime registered its own
+// handlers, so it runs BEFORE them.  From then on nothing is unpinned any more: destructors of static / global containers run
+// during exit too, and hipHostFree on a runtime that is shutting down is exactly what the leaked pool object is there to avoid
+// (ADVICE r03).  A block freed during teardown is simply left to the operating system.
+std::atomic<bool> g_exiting{false};
+void mark_exiting() { g_exiting.store(true, std::memory_order_relaxed); }
 
 Pool& pool() {
   static Pool* p = new Pool();  // intentionally leaked: see the header comment
@@ -53,6 +61,7 @@ bool usable(Pool& p) {  // p.m held
       p.state = -1;
     } else {
       p.state = 1;
+      std::atexit(mark_exiting);
       if (const char* mb = std::getenv("KMC_HOST_POOL_MAX_MB")) p.max_cached = (size_t)std::max(0, std::atoi(mb)) << 20;
     }
   }
@@ -141,8 +150,10 @@ int kmc_host_pool_free(void* ptr) {
   it->second.in_use = false;
   const int cls = it->second.cls;
   if (p.cached_bytes + it->second.bytes > p.max_cached) {
-    (void)hipHostFree(ptr);
-    (void)hipGetLastError();
+    if (!g_exiting.load(std::memory_order_relaxed)) {  // never unpin while the process exits: the block is left to the OS
+      (void)hipHostFree(ptr);
+      (void)hipGetLastError();
+    }
     p.blocks.erase(it);
     return 1;
   }
@@ -158,6 +169,7 @@ int kmc_host_pool_trim(void) {
   Pool& p = pool();
   std::lock_guard<std::mutex> lock(p.m);
   int released = 0;
+  if (g_exiting.load(std::memory_order_relaxed)) return 0;
   for (auto& fl : p.free_lists) {
     for (void* b : fl) {
       (void)hipHostFree(b);

@@ -107,7 +107,8 @@ struct kmc_ctx {
   // context's OWN stream: a caller's stream may hold producers the library does not see.
   struct AoRange { uintptr_t lo, hi; };
   static constexpr int kAoWindow = 32;   // frames between two ordered launches at most
-  bool ao_enabled = true;                // KMC_ANY_ORDER=0 turns it off
+  bool ao_enabled = false;               // set by kmc_hip_create from the run-time probe's verdict (kmc_capi_core.hip); KMC_ANY_ORDER=0 turns it off
+  int ao_verdict = 0;                    // kmc_device_info.any_order_dispatch
   bool ao_valid = false;                 // the window describes EVERYTHING in flight on `stream` after the last ordered launch (it included)
   int ao_count = 0;
   uint64_t ao_launches = 0;              // frames that went out without the barrier bit so far (kmc_hip_any_order_launches)

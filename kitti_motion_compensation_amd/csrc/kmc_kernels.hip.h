@@ -438,6 +438,85 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
 }
 
 // ------------------------------------------------------------------------------------------------
+// frame-list kernel: many SEPARATE frames (each in its own buffers) in one launch -- kmc_hip_deskew_frames_f32
+// ------------------------------------------------------------------------------------------------
+// The reference's caller hands over one frame at a time (handlers.cpp:55-64), each in its own allocation.  One launch per frame
+// leaves the chip draining and refilling between two frames (a 1 M-point frame: 4.7 us of kernel, 6.3 us call to call; a KITTI
+// frame: 0.6 us of kernel, ~5 us call to call).  A caller that holds several ready frames hands the LIST over, and the list runs as
+// one 2-D grid: blockIdx.y = the frame, blockIdx.x = the 64-point tile inside it, grid.x = the tile count of the largest frame.  The
+// frame of a workgroup is a register, not a search: ONE scalar load of the frame's 96-byte record (constants, pointers, size) -- wave
+// uniform, shared by all the frame's tiles, a scalar-cache hit for all but the first of them -- stands between the wave's start and
+// its point load.  Workgroups beyond a shorter frame's last tile retire after that load (KITTI drives: ~7 % of the grid, a few
+// dozen cycles each).  The hardware dispatcher walks x first, so the tiles of a frame stream in order like a single-frame launch;
+// every frame's tiles are cut on the 1 KiB lines of ITS output (`head`, see deskew_frame_f32).  Same per-point arithmetic, same
+// near-origin guard: bit-identical to kmc_hip_deskew_f32 on the same frame.
+struct alignas(16) ListRec {
+  FrameRec f;       // pre2 filled in; pad1 unused
+  const v4f* in;    // moved back by `head` points
+  v4f* out;         // moved back by `head` points: sits on a 1 KiB line
+  uint64_t n;       // points, the dead head included (0: an empty frame)
+  uint32_t head;    // dead leading points of tile 0
+  uint32_t pad;
+};
+static_assert(sizeof(ListRec) == 96, "ListRec must stay one 96-byte record");
+// INLINE: a list of at most kInlineListFrames frames carries its records (and their f64 twins for the guard) in the kernel arguments:
+// nothing to upload, the host never waits, the call only enqueues a launch.
+constexpr int kInlineListFrames = 16;
+struct ListInline {
+  ListRec recs[kInlineListFrames];
+  FrameRecD recs64[kInlineListFrames];
+};
+static_assert(sizeof(ListInline) <= 3800, "the list tables must leave room for the other arguments in the 4 KB kernel-argument segment");
+struct ListNoInline { uint32_t unused; };
+template <bool INLINE> using ListInlineArg = typename std::conditional<INLINE, ListInline, ListNoInline>::type;
+
+template <int TIER, int NT, bool INLINE = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_list_f32(const ListRec* __restrict__ recs_g, const FrameRecD* __restrict__ recs64,
+                                                                                            ListInlineArg<INLINE> inl) {
+  static_assert((NT & kStoreSc1) != 0 && (NT & kBufLoad) == 0, "the list kernel stores through the tile descriptor and loads through plain nt loads");
+  using rec_cp = const ListRec __attribute__((address_space(4)))*;
+  rec_cp recs;
+  if constexpr (INLINE) {
+    struct ArgLayout { const ListRec* recs_g; const FrameRecD* recs64; ListInline inl; };
+    const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    recs = (rec_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(ListInline, recs));
+    recs64 = (const FrameRecD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(ListInline, recs64));
+  } else {
+    recs = (rec_cp)(uintptr_t)recs_g;  // written by the host before the launch: constant for the kernel, uniform reads are scalar loads
+  }
+  const uint32_t fi = blockIdx.y;
+  ListRec r;
+  {
+    const v4u __attribute__((address_space(4)))* w = (const v4u __attribute__((address_space(4)))*)(recs + fi);
+    const v4u a[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+    __builtin_memcpy(&r, a, sizeof(r));
+  }
+  const uint32_t tid = threadIdx.x;
+  const uint64_t base = (uint64_t)blockIdx.x * 64;
+  if (base >= r.n) return;  // beyond this frame's last tile
+  const FrameRec& f = r.f;
+  const cdouble_p d_rec = as_constant(recs64 + opaque_uniform(fi));
+  const uint64_t i = base + tid;
+  if (__builtin_expect(r.head != 0 && blockIdx.x == 0, 0)) {  // the tile that holds the dead head: plain, bounds-checked accesses
+    if (i >= r.head && i < r.n) {
+      const v4f p = load_point<NT>(r.in + i);
+      const v4f o = deskew_point<TIER, false>(p, f);
+      const bool redo = needs_redo(p, o, f);
+      if (!redo) store_point<NT>(r.out + i, o);
+      redo_lanes(redo, p, d_rec, [&](v4f v) { store_point<NT>(r.out + i, v); });
+    }
+    return;
+  }
+  // every other tile, ragged or not: the load is clamped to the last point, the store goes through a descriptor that ends with the frame
+  const v4f p = load_point<NT>(r.in + (i < r.n ? i : r.n - 1));
+  const __amdgpu_buffer_rsrc_t rout = tile_rsrc(r.out + base, (r.n - base) * sizeof(v4f));
+  const v4f o = deskew_point<TIER, false>(p, f);
+  const bool redo = needs_redo(p, o, f);
+  if (!redo) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), o);
+  redo_lanes(redo, p, d_rec, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });  // near-origin guard, cold
+}
+
+// ------------------------------------------------------------------------------------------------
 // f64 Eigen-layout kernel (compatibility path of MotionCompensateFrame(Frame const&, Time))
 // ------------------------------------------------------------------------------------------------
 // One wave per workgroup, TWO consecutive points per lane: every column access is a 16-byte load / store per lane, i.e. 1 KiB

@@ -153,7 +153,7 @@ def test_host_pipeline_many_chunks_matches_device_path(torch_mod, ctx, kitti):
     assert st_pinned.n_launches == 1 and not capi.host_pool_owns(pinned_in.numpy())
     assert np.array_equal(pinned_out.numpy().view(np.uint32), dev.view(np.uint32))
     sel = np.arange(0, n, 1013)
-    _check(out[sel], xyzi[sel], _oracle(xyzi[sel], P1, P2, mode=orc.HOISTED))
+    _check(out[sel], xyzi[sel], _oracle(xyzi[sel], P1, P2))  # FAITHFUL: the reference's per-point Log / Exp sequence
 
 
 @pytest.mark.parametrize("theta,tier", [(0.2499, 0), (0.2501, 1), (0.9999, 1), (1.0001, 2), (2.0, 2), (3.0, 2), (3.1415, 2)])
@@ -168,7 +168,7 @@ def test_tier_boundaries_keep_the_bar(torch_mod, ctx, kitti, theta, tier):
     params = _params(P1, P2, treq=T0)
     got, st = _run_device(torch_mod, ctx, xyzi, params)
     assert st.variant == tier
-    err = _check(got, xyzi, _oracle(xyzi, P1, P2, treq=T0, mode=orc.HOISTED))
+    err = _check(got, xyzi, _oracle(xyzi, P1, P2, treq=T0))  # FAITHFUL oracle (trajectory_interpolation.cpp:31-45 per point)
     assert err < 2e-6, err
 
 
@@ -353,7 +353,7 @@ def _batch_case(kitti, sizes, steps, seed=5):
         treq = T0 + xr * (T1 - T0)
         frames.append(pts)
         params.append(_params(A, B, treq=treq))
-        refs.append(_oracle(pts, A, B, treq=treq, mode=orc.HOISTED)["xyz_f64"] if n else np.zeros((0, 3)))
+        refs.append(_oracle(pts, A, B, treq=treq)["xyz_f64"] if n else np.zeros((0, 3)))  # FAITHFUL
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
     return np.concatenate(frames) if sum(sizes) else np.zeros((0, 4), np.float32), offsets, params, np.concatenate(refs)
 
@@ -416,7 +416,7 @@ def test_batch_soak_many_random_frames(torch_mod, ctx, kitti):
         params.append(_params(A, B, treq=treq))
         s, e = int(offsets[f]), int(offsets[f + 1])
         if e > s:
-            ref[s:e] = _oracle(pts[s:e], A, B, treq=treq, mode=orc.HOISTED)["xyz_f64"]
+            ref[s:e] = _oracle(pts[s:e], A, B, treq=treq)["xyz_f64"]  # FAITHFUL
     d_in = torch.from_numpy(pts).cuda()
     d_out = torch.empty_like(d_in)
     d_idx = torch.full((n,), -1, dtype=torch.int32, device="cuda")
@@ -689,16 +689,15 @@ def test_full_size_properties_10M(torch_mod, ctx):
     assert s.min().item() >= -x_req - 1e-5 and s.max().item() <= 1 - x_req + 1e-5
     frac = (np.pi - torch.atan2(d_in[:, 1].double(), d_in[:, 0].double())) / (2 * np.pi)
     assert (s - (frac - x_req)).abs().max().item() < 2e-5
-    # (4) a sampled slice agrees with the oracle
+    # (4) the whole frame agrees with the oracle
     P1 = orc.oxts_to_pose(orc.oxts(T0, 49.011212804408, 8.4228850417969, 112.8, 0.022, 1e-5, -1.22))
     A, B = _poses(P1, TRAJECTORIES["hard_turn"])
     params = _params(A, B)
     ctx.deskew_f32(d_in, d_out, params)
     torch.cuda.synchronize()
-    sel = torch.arange(0, n, 97, device="cuda")
-    xyzi = d_in[sel].cpu().numpy()
-    got = d_out[sel].cpu().numpy()
-    _check(got, xyzi, _oracle(xyzi, A, B, mode=orc.HOISTED))
+    xyzi = d_in.cpu().numpy()
+    got = d_out.cpu().numpy()
+    _check(got, xyzi, _oracle(xyzi, A, B))  # all 10 M points against the FAITHFUL oracle (the reference's per-point Log / Exp sequence)
     # (5) moving the requested time moves the WHOLE compensated cloud by one rigid transform: with f = Log(T_start^-1 T_end),
     #     p'(x_req) = Exp((x_i - x_req) f) p, and exponentials of the same twist commute, so p'(b) = Exp((a - b) f) p'(a) for every
     #     point -- all 10 M of them, against one 3x4 matrix from the oracle's lie::Exp (RelativePoseBetweenTimes,
@@ -1124,11 +1123,11 @@ def test_frame_queues_same_bits_and_ordering(torch_mod, ctx):
             assert int(total) == int(expect), queues
             for f in range(nf):
                 assert torch.equal(outs[f].view(torch.int32), want[f].view(torch.int32)), (queues, f)
-            # the one-call form: joined on return, whatever the context's setting
+            # the one-call form: ONE launch of the frame-list kernel on the context's stream, whatever the context's queue setting
             outs2 = [torch.zeros_like(ins[f]) for f in range(nf)]
             pack = ctx.prepare_frames(list(zip(ins, outs2)), params)
             st = ctx.deskew_frames_f32(pack)
-            assert st.n_points == n * nf and st.n_launches == nf
+            assert st.n_points == n * nf and st.n_launches == 1
             got = torch.stack(outs2)  # consumer on the context's stream, no explicit sync before it
             assert torch.equal(got.view(torch.int32), torch.stack(want).view(torch.int32)), queues
         # other entry points join by themselves: a batched call right after queued frames sees their results
@@ -1203,6 +1202,10 @@ def test_any_order_frames_same_bits_and_hazards_kept(torch_mod, monkeypatch):
     monkeypatch.delenv("KMC_ANY_ORDER")
     fast = capi.Context(0)  # both on their OWN streams: inputs are synchronised by hand
     try:
+        assert plain.device_info()["any_order_dispatch"] == 0
+        # the feature is on only where kmc_hip_create's probe SAW the device honour it; on MI355X / ROCm 7.2 it does (a box where it
+        # does not fails here, loudly, instead of passing on ordinary launches)
+        assert fast.device_info()["any_order_dispatch"] == 1, fast.device_info()
         ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for _ in range(nf)]
         for f in range(nf):
             plain.synth_points(ins[f], n, 4100 + f)
@@ -1280,8 +1283,8 @@ def test_any_order_frames_same_bits_and_hazards_kept(torch_mod, monkeypatch):
         fast.synchronize()
         for f in range(8):
             assert torch.equal(again[f].view(torch.int32), want[f].view(torch.int32)), f
-        # (5) a caller's stream: frames of ONE kmc_hip_deskew_frames_f32 call with one queue; separate calls only after the caller has
-        # said that nothing is produced in between
+        # (5) a caller's stream: a list handed to kmc_hip_deskew_frames_f32 is ONE ordinary launch; separate calls go out without the
+        # barrier bit only after the caller has said that nothing is produced in between
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             fast.set_stream(side.cuda_stream)
@@ -1290,7 +1293,7 @@ def test_any_order_frames_same_bits_and_hazards_kept(torch_mod, monkeypatch):
             pack = fast.prepare_frames(list(zip(ins, outs2)), params)
             before = fast.any_order_launches()
             st = fast.deskew_frames_f32(pack)
-            assert st.n_launches == nf and fast.any_order_launches() == before + nf - 2
+            assert st.n_launches == 1 and fast.any_order_launches() == before
             got = torch.stack(outs2)  # consumer on the same stream, no sync in between
             assert torch.equal(got.view(torch.int32), torch.stack(want).view(torch.int32))
             outs3 = [torch.zeros_like(x) for x in ins[:8]]
@@ -1310,3 +1313,207 @@ def test_any_order_frames_same_bits_and_hazards_kept(torch_mod, monkeypatch):
     finally:
         plain.close()
         fast.close()
+
+
+def test_any_order_dispatch_is_gated_by_the_runtime_probe(torch_mod, monkeypatch):
+    """hipExtAnyOrderLaunch is documented as unsupported on gfx9, so kmc_hip_create probes the device (an ordinary
+    kernel, a copy and an event behind barrier-free packets must wait for all of them; a barrier-free packet must really start next to
+    the kernel before it) and only a passed probe switches the feature on.  The verdict is exported (kmc_device_info.any_order_dispatch)
+    and GATES the dispatch: with a failed probe (test hook KMC_ANY_ORDER_PROBE=fail) or KMC_ANY_ORDER=0 every launch is ordinary --
+    same bits either way."""
+    torch = torch_mod
+    n, nf = 200_003, 12
+    params = [capi.FrameParams.make([1.3, 0.05 * (f % 3), -0.02, 0.002, -0.004, 0.03 + 0.001 * f], (f % 5) / 4.0) for f in range(nf)]
+    ctxs = {}
+    try:
+        ctxs["probed"] = capi.Context(0)
+        monkeypatch.setenv("KMC_ANY_ORDER_PROBE", "fail")
+        ctxs["probe_failed"] = capi.Context(0)
+        monkeypatch.delenv("KMC_ANY_ORDER_PROBE")
+        monkeypatch.setenv("KMC_ANY_ORDER", "0")
+        ctxs["switched_off"] = capi.Context(0)
+        monkeypatch.delenv("KMC_ANY_ORDER")
+        verdicts = {k: c.device_info()["any_order_dispatch"] for k, c in ctxs.items()}
+        assert verdicts["probe_failed"] == -1 and verdicts["switched_off"] == 0
+        assert verdicts["probed"] in (1, -1, -2, -3)
+        ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for _ in range(nf)]
+        for f in range(nf):
+            ctxs["probed"].synth_points(ins[f], n, 5200 + f)
+        ctxs["probed"].synchronize()
+        outs = {}
+        for k, c in ctxs.items():
+            outs[k] = [torch.zeros_like(x) for x in ins]
+            torch.cuda.synchronize()
+            for f in range(nf):
+                c.deskew_f32(ins[f], outs[k][f], params[f])
+            launched = c.any_order_launches()
+            c.synchronize()
+            if verdicts[k] == 1:
+                assert launched == nf - 1, (k, launched)  # one ordinary launch opens the window, the rest follow without the barrier bit
+            else:
+                assert launched == 0, (k, launched)       # the gate: no verified verdict, no barrier-free dispatch
+        for k in ("probe_failed", "switched_off"):
+            for f in range(nf):
+                assert torch.equal(outs[k][f].view(torch.int32), outs["probed"][f].view(torch.int32)), (k, f)
+    finally:
+        for c in ctxs.values():
+            c.close()
+
+
+def test_frame_list_is_one_launch_with_the_single_frame_kernels_bits(torch_mod, ctx, kitti):
+    """kmc_hip_deskew_frames_f32: separate frames, each in its own buffer, in ONE launch of the frame-list kernel (2-D grid: frame x
+    tile).  Ragged and empty frames, outputs at arbitrary 16-byte offsets (every frame's tiles are cut on ITS output's 1 KiB lines),
+    lists short enough for the kernel-argument tables (<= 16) and long ones (device tables), mixed coefficient tiers: bit for bit what
+    kmc_hip_deskew_f32 writes for each frame alone, and within the bar of the FAITHFUL oracle.  A list whose frames depend on each
+    other is recognised and issued frame by frame, in order."""
+    torch = torch_mod
+    xyzi, P1 = kitti
+    rng = np.random.default_rng(404)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for sizes in ([0, 1, 63, 64, 65, 1023, 1025, 5000, 0, 123_397, 777], list(rng.integers(0, 30_000, size=45)) + [0, 64, 200_001]):
+        nf = len(sizes)
+        big_in = torch.zeros((int(sum(sizes)) + 80 * nf + 64, 4), dtype=torch.float32, device="cuda")
+        big_out = torch.zeros_like(big_in)
+        ins, outs, wants, params, poses = [], [], [], [], []
+        o = 0
+        for f, n in enumerate(sizes):
+            shift_in, shift_out = int(rng.integers(0, 64)), int(rng.integers(0, 64))  # 16-byte granules: any offset within a 1 KiB line
+            pts = np.ascontiguousarray(xyzi[rng.integers(0, xyzi.shape[0], size=int(n))])
+            a = big_in[o + shift_in:o + shift_in + n]
+            b = big_out[o + shift_out:o + shift_out + n]
+            a.copy_(torch.from_numpy(pts))
+            step = np.concatenate([rng.normal(0, 1.5, 3), rng.normal(0, 0.05 if f % 7 else 0.6, 3)])  # every seventh frame turns hard: a wider tier
+            A, B = _poses(P1, step)
+            treq = T0 + rng.uniform(0, 1) * (T1 - T0)
+            ins.append(a); outs.append(b); poses.append((pts, A, B, treq))
+            params.append(_params(A, B, treq=treq))
+            o += int(n) + 80
+        torch.cuda.synchronize()
+        tier = 0
+        for f in range(nf):  # reference bits: one kmc_hip_deskew_f32 call per frame, at the LIST's tier (a launch runs its widest frame's)
+            tier = max(tier, ctx.deskew_f32(ins[f], torch.empty_like(ins[f]), params[f]).variant)
+        ctx.force_tier(tier)
+        try:
+            for f in range(nf):
+                w = torch.empty_like(ins[f])
+                ctx.deskew_f32(ins[f], w, params[f])
+                wants.append(w)
+        finally:
+            ctx.force_tier(-1)
+        pack = ctx.prepare_frames(list(zip(ins, outs)), params)
+        st = ctx.deskew_frames_f32(pack)
+        torch.cuda.synchronize()
+        assert st.n_launches == 1 and st.n_points == sum(sizes) and st.variant == tier
+        for f in range(nf):
+            assert torch.equal(outs[f].view(torch.int32), wants[f].view(torch.int32)), (nf, f, sizes[f])
+            pts, A, B, treq = poses[f]
+            if sizes[f]:
+                _check(outs[f].cpu().numpy(), pts, _oracle(pts, A, B, treq=treq))
+        # nothing outside the frames' own ranges was written (the dead heads and the clipped tails stay untouched)
+        mask = torch.ones(big_out.shape[0], dtype=torch.bool, device="cuda")
+        for b in outs:
+            if b.shape[0]:
+                start = (b.data_ptr() - big_out.data_ptr()) // 16
+                mask[start:start + b.shape[0]] = False
+        assert not big_out[mask].any()
+    # a chain inside one list: frame k reads what frame k-1 wrote -> recognised, issued in order as separate ordinary launches
+    n = 70_001
+    bufs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(6)]
+    ctx.synth_points(bufs[0], n, 31337)
+    prm = [capi.FrameParams.make([1.3, 0.05, -0.02, 0.002, -0.004, 0.03 + 0.001 * f], 0.4) for f in range(5)]
+    ref = [bufs[0]]
+    for f in range(5):
+        w = torch.empty_like(bufs[0])
+        ctx.deskew_f32(ref[-1], w, prm[f])
+        ref.append(w)
+    st = ctx.deskew_frames_f32(ctx.prepare_frames([(bufs[f], bufs[f + 1]) for f in range(5)], prm))
+    torch.cuda.synchronize()
+    assert st.n_launches == 5
+    assert torch.equal(bufs[5].view(torch.int32), ref[5].view(torch.int32))
+    # in place (in == out of the SAME frame) is not a hazard
+    ip = [ref[f].clone() for f in range(3)]
+    st = ctx.deskew_frames_f32(ctx.prepare_frames([(x, x) for x in ip], prm[:3]))
+    torch.cuda.synchronize()
+    assert st.n_launches == 1
+    for f in range(3):
+        assert torch.equal(ip[f].view(torch.int32), ref[f + 1].view(torch.int32)), f
+
+
+def test_f64cols_begin_calls_queue_up_behind_each_other(torch_mod, ctx, kitti):
+    """kmc_hip_deskew_f64cols_begin on device-resident columns may be called K times before ONE _end: the launches queue up on the
+    context's stream without a host wait between them (what bench.py's f64cols leg times), _end returns the combined verdict and stats
+    (a second _begin used to clobber the pending verdict).  Same bits as K separate calls; an out-of-range stamp in ANY of
+    the queued frames surfaces at _end; a staged host call cannot join the queue and leaves it intact."""
+    torch = torch_mod
+    xyzi, P1 = kitti
+    n, K = 50_000, 5
+    rng = np.random.default_rng(64)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    frames = []
+    for k in range(K):
+        A, B = _poses(P1, TRAJECTORIES["hard_turn"])
+        params = _params(A, B)
+        cloud = xyzi[rng.integers(0, xyzi.shape[0], size=n), :3].astype(np.float64)
+        stamps = T0 + rng.uniform(0, 1, size=n) * (T1 - T0)
+        cols = [torch.from_numpy(np.ascontiguousarray(cloud[:, j])).cuda() for j in range(3)] + [torch.ones(n, dtype=torch.float64, device="cuda")]
+        frames.append((cols, torch.from_numpy(stamps).cuda(), params))
+    want = []
+    for cols, st_d, params in frames:
+        outs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(4)]
+        ctx.deskew_f64cols(*cols, st_d, T0, T1, params, *outs)
+        want.append(outs)
+    got = [[torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(4)] for _ in range(K)]
+    for (cols, st_d, params), outs in zip(frames, got):
+        ctx.deskew_f64cols_begin(*cols, st_d, T0, T1, params, *outs)
+    # a staged host call cannot queue behind them, and does not disturb them
+    h = [np.zeros(8) for _ in range(9)]
+    with pytest.raises(capi.KmcError):
+        ctx.deskew_f64cols_begin(h[0], h[1], h[2], h[3], h[4] + T0, T0, T1, frames[0][2], h[5], h[6], h[7], h[8])
+    rc, st = ctx.deskew_f64cols_end()
+    assert rc == capi.OK and st.n_points == K * n and st.n_launches == K and st.n_out_of_range == 0
+    for k in range(K):
+        for j in range(4):
+            assert torch.equal(got[k][j].view(torch.int64), want[k][j].view(torch.int64)), (k, j)
+    # one bad stamp in the THIRD of five queued frames
+    bad = frames[2][1].clone()
+    bad[1234] = T1 + 1.0
+    for k, ((cols, st_d, params), outs) in enumerate(zip(frames, got)):
+        ctx.deskew_f64cols_begin(*cols, bad if k == 2 else st_d, T0, T1, params, *outs)
+    rc, st = ctx.deskew_f64cols_end(raise_on_range=False)
+    assert rc == capi.ERR_TIME_OUT_OF_RANGE and st.n_out_of_range == 1 and st.n_points == K * n
+    # and the context is usable again
+    rc, st = ctx.deskew_f64cols(*frames[0][0], frames[0][1], T0, T1, frames[0][2], *got[0])
+    assert rc == capi.OK and st.n_out_of_range == 0
+    with pytest.raises(capi.KmcError):
+        ctx.deskew_f64cols_end()  # nothing pending
+
+
+def test_batch_on_page_locked_buffers_that_are_only_4_byte_aligned(torch_mod, ctx, kitti):
+    """kmc_hip_deskew_batch_f32 recognises page-locked KMC_MEM_HOST buffers and works on them in place -- but the
+    kernels' 16-byte accesses need 16-byte-aligned pointers.  A pinned buffer at a 4-byte offset is a valid KMC_MEM_HOST argument (the
+    staged route only copies it) and must stay one."""
+    torch = torch_mod
+    xyzi, P1 = kitti
+    sizes = [3000, 0, 4500, 2077]
+    n = sum(sizes)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    rng = np.random.default_rng(9)
+    pts = np.ascontiguousarray(xyzi[rng.integers(0, xyzi.shape[0], size=n)])
+    params = []
+    for f in range(len(sizes)):
+        A, B = _poses(P1, np.concatenate([rng.normal(0, 1.5, 3), rng.normal(0, 0.05, 3)]))
+        params.append(_params(A, B, treq=T0 + 0.3 * (T1 - T0)))
+    pin_in = torch.zeros(4 * n + 8, dtype=torch.float32).pin_memory()
+    pin_out = torch.zeros(4 * n + 8, dtype=torch.float32).pin_memory()
+    aligned = np.empty_like(pts)
+    a16_in, a16_out = pin_in.numpy()[:4 * n].reshape(n, 4), pin_out.numpy()[:4 * n].reshape(n, 4)
+    a16_in[:] = pts
+    st = ctx.deskew_batch_f32(a16_in, a16_out, offsets, params, None)  # 16-byte aligned pinned buffers: in place, one launch
+    aligned[:] = a16_out
+    off_in, off_out = pin_in.numpy()[1:4 * n + 1].reshape(n, 4), pin_out.numpy()[1:4 * n + 1].reshape(n, 4)  # 4 bytes further
+    assert off_in.ctypes.data % 16 == 4 and off_out.ctypes.data % 16 == 4
+    off_in[:] = pts
+    off_out[:] = 0
+    st = ctx.deskew_batch_f32(off_in, off_out, offsets, params, None)
+    assert st.n_points == n
+    assert np.array_equal(off_out.view(np.uint32), aligned.view(np.uint32))

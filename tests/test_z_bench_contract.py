@@ -46,15 +46,30 @@ def test_bench_prints_one_contract_line():
     su = d["sustained"]  # the headline launch back to back for a wall-clock budget, in ~0.1 s windows
     assert su["windows"] >= 5 and su["Mpts_s_min"] <= su["Mpts_s_mean"] <= su["Mpts_s_max"] and su["Mpts_s_mean"] > 50_000
     # the secondary configurations as legs of the same line (round 3): time, GB/s, fraction of peak, kernel, oracle spot check
-    lit = d["configs1_literal"]
-    for k in ("in_order", "in_order_drained", "four_frame_queues"):
+    lit = d["configs1_literal"]  # round 4: driven from C++ (tools/time_frame_stream.hip), separate allocations per frame
+    for k in ("in_order", "in_order_drained", "four_frame_queues", "list_one_launch", "batch_packed"):
         assert lit[k]["us_per_frame"] > 0 and 0.2 < lit[k]["frac"] < 1.0, (k, lit[k])
+    assert lit["any_order_dispatch_verdict"] == 1 and lit["list_equals_per_call_bitwise"] is True
+    assert lit["list_one_launch"]["frac"] > 0.70, lit["list_one_launch"]  # separate frames handed over as a list run as ONE launch: north_star's 70 % target
     # overlapping frames beats draining the chip: over four queues, and on ONE stream by dropping the barrier bit between independent frames
     # (the three are short timed regions of ONE run: which is faster by how much is recorded under profiles/, not gated here -- a hiccup
     # of the box in one region must not fail the suite; what IS checked is that the barrier-free route was really taken)
     assert lit["in_order"]["dispatched_without_barrier_bit"] > 0.9
     assert lit["four_frame_queues"]["us_per_frame"] < 2.0 * lit["in_order_drained"]["us_per_frame"]
     assert lit["parity"]["max_rel_err"] <= 1e-5
+    fb = d["configs2_drive"]["frame_by_frame_from_c"]  # the reference's calling pattern on KITTI-sized frames, from C++
+    assert fb["list_equals_per_call_bitwise"] is True and fb["per_call"]["us_per_frame"] > 0 and fb["list_rate_vs_batched"] > 0.5, fb
+    f64 = d["f64cols"]  # K launches between one event pair; the single-call figure beside it
+    assert "back to back" in f64["timed_as"] and f64["single_call"]["us_per_call"] > 0
+    dc = d["dropin_cpp"]  # the API north_star names, through the C++ library
+    assert dc["MotionCompensateFrame_f64"]["page_locked_containers"]["us_per_frame"] > 0 and dc["MotionCompensateFrame_f64"]["pageable_containers"]["us_per_frame"] > 0
+    assert dc["MotionCompensateKittiCloud_f32"]["page_locked_containers"]["us_per_frame"] > 0
+    assert dc["parity"]["MotionCompensateFrame_f64_max_rel_err"] <= 1e-11 and dc["parity"]["MotionCompensateKittiCloud_f32_max_rel_err"] <= 1e-5
+    assert dc["oracle_faithful_1_thread_ms_per_frame"] > 1.0
+    run = dc["MotionCompensateRun"]
+    assert run["frames_compensated"] == 214 and run["frames_per_s"] > 50 and run["parity"]["max_rel_err"] <= 1e-5
+    rk = d["ranks"]
+    assert rk["world_size"] == 1 and rk["distinct_devices"] == 1 and len(rk["devices"]) == 1
     for leg, bar in (("configs2_drive", 1e-5), ("nknot3", 1e-5), ("f64cols", 1e-11)):
         assert d[leg]["GBps"] > 3000 and abs(d[leg]["frac"] - d[leg]["GBps"] / 8000.0) < 1e-3 and "kernel" in d[leg], (leg, d[leg])
         assert d[leg]["parity"]["max_rel_err"] <= bar and d[leg]["parity"]["bar"] == bar, (leg, d[leg]["parity"])
@@ -71,6 +86,7 @@ def test_bench_rccl_path_initialises_and_reduces_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["value"] > 10_000
+    assert d["ranks"]["collective_backend"].startswith("nccl") and d["ranks"]["rccl_world_size"] == 1  # what the process group itself reports
 
 
 @pytest.mark.gpu
@@ -104,6 +120,48 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     pr = d["per_rank"]
     assert len(pr["Mpts_s"]) == 2 and pr["Mpts_s_min"] <= pr["Mpts_s_max"] and len(pr["configs3_Mpts_s"]) == 2
     assert "configs1_literal" not in d
+    # who measured: the backend, its world size, and every rank's device out of the same all_gather (both ranks share the one GPU HERE,
+    # and the record says so: distinct_devices == 1; on the driver's 8-GPU run it must equal n_gpus)
+    rk = d["ranks"]
+    assert rk["collective_backend"] == "gloo" and rk["rccl_world_size"] is None and rk["world_size"] == 2
+    assert [x["rank"] for x in rk["devices"]] == [0, 1] and rk["distinct_devices"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_reexecutes_itself_under_the_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: not a one-GPU number under a two-GPU label -- the script
+    re-executes itself as the contract's launch line (both ranks on the one GPU of this box through the test knobs)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(KMC_BENCH_BACKEND="gloo", KMC_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--frames-per-step", "32",
+                        "--configs3-frames", "8", "--configs3-frames-per-launch", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "re-executing as" in r.stderr and "torch.distributed.run" in r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2
+
+
+def test_bench_gpus_n_without_a_launcher_never_runs_as_one_process():
+    """CPU: the re-exec path builds the driver's launch line (dry), and refuses -- non-zero, with the line -- on a box with fewer GPUs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "KMC_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2"], capture_output=True, text=True,
+                       timeout=300, env=dict(env, KMC_BENCH_LAUNCH_DRY="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["relaunch"]
+    i = cmd.index("-m")
+    assert cmd[i + 1] == "torch.distributed.run" and "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        return  # a real 8-GPU box would run it; nothing more to check here
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "not measuring one GPU under an N-GPU label" in r.stderr and "n_gpus" not in r.stdout
+    # and a launcher's WORLD_SIZE that disagrees with --gpus is refused as before
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
 
 
 @pytest.mark.gpu
@@ -129,6 +187,8 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     assert c3["parity_first_last_frame_per_rank"]["max_rel_err"] <= 1e-5  # MAX over the eight ranks' own checks
     pr = d["per_rank"]
     assert len(pr["Mpts_s"]) == 8 and len(pr["configs3_Mpts_s"]) == 8 and all(v > 0 for v in pr["Mpts_s"] + pr["configs3_Mpts_s"])
+    rk = d["ranks"]  # (with RCCL, the contract: collective_backend "nccl (= RCCL on ROCm)", rccl_world_size == 8, distinct_devices == 8)
+    assert rk["world_size"] == 8 and [x["rank"] for x in rk["devices"]] == list(range(8)) and "pci" in rk["devices"][0]
     assert abs(d["value"] - 8 * 16 * 1_000_000 * 4 / (d["ms_per_step"] * 4 * 1e-3) / 1e6) / d["value"] < 0.02
     # eight ranks' buffers lived on ONE device here; the default run's 15.4 GB per rank is one rank per 288 GB device
     assert 8 * d["peak_device_GiB_per_rank"] < 250

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """hipcc -Rpass-analysis=kernel-resource-usage output (make -C kitti_motion_compensation_amd/csrc resource-usage) -> one line per kernel
 instantiation: demangled name, VGPRs, AGPRs, SGPRs, SGPR spills, scratch bytes per lane, occupancy (waves per SIMD), LDS bytes.
-  make -C kitti_motion_compensation_amd/csrc resource-usage 2>&1 | python tools/summarize_resource_usage.py > profiles/r03_resource_usage.txt"""
+  make -C kitti_motion_compensation_amd/csrc resource-usage 2>&1 | python tools/summarize_resource_usage.py > profiles/r04_resource_usage.txt"""
 import re
 import subprocess
 import sys

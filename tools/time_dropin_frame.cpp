@@ -1,11 +1,16 @@
-// time_dropin_frame.cpp -- latency of the literal drop-in call kmc::MotionCompensateFrame(Frame const&, Time) on the shipped KITTI
-// frame (f64 Eigen-layout cloud in the drop-in's own containers, result by value), and of the f32 KITTI-layout call next to it.
-// The containers come from the C-ABI's page-locked pool (round 3), so the kernel works on them in place; KMC_HOST_POOL=0 in the
-// environment restores ordinary memory and the staged three-copy route for comparison.
-//   time_dropin_frame <golden_dir> [iterations=200]
+// time_dropin_frame.cpp -- the literal drop-in on the clock: kmc::MotionCompensateFrame(Frame const&, Time) (motion_compensation.cpp:16-28,
+// the API north_star names) on the shipped KITTI frame -- f64 Eigen-layout cloud in the drop-in's own containers, result by value --
+// and hip::MotionCompensateKittiCloud (the same frame in the KITTI f32 layout) next to it, through libkitti_motion_compensation_lib.so
+// (C++, no ctypes).  The containers come from the C-ABI's page-locked pool, so the kernel works on them in place; KMC_HOST_POOL=0 in
+// the environment gives ordinary pageable containers and the staged three-copy route.
+//   time_dropin_frame <golden_dir> [iterations=200] [dump_prefix]
+// Prints ONE JSON object.  With dump_prefix the frame's inputs and the clouds the two calls returned are written next to it
+// (<prefix>.cloud_in.f64 / .stamps.f64 / .cloud_out.f64: column-major N x 4 / N doubles; <prefix>.kitti_in.f32 / .kitti_out.f32: N x 4
+// floats), for bench.py's parity check against the oracle -- this tool itself never touches oracle/.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <string>
 #include <vector>
 
@@ -15,24 +20,38 @@
 
 using namespace kmc;
 
+static void dump(std::string const& path, void const* p, std::size_t bytes) {
+  std::ofstream os{path, std::ios::binary};
+  os.write(static_cast<char const*>(p), static_cast<std::streamsize>(bytes));
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::fprintf(stderr, "usage: time_dropin_frame <golden_dir> [iterations]\n");
+    std::fprintf(stderr, "usage: time_dropin_frame <golden_dir> [iterations] [dump_prefix]\n");
     return 2;
   }
   Path const run{std::string(argv[1]) + "/kitti_2011_09_26_drive_0005"};
   int const iters = argc > 2 ? std::atoi(argv[2]) : 200;
+  std::string const prefix = argc > 3 ? argv[3] : "";
   LidarScan const scan{LoadLidarScan(run, 0)};
+  double const yaw = 0.03, tx = 1.3, ty = 0.05, tz = -0.02;  // T_end = [Rz(yaw) | t]: a gentle turn at 13 m/s
   Affine3d T_end;
-  T_end.rotate(AngleAxisd{0.03, Vector3d{0, 0, 1}});
-  T_end.translation() = Vector3d{1.3, 0.05, -0.02};
+  T_end.rotate(AngleAxisd{yaw, Vector3d{0, 0, 1}});
+  T_end.translation() = Vector3d{tx, ty, tz};
   Frame const frame{Affine3d::Identity(), T_end, scan};
   using clk = std::chrono::steady_clock;
   double checksum = 0;
   for (int i = 0; i < 10; ++i) checksum += MotionCompensateFrame(frame, scan.stamp_middle)(0, 0);
+  std::vector<double> per_call(static_cast<std::size_t>(iters));
   auto t0 = clk::now();
-  for (int i = 0; i < iters; ++i) checksum += MotionCompensateFrame(frame, scan.stamp_middle)(0, 0);
+  for (int i = 0; i < iters; ++i) {
+    auto const a = clk::now();
+    checksum += MotionCompensateFrame(frame, scan.stamp_middle)(0, 0);
+    per_call[static_cast<std::size_t>(i)] = std::chrono::duration<double, std::micro>(clk::now() - a).count();
+  }
   double const us64 = std::chrono::duration<double, std::micro>(clk::now() - t0).count() / iters;
+  double us64_min = per_call.empty() ? 0.0 : per_call[0];
+  for (double v : per_call) us64_min = std::min(us64_min, v);
 
   KittiCloudF32 const raw = KittiPclLoader::LoadRaw(run / "velodyne_points/data/0000000000.bin");  // page-locked when the pool is on
   KittiCloudF32 out(raw.size());
@@ -44,9 +63,21 @@ int main(int argc, char** argv) {
     hip::MotionCompensateKittiCloud(raw.data(), n, frame.T_start, frame.T_end, scan.stamp_start, scan.stamp_end, scan.stamp_middle, out.data());
   double const us32 = std::chrono::duration<double, std::micro>(clk::now() - t0).count() / iters;
   bool const pooled = kmc_host_pool_owns(frame.scan.cloud.data(), sizeof(double)) != 0;
-  std::printf("route: %s\n", pooled ? "containers in the page-locked pool -> ONE kernel in place over the link" : "ordinary host memory -> staged copies (KMC_HOST_POOL=0 or no pool)");
-  std::printf("%zu points: MotionCompensateFrame(Frame, Time) [f64, result by value] %.1f us/frame = %.1f M points/s;  "
-              "hip::MotionCompensateKittiCloud [f32 KITTI layout] %.1f us/frame = %.1f M points/s  (checksum %.6f)\n",
-              n, us64, n / us64, us32, n / us32, checksum + out[0]);
+  if (!prefix.empty()) {
+    Pointcloud const result = MotionCompensateFrame(frame, scan.stamp_middle);
+    auto const rows = static_cast<std::size_t>(result.rows());
+    dump(prefix + ".cloud_in.f64", frame.scan.cloud.data(), rows * 4 * sizeof(double));
+    dump(prefix + ".stamps.f64", frame.scan.timestamps.data(), rows * sizeof(double));
+    dump(prefix + ".cloud_out.f64", result.data(), rows * 4 * sizeof(double));
+    dump(prefix + ".kitti_in.f32", raw.data(), raw.size() * sizeof(float));
+    dump(prefix + ".kitti_out.f32", out.data(), out.size() * sizeof(float));
+  }
+  std::printf(
+      "{\"points\": %zu, \"iterations\": %d, \"containers\": \"%s\", \"route\": \"%s\", "
+      "\"MotionCompensateFrame_f64_us_per_frame\": %.2f, \"MotionCompensateFrame_f64_us_best_call\": %.2f, \"MotionCompensateKittiCloud_f32_us_per_frame\": %.2f, "
+      "\"stamp_start\": %.9f, \"stamp_middle\": %.9f, \"stamp_end\": %.9f, \"T_end\": {\"yaw_z\": %.17g, \"t\": [%.17g, %.17g, %.17g]}, \"checksum\": %.6f}\n",
+      n, iters, pooled ? "page-locked pool (the drop-in's default)" : "ordinary pageable memory (KMC_HOST_POOL=0 or no pool)",
+      pooled ? "one kernel in place over the link" : "staged copies", us64, us64_min, us32, scan.stamp_start, scan.stamp_middle, scan.stamp_end, yaw, tx, ty, tz,
+      checksum + out[0]);
   return 0;
 }

@@ -1,0 +1,178 @@
+// time_frame_stream.hip -- the reference's calling pattern (handlers.cpp:55-64: one frame at a time, each in its own allocation)
+// driven from C++ through the C-ABI, so that the host language does not set the pace (a ctypes call costs ~8 us, a launch ~2).
+//
+//   time_frame_stream <n_frames> <points_per_frame | kitti> [sets=1] [iters=20]
+//
+// n_frames device-resident frames per set, every frame its OWN hipMalloc allocation (in and out); `kitti` draws the sizes from
+// N(121 000, 3 000) clipped to [90 000, 140 000] like bench.py's configs2_drive leg; `sets` rotating sets of such frames (so that a
+// sweep's working set exceeds the 256 MiB Infinity Cache when the frames are small).  Timed with HIP events on the context's stream
+// (kmc_hip_timer_begin / _end, which also join the frame queues), `iters` sweeps over all sets' frames after two warm-up sweeps:
+//   per_call            one kmc_hip_deskew_f32 call per frame, in order on the context's stream (frames that share no buffer with one in
+//                       flight go out without the barrier bit when the run-time probe allowed it: kmc_device_info.any_order_dispatch)
+//   per_call_drained    the same calls on a context created with KMC_ANY_ORDER=0 (every dispatch carries the barrier bit)
+//   per_call_4_queues   the same calls with kmc_hip_set_frame_queues(ctx, 4)
+//   list_one_launch     kmc_hip_deskew_frames_f32: the set's frames handed over as ONE list -> one launch of the frame-list kernel
+//   batch_packed        kmc_hip_deskew_batch_f32 on the same frames packed into one buffer (the ceiling for this frame mix)
+// plus the host's own time per call (steady_clock around the issuing loop) and a bit-for-bit comparison of what the list kernel and
+// the per-frame kernel wrote for every frame.  Prints one JSON object.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "kmc_hip.h"
+
+#define HIP_OK(x)                                                                          \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) {                                                                \
+      std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      std::exit(2);                                                                        \
+    }                                                                                      \
+  } while (0)
+#define KMC_OK_OR_DIE(x)                                                                         \
+  do {                                                                                           \
+    int rc_ = (x);                                                                               \
+    if (rc_ != KMC_OK) {                                                                         \
+      std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, kmc_status_string(rc_)); \
+      std::exit(3);                                                                              \
+    }                                                                                            \
+  } while (0)
+
+struct Set {
+  std::vector<float*> in, out;
+  std::vector<const float*> cin;
+  float *packed_in = nullptr, *packed_out = nullptr;
+};
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: time_frame_stream <n_frames> <points_per_frame | kitti> [sets] [iters]\n");
+    return 2;
+  }
+  const uint32_t F = (uint32_t)std::atoi(argv[1]);
+  const bool kitti = std::strcmp(argv[2], "kitti") == 0;
+  const int n_sets = argc > 3 ? std::atoi(argv[3]) : 1;
+  const int iters = argc > 4 ? std::atoi(argv[4]) : 20;
+  std::vector<uint64_t> sizes(F), offsets(F + 1, 0);
+  {
+    std::mt19937 rng(0x4B4D43 + 2);
+    std::normal_distribution<double> nd(121000.0, 3000.0);
+    for (uint32_t f = 0; f < F; ++f) {
+      sizes[f] = kitti ? (uint64_t)std::min(140000.0, std::max(90000.0, nd(rng))) : std::strtoull(argv[2], nullptr, 10);
+      offsets[f + 1] = offsets[f] + sizes[f];
+    }
+  }
+  const uint64_t total = offsets[F];
+
+  kmc_ctx *ctx = nullptr, *drained = nullptr;
+  KMC_OK_OR_DIE(kmc_hip_create(&ctx, 0));
+  setenv("KMC_ANY_ORDER", "0", 1);
+  KMC_OK_OR_DIE(kmc_hip_create(&drained, 0));
+  unsetenv("KMC_ANY_ORDER");
+  kmc_device_info info;
+  KMC_OK_OR_DIE(kmc_hip_device_info(ctx, &info));
+
+  std::vector<kmc_frame_params> params(F);
+  for (uint32_t f = 0; f < F; ++f) {  // a turning, accelerating vehicle; every frame its own twist and request time
+    const double k = 1.0 + 0.001 * (f % 97);
+    const double tw[6] = {1.3 * k, 0.05, -0.02, 0.002, -0.004, 0.03 * k};
+    std::memcpy(params[f].twist, tw, sizeof(tw));
+    params[f].x_req = 0.25 + 0.5 * ((f % 11) / 10.0);
+  }
+  std::vector<Set> sets(n_sets);
+  for (int s = 0; s < n_sets; ++s) {
+    Set& S = sets[s];
+    S.in.resize(F); S.out.resize(F); S.cin.resize(F);
+    HIP_OK(hipMalloc((void**)&S.packed_in, std::max<uint64_t>(total, 1) * 16));
+    HIP_OK(hipMalloc((void**)&S.packed_out, std::max<uint64_t>(total, 1) * 16));
+    for (uint32_t f = 0; f < F; ++f) {
+      HIP_OK(hipMalloc((void**)&S.in[f], sizes[f] * 16));
+      HIP_OK(hipMalloc((void**)&S.out[f], sizes[f] * 16));
+      S.cin[f] = S.in[f];
+      KMC_OK_OR_DIE(kmc_hip_synth_points(ctx, S.in[f], sizes[f], 0x4B4D43ull + 0xF5000000ull + (uint64_t)s * F + f));
+      KMC_OK_OR_DIE(kmc_hip_synchronize(ctx));
+      HIP_OK(hipMemcpy(S.packed_in + 4 * offsets[f], S.in[f], sizes[f] * 16, hipMemcpyDeviceToDevice));
+    }
+  }
+  HIP_OK(hipDeviceSynchronize());
+
+  double host_us = 0;  // the issuing loop's own time per frame, last mode measured
+  auto timed = [&](kmc_ctx* c, auto&& sweep) {
+    for (int w = 0; w < 2; ++w)
+      for (int s = 0; s < n_sets; ++s) sweep(c, sets[s]);
+    KMC_OK_OR_DIE(kmc_hip_synchronize(c));
+    KMC_OK_OR_DIE(kmc_hip_timer_begin(c));
+    const double t0 = now_us();
+    for (int it = 0; it < iters; ++it)
+      for (int s = 0; s < n_sets; ++s) sweep(c, sets[s]);
+    host_us = (now_us() - t0) / ((double)iters * n_sets * F);
+    float ms = 0;
+    KMC_OK_OR_DIE(kmc_hip_timer_end(c, &ms));
+    return (double)ms * 1e3 / ((double)iters * n_sets * F);  // us per frame
+  };
+  auto per_call = [&](kmc_ctx* c, Set& S) {
+    for (uint32_t f = 0; f < F; ++f) KMC_OK_OR_DIE(kmc_hip_deskew_f32(c, S.in[f], S.out[f], sizes[f], &params[f], KMC_MEM_DEVICE, nullptr));
+  };
+  auto list = [&](kmc_ctx* c, Set& S) {
+    KMC_OK_OR_DIE(kmc_hip_deskew_frames_f32(c, S.cin.data(), S.out.data(), sizes.data(), params.data(), F, nullptr));
+  };
+  auto batch = [&](kmc_ctx* c, Set& S) {
+    KMC_OK_OR_DIE(kmc_hip_deskew_batch_f32(c, S.packed_in, S.packed_out, offsets.data(), F, params.data(), nullptr, KMC_MEM_DEVICE, nullptr));
+  };
+
+  const uint64_t ao0 = kmc_hip_any_order_launches(ctx);
+  const double us_call = timed(ctx, per_call);
+  const double host_call = host_us;
+  const double ao_share = (double)(kmc_hip_any_order_launches(ctx) - ao0) / ((double)(iters + 2) * n_sets * F);
+  const double us_drained = timed(drained, per_call);
+  KMC_OK_OR_DIE(kmc_hip_set_frame_queues(ctx, 4));
+  const double us_q4 = timed(ctx, per_call);
+  KMC_OK_OR_DIE(kmc_hip_set_frame_queues(ctx, 1));
+  // what the per-frame kernel wrote, for the comparison below
+  std::vector<std::vector<float>> want(F);
+  KMC_OK_OR_DIE(kmc_hip_synchronize(ctx));
+  for (uint32_t f = 0; f < F; ++f) {
+    want[f].resize(4 * sizes[f]);
+    HIP_OK(hipMemcpy(want[f].data(), sets[0].out[f], sizes[f] * 16, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemset(sets[0].out[f], 0xFF, sizes[f] * 16));
+  }
+  kmc_stats st;
+  KMC_OK_OR_DIE(kmc_hip_deskew_frames_f32(ctx, sets[0].cin.data(), sets[0].out.data(), sizes.data(), params.data(), F, &st));
+  KMC_OK_OR_DIE(kmc_hip_synchronize(ctx));
+  bool same = true;
+  {
+    std::vector<float> got;
+    for (uint32_t f = 0; f < F; ++f) {
+      got.resize(4 * sizes[f]);
+      HIP_OK(hipMemcpy(got.data(), sets[0].out[f], sizes[f] * 16, hipMemcpyDeviceToHost));
+      same = same && std::memcmp(got.data(), want[f].data(), sizes[f] * 16) == 0;
+    }
+  }
+  const double us_list = timed(ctx, list);
+  const double host_list = host_us;
+  const double us_batch = timed(ctx, batch);
+
+  const double mean_pts = (double)total / F;
+  auto gbps = [&](double us) { return 32.0 * mean_pts / us / 1e3; };
+  std::printf(
+      "{\"frames_per_set\": %u, \"sets\": %d, \"iters\": %d, \"mean_points_per_frame\": %.1f, \"points_per_set\": %llu, \"device\": \"%s\", "
+      "\"any_order_dispatch\": %d, \"list_launches\": %u, \"list_equals_per_call_bitwise\": %s, "
+      "\"per_call\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"dispatched_without_barrier_bit\": %.3f}, "
+      "\"per_call_drained\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}, "
+      "\"per_call_4_queues\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}, "
+      "\"list_one_launch\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
+      "\"batch_packed\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}}\n",
+      F, n_sets, iters, mean_pts, (unsigned long long)total, info.name, info.any_order_dispatch, st.n_launches, same ? "true" : "false", us_call,
+      gbps(us_call), host_call, ao_share, us_drained, gbps(us_drained), us_q4, gbps(us_q4), us_list, gbps(us_list), host_list, us_batch, gbps(us_batch));
+  kmc_hip_destroy(drained);
+  kmc_hip_destroy(ctx);
+  return same ? 0 : 1;
+}
