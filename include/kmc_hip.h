@@ -101,8 +101,7 @@ typedef struct kmc_device_info {
   int clock_khz;
   int any_order_dispatch; /* barrier-free dispatch of independent frames (see kmc_hip_set_frame_queues): 1 = verified on this device at
                              kmc_hip_create and in use; 0 = switched off (KMC_ANY_ORDER=0); -1 = the run-time probe saw an ordinary packet
-                             overtake a barrier-free one (off); -2 = the flag has no effect on this runtime (off); -3 = the probe could
-                             not run (off) */
+                             overtake, or not see the stores of, a barrier-free one (off); -3 = the probe could not run (off) */
 } kmc_device_info;
 
 /* ------------------------------------------------------------------------------------------------
@@ -215,8 +214,8 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  *     stream, (b) on a caller's stream after kmc_hip_set_frame_queue_order(ctx, 0), (c) between the frames of one
  *     kmc_hip_deskew_frames_f32 call; at most 32 frames go out between two ordinary launches.  CONTRACT: the flag is documented as
  *     unsupported on gfx9, so the library does not take it on trust -- kmc_hip_create runs a probe (< 1 ms, once per device and process)
- *     that must SEE, on this device and runtime, (1) an ordinary kernel, a copy and an event behind barrier-free packets wait for all of
- *     them and (2) a barrier-free packet really start next to the kernel before it; only then is the feature on
+ *     that must SEE, on this device and runtime, an ordinary kernel, a device-to-host copy and an event behind barrier-free kernels
+ *     wait for all of them and read every word they stored (from every XCD); only then is the feature on
  *     (kmc_device_info.any_order_dispatch == 1), otherwise every launch is an ordinary one.  KMC_ANY_ORDER=0 switches it off unprobed.
  *     Measured (tools/anyorder_probe.hip, bench.py's configs1_literal leg): 7.0 -> 6.3 us per 1 M-point frame; never on HIP's legacy
  *     default stream (handle NULL) and never while the stream captures a graph.

@@ -148,65 +148,73 @@ bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool 
 }
 
 // ---- barrier-free dispatch: checked at run time before it is used ------------------------------------
-// hipExtAnyOrderLaunch is documented "not supported on GFX9xx"; on MI355X / ROCm 7.2 it does clear the AQL barrier bit
-// (profiles/r03_anyorder_aql_headers.txt).  The library relies on two facts and verifies BOTH on the device it is about to use, once per
-// device and process (< 1 ms), before ao_enabled may become true:
-//   (1) ORDER: an ordinary packet behind barrier-free packets -- a kernel launch, a device-to-host copy, an event record -- waits for
-//       EVERY packet before it, barrier-free ones included.  A (ordinary, spins ~120 us, then raises flag 0), B (barrier-free, stamps the
-//       clock), B2 (barrier-free, spins ~40 us, then raises flag 1), C (ordinary, reads both flags), a D2H copy of the flags, an event:
-//       C and the copy must both have seen both flags raised.  If not, consumers of a frame could read it too early: feature OFF.
-//   (2) OVERLAP: B's time stamp lies before A's end, i.e. the packet processor really started B while A was running.  If not, the
-//       flag is a no-op on this runtime: feature OFF (nothing to gain; the ordinary launch is the documented one).
-// Verdict (kmc_device_info.any_order_dispatch): 1 = verified, on;  0 = switched off (KMC_ANY_ORDER=0);  -1 = order violated;
-// -2 = no overlap observed;  -3 = the probe could not run (a HIP error).
-__global__ void ao_probe_spin(uint32_t* flag, uint64_t ticks, unsigned long long* t_end) {
-  const uint64_t t0 = wall_clock64();  // 100 MHz constant clock
-  while (wall_clock64() - t0 < ticks) {
-  }
-  if (threadIdx.x == 0) {
-    if (t_end) *t_end = wall_clock64();
-    __hip_atomic_store(flag, 0x4B4D43u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
+// hipExtAnyOrderLaunch is documented "not supported on GFX9xx"; on MI355X / ROCm 7.2 it does clear the AQL barrier bit and nothing else
+// (profiles/r03_anyorder_aql_headers.txt).  What that buys is NOT two kernels of one queue running side by side (two single-workgroup
+// 10 ms kernels still take 20 ms, profiles/r03_anyorder_probe.json): the packet processor stops waiting for the previous packet's
+// completion and cache release before it starts the next one, so a barrier-free packet may read memory its predecessor has not
+// released yet -- which is why only frames that share no buffer with a frame in flight go out this way.  The library's CONSUMERS rely on
+// one fact, and it is verified on the device the context is about to use, once per device and process (~0.3 ms), before ao_enabled
+// may become true:
+//   an ORDINARY packet behind barrier-free packets -- a kernel launch, a device-to-host copy, an event -- waits for every packet
+//   before it AND sees everything they stored, from every XCD's L2.
+// Eight rounds of: A (ordinary) and B, B2 (barrier-free) each fill their own 4 MiB region with a pattern through plain stores from
+// 4096 workgroups (all XCDs); C (ordinary) re-reads the three regions through a reversed workgroup -> XCD mapping and counts what it
+// does not find; a D2H copy of B2's last KiB and an event follow; the host checks the copy right after the event.  Any miss: feature OFF.
+// Verdict (kmc_device_info.any_order_dispatch): 1 = verified, on;  0 = switched off (KMC_ANY_ORDER=0);  -1 = an ordinary packet
+// overtook, or did not see, a barrier-free one;  -3 = the probe could not run (a HIP error).
+constexpr uint32_t kAoWords = 1u << 20;  // 4 MiB per region
+__global__ __launch_bounds__(256) void ao_probe_fill(uint32_t* x, uint32_t seed) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  x[i] = seed + i * 2654435761u;
 }
-__global__ void ao_probe_stamp(unsigned long long* t_seen) {
-  if (threadIdx.x == 0) *t_seen = wall_clock64();
-}
-__global__ void ao_probe_read(const uint32_t* flags, uint32_t* seen) {
-  if (threadIdx.x < 2) seen[threadIdx.x] = __hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+__global__ __launch_bounds__(256) void ao_probe_verify(const uint32_t* x, uint32_t seed_a, uint32_t seed_b, uint32_t seed_c, unsigned long long* bad) {
+  const uint32_t b = gridDim.x - 1 - blockIdx.x;  // reversed, and shifted by 3 workgroups: another XCD than the writer's
+  const uint32_t i = ((b + 3) % gridDim.x) * 256 + threadIdx.x;
+  const uint32_t miss = (x[i] != seed_a + i * 2654435761u) + (x[kAoWords + i] != seed_b + i * 2654435761u) + (x[2 * kAoWords + i] != seed_c + i * 2654435761u);
+  if (miss) atomicAdd(bad, (unsigned long long)miss);
 }
 
 static int ao_probe_run(kmc_ctx* c) {
-  struct Words { uint32_t flags[2]; uint32_t seen[2]; unsigned long long t_end_a, t_seen_b; };
-  Words* d = nullptr;
-  Words* h = nullptr;  // [0]: what the D2H copy behind the packets saw, [1]: the final state
+  uint32_t* d = nullptr;
+  unsigned long long* d_bad = nullptr;
+  uint32_t* h = nullptr;  // the D2H copy's target: B2's last 256 words
   int verdict = -3;
   hipStream_t s = c->own_stream;
   hipEvent_t ev = nullptr;
+  const dim3 grid(kAoWords / 256), block(256);
   do {
-    if (hipMalloc((void**)&d, sizeof(Words)) != hipSuccess) break;
-    if (hipHostMalloc((void**)&h, 2 * sizeof(Words), hipHostMallocDefault) != hipSuccess) break;
+    if (hipMalloc((void**)&d, 3 * (size_t)kAoWords * 4) != hipSuccess) break;
+    if (hipMalloc((void**)&d_bad, 8) != hipSuccess) break;
+    if (hipHostMalloc((void**)&h, 1024, hipHostMallocDefault) != hipSuccess) break;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
-    std::memset(h, 0, 2 * sizeof(Words));
-    if (hipMemsetAsync(d, 0, sizeof(Words), s) != hipSuccess) break;
-    hipLaunchKernelGGL(ao_probe_spin, dim3(1), dim3(64), 0, s, &d->flags[0], (uint64_t)12000, &d->t_end_a);                   // A: ordinary
-    hipExtLaunchKernelGGL(ao_probe_stamp, dim3(1), dim3(64), 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, &d->t_seen_b);  // B
-    hipExtLaunchKernelGGL(ao_probe_spin, dim3(1), dim3(64), 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, &d->flags[1], (uint64_t)4000,
-                          (unsigned long long*)nullptr);                                                                          // B2
-    hipLaunchKernelGGL(ao_probe_read, dim3(1), dim3(64), 0, s, (const uint32_t*)d->flags, d->seen);                            // C: ordinary
-    if (hipGetLastError() != hipSuccess) break;
-    if (hipMemcpyAsync(&h[0], d, sizeof(Words), hipMemcpyDeviceToHost, s) != hipSuccess) break;  // a copy behind them
-    if (hipEventRecord(ev, s) != hipSuccess) break;
-    if (hipEventSynchronize(ev) != hipSuccess) break;
-    const bool copy_waited = h[0].flags[0] == 0x4B4D43u && h[0].flags[1] == 0x4B4D43u;  // read right after the EVENT: it waited too
+    if (hipMemsetAsync(d_bad, 0, 8, s) != hipSuccess) break;
+    bool host_ok = true, ran = true;
+    for (uint32_t round = 0; round < 8 && ran; ++round) {
+      const uint32_t sa = 977u * (3 * round + 1), sb = 977u * (3 * round + 2), sc = 977u * (3 * round + 3);
+      hipLaunchKernelGGL(ao_probe_fill, grid, block, 0, s, d, sa);                                                               // A: ordinary
+      hipExtLaunchKernelGGL(ao_probe_fill, grid, block, 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d + kAoWords, sb);      // B
+      hipExtLaunchKernelGGL(ao_probe_fill, grid, block, 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d + 2 * kAoWords, sc);  // B2
+      hipLaunchKernelGGL(ao_probe_verify, grid, block, 0, s, (const uint32_t*)d, sa, sb, sc, d_bad);                             // C: ordinary
+      ran = hipGetLastError() == hipSuccess;
+      if (round & 1) {  // every other round the copy follows the barrier-free packets directly (no ordinary kernel in between)
+        hipExtLaunchKernelGGL(ao_probe_fill, grid, block, 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d + 2 * kAoWords, sc + 1);
+        ran = ran && hipGetLastError() == hipSuccess;
+      }
+      ran = ran && hipMemcpyAsync(h, d + 3 * kAoWords - 256, 1024, hipMemcpyDeviceToHost, s) == hipSuccess;
+      ran = ran && hipEventRecord(ev, s) == hipSuccess && hipEventSynchronize(ev) == hipSuccess;
+      const uint32_t want = (round & 1) ? sc + 1 : sc;
+      for (uint32_t k = 0; ran && k < 256; ++k) host_ok = host_ok && h[k] == want + (kAoWords - 256 + k) * 2654435761u;
+    }
+    if (!ran) break;
+    unsigned long long bad = ~0ull;
     if (hipStreamSynchronize(s) != hipSuccess) break;
-    if (hipMemcpy(&h[1], d, sizeof(Words), hipMemcpyDeviceToHost) != hipSuccess) break;
-    const bool kernel_waited = h[1].seen[0] == 0x4B4D43u && h[1].seen[1] == 0x4B4D43u;
-    const bool overlapped = h[1].t_seen_b != 0 && h[1].t_seen_b < h[1].t_end_a;
-    verdict = !(copy_waited && kernel_waited) ? -1 : (overlapped ? 1 : -2);
+    if (hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+    verdict = (bad == 0 && host_ok) ? 1 : -1;
   } while (false);
   (void)hipGetLastError();
   if (ev) (void)hipEventDestroy(ev);
   if (h) (void)hipHostFree(h);
+  if (d_bad) (void)hipFree(d_bad);
   if (d) (void)hipFree(d);
   return verdict;
 }

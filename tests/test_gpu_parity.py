@@ -1335,7 +1335,7 @@ def test_any_order_dispatch_is_gated_by_the_runtime_probe(torch_mod, monkeypatch
         monkeypatch.delenv("KMC_ANY_ORDER")
         verdicts = {k: c.device_info()["any_order_dispatch"] for k, c in ctxs.items()}
         assert verdicts["probe_failed"] == -1 and verdicts["switched_off"] == 0
-        assert verdicts["probed"] in (1, -1, -2, -3)
+        assert verdicts["probed"] in (1, -1, -3)
         ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for _ in range(nf)]
         for f in range(nf):
             ctxs["probed"].synth_points(ins[f], n, 5200 + f)
