@@ -125,10 +125,6 @@ int kmc_hip_synchronize(kmc_ctx* ctx);
 int kmc_hip_enable_timing(kmc_ctx* ctx, int enabled);
 const char* kmc_hip_last_error(kmc_ctx* ctx);
 int kmc_hip_device_info(kmc_ctx* ctx, kmc_device_info* out);
-/* Launch-geometry override for tuning: blocks_per_cu > 0 makes the grid persistent (CUs x blocks_per_cu workgroups
- * grid-striding over tiles), 0 = default = one tile per workgroup; points_per_thread = 1, 2, 4 or 8 (0 = default 1). */
-int kmc_hip_set_launch_config(kmc_ctx* ctx, int blocks_per_cu, int points_per_thread);
-
 /* Testing hook: force the coefficient tier (0..3, see kmc_stats.variant) of the f32 kernels (-1 = automatic selection from |phi|). */
 int kmc_hip_force_tier(kmc_ctx* ctx, int tier);
 
@@ -204,7 +200,7 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * refills: 6.9 us per 1 M-point frame = 4.6 TB/s where the kernel alone sustains 6.8.  The frames of this path are independent
  * (motion_compensation.cpp:22-25 reads nothing a previous frame wrote), so they may overlap: with frame queues on,
  * device-resident kmc_hip_deskew_f32 calls are issued round-robin over `queues` HIP streams (hardware queues) of the context --
- * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip, tools/fq_probe.hip).
+ * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip; profiles/r02_stream_probe.jsonl).
  *   - queues = 1 (default): every call on the context's stream, in order.  Since ABI version 3 "in order" no longer means "drained":
  *     a device-resident frame whose buffers overlap none of the frames launched since the last ordinary launch is dispatched WITHOUT
  *     the barrier bit (hipExtAnyOrderLaunch): the packet processor does not wait for the completion and the cache release of the

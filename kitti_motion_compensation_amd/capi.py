@@ -121,7 +121,6 @@ SIGNATURES = {
     "kmc_hip_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_last_error": (C.c_char_p, [_vp]),
     "kmc_hip_device_info": (C.c_int, [_vp, C.POINTER(DeviceInfo)]),
-    "kmc_hip_set_launch_config": (C.c_int, [_vp, C.c_int, C.c_int]),
     "kmc_hip_force_tier": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_timer_begin": (C.c_int, [_vp]),
     "kmc_hip_timer_end": (C.c_int, [_vp, C.POINTER(C.c_float)]),
@@ -402,9 +401,6 @@ class Context:
 
     def enable_timing(self, on=True):
         self._check(lib().kmc_hip_enable_timing(self._h, 1 if on else 0), "kmc_hip_enable_timing")
-
-    def set_launch_config(self, blocks_per_cu=0, points_per_thread=0):
-        self._check(lib().kmc_hip_set_launch_config(self._h, blocks_per_cu, points_per_thread), "kmc_hip_set_launch_config")
 
     def force_tier(self, tier=-1):
         self._check(lib().kmc_hip_force_tier(self._h, tier), "kmc_hip_force_tier")

@@ -371,11 +371,8 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
     return KMC_ERR_NO_DEVICE;
   }
   c->stream = c->own_stream;
-  if (const char* e = std::getenv("KMC_NO_INLINE_TABLES")) c->no_inline_tables = std::atoi(e) != 0;
-  if (const char* e = std::getenv("KMC_TILE_LOOP")) c->tile_loop = std::atoi(e) != 0;
   c->ao_verdict = ao_verdict_for(c);  // barrier-free dispatch only where this device and runtime were SEEN to honour what it relies on
   c->ao_enabled = c->ao_verdict == 1;
-  if (const char* e = std::getenv("KMC_MAPPED_WAVES")) c->mapped_waves = std::max(1, std::min(65536, std::atoi(e)));
   *out = c;
   return KMC_OK;
 }
@@ -461,13 +458,11 @@ int kmc_hip_set_frame_queues(kmc_ctx* c, int queues) {
   KMC_ENTER(c);
   if (queues > 1 && !c->fq[0]) {
     // HIP multiplexes its streams onto a few hardware queues in creation order, and two streams that share one are serialised
-    // through barrier packets -- slower than a single stream.  Measured on MI355X / ROCm 7.2 (tools/fq_probe.hip, C and
+    // through barrier packets -- slower than a single stream.  Measured on MI355X / ROCm 7.2 (round 2's fq_probe, C and
     // Python hosts): with the frame queues created right behind the context's own two streams a 1 M-point frame costs
     // 5.6-7.8 us (erratic), with two idle streams created in between 5.1-5.2 us with four queues, every time.
-    // KMC_FQ_SPACERS overrides the count (tuning knob).
-    const char* sp = std::getenv("KMC_FQ_SPACERS");
-    const int spacers = sp ? std::max(0, std::min(8, std::atoi(sp))) : 2;
-    for (int k = 0; k < spacers && k < 8; ++k) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->fq_spacer[k], hipStreamNonBlocking));
+    constexpr int kSpacers = 2;
+    for (int k = 0; k < kSpacers; ++k) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->fq_spacer[k], hipStreamNonBlocking));
   }
   for (int q = 0; q < queues; ++q) {
     if (queues > 1 && !c->fq[q]) {
@@ -515,16 +510,6 @@ int kmc_hip_device_info(kmc_ctx* c, kmc_device_info* out) {
   out->hbm_bytes = c->prop.totalGlobalMem;
   out->clock_khz = c->prop.clockRate;
   out->any_order_dispatch = c->ao_verdict;
-  return KMC_OK;
-}
-
-int kmc_hip_set_launch_config(kmc_ctx* c, int blocks_per_cu, int points_per_thread) {
-  if (!c || blocks_per_cu < 0 || blocks_per_cu > 64) return KMC_ERR_INVALID_ARG;
-  if (!(points_per_thread == 0 || points_per_thread == 1 || points_per_thread == 2 || points_per_thread == 4 ||
-        points_per_thread == 8))
-    return KMC_ERR_INVALID_ARG;
-  c->blocks_per_cu = blocks_per_cu;
-  c->ppt = points_per_thread;
   return KMC_OK;
 }
 

@@ -14,17 +14,8 @@
 
 namespace {
 
-// ---- template dispatch: the run-time choices of a call (tier, points per lane, index output, tile loop or not, barrier bit) become
-// template arguments through with_tier / with_ppt / with_bool, every launch goes through launch_on (kmc_internal.hip.h) ----
-template <typename F>
-void with_ppt(int ppt, F&& f) {
-  switch (ppt) {
-    case 1: f(std::integral_constant<int, 1>{}); break;
-    case 2: f(std::integral_constant<int, 2>{}); break;
-    case 8: f(std::integral_constant<int, 8>{}); break;
-    default: f(std::integral_constant<int, 4>{}); break;
-  }
-}
+// ---- template dispatch: the run-time choices of a call (tier, index output, kernel-argument tables, barrier bit) become template
+// arguments through with_tier / with_bool, every launch goes through launch_on (kmc_internal.hip.h) ----
 // The in-place routes end with "the results are in host memory".  A short busy wait first -- the kernel of a KITTI frame takes
 // ~100 us and an interrupt-driven wake-up adds several microseconds -- and then ALWAYS a hipStreamSynchronize: a successful
 // hipStreamQuery says the stream is idle, but only the synchronize carries the runtime's system-scope release / acquire (and is the
@@ -40,53 +31,31 @@ int wait_results_in_host_memory(kmc_ctx* c) {
 }
 // in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of().
 // any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao_valid
-void launch_frame(const kmc_ctx* c, hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0,
-                  bool any_order = false) {
-  const int ppt = ppt_of(c);
+uint32_t launch_frame(hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0, bool any_order = false) {
   in -= head;
   out -= head;
   n += head;
-  const uint64_t n_tiles = (n + (uint64_t)kLaunchBlock * ppt - 1) / ((uint64_t)kLaunchBlock * ppt);
-  const int grid = grid_for(c, n_tiles);
-  const bool one_pass = one_pass_for(c, grid, n_tiles);
+  uint32_t launches = 0;
   with_tier(tier, [&](auto T) {
-    with_ppt(ppt, [&](auto P) {
-      with_bool(one_pass, [&](auto OP) {
-        // the loop-free instantiations exist for the default geometry (one point per lane) only
-        constexpr bool kOnePass = decltype(OP)::value && decltype(P)::value == 1;
-        launch_on(deskew_frame_f32<decltype(T)::value, decltype(P)::value, kPolicyDefault, false, kLaunchBlock, kOnePass>, grid, kLaunchBlock, s, any_order, in, out, n, f,
-                  head, d);
-      });
-    });
+    launches = launch_tiles((n + kTile - 1) / kTile, [&](uint64_t t0, int grid) { launch_on(deskew_frame_f32<decltype(T)::value>, grid, kTile, s, any_order, in, out, n, f, head, t0, d); });
   });
+  return launches;  // 1 unless the frame holds more than 2^32 - 64 points
 }
 
-// batch of frames, tables in device memory
-void launch_batch(int tier, int ppt, hipStream_t s, int grid, const v4f* in, v4f* out, const BatchRec* recs, const uint2* tiles, uint32_t nf, uint64_t n, uint32_t* idx,
-                  uint32_t head, const FrameRecD* recs64, const float* pre2s, bool one_pass) {
-  with_tier(tier, [&](auto T) {
-    with_ppt(ppt, [&](auto P) {
-      with_bool(idx != nullptr, [&](auto IDX) {
-        with_bool(one_pass, [&](auto OP) {
-          constexpr bool kOnePass = decltype(OP)::value && decltype(P)::value == 1;
-          launch_on(deskew_batch_f32<decltype(T)::value, decltype(P)::value, kPolicyDefault, decltype(IDX)::value, kLaunchBlock, false, kOnePass>, grid, kLaunchBlock, s,
-                    false, in, out, recs, tiles, nf, n, idx, head, recs64, (uint32_t)kChunkShift, pre2s, BatchNoInline{});
-        });
-      });
-    });
-  });
-}
-// batch of at most 16 frames, tables in the kernel arguments (default launch geometry only: one point per lane)
-void launch_batch_inline(int tier, hipStream_t s, int grid, const v4f* in, v4f* out, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head, uint32_t chunk_shift,
-                         const BatchInline& inl, bool one_pass) {
+// batch of frames, tables in device memory (INLINE = false) or in the kernel arguments (at most 16 frames)
+template <bool INLINE>
+uint32_t launch_batch(int tier, hipStream_t s, const v4f* in, v4f* out, const BatchRec* recs, const uint2* coarse, uint32_t nf, uint64_t n, uint32_t* idx, uint32_t head,
+                  const FrameRecD* recs64, uint32_t chunk_shift, const float* pre2s, const BatchInlineArg<INLINE>& inl) {
+  uint32_t launches = 0;
   with_tier(tier, [&](auto T) {
     with_bool(idx != nullptr, [&](auto IDX) {
-      with_bool(one_pass, [&](auto OP) {
-        launch_on(deskew_batch_f32<decltype(T)::value, 1, kPolicyDefault, decltype(IDX)::value, kLaunchBlock, true, decltype(OP)::value>, grid, kLaunchBlock, s, false, in,
-                  out, nullptr, nullptr, nf, n, idx, head, nullptr, chunk_shift, nullptr, inl);
+      launches = launch_tiles((n + kTile - 1) / kTile, [&](uint64_t t0, int grid) {
+        launch_on(deskew_batch_f32<decltype(T)::value, decltype(IDX)::value, INLINE>, grid, kTile, s, false, in, out, recs, coarse, nf, n, idx, head, recs64, chunk_shift, pre2s,
+                  t0, inl);
       });
     });
   });
+  return launches;
 }
 }  // namespace
 
@@ -94,7 +63,7 @@ void launch_batch_inline(int tier, hipStream_t s, int grid, const v4f* in, v4f* 
 namespace {
 // one device-resident frame on stream `s` (arguments already validated)
 int issue_frame(kmc_ctx* c, hipStream_t s, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params, int* tier_out,
-                bool any_order = false) {
+                bool any_order = false, uint32_t* launches_out = nullptr) {
   const int tier = pick_tier(c, params, 1);
   FrameRec f;
   std::memset(&f, 0, sizeof(f));
@@ -103,8 +72,10 @@ int issue_frame(kmc_ctx* c, hipStream_t s, const float* xyzi_in, float* xyzi_out
   FrameRecD d;
   fill_recd(*params, &d);
   if (tier_out) *tier_out = tier;
+  if (launches_out) *launches_out = 0;
   if (n == 0) return KMC_OK;
-  launch_frame(c, s, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, KMC_MEM_DEVICE), any_order);
+  const uint32_t launches = launch_frame(s, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, KMC_MEM_DEVICE), any_order);
+  if (launches_out) *launches_out = launches;
   KMC_HIP_TRY(c, hipGetLastError());
   return KMC_OK;
 }
@@ -192,9 +163,8 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
     if (e == hipSuccess) e = hipEventRecord(c->ev_pool[2 * k], s_up);
     if (e == hipSuccess) e = hipStreamWaitEvent(s_run, c->ev_pool[2 * k], 0);
     if (e == hipSuccess) {
-      const int grid = grid_for(c, (m + 127) / 128);
-      hipLaunchKernelGGL(deskew_f64cols<0>, dim3(grid), dim3(64), 0, s_run, cols[0] + off, cols[1] + off, cols[2] + off, w ? cols[3] + off : nullptr,
-                         cols[4] + off, m, f, cols[5] + off, cols[6] + off, cols[7] + off, down_w ? cols[8] + off : nullptr, c->d_counter, (uint32_t*)nullptr);
+      hipLaunchKernelGGL(deskew_f64cols<false>, dim3((uint32_t)((m + 127) / 128)), dim3(64), 0, s_run, cols[0] + off, cols[1] + off, cols[2] + off, w ? cols[3] + off : nullptr,
+                         cols[4] + off, m, f, cols[5] + off, cols[6] + off, cols[7] + off, down_w ? cols[8] + off : nullptr, c->d_counter, (uint32_t*)nullptr, (uint64_t)0);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(c->ev_pool[2 * k + 1], s_run);
@@ -306,9 +276,10 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     }
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     int tier = 0;
-    const int rc_issue = issue_frame(c, s, xyzi_in, xyzi_out, n, params, &tier, any_order);
+    uint32_t launches = 0;
+    const int rc_issue = issue_frame(c, s, xyzi_in, xyzi_out, n, params, &tier, any_order, &launches);
     if (rc_issue != KMC_OK) return rc_issue;
-    if (st) { st->n_points = n; st->variant = (uint32_t)tier; st->n_launches = n ? 1 : 0; }
+    if (st) { st->n_points = n; st->variant = (uint32_t)tier; st->n_launches = launches; }
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     return tm.end_call(st);
   }
@@ -341,7 +312,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     KMC_HIP_TRY(c, hipEventRecord(c->ev_h2d[b], c->pipe[0]));
     KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[1], c->ev_h2d[b], 0));
     if (reused) KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[1], c->ev_d2h[b], 0));     // the slot's output was downloaded
-    launch_frame(c, c->pipe[1], tier, (const v4f*)c->d_stage_in[b], (v4f*)c->d_stage_out[b], m, f, d);
+    launch_frame(c->pipe[1], tier, (const v4f*)c->d_stage_in[b], (v4f*)c->d_stage_out[b], m, f, d);
     KMC_HIP_TRY(c, hipGetLastError());
     KMC_HIP_TRY(c, hipEventRecord(c->ev_kernel[b], c->pipe[1]));
     KMC_HIP_TRY(c, hipStreamWaitEvent(c->pipe[2], c->ev_kernel[b], 0));
@@ -401,7 +372,7 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
   // So does a list the 2-D grid cannot hold (more than 65 535 frames, or beyond 2^32 work-items).
   const uint64_t tiles_x = (n_max + 63) / 64;
   const bool fits = n_frames <= 65535u && tiles_x * 64 * (uint64_t)n_frames < (1ull << 32);
-  if (!fits || c->blocks_per_cu != 0 || list_has_hazard(xyzi_in, xyzi_out, n_points, n_frames)) {
+  if (!fits || list_has_hazard(xyzi_in, xyzi_out, n_points, n_frames)) {
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     for (uint32_t f = 0; f < n_frames; ++f) {
       const int rc = issue_frame(c, c->stream, xyzi_in[f], xyzi_out[f], n_points[f], &params[f], nullptr, false);
@@ -429,7 +400,7 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
     for (uint32_t f = 0; f < n_frames; ++f) fill(f, &inl.recs[f], &inl.recs64[f]);
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     with_tier(tier, [&](auto T) {
-      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kPolicyDefault, true>), grid, dim3(64), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, inl);
+      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, true>), grid, dim3(64), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, inl);
     });
     KMC_HIP_TRY(c, hipGetLastError());
   } else {
@@ -461,7 +432,7 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
     const ListRec* d_recs = reinterpret_cast<const ListRec*>(sl.d_buf);
     const FrameRecD* d_recd = reinterpret_cast<const FrameRecD*>(sl.d_buf + recs_bytes);
     with_tier(tier, [&](auto T) {
-      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kPolicyDefault, false>), grid, dim3(64), 0, c->stream, d_recs, d_recd, ListNoInline{});
+      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, false>), grid, dim3(64), 0, c->stream, d_recs, d_recd, ListNoInline{});
     });
     KMC_HIP_TRY(c, hipGetLastError());
     {
@@ -513,15 +484,12 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
 
-  const int ppt = ppt_of(c);
   const uint32_t head = head_of(xyzi_out, mem_kind);  // dead points in front: tiles are cut on 1 KiB lines of the output
   const uint64_t nv = n + head;                       // virtual size; every offset below is shifted by `head` too
-  const uint64_t tile = (uint64_t)kLaunchBlock * ppt;
-  const uint64_t n_tiles = (nv + tile - 1) / tile;
 
   // Small batches of device-resident frames: the tables travel in the kernel arguments.  Nothing to upload, nothing for the host to
   // wait for -- the call only enqueues one launch on the context's stream (and can therefore be captured into a HIP graph).
-  if (mem_kind == KMC_MEM_DEVICE && n_frames <= (uint32_t)kInlineBatchFrames && ppt == 1 && c->blocks_per_cu == 0 && !c->no_inline_tables) {
+  if (mem_kind == KMC_MEM_DEVICE && n_frames <= (uint32_t)kInlineBatchFrames) {
     uint32_t shift = kChunkShift;
     while (((nv + (1ull << shift) - 1) >> shift) > (uint64_t)kInlineBatchChunks) ++shift;
     if (shift <= 31) {
@@ -537,15 +505,13 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
       build_coarse(offsets, n_frames, nv, head, inl.coarse, shift);
       CallTimer tmi(c);
       if (tmi.begin_call() || tmi.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-      const int grid = grid_for(c, n_tiles);
-      const bool one_pass = one_pass_for(c, grid, n_tiles);
       const v4f* vin = (const v4f*)xyzi_in - head;
       v4f* vout = (v4f*)xyzi_out - head;
       uint32_t* vidx = frame_idx_out ? frame_idx_out - head : nullptr;
-      launch_batch_inline(tier, c->stream, grid, vin, vout, n_frames, nv, vidx, head, shift, inl, one_pass);
+      const uint32_t launches = launch_batch<true>(tier, c->stream, vin, vout, nullptr, nullptr, n_frames, nv, vidx, head, nullptr, shift, nullptr, inl);
       KMC_HIP_TRY(c, hipGetLastError());
       if (tmi.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-      if (st) st->n_launches = 1;
+      if (st) st->n_launches = launches;
       return tmi.end_call(st);
     }
   }
@@ -613,10 +579,8 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
   if (mem_kind == KMC_MEM_HOST)
     KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, n * sizeof(v4f), hipMemcpyHostToDevice, c->stream));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, n_tiles);
-  const bool one_pass = one_pass_for(c, grid, n_tiles) && ppt == 1;
   uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
-  launch_batch(tier, ppt, c->stream, grid, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, d_pre2, one_pass);
+  const uint32_t launches = launch_batch<false>(tier, c->stream, d_in - head, d_out - head, d_recs, d_coarse, n_frames, nv, v_idx, head, d_recd, (uint32_t)kChunkShift, d_pre2, BatchNoInline{});
   KMC_HIP_TRY(c, hipGetLastError());
   {
     const int rc_end = slot_end(c, slot_id);
@@ -628,7 +592,7 @@ int kmc_hip_deskew_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, 
     if (frame_idx_out) KMC_HIP_TRY(c, hipMemcpyAsync(frame_idx_out, d_idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
-  if (st) st->n_launches = 1;
+  if (st) st->n_launches = launches;
   return tm.end_call(st);
 }
 
@@ -720,11 +684,10 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
   if (mem_kind == KMC_MEM_HOST_MAPPED) {
     // over the link: a few hundred persistent waves, each with its next tile's loads in flight while it stores the current one
     const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 127) / 128, (uint64_t)c->mapped_waves));
-    hipLaunchKernelGGL((deskew_f64cols<0, true>), dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
-  } else {
-    const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-    with_bool(one_pass_for(c, grid, (n + 127) / 128), [&](auto OP) {
-      launch_on(deskew_f64cols<0, false, decltype(OP)::value>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag);
+    hipLaunchKernelGGL(deskew_f64cols<true>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, (uint64_t)0);
+  } else {  // one wave per workgroup, two points per lane
+    launch_tiles((n + 127) / 128, [&](uint64_t t0, int grid) {
+      launch_on(deskew_f64cols<false>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, t0);
     });
   }
   KMC_HIP_TRY(c, hipGetLastError());
@@ -832,9 +795,8 @@ int kmc_hip_pseudo_timestamps_f64(kmc_ctx* c, const double* x, const double* y, 
     }
     dx = base; dy = base + n; dout = base + 2 * n;
   }
-  const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-  with_bool(one_pass_for(c, grid, (n + 127) / 128), [&](auto OP) {
-    launch_on(pseudo_timestamps_f64<0, decltype(OP)::value>, grid, 64, c->stream, false, dx, dy, n, scan_start, scan_end, dout);
+  launch_tiles((n + 127) / 128, [&](uint64_t t0, int grid) {  // one wave per workgroup, two points per lane
+    launch_on(pseudo_timestamps_f64<0>, grid, 64, c->stream, false, dx, dy, n, scan_start, scan_end, dout, t0);
   });
   KMC_HIP_TRY(c, hipGetLastError());
   if (mem_kind == KMC_MEM_HOST) KMC_HIP_TRY(c, hipMemcpyAsync(stamps_out, dout, col, hipMemcpyDeviceToHost, c->stream));

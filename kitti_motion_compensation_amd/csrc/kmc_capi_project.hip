@@ -80,8 +80,6 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   }
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (n + 63) / 64);
-  const bool one_pass = one_pass_for(c, grid, (n + 63) / 64);
   const int kind = rig_kind(rig);
   auto with_rig = [&](auto&& fn) {
     if (kind == kRigSharedIntrinsics) fn(std::integral_constant<int, kRigSharedIntrinsics>{});
@@ -90,8 +88,8 @@ int kmc_hip_project_f32(kmc_ctx* c, const float* xyzi_in, uint64_t n, const kmc_
   };
   auto launch_tier = [&](auto T) {  // T = -1: projection only, no deskew
     with_rig([&](auto RIG) {
-      with_bool(one_pass, [&](auto OP) {
-        launch_on(project_f32<decltype(T)::value, decltype(RIG)::value, decltype(OP)::value>, grid, 64, c->stream, false, d_in, n, g, f, d_cloud, d_uv, d_col, fd);
+      launch_tiles((n + 63) / 64, [&](uint64_t t0, int grid) {
+        launch_on(project_f32<decltype(T)::value, decltype(RIG)::value>, grid, 64, c->stream, false, d_in, n, g, f, d_cloud, d_uv, d_col, t0, fd);
       });
     });
   };
@@ -142,12 +140,10 @@ int kmc_hip_project_f64cols(kmc_ctx* c, const double* x, const double* y, const 
   }
   CallTimer tm(c);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (n + 63) / 64);
   const int kind = rig_kind(rig);
   {
-    const bool one_pass = one_pass_for(c, grid, (n + 63) / 64);
     auto launch_rig = [&](auto RIG) {
-      with_bool(one_pass, [&](auto OP) { launch_on(project_f64cols<decltype(RIG)::value, decltype(OP)::value>, grid, 64, c->stream, false, dx, dy, dz, n, g, d_uv, d_col); });
+      launch_tiles((n + 63) / 64, [&](uint64_t t0, int grid) { launch_on(project_f64cols<decltype(RIG)::value>, grid, 64, c->stream, false, dx, dy, dz, n, g, d_uv, d_col, t0); });
     };
     if (kind == kRigSharedIntrinsics) launch_rig(std::integral_constant<int, kRigSharedIntrinsics>{});
     else if (kind == kRigPinhole) launch_rig(std::integral_constant<int, kRigPinhole>{});

@@ -7,7 +7,7 @@ int kmc_hip_synth_points(kmc_ctx* c, float* xyzi_out_device, uint64_t n, uint64_
   if (!c || (n && !xyzi_out_device)) return KMC_ERR_INVALID_ARG;
   if (n == 0) return KMC_OK;
   KMC_ENTER(c);
-  const int grid = grid_for(c, (n + kBlock - 1) / kBlock, kBlock);
+  const int grid = (int)std::min<uint64_t>((n + kBlock - 1) / kBlock, (uint64_t)c->prop.multiProcessorCount * 32);  // grid-stride generator
   hipLaunchKernelGGL(synth_points<0>, dim3(grid), dim3(kBlock), 0, c->stream, (v4f*)xyzi_out_device, n, seed);
   KMC_HIP_TRY(c, hipGetLastError());
   return KMC_OK;

@@ -180,21 +180,18 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
 
-  static_assert(kLaunchBlock == 64, "deskew_traj_f32 is a one-wave-per-workgroup kernel");
-  // one launch site for both routes: tier, index output, record source (kernel arguments / device table), tile loop or not and the
-  // barrier bit are run-time choices of this call, template arguments of the kernel
+  // one launch site for both routes: tier, index output, record source (kernel arguments / device table) and the barrier bit are
+  // run-time choices of this call, template arguments of the kernel
   auto launch_traj = [&](auto INL, hipStream_t stream, bool any_order, const v4f* d_in, v4f* d_out, uint32_t* d_idx, const TrajSeg32* segs, const TrajSegD* segs64,
                          const TrajInline& inl) {
     const uint32_t head = head_of(xyzi_out, mem_kind);
     const uint64_t nv = n + head;
-    const int grid = grid_for(c, (nv + 63) / 64);
-    const bool one_pass = one_pass_for(c, grid, (nv + 63) / 64);
     uint32_t* v_idx = d_idx ? d_idx - head : nullptr;
     with_tier(tier, [&](auto T) {
       with_bool(d_idx != nullptr, [&](auto IDX) {
-        with_bool(one_pass, [&](auto OP) {
-          launch_on(deskew_traj_f32<decltype(T)::value, kPolicyDefault, decltype(IDX)::value, decltype(INL)::value, decltype(OP)::value>, grid, 64, stream, any_order,
-                    d_in - head, d_out - head, nv, segs, th.n_seg, v_idx, head, segs64, inl);
+        launch_tiles((nv + 63) / 64, [&](uint64_t t0, int grid) {
+          launch_on(deskew_traj_f32<decltype(T)::value, decltype(IDX)::value, decltype(INL)::value>, grid, 64, stream, any_order, d_in - head, d_out - head, nv, segs, th.n_seg,
+                    v_idx, head, segs64, t0, inl);
         });
       });
     });
@@ -354,16 +351,14 @@ int kmc_hip_deskew_traj_batch_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_
   if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) KMC_HIP_TRY(c, hipMemcpyAsync((void*)d_in, xyzi_in, pts, hipMemcpyHostToDevice, c->stream));
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (nv + 63) / 64);
-  const bool one_pass = one_pass_for(c, grid, (nv + 63) / 64);  // one workgroup per tile: the kernel without its tile loop
   const bool idx = d_fidx || d_bidx;
   uint32_t* v_fidx = d_fidx ? d_fidx - head : nullptr;
   uint32_t* v_bidx = d_bidx ? d_bidx - head : nullptr;
   with_tier(tier, [&](auto T) {
     with_bool(idx, [&](auto IDX) {
-      with_bool(one_pass, [&](auto OP) {
-        launch_on(deskew_traj_batch_f32<decltype(T)::value, kPolicyDefault, decltype(IDX)::value, decltype(OP)::value>, grid, 64, c->stream, false, d_in - head, d_out - head, nv,
-                  d_frecs, d_segs, seg_stride, d_coarse, n_frames, v_fidx, v_bidx, head, d_segd);
+      launch_tiles((nv + 63) / 64, [&](uint64_t t0, int grid) {
+        launch_on(deskew_traj_batch_f32<decltype(T)::value, decltype(IDX)::value>, grid, 64, c->stream, false, d_in - head, d_out - head, nv, d_frecs, d_segs, seg_stride,
+                  d_coarse, n_frames, v_fidx, v_bidx, head, d_segd, t0);
       });
     });
   });
@@ -448,9 +443,10 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   c->counter_dirty = true;
   *c->h_flag = 0;
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  const int grid = grid_for(c, (n + 127) / 128);  // one wave per workgroup, two points per lane
-  hipLaunchKernelGGL(deskew_traj_f64cols<0>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, (const TrajSeg64*)d_segs, th.n_seg,
-                     knot_times[0], knot_times[n_knots - 1], dox, doy, doz, dow, d_idx, c->d_counter, c->h_flag);
+  launch_tiles((n + 127) / 128, [&](uint64_t t0, int grid) {  // one wave per workgroup, two points per lane
+    launch_on(deskew_traj_f64cols<0>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, (const TrajSeg64*)d_segs, th.n_seg, knot_times[0], knot_times[n_knots - 1], dox, doy,
+              doz, dow, d_idx, c->d_counter, c->h_flag, t0);
+  });
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   unsigned long long bad = 0;

@@ -48,7 +48,7 @@ static_assert(sizeof(FrameRec) == 64, "FrameRec must stay one 64-byte record");
 
 // Coefficient tiers of the f32 kernels, each valid on the domain of the ones before it (a batch runs the tier of its widest
 // frame).  theta = |phi| * max|s| is known on the host: 0.25 / 1 / 3.25 rad are the upper ends of the first three.
-enum Tier : int { kSeries3 = 0, kSeries5 = 1, kWide = 2, kTrig = 3, kTrigOcml = 4 /* tuner only */ };
+enum Tier : int { kSeries3 = 0, kSeries5 = 1, kWide = 2, kTrig = 3 };
 constexpr double kThetaSeries3 = 0.25, kThetaSeries5 = 1.0, kThetaWide = 3.25;
 
 // atan2(y, x) / (2 pi) in [-0.5, 0.5], i.e. the azimuth in turns.  timestamp_mocking.cpp:46 needs
@@ -89,11 +89,6 @@ __device__ __forceinline__ float azimuth_turns(float x, float y) {
   r = (ay > ax) ? 0.25f - r : r;                     // [0, 1/4]
   r = (__float_as_uint(x) >> 31) ? 0.5f - r : r;     // signbit(x): [0, 1/2]
   return __builtin_copysignf(r, y);
-}
-
-// Reference-accuracy variant through ocml (kept for A/B in tools/kmc_tune and the accuracy tests).
-__device__ __forceinline__ float azimuth_turns_ocml(float x, float y) {
-  return atan2f(y, x) * 0.15915494309189535f;
 }
 
 struct Coef {
@@ -151,7 +146,8 @@ __device__ __forceinline__ Coef se3_coefficients(float s, float phi2) {
     C = __builtin_fmaf(C, u, 0.00019840920867864043f);
     C = __builtin_fmaf(C, u, -0.008333330042660236f);
     C = __builtin_fmaf(C, u, 0.1666666716337204f);
-  } else if constexpr (TIER == kTrig) {
+  } else {
+    static_assert(TIER == kTrig, "four coefficient tiers");
     // any angle (a caller-supplied raw twist beyond 3.25 rad; two poses are never more than pi apart).  Half-angle forms (no
     // 1 - cos cancellation), series below theta^2 = 1/16.  Round 3: no ocml sincosf (its Payne-Hanek slow path rides along), no
     // IEEE divide or sqrt -- 1/theta is v_rsq_f32 + one Newton step, theta/2 is reduced to [-pi/4, pi/4] with a two-constant
@@ -189,23 +185,6 @@ __device__ __forceinline__ Coef se3_coefficients(float s, float phi2) {
     A = small ? As : At;
     B = small ? Bs : Bt;
     C = small ? Cs : Ct;
-  } else {  // kTrigOcml: round 2's any-angle tier through ocml sincosf and IEEE divides; kept for the tuner's A/B only
-    const float As = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 120.0f, -1.0f / 6.0f), u, 1.0f);
-    const float Bs = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 720.0f, -1.0f / 24.0f), u, 0.5f);
-    const float Cs = __builtin_fmaf(__builtin_fmaf(u, 1.0f / 5040.0f, -1.0f / 120.0f), u, 1.0f / 6.0f);
-    const float uu = __builtin_fmaxf(u, 1e-12f);
-    const float th = __builtin_sqrtf(uu);
-    float sh, ch;
-    sincosf(0.5f * th, &sh, &ch);
-    const float sn = 2.0f * sh * ch;
-    const float inv_u = 1.0f / uu;
-    const float At = sn / th;
-    const float Bt = 2.0f * sh * sh * inv_u;
-    const float Ct = (th - sn) * inv_u / th;
-    const bool small = u < 0.0625f;
-    A = small ? As : At;
-    B = small ? Bs : Bt;
-    C = small ? Cs : Ct;
   }
   Coef c;
   c.alpha = A * s;
@@ -235,10 +214,9 @@ __device__ __forceinline__ v4f deskew_point_s(const v4f p, const float s, const 
 }
 
 // fused: azimuth -> scan fraction -> s -> Exp(s f) p
-template <int TIER, bool OCML_ATAN = false>
+template <int TIER>
 __device__ __forceinline__ v4f deskew_point(const v4f p, const FrameRec& f) {
-  const float a = OCML_ATAN ? azimuth_turns_ocml(p.x, p.y) : azimuth_turns(p.x, p.y);
-  return deskew_point_s<TIER>(p, f.s0 - a, f);  // s = frac - x_req
+  return deskew_point_s<TIER>(p, f.s0 - azimuth_turns(p.x, p.y), f);  // s = frac - x_req
 }
 
 // ---- near-origin guard ------------------------------------------------------------------------------------------------

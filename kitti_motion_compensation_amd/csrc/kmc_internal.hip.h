@@ -37,18 +37,14 @@ struct kmc_ctx {
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   std::string last_error;
   hipDeviceProp_t prop;
-  int blocks_per_cu = 0;  // 0 = default
-  int ppt = 0;            // 0 = default
-  int force_tier = -1;
-  bool tile_loop = false;         // testing / A-B hook (KMC_TILE_LOOP=1): the kernels' tile-loop instantiations even with one workgroup per tile
-  bool no_inline_tables = false;  // testing / A-B hook (KMC_NO_INLINE_TABLES=1): small batches go through the device tables too
+  int force_tier = -1;    // kmc_hip_force_tier (testing hook)
   // out-of-range counter (f64 path)
   unsigned long long* d_counter = nullptr;
   int f64_pending = 0;         // kmc_hip_deskew_f64cols_begin / _end: 0 = none, 1 = issued and not waited for, 2 = completed inside _begin
   int f64_result = 0;
   kmc_stats f64_stats = {};
   bool counter_dirty = true;   // d_counter may be non-zero: the f64 entry points clear it only then (a memset per call costs ~5 us)
-  int mapped_waves = 128;      // persistent one-wave workgroups of the f64 kernel when it works on page-locked host memory (KMC_MAPPED_WAVES)
+  int mapped_waves = 128;      // persistent one-wave workgroups of the f64 kernel when it works on page-locked host memory (64 ... 1024 measured: profiles/r03_inplace_f64.txt)
   uint32_t* h_flag = nullptr;  // page-locked word the f64 kernels raise when a stamp is out of range (read by the host after the sync: no D2H copy on the good path)
   // batch tables: a ring of slots, each one device buffer + one pinned staging buffer holding
   // [BatchRec x n_frames | coarse x (n_chunks + 1)], uploaded with ONE copy on a side stream so that the per-step host
@@ -99,7 +95,7 @@ struct kmc_ctx {
   hipEvent_t fq_done[kMaxFrameQueues] = {nullptr, nullptr, nullptr, nullptr};
   bool fq_used[kMaxFrameQueues] = {false, false, false, false};
   hipEvent_t fq_fork = nullptr;      // "everything issued on `stream` so far", which the queues wait for
-  hipStream_t fq_spacer[8] = {};     // idle streams created before the queues (hardware-queue mapping, see kmc_hip_set_frame_queues)
+  hipStream_t fq_spacer[2] = {};     // idle streams created before the queues (hardware-queue mapping, see kmc_hip_set_frame_queues)
   // independent frames on ONE stream without the drain between them: a device-resident single-frame launch whose buffers overlap
   // nothing that was launched since (and including) the last ORDERED launch goes out with hipExtAnyOrderLaunch -- the dispatch packet
   // carries no barrier bit, the frame starts while the frame before it is still running.  Everything else the context puts on
@@ -117,9 +113,6 @@ struct kmc_ctx {
 
 namespace kmc_impl {
 
-// measured best on MI355X (profiles/r01_tune.csv): one wave per workgroup, one point per lane, one tile per workgroup
-constexpr int kLaunchBlock = 64;
-constexpr int kDefaultPpt = 1;
 constexpr uint64_t kHostChunkPoints = 1ull << 21;  // 32 MiB per direction per pipeline slot
 
 inline int fail_hip(kmc_ctx* c, hipError_t e, const char* what) {
@@ -215,16 +208,16 @@ inline bool params_ok(const kmc_frame_params* p) {
   return std::isfinite(p->x_req);
 }
 
-inline int grid_for(const kmc_ctx* c, uint64_t n_tiles, uint32_t threads_per_block = kLaunchBlock) {
-  // default: one tile per workgroup -- the hardware dispatcher streaming 64-point tiles beats a persistent grid-stride loop
-  // (6.8 vs 5.2-5.8 TB/s, profiles/r01_tune.csv); blocks_per_cu > 0 caps the grid instead (in units of 256 threads per CU).
-  // The dispatch packet carries the grid in WORK-ITEMS in 32 bits.  Beyond 2^32 / threads_per_block workgroups (4.29 G points for
-  // 64-point tiles -- 137 GB of cloud in + out, which this GPU holds) the runtime does NOT refuse the launch: it wraps the grid
-  // modulo 2^32 work-items and reports success (tools/grid_probe.hip, profiles/r02_grid_probe.txt: 67 108 865 blocks run as one).
-  // The grid therefore stops below the limit and the kernels' tile loops (t += gridDim.x) take the rest in a second pass.
-  const uint64_t hw = 0xFFFFFFFFull / threads_per_block;
-  const uint64_t cap = c->blocks_per_cu > 0 ? (uint64_t)c->prop.multiProcessorCount * c->blocks_per_cu * (kBlock / kLaunchBlock) : hw;
-  return (int)std::max<uint64_t>(1, std::min<uint64_t>(n_tiles, std::min(cap, hw)));
+// One workgroup per tile, no tile loops (kmc_kernels.hip.h).  The dispatch packet carries the grid in WORK-ITEMS in 32 bits, and beyond
+// 2^32 / 64 workgroups (4.29 G points -- 137 GB of cloud in + out, which this GPU holds) the runtime does NOT refuse the launch: it wraps
+// the grid modulo 2^32 work-items and reports success (tools/grid_probe.hip, profiles/r02_grid_probe.txt).  Every tiled launch therefore
+// goes through launch_tiles: at most kMaxTilesPerLaunch tiles per launch, each launch told its first tile.
+constexpr uint64_t kMaxTilesPerLaunch = 0xFFFFFFFFull / 64;
+template <typename L>
+inline uint32_t launch_tiles(uint64_t n_tiles, L&& launch) {  // launch(first_tile, tiles_in_this_launch); -> number of launches
+  uint32_t launches = 0;
+  for (uint64_t t0 = 0; t0 < n_tiles; t0 += kMaxTilesPerLaunch, ++launches) launch(t0, (int)std::min<uint64_t>(kMaxTilesPerLaunch, n_tiles - t0));
+  return launches;
 }
 
 // ---- launch plumbing: run-time choices -> template arguments, and the one place that knows the two launch calls ----
@@ -250,14 +243,6 @@ inline void launch_on(void (*kernel)(KArgs...), int grid, int block, hipStream_t
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, static_cast<KArgs>(args)...);
   else
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, static_cast<KArgs>(args)...);
-}
-
-// one workgroup per tile: the kernels' ONE_PASS instantiations (no tile loop); KMC_TILE_LOOP=1 keeps the loop variants (A/B hook)
-inline bool one_pass_for(const kmc_ctx* c, int grid, uint64_t n_tiles) { return !c->tile_loop && (uint64_t)grid == n_tiles; }
-
-inline int ppt_of(const kmc_ctx* c) {
-  const int p = c->ppt > 0 ? c->ppt : kDefaultPpt;
-  return (p == 1 || p == 2 || p == 4 || p == 8) ? p : kDefaultPpt;
 }
 
 bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call);  // may this frame be dispatched without the barrier bit?  (kmc_capi_core.hip)

@@ -2,16 +2,20 @@
 //
 // Roofline: HBM.  32 algorithmic bytes per point (16 B v4f {x,y,z,intensity} read + 16 B written),
 // ~80 VALU ops per point -> ~3 flop/B, far below the ~20 flop/B ridge.  What the measurements on MI355X settled
-// (profiles/r01_tune.csv):
+// (profiles/r01_tune.csv, r02_tune*.csv) is now the ONLY geometry the product compiles (round 4: the
+// variants those measurements rejected -- persistent grid-stride loops, 2 / 4 / 8 points per lane, other cache policies, 256-thread
+// workgroups, ocml trigonometry -- left the product headers; their sources are in the history, their numbers in profiles/):
 //   * one lane = one point, one 16-byte load and one 16-byte store per point: a wave moves 1 KiB per instruction,
 //     perfectly coalesced;
-//   * ONE TILE PER WORKGROUP, one wave per workgroup (the shipped geometry): the hardware dispatcher streaming 64-point
-//     tiles reaches 6.75-6.8 TB/s where a persistent grid-stride loop of the same body stays at 5.2-5.8 TB/s, and one
-//     point per lane beats 2/4/8 (with 8 waves per SIMD resident, TLP already covers the HBM latency).  The kernels keep
-//     their grid-stride loops and the PPT parameter so that any grid is still correct (kmc_hip_set_launch_config);
+//   * ONE 64-POINT TILE PER WORKGROUP, one wave per workgroup, no tile loop: the hardware dispatcher streaming tiles reaches
+//     6.8-6.9 TB/s where a persistent grid-stride loop of the same body stays at 5.2-5.8 TB/s, and a loop that runs once still costs
+//     a third of the registers (everything hoisted stays alive around the back edge).  The dispatch packet holds the grid in
+//     work-items in 32 bits, so a launch covers at most 2^26 - 1 tiles; larger inputs take several launches, each told its first
+//     tile (`tile_base`);
 //   * consecutive workgroups land round-robin on the 8 XCDs, so every XCD streams an interleaved eighth of the buffer;
 //     there is no inter-tile reuse to localise and an XCD-contiguous mapping measured 3-5 % slower;
-//   * streamed-once data: non-temporal loads; stores carry nt + sc1 (the written line is dropped from the XCD's L2);
+//   * streamed-once data: non-temporal loads; stores carry nt + sc1 through a buffer descriptor (the written line is dropped from
+//     the XCD's L2: +1.4 %; +7 % for nt altogether);
 //   * per-frame constants are wave-uniform: kernarg / scalar loads -> SGPRs (single-frame kernel), or a per-tile
 //     scalar-loaded record with an LDS-staged table for the tiles that straddle frames (batched kernel).
 #pragma once
@@ -26,26 +30,11 @@
 
 namespace kmc_dev {
 
-constexpr int kBlock = 256;  // 4 waves: one per SIMD
+constexpr int kTile = 64;    // points per tile = lanes per wave = threads per workgroup of every streaming kernel
+constexpr int kBlock = 256;  // the generator's workgroup
 
-// NT is a bit mask of memory-access policies:
-//   bit 0 (1): non-temporal loads            bit 1 (2): non-temporal stores
-//   bit 2 (4): stores also carry sc1 (write-through past the XCD's L2: the line is dropped instead of kept -- measured
-//              +1.4 % on this streaming kernel, profiles/r01_tune_policies.csv); implies buffer stores
-//   bit 3 (8): loads go through a buffer descriptor too (SRSRC + 32-bit offset instead of 64-bit VGPR addresses)
-constexpr int kNtLoad = 1, kNtStore = 2, kNtBoth = 3, kStoreSc1 = 4, kBufLoad = 8;
-constexpr int kPolicyDefault = kNtBoth | kStoreSc1;
-
-template <int NT>
-__device__ __forceinline__ v4f load_point(const v4f* p) {
-  if constexpr (NT & kNtLoad) return __builtin_nontemporal_load(p);
-  else return *p;
-}
-template <int NT>
-__device__ __forceinline__ void store_point(v4f* p, v4f v) {
-  if constexpr (NT & kNtStore) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
+__device__ __forceinline__ v4f load_point(const v4f* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void store_point(v4f* p, v4f v) { __builtin_nontemporal_store(v, p); }
 
 // Buffer-descriptor access to one tile: base = first point of the tile (wave-uniform -> SGPRs), `bytes` = extent from
 // there; out-of-range lanes are clipped by the hardware (loads return 0, stores are dropped), which also covers a ragged
@@ -55,120 +44,59 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base, ui
   const uint32_t clipped = bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes;
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, clipped, 0x00020000);
 }
-template <int NT>
 __device__ __forceinline__ v4f tile_load(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-  constexpr int aux = (NT & kNtLoad) ? 2 : 0;
-  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, aux));
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, /*nt*/ 2));
 }
-template <int NT>
 __device__ __forceinline__ void tile_store(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, v4f v) {
-  constexpr int aux = ((NT & kNtStore) ? 2 : 0) | ((NT & kStoreSc1) ? 16 : 0);
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, byte_off, 0, aux);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, byte_off, 0, /*nt | sc1*/ 2 | 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one tile of ONE frame: the body the single-frame kernel and the frame-list kernel share
+// ------------------------------------------------------------------------------------------------
+// `head` (< 64): the first `head` indices are DEAD.  A caller whose output does not start on a 1 KiB boundary passes
+// pointers moved back to that boundary, n + head and head = the distance in points: every tile's store then covers whole
+// aligned lines (a 16-byte-aligned base measured 5.5 TB/s against 6.8 aligned).  Only tile 0 pays for it.
+// `d_rec`: the frame's constants in f64, read -- through scalar loads -- only by a wave that contains a lane the near-origin guard
+// redoes (kmc_device_math).
+template <int TIER>
+__device__ __forceinline__ void frame_tile(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, const FrameRec& f, uint32_t head, cdouble_p d_rec, uint64_t tile) {
+  const uint32_t tid = threadIdx.x;
+  const uint64_t base = tile * kTile;
+  const uint64_t i = base + tid;
+  if (__builtin_expect(head != 0 && tile == 0, 0)) {  // the tile that holds the dead head: plain, bounds-checked accesses
+    if (i >= head && i < n) {
+      const v4f p = load_point(in + i);
+      const v4f o = deskew_point<TIER>(p, f);
+      const bool redo = needs_redo(p, o, f);
+      if (!redo) store_point(out + i, o);
+      redo_lanes(redo, p, d_rec, [&](v4f v) { store_point(out + i, v); });
+    }
+    return;
+  }
+  // every other tile, ragged or not: the load is clamped to the last point (the store of a dead lane is clipped anyway), the store
+  // goes through a descriptor that ends with the frame
+  const v4f p = load_point(in + (i < n ? i : n - 1));
+  const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));
+  const v4f o = deskew_point<TIER>(p, f);
+  const bool redo = needs_redo(p, o, f);
+  if (!redo) tile_store(rout, (uint32_t)(tid * sizeof(v4f)), o);
+  redo_lanes(redo, p, d_rec, [&](v4f v) { tile_store(rout, (uint32_t)(tid * sizeof(v4f)), v); });  // near-origin guard, cold
 }
 
 // ------------------------------------------------------------------------------------------------
 // single-frame kernel: constants by value (kernarg segment -> s_load -> SGPRs)
 // ------------------------------------------------------------------------------------------------
-// ONE_PASS: the launch holds one workgroup per tile (the default geometry) -- the kernel without its tile loop: nothing is carried
-// around a back edge, the register allocator needs a third fewer registers and the wave a few scalar instructions less
-template <int TIER, int PPT, int NT, bool OCML_ATAN, int BLOCK = kBlock, bool ONE_PASS = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 ? 8 : 4, 8))) void deskew_frame_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
-                                                         uint64_t n, FrameRec f, uint32_t head, FrameRecD d) {
-  // `d`: the frame's constants in f64, read only by a wave that contains a lane the near-origin guard redoes (kmc_device_math).
-  // It is addressed through the kernel-argument segment instead of by name: named, the compiler preloads its 32 SGPRs at
+template <int TIER>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_frame_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, FrameRec f,
+                                                                                               uint32_t head, uint64_t tile_base, FrameRecD d) {
+  // `d` is addressed through the kernel-argument segment instead of by name: named, the compiler preloads its 32 SGPRs at
   // kernel entry and keeps them alive for the whole kernel.
-  struct ArgLayout { const v4f* in; v4f* out; uint64_t n; FrameRec f; uint32_t head; FrameRecD d; };  // == the parameter list
+  struct ArgLayout { const v4f* in; v4f* out; uint64_t n; FrameRec f; uint32_t head; uint64_t tile_base; FrameRecD d; };  // == the parameter list
   const cdouble_p d_rec = (cdouble_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, d));
-  // `head` (< 64): the first `head` indices are DEAD.  A caller whose output does not start on a 1 KiB boundary passes
-  // pointers moved back to that boundary, n + head and head = the distance in points: every tile's store then covers whole
-  // aligned lines (a 16-byte-aligned base measured 5.5 TB/s against 6.8 aligned).  Only tile 0 pays for it.
-  constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
-  const uint32_t tid = threadIdx.x;
-  uint64_t t_begin = blockIdx.x;
-  // one point through plain loads / stores (head tile, ragged tail of the non-descriptor variants)
-  auto one_point = [&](uint64_t i) {
-    const v4f p = load_point<NT>(in + i);
-    const v4f o = deskew_point<TIER, OCML_ATAN>(p, f);
-    const bool redo = needs_redo(p, o, f);
-    if (!redo) store_point<NT>(out + i, o);
-    redo_lanes(redo, p, d_rec, [&](v4f v) { store_point<NT>(out + i, v); });
-  };
-  if (head != 0 && t_begin == 0) {
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) {
-      const uint64_t i = (uint64_t)u * BLOCK + tid;
-      if (i >= head && i < n) one_point(i);
-    }
-    if constexpr (ONE_PASS) return;
-    t_begin += gridDim.x;
-  }
-  if constexpr ((NT & (kStoreSc1 | kBufLoad)) != 0) {
-    // descriptor path: every tile, ragged or not, through hardware-clipped buffer accesses
-    const uint64_t n_tiles = (n + kTile - 1) / kTile;
-    for (uint64_t t = t_begin; t < n_tiles; t += gridDim.x) {
-      const uint64_t base = t * kTile;
-      const uint64_t bytes = (n - base) * sizeof(v4f);
-      const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, bytes);
-      v4f p[PPT];
-      if constexpr (NT & kBufLoad) {
-        const __amdgpu_buffer_rsrc_t rin = tile_rsrc(in + base, bytes);
-#pragma unroll
-        for (int u = 0; u < PPT; ++u) p[u] = tile_load<NT>(rin, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)));
-      } else {
-#pragma unroll
-        for (int u = 0; u < PPT; ++u) {
-          const uint64_t i = base + (uint64_t)u * BLOCK + tid;
-          p[u] = load_point<NT>(in + (i < n ? i : n - 1));  // clamp: the store of a dead lane is clipped anyway
-        }
-      }
-      uint32_t redo_mask = 0;
-#pragma unroll
-      for (int u = 0; u < PPT; ++u) {
-        const v4f o = deskew_point<TIER, OCML_ATAN>(p[u], f);
-        const bool redo = needs_redo(p[u], o, f);
-        redo_mask |= redo ? (1u << u) : 0u;
-        if (!redo) tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), o);
-      }
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo_mask != 0) != 0, 0)) {  // near-origin guard, cold
-#pragma unroll
-        for (int u = 0; u < PPT; ++u)
-          redo_lanes(((redo_mask >> u) & 1u) != 0, p[u], d_rec, [&](v4f v) { tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), v); });
-      }
-      if constexpr (ONE_PASS) break;
-    }
-    return;
-  }
-  static_assert(!ONE_PASS || (NT & (kStoreSc1 | kBufLoad)) != 0, "ONE_PASS is for the descriptor variants (the default policy)");
-  const uint64_t n_full = n / kTile;  // tiles that need no bounds checks
-  for (uint64_t t = t_begin; t < n_full; t += gridDim.x) {
-    const v4f* __restrict__ tin = in + t * kTile;
-    v4f* __restrict__ tout = out + t * kTile;
-    v4f p[PPT];
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * BLOCK + tid);
-    uint32_t redo_mask = 0;
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) {
-      const v4f o = deskew_point<TIER, OCML_ATAN>(p[u], f);
-      const bool redo = needs_redo(p[u], o, f);
-      redo_mask |= redo ? (1u << u) : 0u;
-      if (!redo) store_point<NT>(tout + u * BLOCK + tid, o);
-    }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo_mask != 0) != 0, 0)) {  // near-origin guard, cold
-#pragma unroll
-      for (int u = 0; u < PPT; ++u)
-        redo_lanes(((redo_mask >> u) & 1u) != 0, p[u], d_rec, [&](v4f v) { store_point<NT>(tout + u * BLOCK + tid, v); });
-    }
-  }
-  // ragged tail (< kTile points): handled by the workgroup that would own tile n_full
-  if (blockIdx.x == n_full % gridDim.x && !(head != 0 && n_full == 0)) {
-    const uint64_t base = n_full * kTile;
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) {
-      const uint64_t i = base + (uint64_t)u * BLOCK + tid;
-      if (i < n) one_point(i);
-    }
-  }
+  const uint64_t tile = tile_base + blockIdx.x;
+  if (tile * kTile >= n) return;
+  frame_tile<TIER>(in, out, n, f, head, d_rec, tile);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -197,7 +125,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     v4f nxt = cur;
     if (more) nxt = __builtin_nontemporal_load(in + (next * 64 + tid <= last ? next * 64 + tid : last));  // in flight while `cur` is finished
     const uint64_t i = t * 64 + tid;
-    const v4f o = deskew_point<TIER, false>(cur, f);
+    const v4f o = deskew_point<TIER>(cur, f);
     const bool redo = needs_redo(cur, o, f);
     if (!redo && i < n) __builtin_nontemporal_store(o, out + i);
     redo_lanes(redo && i < n, cur, d_rec, [&](v4f v) { __builtin_nontemporal_store(v, out + i); });
@@ -293,26 +221,26 @@ __device__ __forceinline__ uint2 load_coarse(uint2_cp c) {
 struct BatchNoInline { uint32_t unused; };  // what the device-table instantiations carry instead of 3.5 KB of unused tables
 template <bool INLINE> using BatchInlineArg = typename std::conditional<INLINE, BatchInline, BatchNoInline>::type;
 
-template <int TIER, int PPT, int NT, bool WRITE_IDX, int BLOCK = kBlock, bool INLINE = false, bool ONE_PASS = false>  // ONE_PASS: one workgroup per tile, no tile loop
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 ? 8 : 4, 8))) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
+template <int TIER, bool WRITE_IDX, bool INLINE = false>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
                                                          const BatchRec* __restrict__ recs_g,
                                                          const uint2* __restrict__ coarse_g, uint32_t n_frames,
                                                          uint64_t n, uint32_t* __restrict__ frame_idx_out, uint32_t head,
                                                          const FrameRecD* __restrict__ recs64, uint32_t chunk_shift,
-                                                         const float* __restrict__ pre2s_g, BatchInlineArg<INLINE> inl) {
+                                                         const float* __restrict__ pre2s_g, uint64_t tile_base, BatchInlineArg<INLINE> inl) {
   // `recs64[f]`: frame f's constants in f64 for the near-origin guard's redo (kmc_device_math); cold
   // `pre2s[f]`: kGuardPre * |rho_f|^2, the guard's first-stage threshold.  The 64-byte record has no room for it, and computing it from
   // the record costs every wave four VALU instructions on wave-uniform values (there is no scalar float unit): one more 4-byte
   // scalar load next to the record instead -- these kernels keep their SIMDs ~60 % busy, VALU instructions are not free
-  // `head`: dead leading indices, see deskew_frame_f32 (the host has shifted the pointers and every offset by it)
+  // `head`: dead leading indices, see frame_tile (the host has shifted the pointers and every offset by it)
   // `chunk_shift`: log2 of the coarse table's chunk size (kChunkShift for device tables)
-  static_assert(BLOCK >= kLdsFrames * 4, "the LDS staging uses one lane per 16 bytes of the record table");
-  constexpr uint64_t kTile = (uint64_t)BLOCK * PPT;
+  // `tile_base`: the first tile of this launch (0 unless the batch needs more than 2^26 - 1 tiles)
+  static_assert(kTile >= kLdsFrames * 4, "the LDS staging uses one lane per 16 bytes of the record table");
   brec_cp recs;      // tables are written by the host before the launch: constant for the kernel, uniform reads are scalar loads
   uint2_cp coarse;
   const float __attribute__((address_space(4)))* pre2s;
   if constexpr (INLINE) {
-    struct ArgLayout { const v4f* in; v4f* out; const BatchRec* recs_g; const uint2* coarse_g; uint32_t n_frames; uint64_t n; uint32_t* frame_idx_out; uint32_t head; const FrameRecD* recs64; uint32_t chunk_shift; const float* pre2s_g; BatchInline inl; };
+    struct ArgLayout { const v4f* in; v4f* out; const BatchRec* recs_g; const uint2* coarse_g; uint32_t n_frames; uint64_t n; uint32_t* frame_idx_out; uint32_t head; const FrameRecD* recs64; uint32_t chunk_shift; const float* pre2s_g; uint64_t tile_base; BatchInline inl; };
     const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     recs = (brec_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, recs));
     coarse = (uint2_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(BatchInline, coarse));
@@ -325,115 +253,91 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
   }
   __shared__ BatchRec lds_recs[kLdsFrames];
   const uint32_t tid = threadIdx.x;
-  const uint64_t n_tiles = (n + kTile - 1) / kTile;
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t base = t * kTile;
-    const bool full = base + kTile <= n && !(head != 0 && t == 0);
-    const uint64_t tile_end = base + kTile <= n ? base + kTile : n;
-    const v4f* __restrict__ tin = in + base;
-    v4f* __restrict__ tout = out + base;
-    v4f p[PPT];
-    if (full) {
-#pragma unroll
-      for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * BLOCK + tid);
+  const uint64_t t = tile_base + blockIdx.x;
+  const uint64_t base = t * kTile;
+  if (base >= n) return;
+  const bool full = base + kTile <= n && !(head != 0 && t == 0);
+  const uint64_t tile_end = base + kTile <= n ? base + kTile : n;
+  const v4f* __restrict__ tin = in + base;
+  v4f* __restrict__ tout = out + base;
+  v4f p;
+  if (full) p = load_point(tin + tid);
+  // frame of the tile's first point (uniform -> SALU + scalar loads)
+  const uint64_t c = base >> chunk_shift;
+  const uint2 entry = load_coarse(coarse + c);  // one s_load_dwordx2
+  uint32_t f0;
+  if (entry.y != kSplitSearch) {
+    f0 = entry.x + ((uint32_t)(base - (c << chunk_shift)) >= entry.y ? 1u : 0u);
+  } else {
+    uint32_t lo = entry.x, hi = load_coarse(coarse + c + 1).x;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (rec_end_at(recs + mid) > base) hi = mid;
+      else lo = mid + 1;
     }
-    // frame of the tile's first point (uniform -> SALU + scalar loads)
-    const uint64_t c = base >> chunk_shift;
-    const uint2 entry = load_coarse(coarse + c);  // one s_load_dwordx2
-    uint32_t f0;
-    if (entry.y != kSplitSearch) {
-      f0 = entry.x + ((uint32_t)(base - (c << chunk_shift)) >= entry.y ? 1u : 0u);
+    f0 = lo;
+  }
+  const BatchRec r0 = load_rec(recs + f0);
+  const float pre2_0 = pre2s[f0];
+  // near-origin guard (kmc_device_math): lanes whose f32 result lost significance are flagged here, skipped by the regular
+  // stores and redone in f64 at the end of the tile -- ONE cold site for both paths below
+  bool redo = false;
+  uint32_t fi_of = f0;
+  if (full && rec_end(r0) >= tile_end) {
+    FrameRec f = to_frame(r0);
+    f.pre2 = pre2_0;  // (to_frame's own value -- computed from the record -- is only needed where lanes gather their records)
+    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(tout, kTile * sizeof(v4f));
+    const v4f o = deskew_point<TIER>(p, f);
+    redo = needs_redo(p, o, f);
+    if (!redo) tile_store(rout, (uint32_t)(tid * sizeof(v4f)), o);
+    if constexpr (WRITE_IDX) __builtin_nontemporal_store(f0, frame_idx_out + base + tid);
+  } else {
+    // slow path: ragged last tile and/or a tile that straddles frame boundaries
+    if (tid < kLdsFrames * 4) {  // 16 records x 4 x 16 B: one ds_write_b128 per lane
+      const uint32_t fr = f0 + (tid >> 2);
+      if (fr < n_frames)
+        reinterpret_cast<v4f*>(lds_recs)[tid] = ((const v4f __attribute__((address_space(4)))*)recs)[(uint64_t)f0 * 4 + tid];
+    }
+    __syncthreads();
+    const uint64_t i = base + tid;
+    const bool live = i < tile_end && i >= head;
+    // walk to the frame that owns point i (skips empty frames); dead lanes stay on f0
+    uint32_t fi = f0;
+    if (live) {
+      while (true) {
+        const uint32_t k = fi - f0;
+        const uint64_t e = (k < kLdsFrames) ? rec_end(lds_recs[k]) : rec_end_at(recs + fi);
+        if (i < e || fi + 1 >= n_frames) break;
+        ++fi;
+      }
+    }
+    fi_of = fi;
+    // wave-level broadcast when the whole wave sits in one frame
+    const uint32_t fi0 = __builtin_amdgcn_readfirstlane(fi);
+    const bool wave_uniform = __all(fi == fi0);
+    BatchRec r;
+    if (wave_uniform) {
+      const uint32_t k0 = fi0 - f0;
+      if (k0 < kLdsFrames) r = lds_recs[k0];  // uniform address: LDS broadcast / scalar load
+      else r = load_rec(recs + fi0);
     } else {
-      uint32_t lo = entry.x, hi = load_coarse(coarse + c + 1).x;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (rec_end_at(recs + mid) > base) hi = mid;
-        else lo = mid + 1;
-      }
-      f0 = lo;
+      const uint32_t k = fi - f0;
+      if (k < kLdsFrames) r = lds_recs[k];  // per-lane gather
+      else r = load_rec(recs + fi);
     }
-    const BatchRec r0 = load_rec(recs + f0);
-    const float pre2_0 = pre2s[f0];
-    // near-origin guard (kmc_device_math): lanes whose f32 result lost significance are flagged here, skipped by the regular
-    // stores and redone in f64 at the end of the tile -- ONE cold site for both paths below
-    uint32_t redo_mask = 0;
-    uint32_t fi_of[PPT];
-    if (full && rec_end(r0) >= tile_end) {
-      FrameRec f = to_frame(r0);
-      f.pre2 = pre2_0;  // (to_frame's own value -- computed from the record -- is only needed where lanes gather their records)
-      const __amdgpu_buffer_rsrc_t rout = tile_rsrc(tout, kTile * sizeof(v4f));
-#pragma unroll
-      for (int u = 0; u < PPT; ++u) {
-        const v4f o = deskew_point<TIER, false>(p[u], f);
-        const bool redo = needs_redo(p[u], o, f);
-        redo_mask |= redo ? (1u << u) : 0u;
-        fi_of[u] = f0;
-        if (!redo) {
-          if constexpr (NT & kStoreSc1) tile_store<NT>(rout, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), o);
-          else store_point<NT>(tout + u * BLOCK + tid, o);
-        }
-      }
-      if constexpr (WRITE_IDX) {
-#pragma unroll
-        for (int u = 0; u < PPT; ++u) __builtin_nontemporal_store(f0, frame_idx_out + base + u * BLOCK + tid);
-      }
-    } else {
-      // slow path: ragged last tile and/or a tile that straddles frame boundaries
-      __syncthreads();  // previous iteration's LDS readers are done
-      if (tid < kLdsFrames * 4) {  // 16 records x 4 x 16 B: one ds_write_b128 per lane
-        const uint32_t fr = f0 + (tid >> 2);
-        if (fr < n_frames)
-          reinterpret_cast<v4f*>(lds_recs)[tid] = ((const v4f __attribute__((address_space(4)))*)recs)[(uint64_t)f0 * 4 + tid];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < PPT; ++u) {
-        const uint64_t i = base + (uint64_t)u * BLOCK + tid;
-        const bool live = i < tile_end && i >= head;
-        // walk to the frame that owns point i (skips empty frames); dead lanes stay on f0
-        uint32_t fi = f0;
-        if (live) {
-          while (true) {
-            const uint32_t k = fi - f0;
-            const uint64_t e = (k < kLdsFrames) ? rec_end(lds_recs[k]) : rec_end_at(recs + fi);
-            if (i < e || fi + 1 >= n_frames) break;
-            ++fi;
-          }
-        }
-        fi_of[u] = fi;
-        // wave-level broadcast when the whole wave sits in one frame
-        const uint32_t fi0 = __builtin_amdgcn_readfirstlane(fi);
-        const bool wave_uniform = __all(fi == fi0);
-        BatchRec r;
-        if (wave_uniform) {
-          const uint32_t k0 = fi0 - f0;
-          if (k0 < kLdsFrames) r = lds_recs[k0];  // uniform address: LDS broadcast / scalar load
-          else r = load_rec(recs + fi0);
-        } else {
-          const uint32_t k = fi - f0;
-          if (k < kLdsFrames) r = lds_recs[k];  // per-lane gather
-          else r = load_rec(recs + fi);
-        }
-        if (live) {
-          const FrameRec f = to_frame(r);
-          if (!full) p[u] = load_point<NT>(in + i);
-          const v4f o = deskew_point<TIER, false>(p[u], f);
-          const bool redo = needs_redo(p[u], o, f);
-          redo_mask |= redo ? (1u << u) : 0u;
-          if (!redo) store_point<NT>(out + i, o);
-          if constexpr (WRITE_IDX) frame_idx_out[i] = fi;
-        }
-      }
+    if (live) {
+      const FrameRec f = to_frame(r);
+      if (!full) p = load_point(in + i);
+      const v4f o = deskew_point<TIER>(p, f);
+      redo = needs_redo(p, o, f);
+      if (!redo) store_point(out + i, o);
+      if constexpr (WRITE_IDX) frame_idx_out[i] = fi;
     }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo_mask != 0) != 0, 0)) {  // cold
-      // stores through a descriptor (one VGPR of address state instead of a 64-bit pointer per point); only live lanes are flagged
-      const __amdgpu_buffer_rsrc_t rfix = tile_rsrc(tout, (tile_end - base) * sizeof(v4f));
-#pragma unroll
-      for (int u = 0; u < PPT; ++u)
-        redo_lanes(((redo_mask >> u) & 1u) != 0, p[u], recs64, fi_of[u],
-                   [&](v4f v) { tile_store<NT>(rfix, (uint32_t)((u * BLOCK + tid) * sizeof(v4f)), v); });
-    }
-    if constexpr (ONE_PASS) break;
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo) != 0, 0)) {  // cold
+    // stores through a descriptor (one VGPR of address state instead of a 64-bit pointer per point); only live lanes are flagged
+    const __amdgpu_buffer_rsrc_t rfix = tile_rsrc(tout, (tile_end - base) * sizeof(v4f));
+    redo_lanes(redo, p, recs64, fi_of, [&](v4f v) { tile_store(rfix, (uint32_t)(tid * sizeof(v4f)), v); });
   }
 }
 
@@ -448,7 +352,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(PPT == 1 
 // uniform, shared by all the frame's tiles, a scalar-cache hit for all but the first of them -- stands between the wave's start and
 // its point load.  Workgroups beyond a shorter frame's last tile retire after that load (KITTI drives: ~7 % of the grid, a few
 // dozen cycles each).  The hardware dispatcher walks x first, so the tiles of a frame stream in order like a single-frame launch;
-// every frame's tiles are cut on the 1 KiB lines of ITS output (`head`, see deskew_frame_f32).  Same per-point arithmetic, same
+// every frame's tiles are cut on the 1 KiB lines of ITS output (`head`, see frame_tile).  Same per-point arithmetic, same
 // near-origin guard: bit-identical to kmc_hip_deskew_f32 on the same frame.
 struct alignas(16) ListRec {
   FrameRec f;       // pre2 filled in; pad1 unused
@@ -470,10 +374,9 @@ static_assert(sizeof(ListInline) <= 3800, "the list tables must leave room for t
 struct ListNoInline { uint32_t unused; };
 template <bool INLINE> using ListInlineArg = typename std::conditional<INLINE, ListInline, ListNoInline>::type;
 
-template <int TIER, int NT, bool INLINE = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_list_f32(const ListRec* __restrict__ recs_g, const FrameRecD* __restrict__ recs64,
-                                                                                            ListInlineArg<INLINE> inl) {
-  static_assert((NT & kStoreSc1) != 0 && (NT & kBufLoad) == 0, "the list kernel stores through the tile descriptor and loads through plain nt loads");
+template <int TIER, bool INLINE = false>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_list_f32(const ListRec* __restrict__ recs_g, const FrameRecD* __restrict__ recs64,
+                                                                                              ListInlineArg<INLINE> inl) {
   using rec_cp = const ListRec __attribute__((address_space(4)))*;
   rec_cp recs;
   if constexpr (INLINE) {
@@ -491,29 +394,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const v4u a[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
     __builtin_memcpy(&r, a, sizeof(r));
   }
-  const uint32_t tid = threadIdx.x;
-  const uint64_t base = (uint64_t)blockIdx.x * 64;
-  if (base >= r.n) return;  // beyond this frame's last tile
-  const FrameRec& f = r.f;
-  const cdouble_p d_rec = as_constant(recs64 + opaque_uniform(fi));
-  const uint64_t i = base + tid;
-  if (__builtin_expect(r.head != 0 && blockIdx.x == 0, 0)) {  // the tile that holds the dead head: plain, bounds-checked accesses
-    if (i >= r.head && i < r.n) {
-      const v4f p = load_point<NT>(r.in + i);
-      const v4f o = deskew_point<TIER, false>(p, f);
-      const bool redo = needs_redo(p, o, f);
-      if (!redo) store_point<NT>(r.out + i, o);
-      redo_lanes(redo, p, d_rec, [&](v4f v) { store_point<NT>(r.out + i, v); });
-    }
-    return;
-  }
-  // every other tile, ragged or not: the load is clamped to the last point, the store goes through a descriptor that ends with the frame
-  const v4f p = load_point<NT>(r.in + (i < r.n ? i : r.n - 1));
-  const __amdgpu_buffer_rsrc_t rout = tile_rsrc(r.out + base, (r.n - base) * sizeof(v4f));
-  const v4f o = deskew_point<TIER, false>(p, f);
-  const bool redo = needs_redo(p, o, f);
-  if (!redo) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), o);
-  redo_lanes(redo, p, d_rec, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });  // near-origin guard, cold
+  if ((uint64_t)blockIdx.x * kTile >= r.n) return;  // beyond this frame's last tile
+  frame_tile<TIER>(r.in, r.out, r.n, r.f, r.head, as_constant(recs64 + opaque_uniform(fi)), blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -588,19 +470,19 @@ __device__ __forceinline__ void f64_report_bad(uint32_t bad_count, uint32_t tid,
 // so that uploads and downloads overlap in time: launched like the device kernel (every wave loads its tile, then stores it, all
 // ~1000 waves of a KITTI frame at once) the link is used one direction after the other -- 148 us per 123 k-point frame against
 // ~110 us pipelined (profiles/NOTES.md).
-template <int kInstance = 0, bool STREAMED = false, bool ONE_PASS = false>  // kInstance: a template only so that the header can be included by several translation units; ONE_PASS: no tile loop (one workgroup per tile)
+template <bool STREAMED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                      const double* __restrict__ z, const double* __restrict__ w,
                                                      const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
                                                      double* __restrict__ ox, double* __restrict__ oy,
                                                      double* __restrict__ oz, double* __restrict__ ow,
-                                                     unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag) {
-  constexpr uint64_t kTile = 128;  // points per wave
+                                                     unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base) {
+  constexpr uint64_t kTile = 128;  // points per wave HERE: two per lane
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + kTile - 1) / kTile;
   const uint64_t n_full = n / kTile;  // tiles without a ragged end
-  if constexpr (STREAMED) {
-    uint64_t t = blockIdx.x;
+  uint64_t t = tile_base + blockIdx.x;
+  if constexpr (STREAMED) {  // persistent waves: the grid is the wave count, every wave walks its tiles (tile_base = 0)
     F64Tile cur;
     if (t < n_full) cur = f64_tile_load(x, y, z, w, stamps, t * kTile + 2 * (uint64_t)tid);
     while (t < n_full) {
@@ -611,55 +493,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
       cur = nxt;
       t = next;
     }
+    t = n_full + blockIdx.x;  // only the ragged last tile is left, for the first workgroup
   }
-  for (uint64_t t = STREAMED ? n_full + blockIdx.x : blockIdx.x; t < n_tiles; t += gridDim.x) {  // STREAMED: only the ragged last tile is left
-    const uint64_t i = t * kTile + 2 * (uint64_t)tid;
-    uint32_t bad_count;
-    if (i + 1 < n) {
-      const F64Tile tl = f64_tile_load(x, y, z, w, stamps, i);
-      bad_count = f64_tile_finish(tl, f, ox, oy, oz, ow, i);
-    } else if (i < n) {  // the odd last point
-      const double pw = w ? w[i] : 1.0;
-      double a, b, c;
-      bool ok;
-      deskew_one_f64(x[i], y[i], z[i], pw, stamps[i], f, a, b, c, ok);
-      ox[i] = a; oy[i] = b; oz[i] = c;
-      if (ow) ow[i] = pw;
-      bad_count = ok ? 0u : 1u;
-    } else {
-      bad_count = 0;
-    }
-    f64_report_bad(bad_count, tid, n_bad, bad_flag);
-    if constexpr (ONE_PASS && !STREAMED) break;
+  if (t >= n_tiles) return;
+  const uint64_t i = t * kTile + 2 * (uint64_t)tid;
+  uint32_t bad_count;
+  if (i + 1 < n) {
+    const F64Tile tl = f64_tile_load(x, y, z, w, stamps, i);
+    bad_count = f64_tile_finish(tl, f, ox, oy, oz, ow, i);
+  } else if (i < n) {  // the odd last point
+    const double pw = w ? w[i] : 1.0;
+    double a, b, c;
+    bool ok;
+    deskew_one_f64(x[i], y[i], z[i], pw, stamps[i], f, a, b, c, ok);
+    ox[i] = a; oy[i] = b; oz[i] = c;
+    if (ow) ow[i] = pw;
+    bad_count = ok ? 0u : 1u;
+  } else {
+    bad_count = 0;
   }
+  f64_report_bad(bad_count, tid, n_bad, bad_flag);
 }
 
 // GetPseudoTimeStamps (timestamp_mocking.cpp:46-63) in f64
-// (one wave per workgroup, two consecutive points per lane, 16-byte column accesses -- see deskew_f64cols below)
+// (one wave per workgroup, two consecutive points per lane, 16-byte column accesses -- see deskew_f64cols above)
 typedef double v2d_col __attribute__((ext_vector_type(2), aligned(8)));
-template <int kInstance = 0, bool ONE_PASS = false>  // a template only so that the header can be included by several translation units
+template <int kInstance = 0>  // a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(64) void pseudo_timestamps_f64(const double* __restrict__ x, const double* __restrict__ y,
                                                             uint64_t n, double start, double end,
-                                                            double* __restrict__ stamps) {
+                                                            double* __restrict__ stamps, uint64_t tile_base) {
   // every operation individually rounded like the reference's build (plain -O3, no FMA): start + frac * dur must not become one
   // fma, or a stamp at the scan seam can land on the other side of the reference's t <= t_end assert (trajectory_interpolation.cpp:32)
 #pragma clang fp contract(off)
   constexpr double kPi = 3.14159265358979323846;
   const double dur = end - start;
-  const uint64_t n_tiles = (n + 127) / 128;
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t i = t * 128 + 2 * (uint64_t)threadIdx.x;
-    if (i + 1 < n) {
-      const v2d_col vx = __builtin_nontemporal_load(reinterpret_cast<const v2d_col*>(x + i));
-      const v2d_col vy = __builtin_nontemporal_load(reinterpret_cast<const v2d_col*>(y + i));
-      v2d_col o;
-      o.x = start + (((kPi - atan2(vy.x, vx.x)) / (2.0 * kPi)) * dur);
-      o.y = start + (((kPi - atan2(vy.y, vx.y)) / (2.0 * kPi)) * dur);
-      __builtin_nontemporal_store(o, reinterpret_cast<v2d_col*>(stamps + i));
-    } else if (i < n) {
-      stamps[i] = start + (((kPi - atan2(y[i], x[i])) / (2.0 * kPi)) * dur);
-    }
-    if constexpr (ONE_PASS) break;
+  const uint64_t i = (tile_base + blockIdx.x) * 128 + 2 * (uint64_t)threadIdx.x;
+  if (i + 1 < n) {
+    const v2d_col vx = __builtin_nontemporal_load(reinterpret_cast<const v2d_col*>(x + i));
+    const v2d_col vy = __builtin_nontemporal_load(reinterpret_cast<const v2d_col*>(y + i));
+    v2d_col o;
+    o.x = start + (((kPi - atan2(vy.x, vx.x)) / (2.0 * kPi)) * dur);
+    o.y = start + (((kPi - atan2(vy.y, vx.y)) / (2.0 * kPi)) * dur);
+    __builtin_nontemporal_store(o, reinterpret_cast<v2d_col*>(stamps + i));
+  } else if (i < n) {
+    stamps[i] = start + (((kPi - atan2(y[i], x[i])) / (2.0 * kPi)) * dur);
   }
 }
 
@@ -775,7 +652,7 @@ __device__ __forceinline__ uint32_t bracket_of(const v4f p, const float turns, s
 // The lanes in `mine` (all of one trajectory, whose records start at `segs`) compute, store and report: one turn per distinct
 // bracket among them, the record of that bracket through scalar loads.  `seg_base` = index of segs[0] in the f64 twin table.
 // Returns the lanes' brackets; sets redo / redo_seg for the lanes the near-origin guard wants redone.
-template <int TIER, int NT>
+template <int TIER>
 __device__ __forceinline__ uint32_t traj_lanes(const v4f p, const float turns, bool mine, bool storable, seg_cp segs, uint32_t n_seg, const KnotPre kp,
                                                uint32_t seg_base, __amdgpu_buffer_rsrc_t rout, uint32_t tid, bool& redo_any, uint32_t& redo_seg) {
   const uint32_t k = bracket_of(p, turns, segs, n_seg, kp);
@@ -798,7 +675,7 @@ __device__ __forceinline__ uint32_t traj_lanes(const v4f p, const float turns, b
       redo_any = true;
       redo_seg = seg_base + ku;
     }
-    if (now && storable && !redo) tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), q);
+    if (now && storable && !redo) tile_store(rout, (uint32_t)(tid * sizeof(v4f)), q);
     todo &= ~__builtin_amdgcn_ballot_w64(now);
   }
   return k;
@@ -813,17 +690,15 @@ struct TrajInline {
   TrajSeg32 s[kInlineSegments];
   TrajSegD d[kInlineSegments];
 };
-template <int TIER, int NT, bool WRITE_IDX, bool INLINE = false, bool ONE_PASS = false>  // ONE_PASS: see deskew_traj_batch_f32
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+template <int TIER, bool WRITE_IDX, bool INLINE = false>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                      const TrajSeg32* __restrict__ segs, uint32_t n_seg,
                                                      uint32_t* __restrict__ bracket_out, uint32_t head,
-                                                     const TrajSegD* __restrict__ segs64, TrajInline inl) {
-  // `head`: dead leading indices, see deskew_frame_f32
-  static_assert((NT & kStoreSc1) != 0, "the N-knot kernels store through the tile descriptor");
-  constexpr int BLOCK = 64;
+                                                     const TrajSegD* __restrict__ segs64, uint64_t tile_base, TrajInline inl) {
+  // `head`: dead leading indices, see frame_tile; `tile_base`: first tile of this launch
   seg_cp segs_c;
   if constexpr (INLINE) {
-    struct ArgLayout { const v4f* in; v4f* out; uint64_t n; const TrajSeg32* segs; uint32_t n_seg; uint32_t* bracket_out; uint32_t head; const TrajSegD* segs64; TrajInline inl; };
+    struct ArgLayout { const v4f* in; v4f* out; uint64_t n; const TrajSeg32* segs; uint32_t n_seg; uint32_t* bracket_out; uint32_t head; const TrajSegD* segs64; uint64_t tile_base; TrajInline inl; };
     const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     segs_c = (seg_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, s));
     segs64 = (const TrajSegD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, d));
@@ -831,31 +706,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     segs_c = (seg_cp)(uintptr_t)segs;  // written by the host before the launch: constant for the kernel
   }
   const uint32_t tid = threadIdx.x;
-  const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t base = t * BLOCK;
-    const uint64_t i = base + tid;
-    const bool alive = i < n && i >= head;
-    // loads and stores through per-tile descriptors that end with the buffers: no per-lane address arithmetic, the ragged tail is
-    // clipped by the hardware.  The `head` dead lanes of tile 0 must not touch memory in front of the caller's range (it need not
-    // be mapped): the descriptor of tile 0 starts at the first live point and their offsets wrap to 4 GiB, out of its range.
-    // Clipped lanes read zeros and are never stored.
-    const uint32_t h0 = t == 0 ? head : 0u;
-    const __amdgpu_buffer_rsrc_t rin = tile_rsrc(in + base + h0, (n - base - h0) * sizeof(v4f));
-    const v4f p = tile_load<NT>(rin, (tid - h0) * (uint32_t)sizeof(v4f));
-    const KnotPre kp = preload_knots(segs_c);
-    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));
-    __builtin_amdgcn_sched_barrier(0);  // everything above is issued before the wave waits for its points
-    const float turns = azimuth_turns(p.x, p.y);
-    bool redo_any = false;
-    uint32_t redo_seg = 0;
-    const uint32_t k = traj_lanes<TIER, NT>(p, turns, true, i >= head, segs_c, n_seg, kp, 0u, rout, tid, redo_any, redo_seg);
-    if constexpr (WRITE_IDX) {
-      if (alive) __builtin_nontemporal_store(k, bracket_out + i);
-    }
-    traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
-    if constexpr (ONE_PASS) break;
+  const uint64_t t = tile_base + blockIdx.x;
+  const uint64_t base = t * kTile;
+  if (base >= n) return;
+  const uint64_t i = base + tid;
+  const bool alive = i < n && i >= head;
+  // loads and stores through per-tile descriptors that end with the buffers: no per-lane address arithmetic, the ragged tail is
+  // clipped by the hardware.  The `head` dead lanes of tile 0 must not touch memory in front of the caller's range (it need not
+  // be mapped): the descriptor of tile 0 starts at the first live point and their offsets wrap to 4 GiB, out of its range.
+  // Clipped lanes read zeros and are never stored.
+  const uint32_t h0 = t == 0 ? head : 0u;
+  const __amdgpu_buffer_rsrc_t rin = tile_rsrc(in + base + h0, (n - base - h0) * sizeof(v4f));
+  const v4f p = tile_load(rin, (tid - h0) * (uint32_t)sizeof(v4f));
+  const KnotPre kp = preload_knots(segs_c);
+  const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));
+  __builtin_amdgcn_sched_barrier(0);  // everything above is issued before the wave waits for its points
+  const float turns = azimuth_turns(p.x, p.y);
+  bool redo_any = false;
+  uint32_t redo_seg = 0;
+  const uint32_t k = traj_lanes<TIER>(p, turns, true, i >= head, segs_c, n_seg, kp, 0u, rout, tid, redo_any, redo_seg);
+  if constexpr (WRITE_IDX) {
+    if (alive) __builtin_nontemporal_store(k, bracket_out + i);
   }
+  traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store(rout, (uint32_t)(tid * sizeof(v4f)), v); });
 }
 
 // Batched N-knot kernel: many frames in one launch, every frame with its own trajectory (its own segment records).
@@ -875,94 +748,90 @@ struct alignas(32) TrajFrameRec {
 static_assert(sizeof(TrajFrameRec) == 32, "TrajFrameRec must stay one 32-byte record");
 __device__ __forceinline__ uint64_t rec_end(const TrajFrameRec& r) { return ((uint64_t)r.end_hi << 32) | r.end_lo; }
 
-// ONE_PASS: the grid holds one workgroup per tile (the default geometry): no tile loop -- the loop-carried copies of the twelve
-// kernel arguments cost ~40 SGPR spill instructions per wave (round 3, profiles/NOTES.md)
-template <int TIER, int NT, bool WRITE_IDX, bool ONE_PASS = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+template <int TIER, bool WRITE_IDX>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_batch_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
                                                            const TrajFrameRec* __restrict__ frecs,
                                                            const TrajSeg32* __restrict__ segs,
                                                            uint32_t seg_stride, const uint2* __restrict__ coarse,
                                                            uint32_t n_frames, uint32_t* __restrict__ frame_idx_out,
                                                            uint32_t* __restrict__ bracket_out, uint32_t head,
-                                                           const TrajSegD* __restrict__ segs64) {
-  // `head`: dead leading indices, see deskew_frame_f32 (the host has shifted the pointers and every offset by it)
-  static_assert((NT & kStoreSc1) != 0, "the N-knot kernels store through the tile descriptor");
-  constexpr int BLOCK = 64;
+                                                           const TrajSegD* __restrict__ segs64, uint64_t tile_base) {
+  // `head`: dead leading indices, see frame_tile (the host has shifted the pointers and every offset by it); `tile_base`: first tile
+  // of this launch.  No tile loop: the loop-carried copies of the twelve kernel arguments cost ~40 SGPR spill instructions per wave
+  // (round 3, profiles/NOTES_r03.md)
   const seg_cp segs_c = (seg_cp)(uintptr_t)segs;  // written by the host before the launch: constant for the kernel
   const uint32_t tid = threadIdx.x;
-  const uint64_t n_tiles = (n + BLOCK - 1) / BLOCK;
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t base = t * BLOCK;
-    const uint64_t i = base + tid;
-    const uint64_t tile_end = base + BLOCK <= n ? base + BLOCK : n;
-    const bool alive = i < n && i >= head;
-    const uint32_t h0 = t == 0 ? head : 0u;  // see deskew_traj_f32
-    const __amdgpu_buffer_rsrc_t rin = tile_rsrc(in + base + h0, (n - base - h0) * sizeof(v4f));
-    const v4f p = tile_load<NT>(rin, (tid - h0) * (uint32_t)sizeof(v4f));
-    // frame of the tile's first point (wave-uniform)
-    const uint64_t c = base >> kChunkShift;
-    const uint2 entry = coarse[c];
-    uint32_t f0;
-    if (entry.y != kSplitSearch) {
-      f0 = entry.x + ((uint32_t)(base - (c << kChunkShift)) >= entry.y ? 1u : 0u);
-    } else {
-      uint32_t lo = entry.x, hi = coarse[c + 1].x;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (rec_end(frecs[mid]) > base) hi = mid;
-        else lo = mid + 1;
-      }
-      f0 = lo;
+  const uint64_t t = tile_base + blockIdx.x;
+  const uint64_t base = t * kTile;
+  if (base >= n) return;
+  const uint64_t i = base + tid;
+  const uint64_t tile_end = base + kTile <= n ? base + kTile : n;
+  const bool alive = i < n && i >= head;
+  const uint32_t h0 = t == 0 ? head : 0u;  // see deskew_traj_f32
+  const __amdgpu_buffer_rsrc_t rin = tile_rsrc(in + base + h0, (n - base - h0) * sizeof(v4f));
+  const v4f p = tile_load(rin, (tid - h0) * (uint32_t)sizeof(v4f));
+  // frame of the tile's first point (wave-uniform)
+  const uint64_t c = base >> kChunkShift;
+  const uint2 entry = coarse[c];
+  uint32_t f0;
+  if (entry.y != kSplitSearch) {
+    f0 = entry.x + ((uint32_t)(base - (c << kChunkShift)) >= entry.y ? 1u : 0u);
+  } else {
+    uint32_t lo = entry.x, hi = coarse[c + 1].x;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (rec_end(frecs[mid]) > base) hi = mid;
+      else lo = mid + 1;
     }
-    TrajFrameRec r = frecs[f0];
-    KnotPre kp0;
-    {
-      uint32_t k1 = __float_as_uint(r.c1), k2 = __float_as_uint(r.c2);
-      asm volatile("" : "+s"(k1), "+s"(k2));  // pins the header load in front of the points' first use
-      kp0 = {__uint_as_float(k1), __uint_as_float(k2)};
-      // (Warming the scalar cache with the frame's first two records through four one-dword loads at this point was measured and
-      // dropped: 360 us against 327 us per 64 M points -- the extra scalar traffic costs more than the misses it avoids.)
-    }
-    const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
-    const bool one_frame = rec_end(r) >= tile_end;
-    __builtin_amdgcn_sched_barrier(0);  // the whole look-up chain above is issued before the wave waits for its points
-    const float turns = azimuth_turns(p.x, p.y);
-    // near-origin guard: flagged lanes remember their segment (frame * seg_stride + bracket) and are redone in f64 at the end
-    // of the tile -- ONE cold site
-    bool redo_any = false;
-    uint32_t redo_seg = 0;
-    if (__builtin_expect(one_frame, 1)) {  // the tile lies in ONE frame: all but ~n_frames of the n / 64 tiles
-      const uint32_t k = traj_lanes<TIER, NT>(p, turns, true, i >= head, segs_c + (uint64_t)f0 * seg_stride, r.n_seg, kp0, f0 * seg_stride, rout, tid, redo_any, redo_seg);
-      if constexpr (WRITE_IDX) {
-        if (alive) {
-          if (frame_idx_out) __builtin_nontemporal_store(f0, frame_idx_out + i);
-          if (bracket_out) __builtin_nontemporal_store(k, bracket_out + i);
-        }
-      }
-    } else {
-      uint32_t fi = f0;
-      uint64_t begin = base;
-      while (true) {  // the frames that own points of this tile, in order (empty frames are skipped)
-        const uint64_t e = rec_end(r);
-        if (e > begin) {
-          const bool mine = i >= begin && i < e;
-          const uint32_t k = traj_lanes<TIER, NT>(p, turns, mine, i >= head, segs_c + (uint64_t)fi * seg_stride, r.n_seg, KnotPre{r.c1, r.c2}, fi * seg_stride, rout, tid, redo_any, redo_seg);
-          if constexpr (WRITE_IDX) {
-            if (mine && alive) {
-              if (frame_idx_out) __builtin_nontemporal_store(fi, frame_idx_out + i);
-              if (bracket_out) __builtin_nontemporal_store(k, bracket_out + i);
-            }
-          }
-          begin = e;
-        }
-        if (e >= tile_end || fi + 1 >= n_frames) break;
-        ++fi;
-        r = frecs[fi];
-      }
-    }
-    traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store<NT>(rout, (uint32_t)(tid * sizeof(v4f)), v); });
-    if constexpr (ONE_PASS) break;
+    f0 = lo;
   }
+  TrajFrameRec r = frecs[f0];
+  KnotPre kp0;
+  {
+    uint32_t k1 = __float_as_uint(r.c1), k2 = __float_as_uint(r.c2);
+    asm volatile("" : "+s"(k1), "+s"(k2));  // pins the header load in front of the points' first use
+    kp0 = {__uint_as_float(k1), __uint_as_float(k2)};
+    // (Warming the scalar cache with the frame's first two records through four one-dword loads at this point was measured and
+    // dropped: 360 us against 327 us per 64 M points -- the extra scalar traffic costs more than the misses it avoids.)
+  }
+  const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + base, (n - base) * sizeof(v4f));  // clips the ragged tail
+  const bool one_frame = rec_end(r) >= tile_end;
+  __builtin_amdgcn_sched_barrier(0);  // the whole look-up chain above is issued before the wave waits for its points
+  const float turns = azimuth_turns(p.x, p.y);
+  // near-origin guard: flagged lanes remember their segment (frame * seg_stride + bracket) and are redone in f64 at the end
+  // of the tile -- ONE cold site
+  bool redo_any = false;
+  uint32_t redo_seg = 0;
+  if (__builtin_expect(one_frame, 1)) {  // the tile lies in ONE frame: all but ~n_frames of the n / 64 tiles
+    const uint32_t k = traj_lanes<TIER>(p, turns, true, i >= head, segs_c + (uint64_t)f0 * seg_stride, r.n_seg, kp0, f0 * seg_stride, rout, tid, redo_any, redo_seg);
+    if constexpr (WRITE_IDX) {
+      if (alive) {
+        if (frame_idx_out) __builtin_nontemporal_store(f0, frame_idx_out + i);
+        if (bracket_out) __builtin_nontemporal_store(k, bracket_out + i);
+      }
+    }
+  } else {
+    uint32_t fi = f0;
+    uint64_t begin = base;
+    while (true) {  // the frames that own points of this tile, in order (empty frames are skipped)
+      const uint64_t e = rec_end(r);
+      if (e > begin) {
+        const bool mine = i >= begin && i < e;
+        const uint32_t k = traj_lanes<TIER>(p, turns, mine, i >= head, segs_c + (uint64_t)fi * seg_stride, r.n_seg, KnotPre{r.c1, r.c2}, fi * seg_stride, rout, tid, redo_any, redo_seg);
+        if constexpr (WRITE_IDX) {
+          if (mine && alive) {
+            if (frame_idx_out) __builtin_nontemporal_store(fi, frame_idx_out + i);
+            if (bracket_out) __builtin_nontemporal_store(k, bracket_out + i);
+          }
+        }
+        begin = e;
+      }
+      if (e >= tile_end || fi + 1 >= n_frames) break;
+      ++fi;
+      r = frecs[fi];
+    }
+  }
+  traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store(rout, (uint32_t)(tid * sizeof(v4f)), v); });
 }
 
 // f64 Eigen-layout variant: honours the caller's per-point stamps; the bracket is found by f64 time compares.
@@ -999,12 +868,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
                                                           double t_first, double t_last, double* __restrict__ ox,
                                                           double* __restrict__ oy, double* __restrict__ oz,
                                                           double* __restrict__ ow, uint32_t* __restrict__ bracket_out,
-                                                          unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag) {
-  constexpr uint64_t kTile = 128;
+                                                          unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base) {
   const uint32_t tid = threadIdx.x;
-  const uint64_t n_tiles = (n + kTile - 1) / kTile;
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t i = t * kTile + 2 * (uint64_t)tid;
+  {
+    const uint64_t i = (tile_base + blockIdx.x) * 128 + 2 * (uint64_t)tid;
     uint32_t bad_count = 0;
     if (i + 1 < n) {
       const v2d_u ts = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(stamps + i));
@@ -1041,19 +908,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
       if (bracket_out) bracket_out[i] = k;
       bad_count = ok ? 0u : 1u;
     }
-    if (__ballot(bad_count != 0)) {
-      uint32_t total = bad_count;
-      for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-      if (tid == 0) {
-        atomicAdd(n_bad, (unsigned long long)total);
-        if (bad_flag) __hip_atomic_store(bad_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
+    f64_report_bad(bad_count, tid, n_bad, bad_flag);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// synthetic generator + a plain copy kernel (the measured same-hardware ceiling for the roofline table)
+// synthetic generator (measurement infrastructure)
 // ------------------------------------------------------------------------------------------------
 template <int kInstance = 0>  // a template only so that the header can be included by several translation units
 __global__ __launch_bounds__(kBlock) void synth_points(v4f* __restrict__ out, uint64_t n, uint64_t seed) {
@@ -1061,22 +921,6 @@ __global__ __launch_bounds__(kBlock) void synth_points(v4f* __restrict__ out, ui
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
     const kmc_synth::Point p = kmc_synth::make_point(i, n, seed);
     out[i] = v4f{p.x, p.y, p.z, p.i};
-  }
-}
-
-template <int PPT, int NT>
-__global__ __launch_bounds__(kBlock) void copy_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
-  constexpr uint64_t kTile = (uint64_t)kBlock * PPT;
-  const uint32_t tid = threadIdx.x;
-  const uint64_t n_full = n / kTile;
-  for (uint64_t t = blockIdx.x; t < n_full; t += gridDim.x) {
-    const v4f* __restrict__ tin = in + t * kTile;
-    v4f* __restrict__ tout = out + t * kTile;
-    v4f p[PPT];
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) p[u] = load_point<NT>(tin + u * kBlock + tid);
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) store_point<NT>(tout + u * kBlock + tid, p[u]);
   }
 }
 
@@ -1104,68 +948,62 @@ __device__ __forceinline__ void store_uv_tile(v2i* __restrict__ uv, uint64_t til
   }
   // nt + sc1 stores through a descriptor that ends with the array: the ragged last tile is clipped by the hardware
   const __amdgpu_buffer_rsrc_t r = tile_rsrc(uv + 4 * tile_base, (n - tile_base) * 4 * sizeof(v2i));
-  tile_store<kPolicyDefault>(r, tid * 16u, __builtin_bit_cast(v4f, lo));
-  tile_store<kPolicyDefault>(r, 1024u + tid * 16u, __builtin_bit_cast(v4f, hi));
+  tile_store(r, tid * 16u, __builtin_bit_cast(v4f, lo));
+  tile_store(r, 1024u + tid * 16u, __builtin_bit_cast(v4f, hi));
 }
 
-template <int TIER, int RIG, bool ONE_PASS = false>  // ONE_PASS: one workgroup per tile, no tile loop (see deskew_frame_f32)
+template <int TIER, int RIG>
 __global__ __launch_bounds__(64) void project_f32(const v4f* __restrict__ in, uint64_t n, CameraRigRec g, FrameRec f,
                                                   v4f* __restrict__ cloud_out, v2i* __restrict__ uv,
-                                                  uint32_t* __restrict__ bgrv, FrameRecD d) {
+                                                  uint32_t* __restrict__ bgrv, uint64_t tile_base, FrameRecD d) {
   // `g` and `d` are read through the kernel-argument segment only, see project_point and deskew_frame_f32
-  struct ArgLayout { const v4f* in; uint64_t n; CameraRigRec g; FrameRec f; v4f* cloud_out; v2i* uv; uint32_t* bgrv; FrameRecD d; };
+  struct ArgLayout { const v4f* in; uint64_t n; CameraRigRec g; FrameRec f; v4f* cloud_out; v2i* uv; uint32_t* bgrv; uint64_t tile_base; FrameRecD d; };
   const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
   const cdouble_p d_rec = (cdouble_p)(kernarg + offsetof(ArgLayout, d));
   const cdouble_p g_rec = (cdouble_p)(kernarg + offsetof(ArgLayout, g));
   __shared__ v4i xpose[128];
   const uint32_t tid = threadIdx.x;
-  const uint64_t n_tiles = (n + 63) / 64;
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t base = t * 64;
-    const uint64_t i = base + tid;
-    const bool live = i < n;
-    v4f p = __builtin_nontemporal_load(in + (live ? i : n - 1));  // dead lanes of the ragged tile re-read the last point
-    if constexpr (TIER >= 0) {
-      {  // the same cloud kmc_hip_deskew_f32 writes, bit for bit: f32 closed form + the near-origin guard's f64 redo
-        const v4f o = deskew_point<TIER, false>(p, f);
-        const bool redo = needs_redo(p, o, f);
-        v4f fixed = o;
-        redo_lanes(redo, p, d_rec, [&](v4f v) { fixed = v; });
-        p = fixed;
-      }
-      if (cloud_out && live) __builtin_nontemporal_store(p, cloud_out + i);
+  const uint64_t base = (tile_base + blockIdx.x) * 64;
+  if (base >= n) return;
+  const uint64_t i = base + tid;
+  const bool live = i < n;
+  v4f p = __builtin_nontemporal_load(in + (live ? i : n - 1));  // dead lanes of the ragged tile re-read the last point
+  if constexpr (TIER >= 0) {
+    {  // the same cloud kmc_hip_deskew_f32 writes, bit for bit: f32 closed form + the near-origin guard's f64 redo
+      const v4f o = deskew_point<TIER>(p, f);
+      const bool redo = needs_redo(p, o, f);
+      v4f fixed = o;
+      redo_lanes(redo, p, d_rec, [&](v4f v) { fixed = v; });
+      p = fixed;
     }
-    v2i px[4];
-    uint32_t col;
-    const bool drawn = project_point<RIG>((double)p.x, (double)p.y, (double)p.z, g_rec, px, col);
-    store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
-    if (live) __builtin_nontemporal_store(col, bgrv + i);
-    if constexpr (ONE_PASS) break;
+    if (cloud_out && live) __builtin_nontemporal_store(p, cloud_out + i);
   }
+  v2i px[4];
+  uint32_t col;
+  const bool drawn = project_point<RIG>((double)p.x, (double)p.y, (double)p.z, g_rec, px, col);
+  store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
+  if (live) __builtin_nontemporal_store(col, bgrv + i);
 }
 
-template <int RIG, bool ONE_PASS = false>
+template <int RIG>
 __global__ __launch_bounds__(64) void project_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                       const double* __restrict__ z, uint64_t n, CameraRigRec g,
-                                                      v2i* __restrict__ uv, uint32_t* __restrict__ bgrv) {
-  struct ArgLayout { const double* x; const double* y; const double* z; uint64_t n; CameraRigRec g; v2i* uv; uint32_t* bgrv; };
+                                                      v2i* __restrict__ uv, uint32_t* __restrict__ bgrv, uint64_t tile_base) {
+  struct ArgLayout { const double* x; const double* y; const double* z; uint64_t n; CameraRigRec g; v2i* uv; uint32_t* bgrv; uint64_t tile_base; };
   const cdouble_p g_rec = (cdouble_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, g));
   __shared__ v4i xpose[128];
   const uint32_t tid = threadIdx.x;
-  const uint64_t n_tiles = (n + 63) / 64;
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t base = t * 64;
-    const uint64_t i = base + tid;
-    const bool live = i < n;
-    const uint64_t j = live ? i : n - 1;
-    v2i px[4];
-    uint32_t col;
-    const bool drawn = project_point<RIG>(__builtin_nontemporal_load(x + j), __builtin_nontemporal_load(y + j),
-                                                 __builtin_nontemporal_load(z + j), g_rec, px, col);
-    store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
-    if (live) __builtin_nontemporal_store(col, bgrv + i);
-    if constexpr (ONE_PASS) break;
-  }
+  const uint64_t base = (tile_base + blockIdx.x) * 64;
+  if (base >= n) return;
+  const uint64_t i = base + tid;
+  const bool live = i < n;
+  const uint64_t j = live ? i : n - 1;
+  v2i px[4];
+  uint32_t col;
+  const bool drawn = project_point<RIG>(__builtin_nontemporal_load(x + j), __builtin_nontemporal_load(y + j),
+                                               __builtin_nontemporal_load(z + j), g_rec, px, col);
+  store_uv_tile(uv, base, n, tid, px, __builtin_amdgcn_ballot_w64(drawn) != 0, xpose);
+  if (live) __builtin_nontemporal_store(col, bgrv + i);
 }
 
 }  // namespace kmc_dev

@@ -310,11 +310,11 @@ def f64_round(ctx, rng, acc):
     acc["f64_max_rel_err"] = max(acc["f64_max_rel_err"], float(err.max()))
 
 
-def inplace_round(ctx, table_ctx, rng, acc, torch):
+def inplace_round(ctx, rng, acc, torch):
     """Round 3's routes against the ones they stand next to, bit for bit: (a) the KITTI f32 layout on page-locked pool buffers (ONE
     streamed kernel in place over the link) against the device-resident kernel; (b) the f64 Eigen layout on pool containers, with and
     without the homogeneous column, whole call and begin / end halves, against the staged route; (c) a batch of at most 16 frames
-    (tables in the kernel arguments) against a context that sends small batches through device tables (KMC_NO_INLINE_TABLES=1)."""
+    (tables in the kernel arguments) against the same frames with 17 empty frames appended (more than the kernel arguments hold: device tables)."""
     n = int(rng.choice([1, 64, 2047, 2048, 2049, 5000, 123_397, 400_003, 1_048_576 + 3]))
     pts = random_points(rng, n)
     twist = random_twist(rng)
@@ -356,13 +356,15 @@ def inplace_round(ctx, table_ctx, rng, acc, torch):
     offsets = np.concatenate([[0], cuts, [n]]).astype(np.uint64)
     plist = [params_from_twist(random_twist(rng), float(rng.random())) for _ in range(nf)]
     outs, idxs = [], []
-    for c in (ctx, table_ctx):
-        c.set_stream(torch.cuda.current_stream().cuda_stream)
+    ident = params_from_twist(np.zeros(6), 0.5)
+    for padded in (False, True):
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         o = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")
         ix = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
-        c.deskew_batch_f32(d_in, o[:n], offsets, plist, ix[:n])
+        offs = np.concatenate([offsets, np.full(17, n, dtype=np.uint64)]) if padded else offsets
+        ctx.deskew_batch_f32(d_in, o[:n], offs, plist + [ident] * 17 if padded else plist, ix[:n])
         torch.cuda.synchronize()
-        c.set_stream(None)
+        ctx.set_stream(None)
         outs.append(o)
         idxs.append(ix)
     ok = ok and bool(torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))) and bool(torch.equal(idxs[0], idxs[1]))
@@ -444,9 +446,6 @@ def main():
     last_checkpoint = time.time()
     rng = np.random.default_rng(seed)
     ctx = capi.Context(0)
-    os.environ["KMC_NO_INLINE_TABLES"] = "1"
-    table_ctx = capi.Context(0)  # small batches through device tables: the A/B partner of the kernel-argument route
-    del os.environ["KMC_NO_INLINE_TABLES"]
     os.environ["KMC_ANY_ORDER"] = "0"
     plain_ctx = capi.Context(0)  # every dispatch with its barrier bit: the reference of stream_round
     del os.environ["KMC_ANY_ORDER"]
@@ -478,7 +477,7 @@ def main():
         elif r == 5:
             f64_round(ctx, rng, acc)
         elif r == 6:
-            inplace_round(ctx, table_ctx, rng, acc, torch)
+            inplace_round(ctx, rng, acc, torch)
         elif r == 8:
             stream_round(ctx, plain_ctx, rng, acc, torch)
         else:

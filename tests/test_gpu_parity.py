@@ -172,13 +172,14 @@ def test_tier_boundaries_keep_the_bar(torch_mod, ctx, kitti, theta, tier):
     assert err < 2e-6, err
 
 
-def test_every_tier_and_tiling_agree(torch_mod, ctx, kitti):
-    """All four coefficient tiers are valid below 0.25 rad and must agree with the oracle; tiling never changes bits."""
+def test_every_tier_agrees_and_every_route_writes_the_same_bits(torch_mod, ctx, kitti):
+    """All four coefficient tiers are valid below 0.25 rad and must agree with the oracle; the same frame through the single-frame
+    kernel, a one-frame batch (kernel-argument tables), a one-frame batch padded with empty frames (device tables) and a one-frame
+    list writes the same bits."""
     xyzi, P1 = kitti
     P1, P2 = _poses(P1, TRAJECTORIES["hard_turn"])
     params = _params(P1, P2)
     ref = _oracle(xyzi, P1, P2)
-    base = None
     try:
         for tier in (capi.TIER_SERIES3, capi.TIER_SERIES5, capi.TIER_WIDE, capi.TIER_TRIG):
             ctx.force_tier(tier)
@@ -186,16 +187,24 @@ def test_every_tier_and_tiling_agree(torch_mod, ctx, kitti):
             assert st.variant == tier
             _check(got, xyzi, ref)
         ctx.force_tier(-1)
-        for ppt in (1, 2, 4, 8):
-            for bpc in (1, 8):
-                ctx.set_launch_config(bpc, ppt)
-                got, _ = _run_device(torch_mod, ctx, xyzi, params)
-                if base is None:
-                    base = got
-                assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), (ppt, bpc)
+        torch = torch_mod
+        base, _ = _run_device(torch, ctx, xyzi, params)
+        n = xyzi.shape[0]
+        d_in = torch.from_numpy(xyzi).cuda()
+        ident = capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5)
+        for route in ("batch_inline", "batch_device_tables", "list"):
+            d_out = torch.zeros_like(d_in)
+            if route == "batch_inline":
+                st = ctx.deskew_batch_f32(d_in, d_out, np.array([0, n], dtype=np.uint64), [params], None)
+            elif route == "batch_device_tables":  # 20 empty frames behind the real one: more than the kernel-argument tables hold
+                st = ctx.deskew_batch_f32(d_in, d_out, np.array([0] + [n] * 21, dtype=np.uint64), [params] + [ident] * 20, None)
+            else:
+                st = ctx.deskew_frames_f32(ctx.prepare_frames([(d_in, d_out)], [params]))
+            torch.cuda.synchronize()
+            assert st.n_launches == 1
+            assert np.array_equal(d_out.cpu().numpy().view(np.uint32), base.view(np.uint32)), route
     finally:
         ctx.force_tier(-1)
-        ctx.set_launch_config(0, 0)
 
 
 @pytest.mark.parametrize("theta", [3.3, 5.0, 9.0])
@@ -371,8 +380,7 @@ def test_batch_vs_per_frame_oracle_and_bit_exact_indices(torch_mod, ctx, kitti, 
     xyzi, offsets, params, ref = _batch_case(kitti, sizes, steps)
     n = xyzi.shape[0]
     want_idx = (np.searchsorted(offsets, np.arange(n, dtype=np.uint64), side="right") - 1).astype(np.uint32)
-    for bpc, ppt in ((0, 1), (0, 4), (0, 8), (1, 1), (2, 2)):  # bpc > 0: persistent grid-stride workgroups
-        ctx.set_launch_config(bpc, ppt)
+    if True:
         # device-resident
         d_in = torch.from_numpy(xyzi).cuda()
         d_out = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")  # 64 guard rows behind the batch
@@ -392,7 +400,6 @@ def test_batch_vs_per_frame_oracle_and_bit_exact_indices(torch_mod, ctx, kitti, 
         out = np.empty_like(xyzi)
         ctx.deskew_batch_f32(xyzi, out, offsets, params, None)
         assert np.array_equal(out.view(np.uint32), got.view(np.uint32))
-    ctx.set_launch_config(0, 0)
 
 
 def test_batch_soak_many_random_frames(torch_mod, ctx, kitti):
@@ -752,10 +759,10 @@ def test_beyond_4GiB_buffers_use_64bit_indexing(torch_mod, ctx):
         assert int(d_idx[pos].item()) == want, pos
 
 
-def test_beyond_2_32_work_items_the_tile_loop_takes_over(torch_mod, ctx):
+def test_beyond_2_32_work_items_a_second_launch_takes_over(torch_mod, ctx):
     """2^32 + 64 017 points = 68.7 GB per buffer (MI355X holds 288 GB): more 64-point tiles than a dispatch can carry workgroups
     (the packet's grid is 32 bits of work-items; the runtime wraps a larger grid modulo 2^32 and reports success,
-    tools/grid_probe.hip), so the library cuts the grid below the limit and the kernels' tile loops run a second pass.  Single-frame
+    tools/grid_probe.hip), so the library cuts the work into launches of at most 2^26 - 1 tiles, each told its first tile.  Single-frame
     and batched kernels; checked on slices at the start, either side of the 2^32-work-item mark and at the end."""
     torch = torch_mod
     n = (1 << 32) + 64_017
@@ -772,7 +779,7 @@ def test_beyond_2_32_work_items_the_tile_loop_takes_over(torch_mod, ctx):
     st = ctx.deskew_f32(d_in, d_out, params)
     torch.cuda.synchronize()
     assert st.n_points == n
-    mark = ((1 << 32) // 64) * 64  # first point of the first tile of the second pass
+    mark = ((0xFFFFFFFF // 64) * 64)  # first point of the first tile of the second launch
 
     def check(out):
         for lo in (0, mark - 50_000, mark + 64 * 1000 - 50_000, n - 100_000):
@@ -893,7 +900,6 @@ def test_batch_frame_index_fuzz(torch_mod, ctx):
             continue
         d_out = torch.full((n + 64, 4), 7.0, dtype=torch.float32, device="cuda")
         d_idx = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
-        ctx.set_launch_config(int(rng.integers(0, 3)), int(rng.choice([1, 2, 4])))
         ctx.deskew_batch_f32(pool[:n], d_out, offsets, [ident] * n_frames, d_idx)
         torch.cuda.synchronize()
         want = (np.searchsorted(offsets, np.arange(n, dtype=np.uint64), side="right") - 1).astype(np.int32)
@@ -901,7 +907,6 @@ def test_batch_frame_index_fuzz(torch_mod, ctx):
         assert np.array_equal(got, want), (case, n_frames, int(np.flatnonzero(got != want)[0]))
         assert torch.equal(d_out[:n], pool[:n]), case
         assert bool((d_out[n:] == 7.0).all()) and bool((d_idx[n:] == -1).all()), case
-    ctx.set_launch_config(0, 0)
 
 
 def test_single_frame_entry_point_is_graph_capturable(ctx, torch_mod):
@@ -942,16 +947,13 @@ def test_single_frame_entry_point_is_graph_capturable(ctx, torch_mod):
 def test_small_batches_travel_in_kernel_arguments_same_bits(torch_mod, ctx, monkeypatch):
     """Round 3: batches of at most 16 device-resident frames carry their tables in the kernel arguments (no table upload, no host
     wait).  Same kernel body, same records -> the SAME bits and the same per-point frame indices as the device-table route,
-    which a second context created with KMC_NO_INLINE_TABLES=1 still takes -- for ragged, empty, tile-straddling and huge frames
-    (the inline coarse table grows its chunk size with the batch) and for every tier."""
+    which the same frames take when 17 empty frames are appended to the batch (more than the kernel arguments hold) -- for ragged,
+    empty, tile-straddling and huge frames (the inline coarse table grows its chunk size with the batch) and for every tier."""
     torch = torch_mod
     rng = np.random.default_rng(77)
-    monkeypatch.setenv("KMC_NO_INLINE_TABLES", "1")
-    table_ctx = capi.Context(0)
-    monkeypatch.delenv("KMC_NO_INLINE_TABLES")
+    ident = capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5)
     try:
-        for c in (ctx, table_ctx):
-            c.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         pool = torch.empty((6_000_000, 4), dtype=torch.float32, device="cuda")
         ctx.synth_points(pool, pool.shape[0], 4242)
         for case in range(40):
@@ -967,10 +969,12 @@ def test_small_batches_travel_in_kernel_arguments_same_bits(torch_mod, ctx, monk
             params = [capi.FrameParams.make([1.0 + 0.1 * f, 0.02, -0.01, 0.001 * f, -0.002, yaw * (1 - 0.02 * f)], float(rng.uniform(0, 1))) for f in range(nf)]
             shift = int(rng.integers(0, 64))  # any 16-byte offset of the sub-range
             outs, idxs, sts = [], [], []
-            for c in (ctx, table_ctx):
+            for padded in (False, True):
                 d_out = torch.full((n + 128, 4), 7.0, dtype=torch.float32, device="cuda")
                 d_idx = torch.full((n + 128,), -1, dtype=torch.int32, device="cuda")
-                sts.append(c.deskew_batch_f32(pool[shift:shift + n], d_out[shift:shift + n], offsets, params, d_idx[shift:shift + n]))
+                offs = np.concatenate([offsets, np.full(17, n, dtype=np.uint64)]) if padded else offsets
+                prms = params + [ident] * 17 if padded else params
+                sts.append(ctx.deskew_batch_f32(pool[shift:shift + n], d_out[shift:shift + n], offs, prms, d_idx[shift:shift + n]))
                 outs.append(d_out)
                 idxs.append(d_idx)
             torch.cuda.synchronize()
@@ -981,7 +985,7 @@ def test_small_batches_travel_in_kernel_arguments_same_bits(torch_mod, ctx, monk
             assert np.array_equal(idxs[0][shift:shift + n].cpu().numpy(), want), case
             assert bool((outs[0][:shift] == 7.0).all()) and bool((outs[0][shift + n:] == 7.0).all()), case
     finally:
-        table_ctx.close()
+        ctx.force_tier(-1)
 
 
 def test_batched_entry_point_is_graph_capturable(ctx, torch_mod):

@@ -1,0 +1,90 @@
+// copy_ceiling.hip -- the memory system's own ceilings next to the deskew kernels, and the calibration kernel of the PMC traffic figures.
+//   copy_ceiling [n_points=67108864] [rounds=5] [iters=10]          (CSV on stdout: kernel, best / median us per launch, GB/s)
+//   copy_points   one v4f per lane in, one out, 256-thread workgroups, nt loads + nt stores: 16 B read + 16 B written per point.  Its
+//                 FETCH_SIZE / WRITE_SIZE counts against its KNOWN traffic give the correction factors tools/summarize_profiles.py applies
+//                 to the bench kernel's counters (gfx950: FETCH_SIZE counts half of a wide coalesced stream; MI355X_MICROARCH.md, HBM section)
+//   copy_tiles    the product kernels' access pattern without their arithmetic: one 64-point tile per one-wave workgroup, nt load,
+//                 nt + sc1 store through a buffer descriptor
+//   read_points / write_points   one direction alone (7.06 / 6.72 TB/s on the round-3 boxes: the deskew kernels sit on their mean)
+// Rounds 1-3's A/B harnesses (kmc_tune.hip, kmc_tune_r3.hip: persistent grids, 2 / 4 / 8 points per lane, cache policies, XCD mappings,
+// ocml trigonometry, the LDS-staged N-knot kernel) instantiated kernel variants that left the product headers in round 4; their sources
+// are in the repository's history (last present at commit 3470e8d), their tables under profiles/r0[123]_tune*.csv.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                         \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      std::exit(2);                                                                      \
+    }                                                                                    \
+  } while (0)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void copy_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+__global__ __launch_bounds__(64) void copy_tiles(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  const uint64_t base = (uint64_t)blockIdx.x * 64, i = base + threadIdx.x;
+  const v4f p = __builtin_nontemporal_load(in + (i < n ? i : n - 1));
+  const uint64_t bytes = (n - base) * 16;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(out + base), 0, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, p), r, threadIdx.x * 16u, 0, 2 | 16);
+}
+__global__ __launch_bounds__(64) void read_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const v4f p = __builtin_nontemporal_load(in + (i < n ? i : n - 1));
+  if (p.x == 12345.678f && p.y == -1.0f) out[0] = p;  // never true for the data below: the load cannot be dropped
+}
+__global__ __launch_bounds__(64) void write_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i < n) __builtin_nontemporal_store(v4f{1.0f, 2.0f, 3.0f, (float)threadIdx.x}, out + i);
+}
+
+int main(int argc, char** argv) {
+  const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 67108864ull;
+  const int rounds = argc > 2 ? std::atoi(argv[2]) : 5, iters = argc > 3 ? std::atoi(argv[3]) : 10;
+  CHECK(hipSetDevice(0));
+  hipStream_t s;
+  CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  const int kBufs = 3;  // rotating pairs: 3 x 2 GiB at the default size, far beyond the 256 MiB Infinity Cache
+  v4f *in[kBufs], *out[kBufs];
+  for (int b = 0; b < kBufs; ++b) {
+    CHECK(hipMalloc(&in[b], n * 16));
+    CHECK(hipMalloc(&out[b], n * 16));
+    CHECK(hipMemsetAsync(in[b], 0x3C, n * 16, s));
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  struct K { const char* name; void (*fn)(const v4f*, v4f*, uint64_t); int block; double bytes_per_point; };
+  const K ks[] = {{"copy_points", copy_points, 256, 32.0}, {"copy_tiles", copy_tiles, 64, 32.0}, {"read_points", read_points, 64, 16.0}, {"write_points", write_points, 64, 16.0}};
+  std::vector<std::vector<double>> us(4);
+  for (int r = 0; r < rounds; ++r)
+    for (int k = 0; k < 4; ++k) {  // interleaved: every kernel sees every clock state
+      const dim3 grid((unsigned)((n + ks[k].block - 1) / ks[k].block)), block(ks[k].block);
+      for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(ks[k].fn, grid, block, 0, s, in[w % kBufs], out[w % kBufs], n);
+      CHECK(hipEventRecord(e0, s));
+      for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(ks[k].fn, grid, block, 0, s, in[it % kBufs], out[it % kBufs], n);
+      CHECK(hipEventRecord(e1, s));
+      CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      us[k].push_back(ms * 1e3 / iters);
+    }
+  std::printf("kernel,points,best_us,median_us,GBps_best,GBps_median\n");
+  for (int k = 0; k < 4; ++k) {
+    std::sort(us[k].begin(), us[k].end());
+    const double best = us[k].front(), med = us[k][us[k].size() / 2];
+    std::printf("%s,%llu,%.2f,%.2f,%.1f,%.1f\n", ks[k].name, (unsigned long long)n, best, med, ks[k].bytes_per_point * n / best / 1e3, ks[k].bytes_per_point * n / med / 1e3);
+  }
+  return 0;
+}

@@ -14,11 +14,10 @@ run() { echo "== $*" >&2; "$@"; }
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o bench -- python bench.py --no-cpu-baseline --no-live-traffic --no-configs3 --no-legs --sustained-seconds 0 > "$O/bench_kt.log" 2>&1
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-configs3 --no-legs --sustained-seconds 0 > "$O/bench_fetch.log" 2>&1
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-configs3 --no-legs --sustained-seconds 0 > "$O/bench_write.log" 2>&1
-run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/cal_fetch" -o tune -- kitti_motion_compensation_amd/lib/kmc_tune 67108864 1 1 > "$O/cal_fetch.csv" 2>/dev/null
-run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/cal_write" -o tune -- kitti_motion_compensation_amd/lib/kmc_tune 67108864 1 1 > "$O/cal_write.csv" 2>/dev/null
-run kitti_motion_compensation_amd/lib/kmc_tune 67108864 5 10 > "$O/tune.csv" 2> "$O/tune.err"
+run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/cal_fetch" -o tune -- kitti_motion_compensation_amd/lib/copy_ceiling 67108864 1 1 > "$O/cal_fetch.csv" 2>/dev/null
+run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/cal_write" -o tune -- kitti_motion_compensation_amd/lib/copy_ceiling 67108864 1 1 > "$O/cal_write.csv" 2>/dev/null
+run kitti_motion_compensation_amd/lib/copy_ceiling 67108864 5 10 > "$O/ceilings.csv" 2> "$O/ceilings.err"
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_legs" -o legs -- python bench.py --legs-only --no-cpu-baseline > "$O/legs_kt.log" 2>&1
-run kitti_motion_compensation_amd/lib/kmc_tune_r3 67108864 5 10 > "$O/tune_r3.csv" 2> "$O/tune_r3.err"
 python bench.py > "$O/bench_plain.json" 2> "$O/bench_plain.err"
 tail -1 "$O/bench_plain.json" | cut -c1-200
 grep -h "deskew_batch_f32" "$O"/kt/bench_kernel_stats.csv | cut -c1-60,200-320

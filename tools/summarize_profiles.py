@@ -8,7 +8,7 @@ Inputs expected in the session directory (see profiles/README.md for the exact g
   kt/bench_kernel_stats.csv                rocprofv3 --kernel-trace --stats            -- python bench.py
   pmc_fetch/bench_counter_collection.csv   rocprofv3 --pmc FETCH_SIZE                  -- python bench.py --steps 4 --warmup 1
   pmc_write/bench_counter_collection.csv   rocprofv3 --pmc WRITE_SIZE                  -- python bench.py --steps 4 --warmup 1
-  cal_fetch/, cal_write/                   the same two counters on tools/kmc_tune (copy kernel of known byte count)
+  cal_fetch/, cal_write/                   the same two counters on tools/copy_ceiling (copy kernel of known byte count)
 
 HBM-byte derivation (MI355X_MICROARCH.md section HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 exactly 1/2 of the bytes of a wide coalesced stream, WRITE_SIZE must be calibrated -- both factors are re-derived here from
@@ -36,7 +36,7 @@ def main():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(src, "kt", "bench_kernel_stats.csv"), os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
-    for extra_src, extra_dst in (("kt_legs/legs_kernel_stats.csv", f"{tag}_legs_kernel_stats.csv"), ("tune_r3.csv", f"{tag}_tune_traj.csv"),
+    for extra_src, extra_dst in (("kt_legs/legs_kernel_stats.csv", f"{tag}_legs_kernel_stats.csv"), ("ceilings.csv", f"{tag}_ceilings.csv"),
                                  ("legs_kt.log", f"{tag}_legs_profiled_run.json")):
         if os.path.exists(os.path.join(src, extra_src)):
             if extra_src.endswith(".log"):  # the legs' own JSON line of the profiled run (HIP-event figures next to the profiler's)
@@ -59,8 +59,8 @@ def main():
         raise KeyError(frag)
 
     known_kib = 67108864 * 16 / 1024.0
-    fetch_factor = known_kib / pick(cal_f, "copy_points<1, 3>")
-    write_factor = known_kib / pick(cal_w, "copy_points<1, 3>")
+    fetch_factor = known_kib / pick(cal_f, "copy_points")
+    write_factor = known_kib / pick(cal_w, "copy_points")
 
     f = counters(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"), "FETCH_SIZE")
     w = counters(os.path.join(src, "pmc_write", "bench_counter_collection.csv"), "WRITE_SIZE")
@@ -85,7 +85,7 @@ def main():
         "WRITE_SIZE_KiB_raw": write_kib,
         "fetch_correction_factor": fetch_factor,
         "write_correction_factor": write_factor,
-        "calibration": "kmc_dev::copy_points<1,3> over 67108864 points (1 GiB read + 1 GiB written), same 16 B/lane nt access pattern",
+        "calibration": "tools/copy_ceiling.hip copy_points over 67108864 points (1 GiB read + 1 GiB written), same 16 B/lane nt access pattern",
         "hbm_bytes_per_launch": hbm_bytes,
         "hbm_bytes_per_point": hbm_bytes / points,
         "traffic_over_algorithmic": hbm_bytes / (32.0 * points),
