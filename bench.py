@@ -303,7 +303,8 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         "in_order": stream_leg(fs, "per_call", n, "ONE kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream; frames that share no buffer with one in flight "
                                "go out without the barrier bit where kmc_hip_create's probe verified it (any_order_dispatch_verdict == 1)"),
         "in_order_drained": stream_leg(fs, "per_call_drained", n, "the same calls on a context created with KMC_ANY_ORDER=0: every dispatch waits for the last wave of the one before it"),
-        "four_frame_queues": stream_leg(fs, "per_call_4_queues", n, "the same calls with kmc_hip_set_frame_queues(ctx, 4): round-robin over four HIP streams of the context"),
+        "gathered_calls": stream_leg(fs, "per_call_gathered", n, "the same calls, one per frame, with kmc_hip_set_frame_queues(ctx, 4): the library gathers them on the host and issues "
+                                     "ONE launch of the frame-list kernel per up to 16 frames (deferred issue, in-order results)"),
         "list_one_launch": stream_leg(fs, "list_one_launch", n, "kmc_hip_deskew_frames_f32: the 256 separate frames handed over as ONE list -> one launch of the frame-list kernel "
                                       "(2-D grid: frame x tile); bit-identical to the per-call outputs (checked by the tool: list_equals_per_call_bitwise)"),
         "batch_packed": stream_leg(fs, "batch_packed", n, "the same frames packed into one buffer, kmc_hip_deskew_batch_f32 (the headline's kernel): the ceiling for this frame mix"),
@@ -376,10 +377,11 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         "mean_points_per_frame": npts, "any_order_dispatch_verdict": fd["any_order_dispatch"],
         "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream"),
         "per_call_drained": stream_leg(fd, "per_call_drained", npts, "KMC_ANY_ORDER=0: the barrier bit on every dispatch"),
-        "per_call_4_queues": stream_leg(fd, "per_call_4_queues", npts, "kmc_hip_set_frame_queues(ctx, 4)"),
+        "per_call_gathered": stream_leg(fd, "per_call_gathered", npts, "the same calls with kmc_hip_set_frame_queues(ctx, 4): gathered on the host, one list launch per up to 16 frames"),
         "list_one_launch": stream_leg(fd, "list_one_launch", npts, "kmc_hip_deskew_frames_f32: the 108 separate frames as one list, ONE launch (device tables: one small upload per call)"),
         "batch_packed": stream_leg(fd, "batch_packed", npts, "the same frames packed into one buffer, one batched launch"),
         "per_call_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call"]["us_per_frame"], 3),
+        "gathered_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call_gathered"]["us_per_frame"], 3),
         "list_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["list_one_launch"]["us_per_frame"], 3),
         "list_equals_per_call_bitwise": fd["list_equals_per_call_bitwise"],
     }
@@ -415,17 +417,13 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     ao_before = ctx.any_order_launches()
     ms = timed(traj, 120, 12)
     ao_share = (ctx.any_order_launches() - ao_before) / 132
-    ctx.set_frame_queues(4)  # short trajectories carry their records in the kernel arguments: the calls may overlap like two-pose frames
-    ms_q4 = timed(traj, 120, 12)
-    ctx.set_frame_queues(1)
     ctx.synchronize()
     ctx.set_stream(caller_stream)
     leg = {"workload": "north_star's three bracketing poses used directly (piecewise geodesic, 2 segments): one synthetic 10 M-point frame per kmc_hip_deskew_traj_f32 call, 3 rotating buffer pairs",
            "kernel": "kmc_dev::deskew_traj_f32<series3, nt loads + nt|sc1 stores, inline records> (no LDS: records through scalar loads)",
            "us_per_frame": round(ms * 1e3, 2), "Mpts_s": round(n / ms / 1e3, 1), "GBps": round(32 * n / ms / 1e6, 1), "frac": _frac(32 * n / ms / 1e6),
            "dispatched_without_barrier_bit": round(ao_share, 3),
-           "note": "call to call on one stream: the kernel itself (rocprofv3 row in profiles/) plus the drain / launch gap between two frames (three rotating buffer pairs: two of three frames go out without the barrier bit)",
-           "four_frame_queues": {"us_per_frame": round(ms_q4 * 1e3, 2), "GBps": round(32 * n / ms_q4 / 1e6, 1), "frac": _frac(32 * n / ms_q4 / 1e6)}}
+           "note": "call to call on one stream: the kernel itself (rocprofv3 row in profiles/) plus the drain / launch gap between two frames (three rotating buffer pairs: two of three frames go out without the barrier bit)"}
     if check:
         sel = slice(4_950_000, 5_050_000)  # around mid-scan: both segments
         a, b = bufs[(state["k"] - 1) % 3]

@@ -195,49 +195,52 @@ int kmc_frame_ranges_balanced(const uint64_t* frame_points, uint32_t n_frames, u
 int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint64_t n,
                        const kmc_frame_params* params, int mem_kind, kmc_stats* out_stats);
 
-/* ---- a stream of SEPARATE frames (BASELINE.json configs[1] literally: one 1 M-point frame per call) --------------------------
- * On one HIP stream every launch waits for the last wave of the launch before it, so between two frames the chip drains and
- * refills: 6.9 us per 1 M-point frame = 4.6 TB/s where the kernel alone sustains 6.8.  The frames of this path are independent
- * (motion_compensation.cpp:22-25 reads nothing a previous frame wrote), so they may overlap: with frame queues on,
- * device-resident kmc_hip_deskew_f32 calls are issued round-robin over `queues` HIP streams (hardware queues) of the context --
- * measured 5.1-5.2 us per 1 M-point frame = 6.2 TB/s with four queues (tools/stream_probe.hip; profiles/r02_stream_probe.jsonl).
- *   - queues = 1 (default): every call on the context's stream, in order.  Since ABI version 3 "in order" no longer means "drained":
- *     a device-resident frame whose buffers overlap none of the frames launched since the last ordinary launch is dispatched WITHOUT
- *     the barrier bit (hipExtAnyOrderLaunch): the packet processor does not wait for the completion and the cache release of the
- *     frame before it (it does not run whole kernels of one queue side by side either: four queues stay ahead) -- the results of every frame,
- *     and everything the context or the caller puts on the stream afterwards (copies, events, other kernels: ordinary packets, which
- *     wait for all of them), are the same as before.  This needs no queues and no events; it applies (a) on the context's own
- *     stream, (b) on a caller's stream after kmc_hip_set_frame_queue_order(ctx, 0), (c) between the frames of one
- *     kmc_hip_deskew_frames_f32 call; at most 32 frames go out between two ordinary launches.  CONTRACT: the flag is documented as
- *     unsupported on gfx9, so the library does not take it on trust -- kmc_hip_create runs a probe (< 1 ms, once per device and process)
- *     that must SEE, on this device and runtime, an ordinary kernel, a device-to-host copy and an event behind barrier-free kernels
- *     wait for all of them and read every word they stored (from every XCD); only then is the feature on
- *     (kmc_device_info.any_order_dispatch == 1), otherwise every launch is an ordinary one.  KMC_ANY_ORDER=0 switches it off unprobed.
- *     Measured (tools/anyorder_probe.hip, bench.py's configs1_literal leg): 7.0 -> 6.3 us per 1 M-point frame; never on HIP's legacy
- *     default stream (handle NULL) and never while the stream captures a graph.
- *   - queues = 2..4: consecutive kmc_hip_deskew_f32(KMC_MEM_DEVICE) calls -- and kmc_hip_deskew_traj_f32(KMC_MEM_DEVICE) calls with
- *     at most four knots -- are NOT ordered with each other.  EVERY queued frame is ordered behind what has been issued on
- *     the context's stream up to its call -- its producers --, so the usual loop "produce frame k on the stream, deskew it" is safe
- *     (the library looks at the stream at every call: an idle stream needs no wait, a busy one gets an event record + a device-side
- *     wait, which costs about as much as the overlap gains -- hand frames that are ready to kmc_hip_deskew_frames_f32 instead);
- *     what is NOT ordered is later work on the context's stream against frames still in flight: a producer that OVERWRITES a buffer
- *     a queued frame reads or writes must follow a join.  kmc_hip_frame_queue_join() makes the context's stream wait for every
- *     frame issued so far (device-side, the host does not block).  Every other entry point, kmc_hip_synchronize(),
- *     kmc_hip_timer_end() and kmc_hip_set_stream() join first, so anything issued after the frames sees their results.  With
- *     kmc_hip_enable_timing() on, calls stay on the context's stream (per-call times need order).
- *   - kmc_hip_set_frame_queue_order(ctx, 0): only the FIRST frame after a join waits for the context's stream (round 2's behaviour:
- *     saves one event record + wait per frame); for callers whose frames are all produced before the first call. */
+/* ---- a stream of SEPARATE frames (the reference's calling pattern, handlers.cpp:55-64: one frame per call) ----------------------
+ * One launch per frame is bound by the launch, not by HBM: the host pays 2.5-5 us per launch and the chip drains and refills between
+ * two launches -- 6.1-7.0 us call to call for a 1 M-point frame whose kernel takes 4.7, 2.4-5 us for a KITTI frame whose kernel takes
+ * 0.6.  The frames of this path are independent (motion_compensation.cpp:22-25 reads nothing a previous frame wrote).  Three ways out:
+ *   (1) hand a LIST of ready frames to kmc_hip_deskew_frames_f32: one launch of the frame-list kernel for all of them (84 % of the HBM
+ *       peak on 1 M-point frames, 0.66 us per KITTI frame);
+ *   (2) kmc_hip_set_frame_queues(ctx, q > 1): keep calling kmc_hip_deskew_f32(KMC_MEM_DEVICE) once per frame and let the library GATHER
+ *       the calls -- a call only adds its frame to a pending list (~0.1 us); the list goes out as ONE launch of the same frame-list
+ *       kernel when it holds 16 frames, when the context's stream has run dry (looked at for the first frame and then every fourth:
+ *       an idle device is not kept waiting, a busy one gathers while it works), before a frame that touches a pending frame's buffers
+ *       or needs another coefficient tier (so the frames' results are those of in-order execution, bit for bit), and before anything
+ *       else the context puts on its stream -- every other entry point, kmc_hip_synchronize(), kmc_hip_timer_end(),
+ *       kmc_hip_set_stream() and kmc_hip_frame_queue_join() issue the pending frames first.  What changes for the caller: a frame's
+ *       launch may be DEFERRED until one of those calls.  Work the caller itself puts on the stream (or a hipDeviceSynchronize) does
+ *       not see a pending frame: call kmc_hip_frame_queue_join() (or kmc_hip_synchronize) before consuming results outside the
+ *       library.  (Until ABI 3 `queues` was a number of HIP streams the frames were spread over; the streams are gone, any value
+ *       2..4 switches gathering on.)  With kmc_hip_enable_timing() on, calls are launched one by one (per-call times need it).
+ *   (3) queues = 1 (default): every call is launched at once, in order on the context's stream.  Since ABI 3 "in order" does not
+ *       mean "drained": a device-resident frame whose buffers overlap none of the frames launched since the last ordinary launch is
+ *       dispatched WITHOUT the AQL barrier bit (hipExtAnyOrderLaunch): the packet processor does not wait for the completion and the
+ *       cache release of the frame before it (it does not run whole kernels of one queue side by side either) -- the results of every
+ *       frame, and everything the context or the caller puts on the stream afterwards (copies, events, other kernels: ordinary
+ *       packets, which wait for all of them), are the same as before.  It applies (a) on the context's own stream, (b) on a caller's
+ *       stream after kmc_hip_set_frame_queue_order(ctx, 0) -- the caller's word that nothing is produced between two calls --, never
+ *       on HIP's legacy default stream (handle NULL), never while the stream captures a graph; at most 32 frames go out between two
+ *       ordinary launches.  CONTRACT: the flag is documented as unsupported on gfx9, so the library does not take it on trust --
+ *       kmc_hip_create runs a probe (< 1 ms, once per device and process) that must SEE, on this device and runtime, an ordinary
+ *       kernel, a device-to-host copy and an event behind barrier-free kernels wait for all of them and read every word they stored
+ *       (from every XCD); only then is the feature on (kmc_device_info.any_order_dispatch == 1), otherwise every launch is an
+ *       ordinary one.  KMC_ANY_ORDER=0 switches it off unprobed.  Measured (bench.py's configs1_literal leg): 7.0 -> 6.1 us per
+ *       1 M-point frame.
+ * kmc_hip_set_frame_queue_order(ctx, after_producers): what the library may assume about a CALLER's stream (kmc_hip_set_stream) --
+ * 1 (default): the caller may have put a producer of the next frame on the stream since the last call; 0: every frame was produced
+ * before the first call.  Only (3)'s barrier-free dispatch on a caller's stream depends on it. */
 int kmc_hip_set_frame_queues(kmc_ctx* ctx, int queues);
 int kmc_hip_set_frame_queue_order(kmc_ctx* ctx, int after_producers);
 int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 /* How many frames of this context have been dispatched without the barrier bit so far (a counter for tests and tuning). */
 uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
- * (HOST arrays of device pointers / sizes / params).  Issued over the frame queues -- the count the caller chose with
- * kmc_hip_set_frame_queues (1 = in order on the context's stream); if it never chose: four for a list of at least 64 frames of
- * 400 k points or more on average (the fork and the join cost ~45 us of barrier packets), else one -- and joined: the
- * call as a whole is ordered on the context's stream like any other, all its frames behind everything issued before it (ONE fork for
- * the whole call: every input was handed over before the call).  Same per-point results as kmc_hip_deskew_f32. */
+ * (HOST arrays of device pointers / sizes / params), each frame in its own buffer (any 16-byte-aligned addresses).  ONE launch of the
+ * frame-list kernel (2-D grid: frame x tile) on the context's stream; lists of at most 16 frames carry their records in the kernel
+ * arguments (the call only enqueues a launch and can be captured into a HIP graph), longer ones upload one small table.  Per-point results
+ * are bit-identical to kmc_hip_deskew_f32 on the same frame at the same tier (the list runs its widest frame's tier).  The frames must
+ * be independent of each other (in == out of ONE frame is fine): a list in which one frame's output overlaps another frame's input or
+ * output is recognised and issued frame by frame, in order, instead. */
 int kmc_hip_deskew_frames_f32(kmc_ctx* ctx, const float* const* xyzi_in, float* const* xyzi_out, const uint64_t* n_points,
                               const kmc_frame_params* params, uint32_t n_frames, kmc_stats* out_stats);
 

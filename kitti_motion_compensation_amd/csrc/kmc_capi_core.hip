@@ -69,50 +69,16 @@ int ensure_pipeline(kmc_ctx* c) {
   return KMC_OK;
 }
 
-int fq_stream(kmc_ctx* c, hipStream_t* out) {
-  if (c->fq_count <= 1) {
-    *out = c->stream;
-    return KMC_OK;
-  }
-  if (!c->fq_forked) {
-    for (int q = 0; q < c->fq_count; ++q) c->fq_used[q] = false;
-    c->fq_forked = true;
-    c->fq_next = 0;
-  }
-  const int q = c->fq_next;
-  c->fq_next = (q + 1) % c->fq_count;
-  // EVERY queued frame is ordered behind what the caller has issued on `stream` up to this call -- its producers (with
-  // the fork recorded only for the first frame after a join, the usual loop "produce frame k on the stream, deskew it" raced from
-  // the second frame on).  One event record and one device-side wait per frame; frames still overlap each other.  A caller whose
-  // frames are all produced before the first call may switch this off (kmc_hip_set_frame_queue_order).
-  // The wait is only needed while the caller's stream still has something in flight: an idle stream has no producer left to wait
-  // for, and a cross-stream event per frame is expensive (a barrier packet in the queue: 11.4 us per 1 M-point frame against 5.3).
-  bool fork = !c->fq_used[q] && !c->fq_ordered;  // relaxed mode: once per queue after a join
-  if (c->fq_ordered) {
-    const hipError_t busy = hipStreamQuery(c->stream);
-    if (busy != hipSuccess) {
-      (void)hipGetLastError();  // hipErrorNotReady (or a stream that cannot be queried, e.g. while capturing): order explicitly
-      fork = true;
-    }
-  }
-  if (fork) {
-    KMC_HIP_TRY(c, hipEventRecord(c->fq_fork, c->stream));
-    KMC_HIP_TRY(c, hipStreamWaitEvent(c->fq[q], c->fq_fork, 0));
-  }
-  c->fq_used[q] = true;
-  *out = c->fq[q];
-  return KMC_OK;
-}
-
 int fq_join(kmc_ctx* c) {
   c->ao_valid = false;  // whoever joins is about to put ordinary work on the stream: the any-order window ends here
-  if (!c->fq_forked) return KMC_OK;
-  for (int q = 0; q < c->fq_count; ++q) {
-    if (!c->fq_used[q]) continue;
-    KMC_HIP_TRY(c, hipEventRecord(c->fq_done[q], c->fq[q]));
-    KMC_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->fq_done[q], 0));
-  }
-  c->fq_forked = false;
+  if (c->gather_count == 0) return KMC_OK;
+  const dim3 grid((uint32_t)c->gather_tiles, c->gather_count, 1);
+  with_tier(c->gather_tier, [&](auto T) {
+    hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, true>), grid, dim3(kTile), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, *c->gather);
+  });
+  c->gather_count = 0;
+  c->gather_tiles = 0;
+  KMC_HIP_TRY(c, hipGetLastError());
   return KMC_OK;
 }
 
@@ -364,7 +330,6 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocPortable | hipHostMallocMapped);
   if (e == hipSuccess) *c->h_flag = 0;
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fq_fork, hipEventDisableTiming);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     kmc_hip_destroy(c);
@@ -392,13 +357,7 @@ void kmc_hip_destroy(kmc_ctx* c) {
     if (c->ev_kernel[b]) (void)hipEventDestroy(c->ev_kernel[b]);
     if (c->ev_d2h[b]) (void)hipEventDestroy(c->ev_d2h[b]);
   }
-  for (int q = 0; q < kmc_ctx::kMaxFrameQueues; ++q) {
-    if (c->fq[q]) { (void)hipStreamSynchronize(c->fq[q]); (void)hipStreamDestroy(c->fq[q]); }
-    if (c->fq_done[q]) (void)hipEventDestroy(c->fq_done[q]);
-  }
-  if (c->fq_fork) (void)hipEventDestroy(c->fq_fork);
-  for (auto& sp : c->fq_spacer)
-    if (sp) (void)hipStreamDestroy(sp);
+  delete c->gather;
   if (c->d_tmp) (void)hipFree(c->d_tmp);
   if (c->d_traj) (void)hipFree(c->d_traj);
   if (c->h_traj) (void)hipHostFree(c->h_traj);
@@ -455,24 +414,13 @@ int kmc_hip_synchronize(kmc_ctx* c) {
 
 int kmc_hip_set_frame_queues(kmc_ctx* c, int queues) {
   if (!c || queues < 1 || queues > kmc_ctx::kMaxFrameQueues) return KMC_ERR_INVALID_ARG;
-  KMC_ENTER(c);
-  if (queues > 1 && !c->fq[0]) {
-    // HIP multiplexes its streams onto a few hardware queues in creation order, and two streams that share one are serialised
-    // through barrier packets -- slower than a single stream.  Measured on MI355X / ROCm 7.2 (round 2's fq_probe, C and
-    // Python hosts): with the frame queues created right behind the context's own two streams a 1 M-point frame costs
-    // 5.6-7.8 us (erratic), with two idle streams created in between 5.1-5.2 us with four queues, every time.
-    constexpr int kSpacers = 2;
-    for (int k = 0; k < kSpacers; ++k) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->fq_spacer[k], hipStreamNonBlocking));
-  }
-  for (int q = 0; q < queues; ++q) {
-    if (queues > 1 && !c->fq[q]) {
-      KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->fq[q], hipStreamNonBlocking));
-      KMC_HIP_TRY(c, hipEventCreateWithFlags(&c->fq_done[q], hipEventDisableTiming));
-    }
+  KMC_ENTER(c);  // issues what is pending
+  if (queues > 1 && !c->gather) {
+    c->gather = new (std::nothrow) ListInline();
+    if (!c->gather) return KMC_ERR_ALLOC;
+    std::memset(c->gather, 0, sizeof(ListInline));
   }
   c->fq_count = queues;
-  c->fq_explicit = true;
-  c->fq_next = 0;
   return KMC_OK;
 }
 

@@ -204,6 +204,55 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
   }
   return bad ? KMC_ERR_TIME_OUT_OF_RANGE : KMC_OK;
 }
+// One more frame for the pending list (kmc_ctx::gather).  In-order semantics are kept: a frame that reads or writes a buffer a pending
+// frame writes, or writes one a pending frame reads, makes the pending frames go out first; so does a frame of another coefficient tier
+// (a launch runs ONE tier, and a frame's bits must not depend on its neighbours).  The list goes out when it is full, or -- looked at
+// for the first frame and then every fourth -- when the context's stream has run dry: a device that is idle is not kept waiting for
+// a fuller list, a busy one gathers while it works (the launches clock themselves).
+int gather_push(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params, kmc_stats* st) {
+  const int tier = pick_tier(c, params, 1);
+  const uintptr_t bytes = (uintptr_t)n * sizeof(v4f);
+  const kmc_ctx::AoRange r = {(uintptr_t)xyzi_in, (uintptr_t)xyzi_in + bytes}, w = {(uintptr_t)xyzi_out, (uintptr_t)xyzi_out + bytes};
+  bool flush_first = c->gather_count && tier != c->gather_tier;
+  for (uint32_t k = 0; !flush_first && k < c->gather_count; ++k) {
+    const kmc_ctx::AoRange &pr = c->gather_reads[k], &pw = c->gather_writes[k];
+    flush_first = (w.lo < pr.hi && pr.lo < w.hi) || (w.lo < pw.hi && pw.lo < w.hi) || (r.lo < pw.hi && pw.lo < r.hi);
+  }
+  uint32_t launches = 0;
+  if (flush_first) {
+    const int rc = fq_join(c);
+    if (rc != KMC_OK) return rc;
+    ++launches;
+  }
+  c->ao_valid = false;  // a pending frame is work the any-order window does not describe
+  const uint32_t k = c->gather_count++;
+  const uint32_t head = head_of(xyzi_out, KMC_MEM_DEVICE);
+  ListRec& rec = c->gather->recs[k];
+  std::memset(&rec, 0, sizeof(rec));
+  fill_rec(*params, &rec.f);
+  rec.f.pre2 = guard_pre2(*params);
+  fill_recd(*params, &c->gather->recs64[k]);
+  rec.in = (const v4f*)xyzi_in - head;
+  rec.out = (v4f*)xyzi_out - head;
+  rec.n = n + head;
+  rec.head = head;
+  c->gather_reads[k] = r;
+  c->gather_writes[k] = w;
+  c->gather_tier = tier;
+  c->gather_tiles = std::max<uint64_t>(c->gather_tiles, (n + head + kTile - 1) / kTile);
+  bool go = c->gather_count == (uint32_t)kmc_ctx::kGatherMax;
+  if (!go && (c->gather_count == 1 || (c->gather_count & 3u) == 0)) {
+    go = hipStreamQuery(c->stream) == hipSuccess;  // nothing in flight: issue what there is
+    (void)hipGetLastError();                       // (hipErrorNotReady is the expected answer of a busy stream)
+  }
+  if (go) {
+    const int rc = fq_join(c);
+    if (rc != KMC_OK) return rc;
+    ++launches;
+  }
+  if (st) { st->n_points = n; st->variant = (uint32_t)tier; st->n_launches = launches; }
+  return KMC_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -258,22 +307,17 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   CallTimer tm(c);
   if (mem_kind == KMC_MEM_DEVICE) {
-    // frame queues on (kmc_hip_set_frame_queues) and no per-call timing: the frame goes to the next queue and is NOT ordered
-    // with the frames before it -- they are independent -- until the next join
+    // gathering on (kmc_hip_set_frame_queues(ctx, q > 1)) and no per-call timing: the frame joins the pending list, which goes out as ONE
+    // launch of the frame-list kernel (gather_push)
+    if (c->fq_count > 1 && !c->timing && n && n <= kmc_ctx::kGatherMaxPoints) return gather_push(c, xyzi_in, xyzi_out, n, params, st);
     hipStream_t s = c->stream;
     bool any_order = false;
-    if (c->fq_count > 1 && !c->timing) {
-      c->ao_valid = false;
-      const int rc_q = fq_stream(c, &s);
-      if (rc_q != KMC_OK) return rc_q;
-    } else {
-      if (c->fq_forked || c->timing) {  // joins, event records: ordinary work on the stream, the any-order window ends
-        const int rc_j = fq_join(c);
-        if (rc_j != KMC_OK) return rc_j;
-      }
-      // in order on the context's stream -- but a frame that shares no buffer with the frames still in flight need not wait for them
-      if (n) any_order = ao_admit(c, xyzi_in, xyzi_out, n * sizeof(v4f), false);
+    if (c->gather_count || c->timing) {  // a list launch, event records: ordinary work on the stream, the any-order window ends
+      const int rc_j = fq_join(c);
+      if (rc_j != KMC_OK) return rc_j;
     }
+    // in order on the context's stream -- but a frame that shares no buffer with the frames still in flight need not wait for them
+    if (n) any_order = ao_admit(c, xyzi_in, xyzi_out, n * sizeof(v4f), false);
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     int tier = 0;
     uint32_t launches = 0;

@@ -168,14 +168,12 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (!(requested_time >= stamp_start && requested_time <= stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   const bool inline_records = mem_kind == KMC_MEM_DEVICE && th.n_seg <= (uint32_t)kInlineSegments;
-  const bool queued = inline_records && c->fq_count > 1 && !c->timing;  // goes to a frame queue: not ordered with the frames before it
   // in order on the context's stream, but -- like kmc_hip_deskew_f32 -- not behind frames it shares no buffer with (kmc_ctx::ao_valid)
-  const bool window = inline_records && !queued && !c->timing && !c->fq_forked && !bracket_idx_out && n;
-  if (!queued && !window) {
-    rc = fq_join(c);
+  const bool window = inline_records && !c->timing && c->gather_count == 0 && !bracket_idx_out && n;
+  if (!window) {
+    rc = fq_join(c);  // (also issues two-pose frames that are still being gathered: the N-knot kernel is launched per call)
     if (rc != KMC_OK) return rc;
   }
-  if (queued) c->ao_valid = false;
   const int tier = traj_tier(c, th, stamp_start, stamp_end);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;
@@ -199,16 +197,12 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
 
   if (inline_records) {
     // A short trajectory on device-resident points -- north_star's "three bracketing poses" -- carries its segment records in the
-    // kernel arguments: no table slot, no upload, nothing for the host to wait for.  Like kmc_hip_deskew_f32 the call may then go
-    // to a frame queue (kmc_hip_set_frame_queues).  Same records, same kernel body: same bits as the table path below.
+    // kernel arguments: no table slot, no upload, nothing for the host to wait for.  Same records, same kernel body: same bits as the
+    // table path below.
     TrajInline inl;
     std::memset(&inl, 0, sizeof(inl));
     fill_traj_segs(th, stamp_start, stamp_end, inl.s, inl.d);
     hipStream_t s = c->stream;
-    if (queued) {
-      rc = fq_stream(c, &s);
-      if (rc != KMC_OK) return rc;
-    }
     const v4f* d_in = (const v4f*)xyzi_in;
     v4f* d_out = (v4f*)xyzi_out;
     uint32_t* d_idx = bracket_idx_out;

@@ -83,25 +83,28 @@ struct kmc_ctx {
   bool traj_in_flight = false;
   void* d_tmp = nullptr; // grow-only scratch for the f64 / batch host paths
   size_t tmp_cap = 0;
-  // frame queues (kmc_hip_set_frame_queues): device-resident single-frame calls are issued round-robin over fq_count streams
-  // (hardware queues) so that consecutive, independent frames overlap instead of draining the chip between two launches
-  static constexpr int kMaxFrameQueues = 4;
-  int fq_count = 1;                  // 1 = off: every launch on `stream`
-  bool fq_explicit = false;          // the caller has chosen the count (kmc_hip_set_frame_queues), even if it chose 1
-  int fq_next = 0;
-  bool fq_forked = false;            // frames have been issued on the queues since the last join
-  bool fq_ordered = true;            // every queued frame waits for what `stream` holds at its call (kmc_hip_set_frame_queue_order)
-  hipStream_t fq[kMaxFrameQueues] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t fq_done[kMaxFrameQueues] = {nullptr, nullptr, nullptr, nullptr};
-  bool fq_used[kMaxFrameQueues] = {false, false, false, false};
-  hipEvent_t fq_fork = nullptr;      // "everything issued on `stream` so far", which the queues wait for
-  hipStream_t fq_spacer[2] = {};     // idle streams created before the queues (hardware-queue mapping, see kmc_hip_set_frame_queues)
+  // gathered frames (kmc_hip_set_frame_queues(ctx, q > 1)): device-resident single-frame calls are not launched one by one -- a launch
+  // costs the host 2.5-5 us and the device ~2 us of drain and refill, against 0.6 us of kernel for a KITTI frame -- but gathered on the
+  // host and issued as ONE launch of the frame-list kernel (kmc_kernels.hip.h) per up to kGatherMax frames, their records travelling in
+  // the kernel arguments.  Pending frames go out when the list is full, when the context's stream has run dry (checked every few
+  // frames), before a frame that touches a pending frame's buffers or needs another coefficient tier, and before anything else the
+  // context puts on its stream (fq_join, which every other entry point starts with).
+  static constexpr int kMaxFrameQueues = 4;              // the API's range of `queues`; any value > 1 switches gathering on
+  static constexpr int kGatherMax = kInlineListFrames;   // frames per list launch whose records fit the kernel-argument segment
+  static constexpr uint64_t kGatherMaxPoints = 1ull << 26;  // larger frames gain nothing from sharing a launch (and a 2-D grid holds 2^32 work-items)
+  struct AoRange { uintptr_t lo, hi; };
+  int fq_count = 1;                  // 1 = off: every call launches on `stream`
+  bool fq_ordered = true;            // kmc_hip_set_frame_queue_order: on a CALLER's stream, producers may sit between two calls
+  ListInline* gather = nullptr;      // the pending frames' records: the next list launch's kernel argument, filled in place
+  uint32_t gather_count = 0;
+  int gather_tier = 0;
+  uint64_t gather_tiles = 0;         // tiles of the largest pending frame = grid.x of the next list launch
+  AoRange gather_reads[kGatherMax], gather_writes[kGatherMax];
   // independent frames on ONE stream without the drain between them: a device-resident single-frame launch whose buffers overlap
   // nothing that was launched since (and including) the last ORDERED launch goes out with hipExtAnyOrderLaunch -- the dispatch packet
   // carries no barrier bit, the frame starts while the frame before it is still running.  Everything else the context puts on
   // its stream is an ordinary (barrier) packet and waits for all of them (tools/anyorder_probe.hip measures both facts).  Only on the
   // context's OWN stream: a caller's stream may hold producers the library does not see.
-  struct AoRange { uintptr_t lo, hi; };
   static constexpr int kAoWindow = 32;   // frames between two ordered launches at most
   bool ao_enabled = false;               // set by kmc_hip_create from the run-time probe's verdict (kmc_capi_core.hip); KMC_ANY_ORDER=0 turns it off
   int ao_verdict = 0;                    // kmc_device_info.any_order_dispatch
@@ -148,9 +151,8 @@ inline int tier_of_theta(double theta_max) {
 }
 int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n);
 
-// frame queues: fq_stream() hands out the stream of the next frame (forking from `stream` first if necessary), fq_join() makes
-// `stream` wait for every frame issued since the fork (device-side waits, the host does not block)
-int fq_stream(kmc_ctx* c, hipStream_t* out);
+// gathered frames: fq_join() issues whatever is pending as one list launch on `stream` (and ends the any-order window): what every entry
+// point that puts other work on the stream starts with; gather_push() adds a frame (kmc_capi_deskew.hip)
 int fq_join(kmc_ctx* c);
 
 // what every entry point that issues work on `stream` starts with

@@ -543,13 +543,15 @@ def test_f64cols_in_place_on_page_locked_containers_same_bits(ctx, kitti):
         rc, st = ctx.deskew_f64cols(pin.a[0], pin.a[1], pin.a[2], pin.a[3], pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], pout.a[3])
         assert rc == capi.OK and st.n_out_of_range == 0, "the flag word must be cleared between calls"
         # the call in two halves (what the C++ drop-in uses to fill the homogeneous column while the kernel runs): same bits, the
-        # verdict arrives with _end; a second _begin before the _end is refused; staged buffers complete inside _begin
+        # verdict arrives with _end; a second _begin on device-addressable buffers queues up behind the first (round 4), a plain call
+        # in between is refused; staged buffers complete inside _begin
         pout.a[:] = -7.0
         ctx.deskew_f64cols_begin(pin.a[0], pin.a[1], pin.a[2], None, pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], None)
+        ctx.deskew_f64cols_begin(pin.a[0], pin.a[1], pin.a[2], None, pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], None)
         with pytest.raises(capi.KmcError):
-            ctx.deskew_f64cols_begin(pin.a[0], pin.a[1], pin.a[2], None, pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], None)
+            ctx.deskew_f64cols(pin.a[0], pin.a[1], pin.a[2], pin.a[3], pst.a, T0, T1, params, pout.a[0], pout.a[1], pout.a[2], pout.a[3])
         rc, st = ctx.deskew_f64cols_end()
-        assert rc == capi.OK and st.n_points == n and st.n_out_of_range == 0
+        assert rc == capi.OK and st.n_points == 2 * n and st.n_launches == 2 and st.n_out_of_range == 0
         for j in range(3):
             assert np.array_equal(pout.a[j].view(np.uint64), staged[j].view(np.uint64)), j
         assert (pout.a[3] == -7.0).all(), "no w column asked for: the output's column is the caller's"
@@ -1096,9 +1098,9 @@ def test_device_buffers_at_any_16_byte_offset(ctx, torch_mod, kitti, shift_in, s
 
 # ---- frame queues: a stream of separate frames over several hardware queues -------------------------------------------
 def test_frame_queues_same_bits_and_ordering(torch_mod, ctx):
-    """kmc_hip_set_frame_queues / kmc_hip_deskew_frames_f32: consecutive independent frames are issued round-robin over 2-4 HIP
-    streams.  Same bits as the in-order path; a producer issued on the context's stream BEFORE the frames and a consumer issued
-    AFTER the join see the right data (fork / join through events, no host sync)."""
+    """kmc_hip_set_frame_queues(q > 1) / kmc_hip_deskew_frames_f32: consecutive single-frame calls are gathered on the host and issued
+    as list launches (until ABI 3: spread over 2-4 HIP streams; the contract is the same).  Same bits as the in-order path; a producer
+    issued on the context's stream BEFORE the frames and a consumer issued AFTER the join see the right data (no host sync)."""
     torch = torch_mod
     n, nf = 200_003, 24
     params = [capi.FrameParams.make([1.3, 0.05 * (f % 3), -0.02, 0.002, -0.004, 0.03 + 0.001 * f], (f % 5) / 4.0) for f in range(nf)]
@@ -1521,3 +1523,85 @@ def test_batch_on_page_locked_buffers_that_are_only_4_byte_aligned(torch_mod, ct
     st = ctx.deskew_batch_f32(off_in, off_out, offsets, params, None)
     assert st.n_points == n
     assert np.array_equal(off_out.view(np.uint32), aligned.view(np.uint32))
+
+
+def test_gathered_calls_keep_in_order_results(torch_mod, kitti):
+    """kmc_hip_set_frame_queues(ctx, q > 1): one kmc_hip_deskew_f32 call per frame, gathered by the library into launches of the
+    frame-list kernel (up to 16 frames each).  The RESULTS are those of in-order execution, bit for bit: frames that depend on each other
+    (a chain, the same buffer twice, an overwritten input), frames of different coefficient tiers, empty and ragged frames, outputs at
+    any 16-byte offset; whatever else the context puts on its stream afterwards sees every gathered frame; far fewer launches than
+    frames."""
+    torch = torch_mod
+    xyzi, _ = kitti
+    rng = np.random.default_rng(1616)
+    plain, g = capi.Context(0), capi.Context(0)  # both on their OWN streams
+    try:
+        g.set_frame_queues(4)
+        nf = 70
+        sizes = [int(v) for v in rng.choice([0, 1, 63, 64, 65, 1000, 4097, 30_000, 123_397], nf)]
+        big_in = torch.zeros((sum(sizes) + 80 * nf + 64, 4), dtype=torch.float32, device="cuda")
+        big_out = torch.zeros_like(big_in)
+        big_ref = torch.zeros_like(big_in)
+        ins, outs, refs, params = [], [], [], []
+        o = 0
+        for f, n in enumerate(sizes):
+            si, so = int(rng.integers(0, 64)), int(rng.integers(0, 64))
+            a = big_in[o + si:o + si + n]
+            a.copy_(torch.from_numpy(np.ascontiguousarray(xyzi[rng.integers(0, xyzi.shape[0], size=n)])))
+            ins.append(a); outs.append(big_out[o + so:o + so + n]); refs.append(big_ref[o + so:o + so + n])
+            yaw = [0.03, 0.03, 0.03, 0.6, 2.0][f % 5]  # mostly series3, some series5 / wide: tier changes inside the stream of calls
+            params.append(capi.FrameParams.make([1.0 + 0.01 * f, 0.02, -0.01, 0.001, -0.002, yaw], float(rng.uniform(0, 1))))
+            o += n + 80
+        torch.cuda.synchronize()
+        for f in range(nf):
+            plain.deskew_f32(ins[f], refs[f], params[f])
+        plain.synchronize()
+        launches = sum(g.deskew_f32(ins[f], outs[f], params[f]).n_launches for f in range(nf))
+        # anything else on the context's stream issues the pending frames first: an identity batch over the WHOLE output buffer
+        ident = capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5)
+        copy = torch.zeros_like(big_out)
+        g.deskew_batch_f32(big_out, copy, np.array([0, big_out.shape[0]], dtype=np.uint64), [ident], None)
+        g.synchronize()
+        assert torch.equal(copy.view(torch.int32), big_ref.view(torch.int32))
+        assert launches < nf // 2, (launches, nf)  # gathered: tier changes and the idle checks split the stream, not every frame
+        # a chain: frame k reads what frame k-1 wrote -- the library sees the overlap and issues the pending frame first
+        n = 50_003
+        bufs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(7)]
+        plain.synth_points(bufs[0], n, 99)
+        plain.synchronize()
+        ref = [bufs[0]]
+        for f in range(6):
+            w = torch.empty_like(bufs[0])
+            plain.deskew_f32(ref[-1], w, params[f])
+            ref.append(w)
+        plain.synchronize()
+        for f in range(6):
+            g.deskew_f32(bufs[f], bufs[f + 1], params[f])
+        g.frame_queue_join()
+        g.synchronize()
+        assert torch.equal(bufs[6].view(torch.int32), ref[6].view(torch.int32))
+        # the same buffer in place, three times; then an input overwritten by a later frame (write after read)
+        y = ref[0].clone()
+        torch.cuda.synchronize()
+        for f in range(3):
+            g.deskew_f32(y, y, params[f])
+        x_in, x_out = ref[0].clone(), torch.zeros_like(ref[0])
+        torch.cuda.synchronize()
+        g.deskew_f32(x_in, x_out, params[0])       # reads x_in
+        g.deskew_f32(ref[2], x_in, params[1])      # overwrites x_in: must not reach the device before the frame above has read it
+        g.synchronize()
+        assert torch.equal(y.view(torch.int32), ref[3].view(torch.int32))
+        assert torch.equal(x_out.view(torch.int32), ref[1].view(torch.int32))
+        want = torch.empty_like(ref[0])
+        plain.deskew_f32(ref[2], want, params[1])
+        plain.synchronize()
+        assert torch.equal(x_in.view(torch.int32), want.view(torch.int32))
+        # nothing stays pending behind a synchronize, and switching gathering off issues what is pending
+        z = torch.zeros_like(ref[0])
+        g.deskew_f32(ref[0], z, params[0])
+        g.set_frame_queues(1)
+        g.synchronize()
+        assert torch.equal(z.view(torch.int32), ref[1].view(torch.int32))
+    finally:
+        plain.close()
+        g.close()

@@ -47,7 +47,7 @@ def test_bench_prints_one_contract_line():
     assert su["windows"] >= 5 and su["Mpts_s_min"] <= su["Mpts_s_mean"] <= su["Mpts_s_max"] and su["Mpts_s_mean"] > 50_000
     # the secondary configurations as legs of the same line (round 3): time, GB/s, fraction of peak, kernel, oracle spot check
     lit = d["configs1_literal"]  # round 4: driven from C++ (tools/time_frame_stream.hip), separate allocations per frame
-    for k in ("in_order", "in_order_drained", "four_frame_queues", "list_one_launch", "batch_packed"):
+    for k in ("in_order", "in_order_drained", "gathered_calls", "list_one_launch", "batch_packed"):
         assert lit[k]["us_per_frame"] > 0 and 0.2 < lit[k]["frac"] < 1.0, (k, lit[k])
     assert lit["any_order_dispatch_verdict"] == 1 and lit["list_equals_per_call_bitwise"] is True
     assert lit["list_one_launch"]["frac"] > 0.70, lit["list_one_launch"]  # separate frames handed over as a list run as ONE launch: north_star's 70 % target
@@ -55,10 +55,11 @@ def test_bench_prints_one_contract_line():
     # (the three are short timed regions of ONE run: which is faster by how much is recorded under profiles/, not gated here -- a hiccup
     # of the box in one region must not fail the suite; what IS checked is that the barrier-free route was really taken)
     assert lit["in_order"]["dispatched_without_barrier_bit"] > 0.9
-    assert lit["four_frame_queues"]["us_per_frame"] < 2.0 * lit["in_order_drained"]["us_per_frame"]
+    assert lit["gathered_calls"]["frac"] > 0.70, lit["gathered_calls"]  # one call per frame, gathered by the library: north_star's 70 % target
     assert lit["parity"]["max_rel_err"] <= 1e-5
     fb = d["configs2_drive"]["frame_by_frame_from_c"]  # the reference's calling pattern on KITTI-sized frames, from C++
     assert fb["list_equals_per_call_bitwise"] is True and fb["per_call"]["us_per_frame"] > 0 and fb["list_rate_vs_batched"] > 0.5, fb
+    assert fb["gathered_rate_vs_batched"] > 0.25, fb  # KITTI-sized per-frame calls at >= 25 % of the batched rate, from C
     f64 = d["f64cols"]  # K launches between one event pair; the single-call figure beside it
     assert "back to back" in f64["timed_as"] and f64["single_call"]["us_per_call"] > 0
     dc = d["dropin_cpp"]  # the API north_star names, through the C++ library

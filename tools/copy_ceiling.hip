@@ -39,14 +39,25 @@ __global__ __launch_bounds__(64) void copy_tiles(const v4f* __restrict__ in, v4f
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(out + base), 0, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bytes, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, p), r, threadIdx.x * 16u, 0, 2 | 16);
 }
+// one direction alone: four points per lane, 256 points per wave (a wave that issues ONE load and retires is bound by the wave launch
+// rate -- ~4.7 waves per ns on MI355X -- not by HBM: 4.8 TB/s where four loads per wave reach the memory's own ceiling)
 __global__ __launch_bounds__(64) void read_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  const v4f p = __builtin_nontemporal_load(in + (i < n ? i : n - 1));
-  if (p.x == 12345.678f && p.y == -1.0f) out[0] = p;  // never true for the data below: the load cannot be dropped
+  const uint64_t base = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  v4f acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint64_t i = base + 64 * u;
+    acc += __builtin_nontemporal_load(in + (i < n ? i : n - 1));
+  }
+  if (acc.x == 12345.678f && acc.y == -1.0f) out[0] = acc;  // never true for the data below: the loads cannot be dropped
 }
 __global__ __launch_bounds__(64) void write_points(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i < n) __builtin_nontemporal_store(v4f{1.0f, 2.0f, 3.0f, (float)threadIdx.x}, out + i);
+  const uint64_t base = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint64_t i = base + 64 * u;
+    if (i < n) __builtin_nontemporal_store(v4f{1.0f, 2.0f, 3.0f, (float)threadIdx.x}, out + i);
+  }
 }
 
 int main(int argc, char** argv) {
@@ -65,12 +76,12 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  struct K { const char* name; void (*fn)(const v4f*, v4f*, uint64_t); int block; double bytes_per_point; };
-  const K ks[] = {{"copy_points", copy_points, 256, 32.0}, {"copy_tiles", copy_tiles, 64, 32.0}, {"read_points", read_points, 64, 16.0}, {"write_points", write_points, 64, 16.0}};
+  struct K { const char* name; void (*fn)(const v4f*, v4f*, uint64_t); int block; int points_per_block; double bytes_per_point; };
+  const K ks[] = {{"copy_points", copy_points, 256, 256, 32.0}, {"copy_tiles", copy_tiles, 64, 64, 32.0}, {"read_points", read_points, 64, 256, 16.0}, {"write_points", write_points, 64, 256, 16.0}};
   std::vector<std::vector<double>> us(4);
   for (int r = 0; r < rounds; ++r)
     for (int k = 0; k < 4; ++k) {  // interleaved: every kernel sees every clock state
-      const dim3 grid((unsigned)((n + ks[k].block - 1) / ks[k].block)), block(ks[k].block);
+      const dim3 grid((unsigned)((n + ks[k].points_per_block - 1) / ks[k].points_per_block)), block(ks[k].block);
       for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(ks[k].fn, grid, block, 0, s, in[w % kBufs], out[w % kBufs], n);
       CHECK(hipEventRecord(e0, s));
       for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(ks[k].fn, grid, block, 0, s, in[it % kBufs], out[it % kBufs], n);
