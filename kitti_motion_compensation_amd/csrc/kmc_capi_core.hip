@@ -72,6 +72,7 @@ int ensure_pipeline(kmc_ctx* c) {
 int fq_join(kmc_ctx* c) {
   c->ao_valid = false;  // whoever joins is about to put ordinary work on the stream: the any-order window ends here
   if (c->gather_count == 0) return KMC_OK;
+  KMC_HIP_TRY(c, hipSetDevice(c->device));
   const dim3 grid((uint32_t)c->gather_tiles, c->gather_count, 1);
   with_tier(c->gather_tier, [&](auto T) {
     hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, true>), grid, dim3(kTile), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, *c->gather);

@@ -304,12 +304,12 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     if (rc_args != KMC_OK) return rc_args;
   }
   if (st) std::memset(st, 0, sizeof(*st));
+  // gathering on (kmc_hip_set_frame_queues(ctx, q > 1)) and no per-call timing: the frame joins the pending list, which goes out as ONE
+  // launch of the frame-list kernel (gather_push) -- host work only unless the list goes out
+  if (mem_kind == KMC_MEM_DEVICE && c->fq_count > 1 && !c->timing && n && n <= kmc_ctx::kGatherMaxPoints) return gather_push(c, xyzi_in, xyzi_out, n, params, st);
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   CallTimer tm(c);
   if (mem_kind == KMC_MEM_DEVICE) {
-    // gathering on (kmc_hip_set_frame_queues(ctx, q > 1)) and no per-call timing: the frame joins the pending list, which goes out as ONE
-    // launch of the frame-list kernel (gather_push)
-    if (c->fq_count > 1 && !c->timing && n && n <= kmc_ctx::kGatherMaxPoints) return gather_push(c, xyzi_in, xyzi_out, n, params, st);
     hipStream_t s = c->stream;
     bool any_order = false;
     if (c->gather_count || c->timing) {  // a list launch, event records: ordinary work on the stream, the any-order window ends

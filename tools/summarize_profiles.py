@@ -76,6 +76,24 @@ def main():
             if "deskew_batch_f32" in r["Name"]:
                 stats = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                          "max_ns": float(r["MaxNs"])}
+    # the timed region alone: the per-launch trace of the same run, in launch order -- bench.py's defaults are
+    # 12 spin-up + 20 warm-up + 200 timed launches, so the LAST 200 rows of the kernel are the timed region (no other leg ran here)
+    timed = {}
+    trace = os.path.join(src, "kt", "bench_kernel_trace.csv")
+    if os.path.exists(trace):
+        rows = []
+        with open(trace) as fh:
+            for r in csv.DictReader(fh):
+                if "deskew_batch_f32" in r.get("Kernel_Name", ""):
+                    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        rows.sort()
+        last = rows[-200:]
+        if last:
+            d = [e - b for b, e in last]
+            gaps = [last[i + 1][0] - last[i][1] for i in range(len(last) - 1)]
+            timed = {"launches": len(last), "of_launches_in_trace": len(rows), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d),
+                     "avg_gap_to_next_launch_ns": (sum(gaps) / len(gaps)) if gaps else None,
+                     "start_to_start_avg_ns": ((last[-1][0] - last[0][0]) / (len(last) - 1)) if len(last) > 1 else None}
     summary = {
         "tag": tag,
         "kernel": kname,
@@ -90,6 +108,7 @@ def main():
         "hbm_bytes_per_point": hbm_bytes / points,
         "traffic_over_algorithmic": hbm_bytes / (32.0 * points),
         "kernel_trace_stats": stats,
+        "kernel_trace_timed_region": timed,
     }
     with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
