@@ -683,7 +683,7 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
   const size_t col = n * sizeof(double);
   // Host containers made of the page-locked pool (the C++ drop-in's Pointcloud / VectorXd are): the kernel works on them in place.
   // ONE launch -- the 40 B per point coming up and the 24-32 B going down share the full-duplex link -- instead of three staged copies
-  // with ~20 us of fixed cost each (123 k-point frame: 224-239 us staged, see profiles/NOTES.md for the in-place figure).
+  // with ~20 us of fixed cost each (123 k-point frame: 224-239 us staged, see profiles/NOTES_r03.md for the in-place figure).
   if (mem_kind == KMC_MEM_HOST && n >= kMappedMinPoints && host_in_place_ok(x, col) && host_in_place_ok(y, col) && host_in_place_ok(z, col) &&
       (!w || host_in_place_ok(w, col)) && host_in_place_ok(stamps, col) && host_in_place_ok(ox, col) && host_in_place_ok(oy, col) &&
       host_in_place_ok(oz, col) && (!ow || host_in_place_ok(ow, col)))

@@ -469,7 +469,7 @@ __device__ __forceinline__ void f64_report_bad(uint32_t bad_count, uint32_t tid,
 // hundred persistent waves each walk many tiles with the NEXT tile's loads issued before the current tile is computed and stored,
 // so that uploads and downloads overlap in time: launched like the device kernel (every wave loads its tile, then stores it, all
 // ~1000 waves of a KITTI frame at once) the link is used one direction after the other -- 148 us per 123 k-point frame against
-// ~110 us pipelined (profiles/NOTES.md).
+// ~110 us pipelined (profiles/NOTES_r03.md).
 template <bool STREAMED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                      const double* __restrict__ z, const double* __restrict__ w,
