@@ -372,7 +372,7 @@ def inplace_round(ctx, rng, acc, torch):
     acc["inplace_failures"] += 0 if ok else 1
 
 
-def stream_round(ctx, plain_ctx, rng, acc, torch):
+def stream_round(ctx, plain_ctx, gather_ctx, rng, acc, torch):
     """A random PROGRAM of device-resident single-frame calls on the context's own stream, issued back to back: every call reads one
     buffer of a small pool and writes another (or the same one, or a sub-range of one), so that consecutive calls are independent,
     chained, write-after-read or write-after-write at random; two-pose and short N-knot frames, now and then another entry point in
@@ -423,6 +423,12 @@ def stream_round(ctx, plain_ctx, rng, acc, torch):
     run(ctx, got, False)
     acc["stream_any_order_launches"] += ctx.any_order_launches() - before
     ok = all(bool(torch.equal(g.view(torch.int32), w.view(torch.int32))) for g, w in zip(got, want))
+    # the same program once more through a context that GATHERS its single-frame calls into list launches (kmc_hip_set_frame_queues(ctx, 4)):
+    # deferred issue, but the results of in-order execution -- bit for bit again
+    got2 = [x.clone() for x in base]
+    torch.cuda.synchronize()
+    run(gather_ctx, got2, False)
+    ok = ok and all(bool(torch.equal(g.view(torch.int32), w.view(torch.int32))) for g, w in zip(got2, want))
     # the first call of the program against the oracle (its input is still the pristine buffer in `base`)
     kind, src, dst, lo, m, arg = prog[0]
     if kind != "traj":
@@ -449,6 +455,8 @@ def main():
     os.environ["KMC_ANY_ORDER"] = "0"
     plain_ctx = capi.Context(0)  # every dispatch with its barrier bit: the reference of stream_round
     del os.environ["KMC_ANY_ORDER"]
+    gather_ctx = capi.Context(0)
+    gather_ctx.set_frame_queues(4)  # single-frame calls gathered into list launches
     calib = util.load_kitti_calibration(os.path.join(ROOT, "tests", "golden"))
     acc = dict(seed=seed, seconds=budget, rounds=0, deskew_points=0, deskew_intensity_mismatch=0, batch_points=0, batch_index_mismatch=0, projection_points=0, projection_drawn=0,
                projection_int_mismatch=0, oracle_threads=orc.num_threads())
@@ -479,7 +487,7 @@ def main():
         elif r == 6:
             inplace_round(ctx, rng, acc, torch)
         elif r == 8:
-            stream_round(ctx, plain_ctx, rng, acc, torch)
+            stream_round(ctx, plain_ctx, gather_ctx, rng, acc, torch)
         else:
             traj_round(ctx, rng, acc, torch)
         acc["rounds"] += 1
