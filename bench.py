@@ -788,7 +788,12 @@ def main():
     legs = None
     if world == 1 and dist is None and headline and not args.no_legs:
         torch.cuda.empty_cache()
-        legs = run_secondary_legs(capi, torch, ctx, dev, check=not args.no_cpu_baseline)
+        try:  # a secondary leg that cannot run (a tool that did not build, a box without rocprof...) must not take the headline line with it
+            legs = run_secondary_legs(capi, torch, ctx, dev, check=not args.no_cpu_baseline)
+        except AssertionError:
+            raise  # a parity check that fails is not a leg that could not run
+        except (Exception, SystemExit) as e:
+            legs = {"secondary_legs_error": f"{type(e).__name__}: {e}"[:2000]}
 
     # the job's ONLY data collective (RCCL when N > 1): one all_gather of every rank's counters; SUM of points, MAX of times.
     # (The four dist.barrier() calls around the two timed regions are collectives too -- one-element all-reduces on the nccl
