@@ -203,8 +203,8 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  *       peak on 1 M-point frames, 0.66 us per KITTI frame);
  *   (2) kmc_hip_set_frame_queues(ctx, q > 1): keep calling kmc_hip_deskew_f32(KMC_MEM_DEVICE) once per frame and let the library GATHER
  *       the calls -- a call only adds its frame to a pending list (~0.1 us); the list goes out as ONE launch of the same frame-list
- *       kernel when it holds 16 frames, when the context's stream has run dry (looked at for the first frame and then every fourth:
- *       an idle device is not kept waiting, a busy one gathers while it works), before a frame that touches a pending frame's buffers
+ *       kernel when the context's stream has run dry (looked at for the first frame and then every fourth: an idle device is not kept
+ *       waiting, a busy one gathers while it works -- up to 64 frames), before a frame that touches a pending frame's buffers
  *       or needs another coefficient tier (so the frames' results are those of in-order execution, bit for bit), and before anything
  *       else the context puts on its stream -- every other entry point, kmc_hip_synchronize(), kmc_hip_timer_end(),
  *       kmc_hip_set_stream() and kmc_hip_frame_queue_join() issue the pending frames first.  What changes for the caller: a frame's

@@ -69,18 +69,67 @@ int ensure_pipeline(kmc_ctx* c) {
   return KMC_OK;
 }
 
+int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t count, int tier, uint32_t* launches_out) {
+  if (launches_out) *launches_out = 0;
+  if (count == 0) return KMC_OK;
+  auto tiles_of = [&](uint32_t first, uint32_t n_recs) {
+    uint64_t n_max = 0;
+    for (uint32_t k = 0; k < n_recs; ++k) n_max = std::max<uint64_t>(n_max, recs[first + k].n);
+    return (uint32_t)((n_max + kTile - 1) / kTile);
+  };
+  auto launch_inline = [&](uint32_t first, uint32_t n_recs) {
+    ListInline inl;
+    std::memcpy(inl.recs, recs + first, n_recs * sizeof(ListRec));
+    std::memcpy(inl.recs64, recd + first, n_recs * sizeof(FrameRecD));
+    const dim3 grid(std::max(1u, tiles_of(first, n_recs)), n_recs, 1);
+    with_tier(tier, [&](auto T) {
+      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, true>), grid, dim3(kTile), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, inl);
+    });
+  };
+  uint32_t launches = 0;
+  bool capturing = false;
+  if (count > (uint32_t)kInlineListFrames) {  // a table upload cannot be part of a stream capture (the slot is reused by later calls, and the host waits for the copy)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    capturing = hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+  }
+  if (count <= (uint32_t)kInlineListFrames || capturing) {
+    for (uint32_t first = 0; first < count; first += kInlineListFrames, ++launches) launch_inline(first, std::min<uint32_t>(kInlineListFrames, count - first));
+    KMC_HIP_TRY(c, hipGetLastError());
+  } else {
+    // slot layout: [ListRec x F | FrameRecD x F], one upload on the side stream, awaited on the host (like a batch's tables)
+    const size_t recs_bytes = ((size_t)count * sizeof(ListRec) + 255) & ~(size_t)255;
+    const size_t need = recs_bytes + (size_t)count * sizeof(FrameRecD);
+    int slot_id = 0;
+    int rc = slot_begin(c, need, &slot_id);
+    if (rc != KMC_OK) return rc;
+    kmc_ctx::TableSlot& sl = c->slots[slot_id];
+    std::memcpy(sl.h_buf, recs, (size_t)count * sizeof(ListRec));
+    std::memcpy(sl.h_buf + recs_bytes, recd, (size_t)count * sizeof(FrameRecD));
+    rc = slot_upload(c, slot_id, need);
+    if (rc != KMC_OK) return rc;
+    const dim3 grid(std::max(1u, tiles_of(0, count)), count, 1);
+    const ListRec* d_recs = reinterpret_cast<const ListRec*>(sl.d_buf);
+    const FrameRecD* d_recd = reinterpret_cast<const FrameRecD*>(sl.d_buf + recs_bytes);
+    with_tier(tier, [&](auto T) {
+      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, false>), grid, dim3(kTile), 0, c->stream, d_recs, d_recd, ListNoInline{});
+    });
+    KMC_HIP_TRY(c, hipGetLastError());
+    rc = slot_end(c, slot_id);
+    if (rc != KMC_OK) return rc;
+    launches = 1;
+  }
+  if (launches_out) *launches_out = launches;
+  return KMC_OK;
+}
+
 int fq_join(kmc_ctx* c) {
   c->ao_valid = false;  // whoever joins is about to put ordinary work on the stream: the any-order window ends here
   if (c->gather_count == 0) return KMC_OK;
   KMC_HIP_TRY(c, hipSetDevice(c->device));
-  const dim3 grid((uint32_t)c->gather_tiles, c->gather_count, 1);
-  with_tier(c->gather_tier, [&](auto T) {
-    hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, true>), grid, dim3(kTile), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, *c->gather);
-  });
-  c->gather_count = 0;
-  c->gather_tiles = 0;
-  KMC_HIP_TRY(c, hipGetLastError());
-  return KMC_OK;
+  const uint32_t count = c->gather_count;
+  c->gather_count = 0;  // (first: launch_list's table route may re-enter fq_join through slot_begin)
+  return launch_list(c, c->gather, c->gather64, count, c->gather_tier, nullptr);
 }
 
 // May this frame start before the launches ahead of it on the context's stream have finished?  Yes if
@@ -346,6 +395,7 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
 void kmc_hip_destroy(kmc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->stream || c->own_stream) (void)fq_join(c);  // frames still being gathered are issued, not dropped
   (void)hipStreamSynchronize(c->stream);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (int b = 0; b < 3; ++b)
@@ -358,7 +408,8 @@ void kmc_hip_destroy(kmc_ctx* c) {
     if (c->ev_kernel[b]) (void)hipEventDestroy(c->ev_kernel[b]);
     if (c->ev_d2h[b]) (void)hipEventDestroy(c->ev_d2h[b]);
   }
-  delete c->gather;
+  delete[] c->gather;
+  delete[] c->gather64;
   if (c->d_tmp) (void)hipFree(c->d_tmp);
   if (c->d_traj) (void)hipFree(c->d_traj);
   if (c->h_traj) (void)hipHostFree(c->h_traj);
@@ -417,9 +468,9 @@ int kmc_hip_set_frame_queues(kmc_ctx* c, int queues) {
   if (!c || queues < 1 || queues > kmc_ctx::kMaxFrameQueues) return KMC_ERR_INVALID_ARG;
   KMC_ENTER(c);  // issues what is pending
   if (queues > 1 && !c->gather) {
-    c->gather = new (std::nothrow) ListInline();
-    if (!c->gather) return KMC_ERR_ALLOC;
-    std::memset(c->gather, 0, sizeof(ListInline));
+    c->gather = new (std::nothrow) ListRec[kmc_ctx::kGatherMax];
+    c->gather64 = new (std::nothrow) FrameRecD[kmc_ctx::kGatherMax];
+    if (!c->gather || !c->gather64) return KMC_ERR_ALLOC;
   }
   c->fq_count = queues;
   return KMC_OK;

@@ -206,9 +206,9 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
 }
 // One more frame for the pending list (kmc_ctx::gather).  In-order semantics are kept: a frame that reads or writes a buffer a pending
 // frame writes, or writes one a pending frame reads, makes the pending frames go out first; so does a frame of another coefficient tier
-// (a launch runs ONE tier, and a frame's bits must not depend on its neighbours).  The list goes out when it is full, or -- looked at
-// for the first frame and then every fourth -- when the context's stream has run dry: a device that is idle is not kept waiting for
-// a fuller list, a busy one gathers while it works (the launches clock themselves).
+// (a launch runs ONE tier, and a frame's bits must not depend on its neighbours).  The list goes out when it is full (kGatherMax), or
+// -- looked at for the first frame and then every fourth -- when the context's stream has run dry: a device that is idle is not kept
+// waiting for a fuller list, a busy one gathers while it works (the launches clock themselves: lists only grow long behind a busy device).
 int gather_push(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, const kmc_frame_params* params, kmc_stats* st) {
   const int tier = pick_tier(c, params, 1);
   const uintptr_t bytes = (uintptr_t)n * sizeof(v4f);
@@ -227,11 +227,11 @@ int gather_push(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, c
   c->ao_valid = false;  // a pending frame is work the any-order window does not describe
   const uint32_t k = c->gather_count++;
   const uint32_t head = head_of(xyzi_out, KMC_MEM_DEVICE);
-  ListRec& rec = c->gather->recs[k];
+  ListRec& rec = c->gather[k];
   std::memset(&rec, 0, sizeof(rec));
   fill_rec(*params, &rec.f);
   rec.f.pre2 = guard_pre2(*params);
-  fill_recd(*params, &c->gather->recs64[k]);
+  fill_recd(*params, &c->gather64[k]);
   rec.in = (const v4f*)xyzi_in - head;
   rec.out = (v4f*)xyzi_out - head;
   rec.n = n + head;
@@ -239,11 +239,15 @@ int gather_push(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, c
   c->gather_reads[k] = r;
   c->gather_writes[k] = w;
   c->gather_tier = tier;
-  c->gather_tiles = std::max<uint64_t>(c->gather_tiles, (n + head + kTile - 1) / kTile);
   bool go = c->gather_count == (uint32_t)kmc_ctx::kGatherMax;
   if (!go && (c->gather_count == 1 || (c->gather_count & 3u) == 0)) {
-    go = hipStreamQuery(c->stream) == hipSuccess;  // nothing in flight: issue what there is
-    (void)hipGetLastError();                       // (hipErrorNotReady is the expected answer of a busy stream)
+    bool may_query = true;
+    if (c->stream != c->own_stream) {  // a caller's stream may be capturing a graph: a query is not allowed there (it would invalidate the capture)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      may_query = hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    }
+    go = may_query && hipStreamQuery(c->stream) == hipSuccess;  // nothing in flight: issue what there is
+    (void)hipGetLastError();                                    // (hipErrorNotReady is the expected answer of a busy stream)
   }
   if (go) {
     const int rc = fq_join(c);
@@ -426,66 +430,28 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
     if (st) st->n_launches = n_frames;
     return tm.end_call(st);
   }
-  auto fill = [&](uint32_t f, ListRec* r, FrameRecD* d) {
+  std::vector<ListRec> recs(n_frames);
+  std::vector<FrameRecD> recd(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    ListRec* r = &recs[f];
     std::memset(r, 0, sizeof(*r));
     fill_rec(params[f], &r->f);
     r->f.pre2 = guard_pre2(params[f]);
-    fill_recd(params[f], d);
+    fill_recd(params[f], &recd[f]);
     const uint32_t head = n_points[f] ? head_of(xyzi_out[f], KMC_MEM_DEVICE) : 0u;
     r->in = (const v4f*)xyzi_in[f] - head;
     r->out = (v4f*)xyzi_out[f] - head;
     r->n = n_points[f] ? n_points[f] + head : 0;
     r->head = head;
-  };
-  const dim3 grid((uint32_t)tiles_x, n_frames, 1);
-  if (n_frames <= (uint32_t)kInlineListFrames) {  // the records travel in the kernel arguments: the call only enqueues a launch
-    ListInline inl;
-    std::memset(&inl, 0, sizeof(inl));
-    for (uint32_t f = 0; f < n_frames; ++f) fill(f, &inl.recs[f], &inl.recs64[f]);
-    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    with_tier(tier, [&](auto T) {
-      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, true>), grid, dim3(64), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, inl);
-    });
-    KMC_HIP_TRY(c, hipGetLastError());
-  } else {
-    {  // a table upload cannot be part of a stream capture (the slot is reused by later calls, and the host waits for the copy)
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
-        c->last_error = "kmc_hip_deskew_frames_f32: only lists of at most 16 frames can be captured into a HIP graph";
-        return KMC_ERR_INVALID_ARG;
-      }
-      (void)hipGetLastError();
-    }
-    // slot layout: [ListRec x F | FrameRecD x F], one upload on the side stream, awaited on the host (like a batch's tables)
-    const size_t recs_bytes = ((size_t)n_frames * sizeof(ListRec) + 255) & ~(size_t)255;
-    const size_t need = recs_bytes + (size_t)n_frames * sizeof(FrameRecD);
-    int slot_id = 0;
-    {
-      const int rc_slot = slot_begin(c, need, &slot_id);
-      if (rc_slot != KMC_OK) return rc_slot;
-    }
-    kmc_ctx::TableSlot& sl = c->slots[slot_id];
-    ListRec* h_recs = reinterpret_cast<ListRec*>(sl.h_buf);
-    FrameRecD* h_recd = reinterpret_cast<FrameRecD*>(sl.h_buf + recs_bytes);
-    for (uint32_t f = 0; f < n_frames; ++f) fill(f, &h_recs[f], &h_recd[f]);
-    {
-      const int rc_up = slot_upload(c, slot_id, need);
-      if (rc_up != KMC_OK) return rc_up;
-    }
-    if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    const ListRec* d_recs = reinterpret_cast<const ListRec*>(sl.d_buf);
-    const FrameRecD* d_recd = reinterpret_cast<const FrameRecD*>(sl.d_buf + recs_bytes);
-    with_tier(tier, [&](auto T) {
-      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, false>), grid, dim3(64), 0, c->stream, d_recs, d_recd, ListNoInline{});
-    });
-    KMC_HIP_TRY(c, hipGetLastError());
-    {
-      const int rc_end = slot_end(c, slot_id);
-      if (rc_end != KMC_OK) return rc_end;
-    }
+  }
+  if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+  uint32_t launches = 0;
+  {
+    const int rc_list = launch_list(c, recs.data(), recd.data(), n_frames, tier, &launches);
+    if (rc_list != KMC_OK) return rc_list;
   }
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  if (st) st->n_launches = 1;
+  if (st) st->n_launches = launches;
   return tm.end_call(st);
 }
 

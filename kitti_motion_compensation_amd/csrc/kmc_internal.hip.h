@@ -90,12 +90,14 @@ struct kmc_ctx {
   // frames), before a frame that touches a pending frame's buffers or needs another coefficient tier, and before anything else the
   // context puts on its stream (fq_join, which every other entry point starts with).
   static constexpr int kMaxFrameQueues = 4;              // the API's range of `queues`; any value > 1 switches gathering on
-  static constexpr int kGatherMax = kInlineListFrames;   // frames per list launch whose records fit the kernel-argument segment
-  static constexpr uint64_t kGatherMaxPoints = 1ull << 26;  // larger frames gain nothing from sharing a launch (and a 2-D grid holds 2^32 work-items)
+  static constexpr int kGatherMax = 64;                  // pending frames at most: 16 travel in the kernel arguments, a longer list -- it only grows
+                                                         // that long while the device is busy -- uploads one small table
+  static constexpr uint64_t kGatherMaxPoints = 1ull << 24;  // larger frames gain nothing from sharing a launch (and a 2-D grid of kGatherMax such frames stays below 2^32 work-items)
   struct AoRange { uintptr_t lo, hi; };
   int fq_count = 1;                  // 1 = off: every call launches on `stream`
   bool fq_ordered = true;            // kmc_hip_set_frame_queue_order: on a CALLER's stream, producers may sit between two calls
-  ListInline* gather = nullptr;      // the pending frames' records: the next list launch's kernel argument, filled in place
+  ListRec* gather = nullptr;         // the pending frames' records (kGatherMax of each)
+  FrameRecD* gather64 = nullptr;
   uint32_t gather_count = 0;
   int gather_tier = 0;
   uint64_t gather_tiles = 0;         // tiles of the largest pending frame = grid.x of the next list launch
@@ -154,6 +156,9 @@ int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n);
 // gathered frames: fq_join() issues whatever is pending as one list launch on `stream` (and ends the any-order window): what every entry
 // point that puts other work on the stream starts with; gather_push() adds a frame (kmc_capi_deskew.hip)
 int fq_join(kmc_ctx* c);
+// ONE launch of the frame-list kernel for `count` filled records on the context's stream: kernel-argument records for at most
+// kInlineListFrames frames, else one table upload (under stream capture: several kernel-argument launches).  -> launches_out
+int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t count, int tier, uint32_t* launches_out);
 
 // what every entry point that issues work on `stream` starts with
 #define KMC_ENTER(ctx)                                      \
