@@ -200,7 +200,7 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * two launches -- 6.1-7.0 us call to call for a 1 M-point frame whose kernel takes 4.7, 2.4-5 us for a KITTI frame whose kernel takes
  * 0.6.  The frames of this path are independent (motion_compensation.cpp:22-25 reads nothing a previous frame wrote).  Three ways out:
  *   (1) hand a LIST of ready frames to kmc_hip_deskew_frames_f32: one launch of the frame-list kernel for all of them (84 % of the HBM
- *       peak on 1 M-point frames, 0.66 us per KITTI frame);
+ *       peak on 1 M-point frames, 0.66 us per KITTI frame; gathered calls, (2), reach 83-84 % and 0.70 us);
  *   (2) kmc_hip_set_frame_queues(ctx, q > 1): keep calling kmc_hip_deskew_f32(KMC_MEM_DEVICE) once per frame and let the library GATHER
  *       the calls -- a call only adds its frame to a pending list (~0.1 us); the list goes out as ONE launch of the same frame-list
  *       kernel when the context's stream has run dry (looked at for the first frame and then every fourth: an idle device is not kept
