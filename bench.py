@@ -256,9 +256,17 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         from oracle import oracle as orc
 
     def timed(fn, iters, warm, on=None):
+        """ms per call.  Warm-up: `warm` calls AND at least ~40 ms of them -- an MI355X that sat idle while the previous leg was set up
+        needs ~10 ms of launches to settle its clocks (round 4: the 10 M-point N-knot kernel drifted between 49 and 64 us per launch
+        during a 7 ms leg that followed a pause; `profiles/r04_legs_serialized_kernel_stats.csv`)."""
         on = on or ctx
-        for _ in range(warm):
+        t_warm, done = time.perf_counter(), 0
+        while done < warm or time.perf_counter() - t_warm < 0.04:
             fn()
+            done += 1
+            if done % 16 == 0:
+                on.synchronize()  # (keeps the host from running seconds ahead of the device)
+        on.synchronize()
         torch.cuda.synchronize()
         on.timer_begin()
         for _ in range(iters):
