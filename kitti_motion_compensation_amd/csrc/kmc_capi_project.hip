@@ -33,6 +33,9 @@ CameraRigRec rig_rec(const kmc_camera_rig* g) {
   r.max_range = g->max_range;
   r.range_den = g->max_range - 0.01;  // camera_model.cpp:28
   r.range_rcp = 1.0 / r.range_den;
+  r.same_den = 0;
+  for (int c = 1; c < 4; ++c)
+    if (std::memcmp(&g->P_rect[c][11], &g->P_rect[c - 1][11], sizeof(double)) == 0) r.same_den |= 1ull << c;
   return r;
 }
 }  // namespace

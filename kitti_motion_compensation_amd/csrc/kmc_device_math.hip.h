@@ -610,6 +610,7 @@ struct CameraRigRec {
   double max_range;  // camera_model.hpp:8
   double range_den;  // max_range - 0.01, camera_model.cpp:28
   double range_rcp;  // ~ 1 / range_den: first guess of the colour ramp's quotient, confirmed or redone exactly per point
+  uint64_t same_den; // bit c (1..3): P[c][11] is bit for bit P[c-1][11] -- camera c divides by the same h2 as camera c-1 (KITTI: cameras 0 and 1)
 };
 using v2i = int __attribute__((ext_vector_type(2)));
 using v4i = int __attribute__((ext_vector_type(4)));
@@ -634,9 +635,11 @@ __device__ __forceinline__ uint32_t sat_u8(double v) {  // cv::saturate_cast<uch
 // `>` comparisons and are therefore never "certain".
 // The verdict comes back as a LANE MASK (ballot): the caller combines the masks of the four cameras with scalar ANDs; as `bool`s
 // the compiler materialised every one of them in a VGPR and combined them with 16-bit vector logic (~25 VALU instructions).
-__device__ __forceinline__ uint64_t trunc_quotients_fast(double a, double b, double d, int& ta, int& tb) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+__device__ __forceinline__ double refined_rcp(double d) {
+  const double r = __builtin_amdgcn_rcp(d);
+  return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+}
+__device__ __forceinline__ uint64_t trunc_quotients_with(double a, double b, double r, int& ta, int& tb) {  // r = refined_rcp(d)
   const double qa = a * r, qb = b * r;
   constexpr double kEps = 0x1p-36;  // the margin kEps (1 + |q|) >= kEps max(1, |q|): one fma instead of max + mul, a little more cautious
   const double big = __builtin_fmax(__builtin_fabs(qa), __builtin_fabs(qb));
@@ -647,6 +650,9 @@ __device__ __forceinline__ uint64_t trunc_quotients_fast(double a, double b, dou
   ta = (int)qa;
   tb = (int)qb;
   return sure_a & sure_b & in_range;
+}
+__device__ __forceinline__ uint64_t trunc_quotients_fast(double a, double b, double d, int& ta, int& tb) {
+  return trunc_quotients_with(a, b, refined_rcp(d), ta, tb);
 }
 
 // P_rect_c * r for one camera, :9.  STRUCTURED: the products with the literal 0s and 1 of a pinhole matrix are skipped.
@@ -667,10 +673,10 @@ __device__ __forceinline__ void camera_rows(cdouble_p P, const double r[3], doub
 // compiler preloads all of it and spills (round 1: 124 v_writelane + 124 v_readlane in a ~700-instruction kernel).  It is
 // therefore read through the kernel-argument segment in phases (`after`, see the guarded redo): T, R and the range constants up
 // front, cameras 0-1 once the camera-frame point exists, cameras 2-3 once the rectified point exists.
-constexpr int kRigT = 0, kRigR = 12, kRigP = 21, kRigMaxRange = 69, kRigRangeDen = 70, kRigRangeRcp = 71;
+constexpr int kRigT = 0, kRigR = 12, kRigP = 21, kRigMaxRange = 69, kRigRangeDen = 70, kRigRangeRcp = 71, kRigSameDen = 72;
 static_assert(offsetof(CameraRigRec, T) == 8 * kRigT && offsetof(CameraRigRec, R) == 8 * kRigR && offsetof(CameraRigRec, P) == 8 * kRigP &&
                   offsetof(CameraRigRec, max_range) == 8 * kRigMaxRange && offsetof(CameraRigRec, range_den) == 8 * kRigRangeDen &&
-                  offsetof(CameraRigRec, range_rcp) == 8 * kRigRangeRcp,
+                  offsetof(CameraRigRec, range_rcp) == 8 * kRigRangeRcp && offsetof(CameraRigRec, same_den) == 8 * kRigSameDen,
               "project_point indexes CameraRigRec as an array of doubles");
 
 // -> validity; uv[c] = pixel cv::circle would be centred on; bgrv = {255-cs, cs, 255-cs, 1} packed little-endian.
@@ -708,10 +714,16 @@ __device__ __forceinline__ bool project_point(double x, double y, double z, cdou
   if constexpr (RIG == kRigSharedIntrinsics) {
     const double a0 = P[0] * r[0] + P[2] * r[2];  // :9, rows 0 and 1 of P_rect without their last column
     const double a1 = P[5] * r[1] + P[6] * r[2];
+    // cameras whose h2 = z + tz is the same rounded value as the previous camera's (the host compared the tz bit for bit: KITTI's
+    // cameras 0 and 1) reuse its refined reciprocal: identical operands, identical operations, one v_rcp_f64 + two fma less (round 4:
+    // the all-drawn pattern is f64-VALU-bound)
+    const uint32_t same = (uint32_t)__builtin_bit_cast(uint64_t, g[kRigSameDen]);
+    double rc = 0.0;
 #pragma unroll
     for (int cam = 0; cam < 4; ++cam) {
+      if (cam == 0 || !((same >> cam) & 1u)) rc = refined_rcp(r[2] + P[12 * cam + 11]);  // wave-uniform
       int tu, tv;
-      sure &= trunc_quotients_fast(a0 + P[12 * cam + 3], a1 + P[12 * cam + 7], r[2] + P[12 * cam + 11], tu, tv);
+      sure &= trunc_quotients_with(a0 + P[12 * cam + 3], a1 + P[12 * cam + 7], rc, tu, tv);
       uv[cam].x = tu;
       uv[cam].y = tv;
     }

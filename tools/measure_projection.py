@@ -45,8 +45,9 @@ def main():
         "deskew+project+cloud (68 B/pt)": (lambda: ctx.project_f32(d_in, rig, d_uv, d_col, deskew=params, xyzi_out=d_out), 68),
     }
     for name, (fn, bpp) in cases.items():
-        for _ in range(5):
+        for _ in range(300):  # ~45 ms: clocks settled (a handful of launches after a pause times a transient)
             fn()
+        ctx.synchronize()
         ctx.timer_begin()
         for _ in range(iters):
             fn()
@@ -55,8 +56,9 @@ def main():
     x = torch.empty(n, dtype=torch.float64, device="cuda").uniform_(-40, 40)
     y = torch.empty(n, dtype=torch.float64, device="cuda").uniform_(-40, 40)
     z = torch.empty(n, dtype=torch.float64, device="cuda").uniform_(-3, 1)
-    for _ in range(5):
+    for _ in range(300):
         ctx.project_f64cols(x, y, z, rig, d_uv, d_col)
+    ctx.synchronize()
     ctx.timer_begin()
     for _ in range(iters):
         ctx.project_f64cols(x, y, z, rig, d_uv, d_col)
