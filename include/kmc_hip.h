@@ -291,9 +291,11 @@ int kmc_hip_deskew_f64cols_end(kmc_ctx* ctx, kmc_stats* out_stats);
  * "timestamp index".  In the f32 entry point it is decided by trig-free half-plane tests on (x, y) so that it is bit-exact
  * against the CPU oracle; in the f64 entry point by f64 compares of the caller's stamps against the knot times.
  * kmc_hip_deskew_traj_f32 on KMC_MEM_DEVICE points with n_knots <= 4 (north_star's three bracketing poses included) passes its
- * segment records in the kernel arguments: no table upload, the host never waits, and with frame queues on
- * (kmc_hip_set_frame_queues) consecutive calls overlap like kmc_hip_deskew_f32 calls do -- 12 us per call instead of 29.  Longer
- * trajectories and host buffers go through a device table (same kernel body, same bits) on the context's stream. */
+ * segment records in the kernel arguments: no table upload, the host never waits (12 us per call instead of 29), and -- like
+ * kmc_hip_deskew_f32 calls, under the same conditions -- a frame that shares no buffer with the frames in flight is dispatched without
+ * the barrier bit.  (N-knot calls are launched one per call; with gathering on, kmc_hip_set_frame_queues, they first issue the
+ * two-pose frames that are pending.)  Longer trajectories and host buffers go through a device table (same kernel body, same bits)
+ * on the context's stream. */
 int kmc_hip_deskew_traj_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint64_t n, const double* knot_times,
                             const double* knot_poses, uint32_t n_knots, double stamp_start, double stamp_end,
                             double requested_time, uint32_t* bracket_idx_out, int mem_kind, kmc_stats* out_stats);

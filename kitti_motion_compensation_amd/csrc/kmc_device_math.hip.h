@@ -759,8 +759,18 @@ __device__ __forceinline__ bool project_point(double x, double y, double z, cdou
   // host's reciprocal is within ~1e-13 of the reference's; the bytes can only differ if cs sits that close to a half-integer, and
   // exactly those lanes (and NaNs: the comparison is false for them) redo the IEEE division.
   double cs = 255.0 * (r[2] * g[kRigRangeRcp]);
-  if (__builtin_expect(valid && !(__builtin_fabs((cs - __builtin_floor(cs)) - 0.5) > 1e-9), 0)) cs = 255.0 * (r[2] / g[kRigRangeDen]);
-  const uint32_t a = sat_u8(255.0 - cs), b = sat_u8(cs);
+  const bool near_half = valid && !(__builtin_fabs((cs - __builtin_floor(cs)) - 0.5) > 1e-9);
+  uint32_t a, b;
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(near_half) != 0, 0)) {  // wave-uniform, cold: the reference's own two roundings
+    if (near_half) cs = 255.0 * (r[2] / g[kRigRangeDen]);
+    a = sat_u8(255.0 - cs);
+    b = sat_u8(cs);
+  } else {
+    // a valid lane's cs lies in [0.17, 255.2] and not within 1e-9 of a half-integer: rint(255 - cs) = 255 - rint(cs), clamps
+    // included (cs > 255 rounds to 255 and 255 - cs to -0 -> 0) -- one rounding and one integer subtraction instead of two roundings
+    b = sat_u8(cs);
+    a = 255u - b;
+  }
   bgrv = valid ? (a | (b << 8) | (a << 16) | (1u << 24)) : 0u;  // :32
   return valid;
 }
