@@ -79,6 +79,7 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
   };
   auto launch_inline = [&](uint32_t first, uint32_t n_recs) {
     ListInline inl;
+    if (n_recs < (uint32_t)kInlineListFrames) std::memset(&inl, 0, sizeof(inl));  // (no stale stack bytes in the kernel arguments)
     std::memcpy(inl.recs, recs + first, n_recs * sizeof(ListRec));
     std::memcpy(inl.recs64, recd + first, n_recs * sizeof(FrameRecD));
     const dim3 grid(std::max(1u, tiles_of(first, n_recs)), n_recs, 1);

@@ -23,6 +23,8 @@ KMC_ANY_ORDER=0 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/
 # the C++ frame-stream client on its own (bench.py runs it as a child process, which the passes above do not trace): rows of the
 # per-frame kernel, the frame-list kernel (list call and gathered calls) and the packed batch on the same frames
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_stream" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 4 > "$O/stream_kt.json" 2> "$O/stream_kt.err"
+run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_stream_fetch" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 2 > /dev/null 2>&1
+run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_stream_write" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 2 > /dev/null 2>&1
 python bench.py > "$O/bench_plain.json" 2> "$O/bench_plain.err"
 tail -1 "$O/bench_plain.json" | cut -c1-200
 grep -h "deskew_batch_f32" "$O"/kt/bench_kernel_stats.csv | cut -c1-60,200-320

@@ -95,6 +95,17 @@ def main():
             timed = {"launches": len(last), "of_launches_in_trace": len(rows), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d),
                      "avg_gap_to_next_launch_ns": (sum(gaps) / len(gaps)) if gaps else None,
                      "start_to_start_avg_ns": ((last[-1][0] - last[0][0]) / (len(last) - 1)) if len(last) > 1 else None}
+    # the frame-list kernel on 256 separate 1 M-point frames (tools/time_frame_stream under the same two counters): its traffic per launch
+    list_traffic = {}
+    lf_path, lw_path = (os.path.join(src, d, "stream_counter_collection.csv") for d in ("pmc_stream_fetch", "pmc_stream_write"))
+    if os.path.exists(lf_path) and os.path.exists(lw_path):
+        lf, lw = counters(lf_path, "FETCH_SIZE"), counters(lw_path, "WRITE_SIZE")
+        pick_list = lambda d: [v for (k, grid, wg), v in d.items() if "deskew_list_f32<0, false>" in k and grid == 256000000]
+        if pick_list(lf) and pick_list(lw):
+            fv2, wv2 = pick_list(lf)[0], pick_list(lw)[0]
+            b = (sum(fv2) / len(fv2) * fetch_factor + sum(wv2) / len(wv2) * write_factor) * 1024.0
+            list_traffic = {"kernel": "deskew_list_f32<0, false>, 2-D grid 15625 x 256 (256 separate 1 M-point frames, device tables)", "launches": len(fv2),
+                            "hbm_bytes_per_launch": b, "traffic_over_algorithmic": b / (32.0 * 256000000)}
     summary = {
         "tag": tag,
         "kernel": kname,
@@ -110,6 +121,7 @@ def main():
         "traffic_over_algorithmic": hbm_bytes / (32.0 * points),
         "kernel_trace_stats": stats,
         "kernel_trace_timed_region": timed,
+        "frame_list_kernel_traffic": list_traffic,
     }
     with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
