@@ -1,7 +1,7 @@
 // time_frame_stream.hip -- the reference's calling pattern (handlers.cpp:55-64: one frame at a time, each in its own allocation)
 // driven from C++ through the C-ABI, so that the host language does not set the pace (a ctypes call costs ~8 us, a launch ~2).
 //
-//   time_frame_stream <n_frames> <points_per_frame | kitti> [sets=1] [iters=20]
+//   time_frame_stream <n_frames> <points_per_frame | kitti> [sets=1] [iters=20] [carve]
 //
 // n_frames device-resident frames per set, every frame its OWN hipMalloc allocation (in and out); `kitti` draws the sizes from
 // N(121 000, 3 000) clipped to [90 000, 140 000] like bench.py's configs2_drive leg; `sets` rotating sets of such frames (so that a
@@ -61,6 +61,7 @@ int main(int argc, char** argv) {
   const bool kitti = std::strcmp(argv[2], "kitti") == 0;
   const int n_sets = argc > 3 ? std::atoi(argv[3]) : 1;
   const int iters = argc > 4 ? std::atoi(argv[4]) : 20;
+  const bool carve = argc > 5 && std::strcmp(argv[5], "carve") == 0;  // frames carved out of ONE allocation per set (1 KiB-aligned starts) instead of one hipMalloc each
   std::vector<uint64_t> sizes(F), offsets(F + 1, 0);
   {
     std::mt19937 rng(0x4B4D43 + 2);
@@ -93,9 +94,22 @@ int main(int argc, char** argv) {
     S.in.resize(F); S.out.resize(F); S.cin.resize(F);
     HIP_OK(hipMalloc((void**)&S.packed_in, std::max<uint64_t>(total, 1) * 16));
     HIP_OK(hipMalloc((void**)&S.packed_out, std::max<uint64_t>(total, 1) * 16));
+    float *pool_in = nullptr, *pool_out = nullptr;
+    uint64_t pool_pts = 0, cursor = 0;
+    for (uint32_t f = 0; f < F; ++f) pool_pts += (sizes[f] + 63) / 64 * 64;
+    if (carve) {
+      HIP_OK(hipMalloc((void**)&pool_in, std::max<uint64_t>(pool_pts, 1) * 16));
+      HIP_OK(hipMalloc((void**)&pool_out, std::max<uint64_t>(pool_pts, 1) * 16));
+    }
     for (uint32_t f = 0; f < F; ++f) {
-      HIP_OK(hipMalloc((void**)&S.in[f], sizes[f] * 16));
-      HIP_OK(hipMalloc((void**)&S.out[f], sizes[f] * 16));
+      if (carve) {
+        S.in[f] = pool_in + 4 * cursor;
+        S.out[f] = pool_out + 4 * cursor;
+        cursor += (sizes[f] + 63) / 64 * 64;
+      } else {
+        HIP_OK(hipMalloc((void**)&S.in[f], sizes[f] * 16));
+        HIP_OK(hipMalloc((void**)&S.out[f], sizes[f] * 16));
+      }
       S.cin[f] = S.in[f];
       KMC_OK_OR_DIE(kmc_hip_synth_points(ctx, S.in[f], sizes[f], 0x4B4D43ull + 0xF5000000ull + (uint64_t)s * F + f));
       KMC_OK_OR_DIE(kmc_hip_synchronize(ctx));
@@ -171,14 +185,14 @@ int main(int argc, char** argv) {
   const double mean_pts = (double)total / F;
   auto gbps = [&](double us) { return 32.0 * mean_pts / us / 1e3; };
   std::printf(
-      "{\"frames_per_set\": %u, \"sets\": %d, \"iters\": %d, \"mean_points_per_frame\": %.1f, \"points_per_set\": %llu, \"device\": \"%s\", "
+      "{\"frames_per_set\": %u, \"frames_are\": \"%s\", \"sets\": %d, \"iters\": %d, \"mean_points_per_frame\": %.1f, \"points_per_set\": %llu, \"device\": \"%s\", "
       "\"any_order_dispatch\": %d, \"list_launches\": %u, \"list_equals_per_call_bitwise\": %s, "
       "\"per_call\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"dispatched_without_barrier_bit\": %.3f}, "
       "\"per_call_drained\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}, "
       "\"per_call_gathered\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
       "\"list_one_launch\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
       "\"batch_packed\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}}\n",
-      F, n_sets, iters, mean_pts, (unsigned long long)total, info.name, info.any_order_dispatch, st.n_launches, same ? "true" : "false", us_call,
+      F, carve ? "carved out of one allocation per set (1 KiB-aligned starts)" : "separate hipMalloc allocations", n_sets, iters, mean_pts, (unsigned long long)total, info.name, info.any_order_dispatch, st.n_launches, same ? "true" : "false", us_call,
       gbps(us_call), host_call, ao_share, us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_batch, gbps(us_batch));
   kmc_hip_destroy(drained);
   kmc_hip_destroy(ctx);
