@@ -759,6 +759,12 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   // `head`: dead leading indices, see frame_tile (the host has shifted the pointers and every offset by it); `tile_base`: first tile
   // of this launch.  No tile loop: the loop-carried copies of the twelve kernel arguments cost ~40 SGPR spill instructions per wave
   // (round 3, profiles/NOTES_r03.md)
+  // The arguments only the cold paths or the tile's last instructions need -- `n_frames` (tiles that straddle frames), `segs64` (the
+  // guard's redo), the two index outputs -- are read through the kernel-argument segment where they are used: named, they would sit in
+  // SGPRs for the whole wave, and this kernel has none to spare (78 at 8 waves per SIMD; 4-12 spills before, 2-8 now)
+  struct ArgLayout { const v4f* in; v4f* out; uint64_t n; const TrajFrameRec* frecs; const TrajSeg32* segs; uint32_t seg_stride; const uint2* coarse; uint32_t n_frames;
+                     uint32_t* frame_idx_out; uint32_t* bracket_out; uint32_t head; const TrajSegD* segs64; uint64_t tile_base; };
+  const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
   const seg_cp segs_c = (seg_cp)(uintptr_t)segs;  // written by the host before the launch: constant for the kernel
   const uint32_t tid = threadIdx.x;
   const uint64_t t = tile_base + blockIdx.x;
@@ -806,8 +812,10 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint32_t k = traj_lanes<TIER>(p, turns, true, i >= head, segs_c + (uint64_t)f0 * seg_stride, r.n_seg, kp0, f0 * seg_stride, rout, tid, redo_any, redo_seg);
     if constexpr (WRITE_IDX) {
       if (alive) {
-        if (frame_idx_out) __builtin_nontemporal_store(f0, frame_idx_out + i);
-        if (bracket_out) __builtin_nontemporal_store(k, bracket_out + i);
+        uint32_t* const fio = *(uint32_t* const __attribute__((address_space(4)))*)(kernarg + offsetof(ArgLayout, frame_idx_out));
+        uint32_t* const bo = *(uint32_t* const __attribute__((address_space(4)))*)(kernarg + offsetof(ArgLayout, bracket_out));
+        if (fio) __builtin_nontemporal_store(f0, fio + i);
+        if (bo) __builtin_nontemporal_store(k, bo + i);
       }
     }
   } else {
@@ -820,18 +828,20 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const uint32_t k = traj_lanes<TIER>(p, turns, mine, i >= head, segs_c + (uint64_t)fi * seg_stride, r.n_seg, KnotPre{r.c1, r.c2}, fi * seg_stride, rout, tid, redo_any, redo_seg);
         if constexpr (WRITE_IDX) {
           if (mine && alive) {
-            if (frame_idx_out) __builtin_nontemporal_store(fi, frame_idx_out + i);
-            if (bracket_out) __builtin_nontemporal_store(k, bracket_out + i);
+            uint32_t* const fio = *(uint32_t* const __attribute__((address_space(4)))*)(kernarg + offsetof(ArgLayout, frame_idx_out));
+            uint32_t* const bo = *(uint32_t* const __attribute__((address_space(4)))*)(kernarg + offsetof(ArgLayout, bracket_out));
+            if (fio) __builtin_nontemporal_store(fi, fio + i);
+            if (bo) __builtin_nontemporal_store(k, bo + i);
           }
         }
         begin = e;
       }
-      if (e >= tile_end || fi + 1 >= n_frames) break;
+      if (e >= tile_end || fi + 1 >= *(const uint32_t __attribute__((address_space(4)))*)(kernarg + offsetof(ArgLayout, n_frames))) break;
       ++fi;
       r = frecs[fi];
     }
   }
-  traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store(rout, (uint32_t)(tid * sizeof(v4f)), v); });
+  traj_redo_lanes(redo_any && alive, p, *(const TrajSegD* const __attribute__((address_space(4)))*)(kernarg + offsetof(ArgLayout, segs64)), redo_seg, [&](v4f v) { tile_store(rout, (uint32_t)(tid * sizeof(v4f)), v); });
 }
 
 // f64 Eigen-layout variant: honours the caller's per-point stamps; the bracket is found by f64 time compares.
