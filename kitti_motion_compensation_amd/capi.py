@@ -431,11 +431,12 @@ class Context:
         return st
 
     def set_frame_queues(self, queues: int):
-        """queues > 1: device-resident deskew_f32 calls go round-robin over that many HIP streams and may overlap (see kmc_hip.h)."""
+        """queues > 1: device-resident deskew_f32 calls are GATHERED on the host and issued as list launches (deferred issue, in-order
+        results; see kmc_hip.h); 1 = every call issues its own launch."""
         self._check(lib().kmc_hip_set_frame_queues(self._h, int(queues)), "kmc_hip_set_frame_queues")
 
     def set_frame_queue_order(self, after_producers: bool = True):
-        """False: only the first frame after a join waits for the context's stream (all inputs produced up front)."""
+        """False: the caller's word that nothing is produced on its stream between two calls (kmc_hip_set_frame_queue_order)."""
         self._check(lib().kmc_hip_set_frame_queue_order(self._h, 1 if after_producers else 0), "kmc_hip_set_frame_queue_order")
 
     def frame_queue_join(self):

@@ -1605,3 +1605,90 @@ def test_gathered_calls_keep_in_order_results(torch_mod, kitti):
     finally:
         plain.close()
         g.close()
+
+
+@pytest.mark.gpu
+def test_calls_can_be_captured_into_a_hip_graph_and_replayed(torch_mod, kitti):
+    """The device-resident entry points that only ENQUEUE launches -- single frames, a list (here 20 frames: while the stream captures, a
+    list beyond the 16 frames of the kernel-argument table goes out as two such launches instead of a table upload), a batch of at most
+    16 frames, a 3-knot frame, and gathered calls closed by kmc_hip_frame_queue_join -- are captured into a HIP graph on the caller's
+    stream; nothing runs during the capture; a replay over NEW contents of the same buffers writes what eager calls write, bit for bit.
+    A batch that needs a table upload refuses to be captured (KMC_ERR_INVALID_ARG) and leaves the capture alive."""
+    torch = torch_mod
+    xyzi, P1 = kitti
+    rng = np.random.default_rng(777)
+    n = 20_000
+    nf_single, nf_list, nf_batch, nf_gather = 4, 20, 10, 5
+    total = nf_single + nf_list + nf_batch + 1 + nf_gather
+    side = torch.cuda.Stream()
+    c, eager = capi.Context(0), capi.Context(0)
+    try:
+        def draw():
+            return torch.from_numpy(np.ascontiguousarray(xyzi[rng.integers(0, xyzi.shape[0], size=(total, n))])).cuda()
+
+        d_in = draw()                      # (total, n, 4): frame k is d_in[k]
+        d_out = torch.zeros_like(d_in)
+        params = []
+        for k in range(total):
+            A, B = _poses(P1, np.concatenate([rng.normal(0, 1.5, 3), rng.normal(0, 0.05, 3)]))
+            params.append(_params(A, B, treq=T0 + rng.uniform(0, 1) * (T1 - T0)))
+        k_list, k_batch, k_traj, k_gather = nf_single, nf_single + nf_list, nf_single + nf_list + nf_batch, nf_single + nf_list + nf_batch + 1
+        knots_t = np.array([T0, 0.5 * (T0 + T1), T1])
+        Pa, Pb = _poses(P1, np.array([0.6, 0.02, 0.0, 0.0, 0.0, 0.012]))
+        Pc = orc.affine_mul(Pb, orc.se3_exp(np.array([0.7, -0.01, 0.01, 0.001, 0.0, 0.02])))
+        knots_P = np.stack([P.rt12() for P in (Pa, Pb, Pc)])
+        offsets = np.arange(nf_batch + 1, dtype=np.uint64) * n
+        batch_in, batch_out = d_in[k_batch:k_batch + nf_batch].view(-1, 4), d_out[k_batch:k_batch + nf_batch].view(-1, 4)
+
+        def calls(cx, dst):
+            sts = {}
+            for k in range(nf_single):
+                cx.deskew_f32(d_in[k], dst[k], params[k])
+            pack = cx.prepare_frames([(d_in[k_list + f], dst[k_list + f]) for f in range(nf_list)], params[k_list:k_list + nf_list])
+            sts["list"] = cx.deskew_frames_f32(pack)
+            sts["batch"] = cx.deskew_batch_f32(d_in[k_batch:k_batch + nf_batch].view(-1, 4), dst[k_batch:k_batch + nf_batch].view(-1, 4), offsets,
+                                               params[k_batch:k_batch + nf_batch])
+            cx.deskew_traj_f32(d_in[k_traj], dst[k_traj], knots_t, knots_P, T0, T1, TREQ)
+            cx.set_frame_queues(4)
+            for f in range(nf_gather):
+                cx.deskew_f32(d_in[k_gather + f], dst[k_gather + f], params[k_gather + f])
+            cx.frame_queue_join()
+            cx.set_frame_queues(1)
+            return sts, pack
+
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            c.set_stream(side.cuda_stream)
+            calls(c, d_out)  # warm-up on the capture stream (tables, pools)
+            side.synchronize()
+            d_out.zero_()
+            side.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                sts, keep = calls(c, d_out)
+                # 40 frames need a device table: not capturable, refused with a message, the capture goes on
+                many = np.arange(41, dtype=np.uint64) * 500
+                with pytest.raises(capi.KmcError) as ei:
+                    c.deskew_batch_f32(batch_in, batch_out, many, [params[0]] * 40)
+                assert ei.value.status == capi.ERR_INVALID_ARG
+        assert sts["list"].n_launches == 2 and sts["batch"].n_launches == 1
+        torch.cuda.synchronize()
+        assert not bool(d_out.any()), "a captured call ran during the capture"
+        for rep in range(2):
+            d_in.copy_(draw())             # new contents, same buffers
+            d_out.zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            want = torch.zeros_like(d_in)
+            eager.set_stream(torch.cuda.current_stream().cuda_stream)
+            calls(eager, want)
+            eager.synchronize()
+            torch.cuda.synchronize()
+            assert torch.equal(d_out.view(torch.int32), want.view(torch.int32)), rep
+            assert bool(d_out[:, :, :3].ne(d_in[:, :, :3]).any(dim=2).any(dim=1).all()), "every frame was written"
+        del keep
+    finally:
+        c.set_stream(None)
+        c.close()
+        eager.close()
