@@ -1692,3 +1692,57 @@ def test_calls_can_be_captured_into_a_hip_graph_and_replayed(torch_mod, kitti):
         c.set_stream(None)
         c.close()
         eager.close()
+
+
+@pytest.mark.gpu
+def test_per_call_timing_and_the_contexts_page_locked_allocator(torch_mod, kitti):
+    """kmc_hip_enable_timing: kmc_stats carries HIP-event times -- kernel_ms > 0, total_ms >= kernel_ms, a staged host call's total well above
+    its kernel; off again: both 0.  kmc_hip_host_alloc hands out page-locked memory (64-byte aligned) that a KMC_MEM_HOST call recognises
+    and works on in place, same bits as the staged route; kmc_hip_host_free takes it back, and a pointer it does not own is an error."""
+    import ctypes as C
+
+    torch = torch_mod
+    xyzi, P1 = kitti
+    n = xyzi.shape[0]
+    A, B = _poses(P1, np.array(TRAJECTORIES["gentle_turn"], dtype=np.float64))
+    prm = _params(A, B)
+    c = capi.Context(0)
+    try:
+        d_in = torch.from_numpy(xyzi).cuda()
+        d_out = torch.empty_like(d_in)
+        h_out = np.empty_like(xyzi)
+        st0 = c.deskew_f32(d_in, d_out, prm)
+        assert st0.kernel_ms == 0.0 and st0.total_ms == 0.0
+        c.enable_timing(True)
+        st_dev = c.deskew_f32(d_in, d_out, prm)
+        st_host = c.deskew_f32(xyzi, h_out, prm)
+        offsets = np.array([0, n // 3, n], dtype=np.uint64)
+        st_batch = c.deskew_batch_f32(d_in, d_out, offsets, [prm, prm])
+        c.enable_timing(False)
+        st_off = c.deskew_f32(d_in, d_out, prm)
+        for st in (st_dev, st_host, st_batch):
+            assert st.kernel_ms > 0.0 and st.total_ms >= st.kernel_ms * 0.999, (st.kernel_ms, st.total_ms)
+        assert st_dev.kernel_ms < 1.0 and st_host.total_ms > 2 * st_dev.kernel_ms  # 2 MB each way over PCIe against 4 MB through HBM
+        assert st_off.kernel_ms == 0.0 and st_off.total_ms == 0.0
+        c.synchronize()
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint32), h_out.view(np.uint32))
+
+        lib = capi.lib()
+        ptrs = []
+        for _ in range(2):
+            p = C.c_void_p()
+            assert lib.kmc_hip_host_alloc(c._h, n * 16, C.byref(p)) == capi.OK and p.value and p.value % 64 == 0
+            ptrs.append(p)
+        a_in = np.ctypeslib.as_array(C.cast(ptrs[0], C.POINTER(C.c_float)), shape=(n, 4))
+        a_out = np.ctypeslib.as_array(C.cast(ptrs[1], C.POINTER(C.c_float)), shape=(n, 4))
+        a_in[:] = xyzi
+        a_out[:] = 0
+        st = c.deskew_f32(a_in, a_out, prm)          # KMC_MEM_HOST: recognised as device-addressable, one kernel in place
+        assert st.n_launches == 1
+        assert np.array_equal(a_out.view(np.uint32), h_out.view(np.uint32))
+        del a_in, a_out
+        for p in ptrs:
+            assert lib.kmc_hip_host_free(c._h, p) == capi.OK
+        assert lib.kmc_hip_host_free(c._h, C.c_void_p(h_out.ctypes.data)) != capi.OK
+    finally:
+        c.close()
