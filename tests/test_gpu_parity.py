@@ -1746,3 +1746,74 @@ def test_per_call_timing_and_the_contexts_page_locked_allocator(torch_mod, kitti
         assert lib.kmc_hip_host_free(c._h, C.c_void_p(h_out.ctypes.data)) != capi.OK
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_contexts_on_concurrent_host_threads(torch_mod, kitti):
+    """"Thread-safe per context": four host threads, each with its OWN context on the same GPU (ctypes drops the GIL during a call), run
+    single-frame, batched, list and staged-host calls at the same time, contexts being created and destroyed while the others work (the
+    any-order probe's per-device verdict, the page-locked pool and the table slots are the shared state); every thread's results equal
+    the bits a lone context wrote beforehand."""
+    import threading
+
+    torch = torch_mod
+    xyzi, P1 = kitti
+    n = 30_000
+    rng = np.random.default_rng(2024)
+    n_threads, rounds, nf = 4, 12, 6
+    work = []
+    for t in range(n_threads):
+        pts = np.ascontiguousarray(xyzi[rng.integers(0, xyzi.shape[0], size=(nf, n))])
+        params = []
+        for f in range(nf):
+            A, B = _poses(P1, np.concatenate([rng.normal(0, 1.5, 3), rng.normal(0, 0.05, 3)]))
+            params.append(_params(A, B, treq=T0 + rng.uniform(0, 1) * (T1 - T0)))
+        work.append((pts, params))
+
+    def run(cx, pts, params, stream):
+        cx.set_stream(stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            d_in = torch.from_numpy(pts).cuda()
+            outs = {k: torch.zeros_like(d_in) for k in ("single", "batch", "list")}
+            stream.synchronize()
+        for f in range(nf):
+            cx.deskew_f32(d_in[f], outs["single"][f], params[f])
+        cx.deskew_batch_f32(d_in.view(-1, 4), outs["batch"].view(-1, 4), np.arange(nf + 1, dtype=np.uint64) * n, params)
+        cx.deskew_frames_f32(cx.prepare_frames([(d_in[f], outs["list"][f]) for f in range(nf)], params))
+        h = np.empty_like(pts[0])
+        cx.deskew_f32(pts[0], h, params[0])  # pageable host buffers: the staged pipeline
+        cx.synchronize()
+        return {k: v.cpu().numpy().view(np.uint32) for k, v in outs.items()}, h.view(np.uint32)
+
+    lone = capi.Context(0)
+    try:
+        lone.force_tier(0)
+        want = [run(lone, *work[t], torch.cuda.Stream()) for t in range(n_threads)]
+    finally:
+        lone.close()
+    errors = []
+
+    def worker(t):
+        try:
+            stream = torch.cuda.Stream()
+            for r in range(rounds):
+                cx = capi.Context(0)
+                try:
+                    cx.force_tier(0)
+                    got, got_h = run(cx, *work[t], stream)
+                finally:
+                    cx.close()
+                for k in got:
+                    if not np.array_equal(got[k], want[t][0][k]):
+                        errors.append((t, r, k))
+                if not np.array_equal(got_h, want[t][1]):
+                    errors.append((t, r, "host"))
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
