@@ -1,5 +1,6 @@
 // copy_ceiling.hip -- the memory system's own ceilings next to the deskew kernels, and the calibration kernel of the PMC traffic figures.
-//   copy_ceiling [n_points=67108864] [rounds=5] [iters=10]          (CSV on stdout: kernel, best / median us per launch, GB/s)
+//   copy_ceiling [n_points=67108864] [rounds=5] [iters=10] [out_shift_bytes=0]   (CSV on stdout: kernel, best / median us per launch, GB/s;
+//                 out_shift_bytes moves every output buffer relative to its input: does the memory care how the two streams line up?)
 //   copy_points   one v4f per lane in, one out, 256-thread workgroups, nt loads + nt stores: 16 B read + 16 B written per point.  Its
 //                 FETCH_SIZE / WRITE_SIZE counts against its KNOWN traffic give the correction factors tools/summarize_profiles.py applies
 //                 to the bench kernel's counters (gfx950: FETCH_SIZE counts half of a wide coalesced stream; MI355X_MICROARCH.md, HBM section)
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(64) void write_points(const v4f* __restrict__ in, v
 int main(int argc, char** argv) {
   const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 67108864ull;
   const int rounds = argc > 2 ? std::atoi(argv[2]) : 5, iters = argc > 3 ? std::atoi(argv[3]) : 10;
+  const size_t shift = argc > 4 ? std::strtoull(argv[4], nullptr, 10) & ~(size_t)15 : 0;
   CHECK(hipSetDevice(0));
   hipStream_t s;
   CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -70,7 +72,8 @@ int main(int argc, char** argv) {
   v4f *in[kBufs], *out[kBufs];
   for (int b = 0; b < kBufs; ++b) {
     CHECK(hipMalloc(&in[b], n * 16));
-    CHECK(hipMalloc(&out[b], n * 16));
+    CHECK(hipMalloc(&out[b], n * 16 + shift));
+    out[b] = (v4f*)((char*)out[b] + shift);
     CHECK(hipMemsetAsync(in[b], 0x3C, n * 16, s));
   }
   hipEvent_t e0, e1;
