@@ -593,7 +593,7 @@ def run_dropin_cpp_leg(run_tool, rel_err, orc):
             "process_wall_s_best_of_3": round(best, 3), "process_wall_s_all": [round(x, 3) for x in walls],
             "frames_per_s": round((n_run - 2) / best, 1), "Mpts_s": round(pts_run / best / 1e6, 1),
             "busy_seconds_per_stage_last_run": stages[-1].split("busy seconds per stage:")[-1].strip() if stages else None,
-            "note": "whole process: HIP runtime start-up, context, page-locking the two buffer sets, text parsing, reading, one batched GPU round trip per 16 frames, writing",
+            "note": "whole process: HIP runtime start-up, context, page-locking the two buffer sets, text parsing, reading, one batched GPU round trip per 8 frames, writing",
         }
         if orc is not None:  # one frame the driver wrote, against oracle MakeFrame + the FAITHFUL loop
             from tests import util

@@ -23,6 +23,7 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <system_error>
 
 #include "kitti_motion_compensation/data_io.hpp"
 #include "kitti_motion_compensation/handlers.hpp"
@@ -165,6 +166,8 @@ void WriteRaw(Path const data_folder, std::size_t const frame_id, float const* x
   std::ofstream out(file, std::ios::out | std::ios::binary);
   if (!out.is_open()) throw std::runtime_error("Unable to open output pointcloud file: " + file.string());
   out.write(reinterpret_cast<char const*>(xyzi), static_cast<std::streamsize>(n * 4 * sizeof(float)));
+  out.close();
+  if (out.fail()) throw std::runtime_error("Failed writing output pointcloud file: " + file.string());  // (the reference does not look: data_io.cpp:287-313)
 }
 
 void WritePointcloud(Path const data_folder, std::size_t const frame_id, Pointcloud const& cloud, VectorXd const& intensities) {  // :287-313
@@ -246,8 +249,9 @@ namespace {
 //   reader thread : .bin payloads read STRAIGHT into pinned memory (the on-disk layout is the kernel's layout: no
 //                   conversion, no extra copy) + the per-frame poses (MakeFrame, data_io.cpp:253-269)
 //   this thread   : one batched GPU call per buffer set (H2D, kernel, D2H) on the thread's own device context
-//   writer thread : results written from pinned memory
-// so reading batch k+1, deskewing batch k and writing batch k-1 overlap.
+//   writer thread : results written from pinned memory, a batch's files split over two threads (writing is the longest stage)
+// so reading batch k+1, deskewing batch k and writing batch k-1 overlap.  The second buffer set is page-locked while the reader
+// already fills the first (page-locking costs ~0.3 ms/MiB: a third of a short run's pipeline time).
 struct RunInputs {
   Path velodyne, out_dir;
   std::vector<Time> const* t_start;
@@ -279,10 +283,10 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
     std::vector<std::uint64_t> offsets;
     std::vector<Path> files;
   };
-  enum class State { kFree, kReady, kDone };
+  enum class State { kUnallocated, kFree, kReady, kDone };
   struct BufferSet {
     Pinned in, out;
-    State state = State::kFree;
+    State state = State::kUnallocated;
     std::vector<hip::FramePoses> frames;
     std::vector<hip::FrameTrajectory> trajectories;  // KMC_RUN_KNOTS=3
   };
@@ -312,11 +316,13 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
   auto const t_ctx0 = clk::now();
   kmc_ctx* ctx = detail::thread_context();
   BufferSet sets[2];
-  for (auto& set : sets) {
+  auto const alloc_set = [&](BufferSet& set) {
     set.in.alloc(ctx, 4 * max_points + 16);
     set.out.alloc(ctx, 4 * max_points + 16);
-  }
-  double const t_ctx = secs(t_ctx0, clk::now());
+  };
+  alloc_set(sets[0]);
+  sets[0].state = State::kFree;
+  double t_ctx = secs(t_ctx0, clk::now());
 
   std::mutex mu;
   std::condition_variable cv;
@@ -387,10 +393,35 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
         BatchPlan const& plan = plans[k];
         if (!wait_for(set, State::kDone)) return;
         auto const t0 = clk::now();
-        for (std::size_t j = 0; j < plan.files.size(); ++j) {
-          WriteRaw(in.out_dir, plan.first + j, set.out.p + 4 * plan.offsets[j], static_cast<std::size_t>(plan.offsets[j + 1] - plan.offsets[j]));
+        auto const write_files = [&](std::size_t j0) {  // every second file of the batch, from j0
+          for (std::size_t j = j0; j < plan.files.size(); j += 2)
+            WriteRaw(in.out_dir, plan.first + j, set.out.p + 4 * plan.offsets[j], static_cast<std::size_t>(plan.offsets[j + 1] - plan.offsets[j]));
+        };
+        std::exception_ptr helper_error;
+        std::thread helper;
+        try {
+          helper = std::thread([&] {
+            try {
+              write_files(1);
+            } catch (...) {
+              helper_error = std::current_exception();
+            }
+          });
+        } catch (std::system_error const&) {  // no helper thread to be had: this thread writes the whole batch
+          write_files(1);
+        }
+        try {
+          write_files(0);
+        } catch (...) {
+          if (helper.joinable()) helper.join();
+          throw;
+        }
+        if (helper.joinable()) helper.join();
+        if (helper_error) std::rethrow_exception(helper_error);
+        {
           std::lock_guard<std::mutex> lock(g_cout_mu);
-          std::cout << "Motion compensated pointcloud number: " << plan.first + j << std::endl;  // handlers.cpp:63
+          for (std::size_t j = 0; j < plan.files.size(); ++j)
+            std::cout << "Motion compensated pointcloud number: " << plan.first + j << std::endl;  // handlers.cpp:63 (ascending, like the reference's loop)
         }
         t_write += secs(t0, clk::now());
         publish(set, State::kFree);
@@ -408,6 +439,12 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
     throw;
   }
   try {
+    if (plans.size() > 1) {  // the second buffer set, while the reader is busy with the first batch
+      auto const t0 = clk::now();
+      alloc_set(sets[1]);
+      t_ctx += secs(t0, clk::now());
+      publish(sets[1], State::kFree);
+    }
     for (std::size_t k = 0; k < plans.size(); ++k) {
       BufferSet& set = sets[k % 2];
       if (!wait_for(set, State::kReady)) break;
@@ -470,10 +507,10 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
   in.t_end = &t_end;
   in.oxts = &oxts;
   in.frame_points = &frame_points;
-  in.max_batch_frames = [] {  // page-locking costs ~0.3 ms/MiB, so modest batches win for one-off runs
+  in.max_batch_frames = [] {  // page-locking costs ~0.3 ms/MiB, so modest batches win for one-off runs (tools/time_run_cli.sh: 8 beats 16 by ~20 ms per 216-frame run)
     char const* e = std::getenv("KMC_RUN_BATCH_FRAMES");
     long const v = e ? std::atol(e) : 0;
-    return static_cast<std::size_t>(v > 0 ? std::min(v, 4096L) : 16L);
+    return static_cast<std::size_t>(v > 0 ? std::min(v, 4096L) : 8L);
   }();
   in.timing = [] { char const* e = std::getenv("KMC_RUN_TIMING"); return e && e[0] == '1'; }();
   // KMC_RUN_KNOTS=3: interpolate along the piecewise geodesic through the three OXTS poses around the frame, used as they
