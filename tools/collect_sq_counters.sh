@@ -7,7 +7,8 @@ cd "$(dirname "$0")/.."
 O=$PWD/gpurun_out/$TAG
 mkdir -p "$O"
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-configs3 --no-legs --sustained-seconds 0"
+# KMC_SQ_CMD overrides the profiled command (e.g. "python bench.py --legs-only --no-cpu-baseline" for the secondary kernels)
+BENCH=${KMC_SQ_CMD:-"python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-configs3 --no-legs --sustained-seconds 0"}
 i=0
 for group in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" \
              "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch averages of the SQ / TCC counters tools/collect_sq_counters.sh collected for the bench kernel (deskew_batch_f32),
-plus the ratios worth reading.   python tools/summarize_sq_counters.py gpurun_out/r02 r02   -> profiles/r02_pmc_sq_tcc.json"""
+plus the ratios worth reading.   python tools/summarize_sq_counters.py gpurun_out/r02 r02   -> profiles/r02_pmc_sq_tcc.json
+Another kernel of another profiled command:   ... gpurun_out/r04sqlegs r04 "deskew_f64cols<false>" f64cols   -> profiles/r04_pmc_sq_tcc_f64cols.json"""
 import collections
 import csv
 import glob
@@ -11,15 +12,17 @@ import sys
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    kernel = sys.argv[3] if len(sys.argv) > 3 else "deskew_batch_f32"
+    suffix = "_" + sys.argv[4] if len(sys.argv) > 4 else ""
     acc = collections.defaultdict(list)
     for path in sorted(glob.glob(os.path.join(src, "sq_*", "**", "*counter_collection.csv"), recursive=True)):
         with open(path) as f:
             for r in csv.DictReader(f):
-                if "deskew_batch_f32" in r["Kernel_Name"]:
+                if kernel in r["Kernel_Name"]:
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {k: sum(v) / len(v) for k, v in sorted(acc.items())}
     if not out:
-        raise SystemExit("no deskew_batch_f32 rows found under " + src)
+        raise SystemExit(f"no {kernel} rows found under " + src)
     w = out.get("SQ_WAVES")
     derived = {}
     if w:
@@ -32,10 +35,10 @@ def main():
         derived["wave_time_waiting"] = round(out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"], 4)
     if "TCC_HIT_sum" in out and "TCC_MISS_sum" in out:
         derived["l2_hit_rate"] = round(out["TCC_HIT_sum"] / max(1.0, out["TCC_HIT_sum"] + out["TCC_MISS_sum"]), 5)
-    res = {"kernel": "deskew_batch_f32 (bench.py --steps 4 --warmup 1, 256 M points per launch)", "per_launch": out, "derived": derived,
+    res = {"kernel": "deskew_batch_f32 (bench.py --steps 4 --warmup 1, 256 M points per launch)" if kernel == "deskew_batch_f32" else kernel, "per_launch": out, "derived": derived,
            "launches_averaged": {k: len(v) for k, v in acc.items()}}
     os.makedirs("profiles", exist_ok=True)
-    with open(os.path.join("profiles", f"{tag}_pmc_sq_tcc.json"), "w") as fh:
+    with open(os.path.join("profiles", f"{tag}_pmc_sq_tcc{suffix}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res, indent=1))
 
