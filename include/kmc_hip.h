@@ -210,7 +210,8 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  *       kmc_hip_set_stream() and kmc_hip_frame_queue_join() issue the pending frames first.  What changes for the caller: a frame's
  *       launch may be DEFERRED until one of those calls.  Work the caller itself puts on the stream (or a hipDeviceSynchronize) does
  *       not see a pending frame: call kmc_hip_frame_queue_join() (or kmc_hip_synchronize) before consuming results outside the
- *       library.  (Until ABI 3 `queues` was a number of HIP streams the frames were spread over; the streams are gone, any value
+ *       library -- and before freeing a pending frame's buffers or overwriting its input outside the library (the frame still has
+ *       to read it; inside the library the hazard check orders such frames by itself).  (Until ABI 3 `queues` was a number of HIP streams the frames were spread over; the streams are gone, any value
  *       2..4 switches gathering on.)  With kmc_hip_enable_timing() on, calls are launched one by one (per-call times need it).
  *   (3) queues = 1 (default): every call is launched at once, in order on the context's stream.  Since ABI 3 "in order" does not
  *       mean "drained": a device-resident frame whose buffers overlap none of the frames launched since the last ordinary launch is
