@@ -470,8 +470,11 @@ __device__ __forceinline__ void f64_report_bad(uint32_t bad_count, uint32_t tid,
 // so that uploads and downloads overlap in time: launched like the device kernel (every wave loads its tile, then stores it, all
 // ~1000 waves of a KITTI frame at once) the link is used one direction after the other -- 148 us per 123 k-point frame against
 // ~110 us pipelined (profiles/NOTES_r03.md).
+#ifndef KMC_F64_WAVES
+#define KMC_F64_WAVES 4  // waves per SIMD of the f64 column kernels (2 / 6 / 8 measured: profiles/NOTES.md)
+#endif
 template <bool STREAMED = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, KMC_F64_WAVES))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                      const double* __restrict__ z, const double* __restrict__ w,
                                                      const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
                                                      double* __restrict__ ox, double* __restrict__ oy,
