@@ -246,6 +246,14 @@ def _frac(gbps):
     return round(gbps / HBM_PEAK_GBPS, 4)
 
 
+def unprofiled_env(env=None):
+    """The environment of a child process without an inherited rocprofv3 tool: the C++ clients run un-profiled even when this process is
+    being profiled (a counter pass, --pmc, inherited through the environment crashes a second process on the same device; the tools have
+    their own passes, profiles/README.md)."""
+    return {k: v for k, v in (os.environ if env is None else env).items()
+            if not (k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES") and "rocprof" in v.lower()) and not k.startswith(("ROCPROF", "ROCPROFILER_"))}
+
+
 def run_secondary_legs(capi, torch, ctx, dev, check):
     """N = 1 only: the secondary configurations as legs of the ONE bench line.  Every leg: device-resident inputs generated before its
     timed region, HIP events on the launch stream around it (kmc_hip_timer_begin / _end), rotating buffers beyond the 256 MiB
@@ -282,7 +290,7 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
 
         if not os.path.exists(cmd[0]):
             raise SystemExit(f"{cmd[0]} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=unprofiled_env(env))
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             raise SystemExit(f"{' '.join(cmd)} failed ({r.returncode}): {r.stdout[-1000:]} {r.stderr[-2000:]}")
@@ -579,7 +587,7 @@ def run_dropin_cpp_leg(run_tool, rel_err, orc):
         for rep in range(3):
             shutil.rmtree(os.path.join(run, "velodyne_points", "data_motion_compensated"), ignore_errors=True)
             t0 = time.perf_counter()
-            rr = subprocess.run([cli, data_dir + "/", os.path.basename(run)], capture_output=True, text=True, env=dict(os.environ, KMC_RUN_TIMING="1"), timeout=900)
+            rr = subprocess.run([cli, data_dir + "/", os.path.basename(run)], capture_output=True, text=True, env=unprofiled_env(dict(os.environ, KMC_RUN_TIMING="1")), timeout=900)
             walls.append(time.perf_counter() - t0)
             if rr.returncode != 0:
                 raise SystemExit("motion_compensate_runs failed: " + rr.stderr[-2000:])
