@@ -480,26 +480,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, KMC_F64_W
                                                      double* __restrict__ ox, double* __restrict__ oy,
                                                      double* __restrict__ oz, double* __restrict__ ow,
                                                      unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base) {
-  constexpr uint64_t kTile = 128;  // points per wave HERE: two per lane
+  constexpr uint64_t kTile64 = 128;  // points per wave HERE: two per lane
   const uint32_t tid = threadIdx.x;
-  const uint64_t n_tiles = (n + kTile - 1) / kTile;
-  const uint64_t n_full = n / kTile;  // tiles without a ragged end
+  const uint64_t n_tiles = (n + kTile64 - 1) / kTile64;
+  const uint64_t n_full = n / kTile64;  // tiles without a ragged end
   uint64_t t = tile_base + blockIdx.x;
   if constexpr (STREAMED) {  // persistent waves: the grid is the wave count, every wave walks its tiles (tile_base = 0)
     F64Tile cur;
-    if (t < n_full) cur = f64_tile_load(x, y, z, w, stamps, t * kTile + 2 * (uint64_t)tid);
+    if (t < n_full) cur = f64_tile_load(x, y, z, w, stamps, t * kTile64 + 2 * (uint64_t)tid);
     while (t < n_full) {
       const uint64_t next = t + gridDim.x;
       F64Tile nxt = cur;
-      if (next < n_full) nxt = f64_tile_load(x, y, z, w, stamps, next * kTile + 2 * (uint64_t)tid);  // in flight while `cur` is finished
-      f64_report_bad(f64_tile_finish(cur, f, ox, oy, oz, ow, t * kTile + 2 * (uint64_t)tid), tid, n_bad, bad_flag);
+      if (next < n_full) nxt = f64_tile_load(x, y, z, w, stamps, next * kTile64 + 2 * (uint64_t)tid);  // in flight while `cur` is finished
+      f64_report_bad(f64_tile_finish(cur, f, ox, oy, oz, ow, t * kTile64 + 2 * (uint64_t)tid), tid, n_bad, bad_flag);
       cur = nxt;
       t = next;
     }
     t = n_full + blockIdx.x;  // only the ragged last tile is left, for the first workgroup
   }
   if (t >= n_tiles) return;
-  const uint64_t i = t * kTile + 2 * (uint64_t)tid;
+  const uint64_t i = t * kTile64 + 2 * (uint64_t)tid;
   uint32_t bad_count;
   if (i + 1 < n) {
     const F64Tile tl = f64_tile_load(x, y, z, w, stamps, i);
