@@ -195,6 +195,22 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     assert 8 * d["peak_device_GiB_per_rank"] < 250
 
 
+def test_bench_child_tools_do_not_inherit_a_profiler():
+    """CPU: the C++ clients bench.py runs as child processes get an environment without an inherited rocprofv3 tool (a counter pass
+    inherited through LD_PRELOAD crashed them on the GPU box); everything else passes through."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("kmc_bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    env = {"PATH": "/usr/bin", "LD_PRELOAD": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so", "ROCPROF_COUNTERS": "pmc: SQ_WAVES",
+           "ROCPROFILER_LIBRARY_CTOR": "1", "HSA_TOOLS_LIB": "/opt/rocm/lib/librocprofiler-sdk.so", "KMC_RUN_TIMING": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    out = bench.unprofiled_env(env)
+    assert out == {"PATH": "/usr/bin", "KMC_RUN_TIMING": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    keep = {"LD_PRELOAD": "/usr/lib/libjemalloc.so", "HSA_TOOLS_LIB": "/opt/other/libtool.so"}  # somebody else's preloads are not ours to drop
+    assert bench.unprofiled_env(keep) == keep
+
+
 @pytest.mark.gpu
 def test_bench_live_traffic_matches_the_algorithmic_bytes():
     """The default at N = 1: HBM bytes per launch from rocprofv3 --pmc child runs of the same invocation (FETCH_SIZE and WRITE_SIZE
