@@ -7,6 +7,11 @@
 //   copy_tiles    the product kernels' access pattern without their arithmetic: one 64-point tile per one-wave workgroup, nt load,
 //                 nt + sc1 store through a buffer descriptor
 //   read_points / write_points   one direction alone (7.06 / 6.72 TB/s on the round-3 boxes: the deskew kernels sit on their mean)
+//   copy_cols9 / copy_cols7   (round 5) the f64 Eigen-layout kernel's access pattern without its arithmetic: five (four) `double[n]`
+//                 columns read, four (three) written, two consecutive points = 16 B per lane and column, one 128-point tile per one-wave
+//                 workgroup, nt -- 72 (56) B per point.  copy_cols9_w4: the same with resident waves capped at 4 per SIMD through dynamic
+//                 LDS (what deskew_f64cols runs at); copy_cols9_sc1: stores through descriptors with nt + sc1.  `points` of these rows =
+//                 n_points of the command line (every column holds n doubles).
 // Rounds 1-3's A/B harnesses (kmc_tune.hip, kmc_tune_r3.hip: persistent grids, 2 / 4 / 8 points per lane, cache policies, XCD mappings,
 // ocml trigonometry, the LDS-staged N-knot kernel) instantiated kernel variants that left the product headers in round 4; their sources
 // are in the repository's history (last present at commit 3470e8d), their tables under profiles/r0[123]_tune*.csv.
@@ -61,6 +66,30 @@ __global__ __launch_bounds__(64) void write_points(const v4f* __restrict__ in, v
   }
 }
 
+// ---- nine column streams (deskew_f64cols' pattern) ----
+typedef double v2d_u __attribute__((ext_vector_type(2), aligned(8)));
+struct Cols { const double* in[5]; double* out[4]; };
+template <int NIN, int NOUT, bool SC1>
+__global__ __launch_bounds__(64) void copy_cols(Cols c, uint64_t n) {
+  extern __shared__ char occupancy_cap[];  // dynamic LDS only limits how many workgroups a CU holds
+  const uint64_t base = (uint64_t)blockIdx.x * 128, i = base + 2 * (uint64_t)threadIdx.x;
+  if (i + 1 >= n) return;  // (n is a multiple of 128 here)
+  v2d_u v[NIN];
+#pragma unroll
+  for (int k = 0; k < NIN; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(c.in[k] + i));
+#pragma unroll
+  for (int k = 0; k < NOUT; ++k) {
+    v2d_u o = v[k + 1];
+    o.x += v[0].x * 0.0;  // every output depends on the stamps column like the real kernel's (nothing can be stored before all loads land)
+    if constexpr (SC1) {
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(c.out[k] + base), 0, 128 * 8, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), r, threadIdx.x * 16u, 0, 2 | 16);
+    } else {
+      __builtin_nontemporal_store(o, reinterpret_cast<v2d_u*>(c.out[k] + i));
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 67108864ull;
   const int rounds = argc > 2 ? std::atoi(argv[2]) : 5, iters = argc > 3 ? std::atoi(argv[3]) : 10;
@@ -99,6 +128,42 @@ int main(int argc, char** argv) {
     std::sort(us[k].begin(), us[k].end());
     const double best = us[k].front(), med = us[k][us[k].size() / 2];
     std::printf("%s,%llu,%.2f,%.2f,%.1f,%.1f\n", ks[k].name, (unsigned long long)n, best, med, ks[k].bytes_per_point * n / best / 1e3, ks[k].bytes_per_point * n / med / 1e3);
+  }
+  // ---- the column streams: the point buffers above are re-used as 2 x 3 sets of columns (6 x 16 n bytes = 12 n doubles >= 9 n) ----
+  {
+    double* pool[6] = {(double*)in[0], (double*)in[1], (double*)in[2], (double*)((char*)out[0] - shift), (double*)((char*)out[1] - shift), (double*)((char*)out[2] - shift)};
+    // every 16 n-byte buffer holds two n-double columns; sets rotate so that consecutive launches touch different memory
+    auto col = [&](int j) { return pool[(j / 2) % 6] + (size_t)(j % 2) * n; };
+    Cols sets[2];
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      // set 0: inputs = columns 0..4, outputs = 5..8; set 1: the roles shifted by three buffers
+      for (int k = 0; k < 5; ++k) sets[sidx].in[k] = col((k + 6 * sidx) % 12);
+      for (int k = 0; k < 4; ++k) sets[sidx].out[k] = col((5 + k + 6 * sidx) % 12);
+    }
+    struct KC { const char* name; void (*fn)(Cols, uint64_t); double bytes_per_point; unsigned lds; };
+    // 160 KiB of LDS per CU, 16 resident one-wave workgroups per CU = 4 per SIMD  <=>  10 KiB each
+    const KC kc[] = {{"copy_cols9", copy_cols<5, 4, false>, 72.0, 0},       {"copy_cols9_w4", copy_cols<5, 4, false>, 72.0, 10 * 1024},
+                     {"copy_cols9_sc1", copy_cols<5, 4, true>, 72.0, 0},    {"copy_cols7", copy_cols<4, 3, false>, 56.0, 0},
+                     {"copy_cols7_w4", copy_cols<4, 3, false>, 56.0, 10 * 1024}};
+    const int nk = (int)(sizeof(kc) / sizeof(kc[0]));
+    std::vector<std::vector<double>> usc((size_t)nk);
+    const dim3 grid((unsigned)(n / 128)), block(64);
+    for (int r = 0; r < rounds; ++r)
+      for (int k = 0; k < nk; ++k) {
+        for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kc[k].fn, grid, block, kc[k].lds, s, sets[w % 2], n);
+        CHECK(hipEventRecord(e0, s));
+        for (int it = 0; it < iters; ++it) hipLaunchKernelGGL(kc[k].fn, grid, block, kc[k].lds, s, sets[it % 2], n);
+        CHECK(hipEventRecord(e1, s));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        usc[(size_t)k].push_back(ms * 1e3 / iters);
+      }
+    for (int k = 0; k < nk; ++k) {
+      std::sort(usc[(size_t)k].begin(), usc[(size_t)k].end());
+      const double best = usc[(size_t)k].front(), med = usc[(size_t)k][usc[(size_t)k].size() / 2];
+      std::printf("%s,%llu,%.2f,%.2f,%.1f,%.1f\n", kc[k].name, (unsigned long long)n, best, med, kc[k].bytes_per_point * n / best / 1e3, kc[k].bytes_per_point * n / med / 1e3);
+    }
   }
   return 0;
 }
