@@ -246,6 +246,10 @@ def _frac(gbps):
     return round(gbps / HBM_PEAK_GBPS, 4)
 
 
+class ToolMissing(Exception):
+    """A C++ benchmark client under kitti_motion_compensation_amd/lib was not built (tools/Makefile is best effort)."""
+
+
 def unprofiled_env(env=None):
     """The environment of a child process without an inherited rocprofv3 tool: the C++ clients run un-profiled even when this process is
     being profiled (a counter pass, --pmc, inherited through the environment crashes a second process on the same device; the tools have
@@ -288,8 +292,8 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         """A C++ client of the product libraries (built by __graft_entry__.build() under kitti_motion_compensation_amd/lib): its one JSON line."""
         import subprocess
 
-        if not os.path.exists(cmd[0]):
-            raise SystemExit(f"{cmd[0]} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        if not os.path.exists(cmd[0]):  # a benchmark CLIENT (tools/Makefile, best effort) did not build: its leg is skipped, the line still comes out
+            raise ToolMissing(f"{os.path.basename(cmd[0])} is missing (tools/Makefile builds it; `python -c 'import __graft_entry__ as g; g.build()'`)")
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=unprofiled_env(env))
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
@@ -302,7 +306,11 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     n = 1_000_000
     torch.cuda.synchronize()
     stream_tool = os.path.join(ROOT, "kitti_motion_compensation_amd", "lib", "time_frame_stream")
-    fs = run_tool([stream_tool, "256", str(n), "1", "8"])
+    try:
+        fs = run_tool([stream_tool, "256", str(n), "1", "8"])
+    except ToolMissing as e:
+        fs = None
+        out["configs1_literal"] = {"skipped": str(e)}
 
     def stream_leg(d, key, npts, note):
         us = d[key]["us_per_frame"]
@@ -312,38 +320,39 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
                 o[k] = d[key][k]
         return o
 
-    leg = {
-        "workload": "configs[1] literally: synthetic 1 M-point frames, each in its own allocation (256 distinct frames, 8.2 GB), per-frame twists; driven from C++ through the C-ABI (tools/time_frame_stream.hip), HIP events on the context's stream, 8 timed sweeps",
-        "kernel": "kmc_dev::deskew_frame_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64> per call; kmc_dev::deskew_list_f32 for the list",
-        "any_order_dispatch_verdict": fs["any_order_dispatch"],
-        "in_order": stream_leg(fs, "per_call", n, "ONE kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream; frames that share no buffer with one in flight "
-                               "go out without the barrier bit where kmc_hip_create's probe verified it (any_order_dispatch_verdict == 1)"),
-        "in_order_drained": stream_leg(fs, "per_call_drained", n, "the same calls on a context created with KMC_ANY_ORDER=0: every dispatch waits for the last wave of the one before it"),
-        "gathered_calls": stream_leg(fs, "per_call_gathered", n, "the same calls, one per frame, with kmc_hip_set_frame_queues(ctx, 4): the library gathers them on the host and issues "
-                                     "ONE launch of the frame-list kernel per up to 16 frames (deferred issue, in-order results)"),
-        "list_one_launch": stream_leg(fs, "list_one_launch", n, "kmc_hip_deskew_frames_f32: the 256 separate frames handed over as ONE list -> one launch of the frame-list kernel "
-                                      "(2-D grid: frame x tile); bit-identical to the per-call outputs (checked by the tool: list_equals_per_call_bitwise)"),
-        "batch_packed": stream_leg(fs, "batch_packed", n, "the same frames packed into one buffer, kmc_hip_deskew_batch_f32 (the headline's kernel): the ceiling for this frame mix"),
-        "list_equals_per_call_bitwise": fs["list_equals_per_call_bitwise"],
-    }
-    assert fs["list_equals_per_call_bitwise"] is True and fs["list_launches"] == 1, fs
-    if check:  # oracle spot check of the per-call entry point on this workload's first frame shape (outside any timing)
-        work = make_workload(capi, 1, 0, yaw_per_frame=0.03)[0]
-        prm, (t0, tm, t1), oxs = work
-        a = torch.empty((100_000, 4), dtype=torch.float32, device=dev)
-        ctx.synth_points(a, 100_000, SEED + 0xC1000000)
-        b = torch.empty_like(a)
-        ctx.deskew_f32(a, b, prm)
-        torch.cuda.synchronize()
-        pts, got = a.cpu().numpy(), b.cpu().numpy()
-        oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
-        rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
-        ref = orc.deskew_xyzi_f32(pts, t0, A, t1, B, tm, mode=orc.FAITHFUL)
-        assert rc == orc.OK and ref["rc"] == orc.OK
-        leg["parity"] = {"max_rel_err": rel_err(got[:, :3], ref["xyz_f64"]), "bar": 1e-5, "points": 100_000}
-        assert leg["parity"]["max_rel_err"] <= 1e-5, leg
-        del a, b
-    out["configs1_literal"] = leg
+    if fs is not None:
+        leg = {
+            "workload": "configs[1] literally: synthetic 1 M-point frames, each in its own allocation (256 distinct frames, 8.2 GB), per-frame twists; driven from C++ through the C-ABI (tools/time_frame_stream.hip), HIP events on the context's stream, 8 timed sweeps",
+            "kernel": "kmc_dev::deskew_frame_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64> per call; kmc_dev::deskew_list_f32 for the list",
+            "any_order_dispatch_verdict": fs["any_order_dispatch"],
+            "in_order": stream_leg(fs, "per_call", n, "ONE kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream; frames that share no buffer with one in flight "
+                                   "go out without the barrier bit where kmc_hip_create's probe verified it (any_order_dispatch_verdict == 1)"),
+            "in_order_drained": stream_leg(fs, "per_call_drained", n, "the same calls on a context created with KMC_ANY_ORDER=0: every dispatch waits for the last wave of the one before it"),
+            "gathered_calls": stream_leg(fs, "per_call_gathered", n, "the same calls, one per frame, with kmc_hip_set_frame_queues(ctx, 4): the library gathers them on the host and issues "
+                                         "ONE launch of the frame-list kernel per up to 16 frames (deferred issue, in-order results)"),
+            "list_one_launch": stream_leg(fs, "list_one_launch", n, "kmc_hip_deskew_frames_f32: the 256 separate frames handed over as ONE list -> one launch of the frame-list kernel "
+                                          "(2-D grid: frame x tile); bit-identical to the per-call outputs (checked by the tool: list_equals_per_call_bitwise)"),
+            "batch_packed": stream_leg(fs, "batch_packed", n, "the same frames packed into one buffer, kmc_hip_deskew_batch_f32 (the headline's kernel): the ceiling for this frame mix"),
+            "list_equals_per_call_bitwise": fs["list_equals_per_call_bitwise"],
+        }
+        assert fs["list_equals_per_call_bitwise"] is True and fs["list_launches"] == 1, fs
+        if check:  # oracle spot check of the per-call entry point on this workload's first frame shape (outside any timing)
+            work = make_workload(capi, 1, 0, yaw_per_frame=0.03)[0]
+            prm, (t0, tm, t1), oxs = work
+            a = torch.empty((100_000, 4), dtype=torch.float32, device=dev)
+            ctx.synth_points(a, 100_000, SEED + 0xC1000000)
+            b = torch.empty_like(a)
+            ctx.deskew_f32(a, b, prm)
+            torch.cuda.synchronize()
+            pts, got = a.cpu().numpy(), b.cpu().numpy()
+            oo = [orc.oxts(o.stamp, o.lat, o.lon, o.alt, o.roll, o.pitch, o.yaw) for o in oxs]
+            rc, A, B = orc.make_frame_poses(oo[0], oo[1], oo[2], t0, t1)
+            ref = orc.deskew_xyzi_f32(pts, t0, A, t1, B, tm, mode=orc.FAITHFUL)
+            assert rc == orc.OK and ref["rc"] == orc.OK
+            leg["parity"] = {"max_rel_err": rel_err(got[:, :3], ref["xyz_f64"]), "bar": 1e-5, "points": 100_000}
+            assert leg["parity"]["max_rel_err"] <= 1e-5, leg
+            del a, b
+        out["configs1_literal"] = leg
     caller_stream = torch.cuda.current_stream().cuda_stream
     state = {"k": 0}
 
@@ -386,22 +395,25 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     # its own allocation, 3 rotating sets; one kmc_hip_deskew_f32 call per frame, the list call, and the packed batch beside them
     del sets
     torch.cuda.empty_cache()
-    fd = run_tool([stream_tool, "108", "kitti", "3", "50"])
-    npts = fd["mean_points_per_frame"]
-    leg["frame_by_frame_from_c"] = {
-        "workload": "108 separate frames ~N(121 k, 3 k) points, each in its own allocation, 3 rotating sets, per-frame twists; tools/time_frame_stream.hip, 50 timed sweeps",
-        "mean_points_per_frame": npts, "any_order_dispatch_verdict": fd["any_order_dispatch"],
-        "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream"),
-        "per_call_drained": stream_leg(fd, "per_call_drained", npts, "KMC_ANY_ORDER=0: the barrier bit on every dispatch"),
-        "per_call_gathered": stream_leg(fd, "per_call_gathered", npts, "the same calls with kmc_hip_set_frame_queues(ctx, 4): gathered on the host, one list launch per up to 16 frames"),
-        "list_one_launch": stream_leg(fd, "list_one_launch", npts, "kmc_hip_deskew_frames_f32: the 108 separate frames as one list, ONE launch (device tables: one small upload per call)"),
-        "batch_packed": stream_leg(fd, "batch_packed", npts, "the same frames packed into one buffer, one batched launch"),
-        "per_call_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call"]["us_per_frame"], 3),
-        "gathered_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call_gathered"]["us_per_frame"], 3),
-        "list_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["list_one_launch"]["us_per_frame"], 3),
-        "list_equals_per_call_bitwise": fd["list_equals_per_call_bitwise"],
-    }
-    assert fd["list_equals_per_call_bitwise"] is True, fd
+    try:
+        fd = run_tool([stream_tool, "108", "kitti", "3", "50"])
+        npts = fd["mean_points_per_frame"]
+        leg["frame_by_frame_from_c"] = {
+            "workload": "108 separate frames ~N(121 k, 3 k) points, each in its own allocation, 3 rotating sets, per-frame twists; tools/time_frame_stream.hip, 50 timed sweeps",
+            "mean_points_per_frame": npts, "any_order_dispatch_verdict": fd["any_order_dispatch"],
+            "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream"),
+            "per_call_drained": stream_leg(fd, "per_call_drained", npts, "KMC_ANY_ORDER=0: the barrier bit on every dispatch"),
+            "per_call_gathered": stream_leg(fd, "per_call_gathered", npts, "the same calls with kmc_hip_set_frame_queues(ctx, 4): gathered on the host, one list launch per up to 16 frames"),
+            "list_one_launch": stream_leg(fd, "list_one_launch", npts, "kmc_hip_deskew_frames_f32: the 108 separate frames as one list, ONE launch (device tables: one small upload per call)"),
+            "batch_packed": stream_leg(fd, "batch_packed", npts, "the same frames packed into one buffer, one batched launch"),
+            "per_call_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call"]["us_per_frame"], 3),
+            "gathered_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call_gathered"]["us_per_frame"], 3),
+            "list_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["list_one_launch"]["us_per_frame"], 3),
+            "list_equals_per_call_bitwise": fd["list_equals_per_call_bitwise"],
+        }
+        assert fd["list_equals_per_call_bitwise"] is True, fd
+    except ToolMissing as e:
+        leg["frame_by_frame_from_c"] = {"skipped": str(e)}
     out["configs2_drive"] = leg
 
     # ---- nknot3: three bracketing poses used directly, 10 M-point frames ---------------------------------------------------------
@@ -498,7 +510,10 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     out["f64cols"] = leg
     del cols, w, stamps, outs
     torch.cuda.empty_cache()
-    out["dropin_cpp"] = run_dropin_cpp_leg(run_tool, rel_err, orc if check else None)
+    try:
+        out["dropin_cpp"] = run_dropin_cpp_leg(run_tool, rel_err, orc if check else None)
+    except ToolMissing as e:
+        out["dropin_cpp"] = {"skipped": str(e)}
     return out
 
 

@@ -55,6 +55,24 @@ int GetDevice();
 void SetRunDevices(std::vector<int> const& devices);
 std::vector<int> GetRunDevices();
 
+// Where the microseconds of the calling thread's last MotionCompensateFrame(Frame const&, Time) call went (profiles/r05_dropin_trace.json
+// is made of these).  Host stamps: steady_clock microseconds; device stamps: the GPU's own 100 MHz clock in microseconds (only their
+// difference means anything; 0 when the call took a route without stamps, e.g. pageable containers).  Off by default.
+struct FrameTrace {
+  double enter_us = 0;         // MotionCompensateFrame entered
+  double params_us = 0;        // f64 host pre-step done: Log(T_start^-1 T_end), x_req
+  double alloc_us = 0;         // the result cloud exists (page-locked pool block)
+  double begin_returned_us = 0;  // kmc_hip_deskew_f64cols_begin has returned: the kernel is enqueued
+  double fill_done_us = 0;     // the host has filled the result's homogeneous column (while the kernel runs)
+  double end_returned_us = 0;  // kmc_hip_deskew_f64cols_end has returned: the results are in host memory
+  double return_us = 0;        // about to return the cloud
+  // the C-ABI's own stamps of the same call (kmc_call_trace, kmc_hip.h)
+  double issue_begin_us = 0, issue_end_us = 0, wait_begin_us = 0, wait_end_us = 0, dev_first_wave_us = 0, dev_last_store_us = 0;
+  unsigned waves = 0, route = 0;
+};
+void EnableFrameTrace(bool enabled);
+FrameTrace LastFrameTrace();
+
 // One frame in the on-disk KITTI layout (f32 AoS x,y,z,intensity): fuses GetPseudoTimeStamps (data_io.cpp:163),
 // MotionCompensateFrame (handlers.cpp:60) and WritePointcloud's f64->f32 cast (data_io.cpp:300-310) in one kernel.
 // xyzi_in / xyzi_out are HOST pointers here (16-byte aligned); use the C-ABI directly for device-resident buffers.

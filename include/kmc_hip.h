@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define KMC_ABI_VERSION 4
+#define KMC_ABI_VERSION 5
 
 /* ---- status codes ---- */
 #define KMC_OK 0
@@ -125,6 +125,23 @@ int kmc_hip_synchronize(kmc_ctx* ctx);
 int kmc_hip_enable_timing(kmc_ctx* ctx, int enabled);
 const char* kmc_hip_last_error(kmc_ctx* ctx);
 int kmc_hip_device_info(kmc_ctx* ctx, kmc_device_info* out);
+/* Where the microseconds of an in-place call go (the routes that work on page-locked host buffers over the link: kmc_hip_deskew_f32 and
+ * kmc_hip_deskew_f64cols[_begin/_end] with KMC_MEM_HOST_MAPPED or page-locked KMC_MEM_HOST pointers).  With the trace enabled every such
+ * call leaves its stage times: host times are steady_clock microseconds (compare them with your own steady_clock stamps), device times
+ * are the GPU's constant 100 MHz clock in microseconds since ITS epoch (only their difference means anything).  Off by default; costs
+ * two 8-byte device writes per call when on.  kmc_hip_last_call_trace: KMC_ERR_INVALID_ARG while the trace is off. */
+typedef struct kmc_call_trace {
+  double issue_begin_us; /* host: the entry point (the _begin half) was entered                                  */
+  double issue_end_us;   /* host: the launch has been enqueued, the entry point (the _begin half) returns        */
+  double wait_begin_us;  /* host: the wait (the _end half) starts                                                */
+  double wait_end_us;    /* host: the kernel's completion word was seen -- the results are in host memory        */
+  double dev_first_wave_us; /* device clock: the first wave starts                                               */
+  double dev_last_store_us; /* device clock: the last wave has stored and released                               */
+  uint32_t waves;        /* persistent one-wave workgroups of the launch                                         */
+  uint32_t route;        /* 1 = kmc_hip_deskew_f32 in place, 2 = kmc_hip_deskew_f64cols in place; 0 = the last call took another route */
+} kmc_call_trace;
+int kmc_hip_enable_call_trace(kmc_ctx* ctx, int enabled);
+int kmc_hip_last_call_trace(kmc_ctx* ctx, kmc_call_trace* out);
 /* Testing hook: force the coefficient tier (0..3, see kmc_stats.variant) of the f32 kernels (-1 = automatic selection from |phi|). */
 int kmc_hip_force_tier(kmc_ctx* ctx, int tier);
 
@@ -233,13 +250,20 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
 int kmc_hip_set_frame_queues(kmc_ctx* ctx, int queues);
 int kmc_hip_set_frame_queue_order(kmc_ctx* ctx, int after_producers);
 int kmc_hip_frame_queue_join(kmc_ctx* ctx);
+/* Gathered frames and errors: a gathered call returns KMC_OK when its frame has been QUEUED.  If the launch that later issues the queue
+ * fails (first the table route, then a fallback of kernel-argument launches that needs no table), the frames of that queue were never
+ * computed; the error is returned by whichever entry point triggered the join AND stays sticky -- kmc_hip_frame_queue_join and
+ * kmc_hip_synchronize return it (once) even when the join happened inside an unrelated call -- and kmc_hip_frame_queue_dropped counts
+ * the frames lost that way over the context's life (0 in every run so far: a launch only fails when the runtime itself is failing). */
+uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* ctx);
 /* How many frames of this context have been dispatched without the barrier bit so far (a counter for tests and tuning). */
 uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
  * (HOST arrays of device pointers / sizes / params), each frame in its own buffer (any 16-byte-aligned addresses).  ONE launch of the
  * frame-list kernel (2-D grid: frame x tile) on the context's stream; lists of at most 16 frames carry their records in the kernel
  * arguments (the call only enqueues a launch and can be captured into a HIP graph), longer ones upload one small table.  Per-point results
- * are bit-identical to kmc_hip_deskew_f32 on the same frame at the same tier (the list runs its widest frame's tier).  The frames must
+ * are bit-identical to kmc_hip_deskew_f32 on the same frame: every frame runs at its own coefficient tier (a list that mixes tiers goes
+ * out as one launch per tier present -- at most four; out_stats->variant reports the widest).  The frames must
  * be independent of each other (in == out of ONE frame is fine): a list in which one frame's output overlaps another frame's input or
  * output is recognised and issued frame by frame, in order, instead. */
 int kmc_hip_deskew_frames_f32(kmc_ctx* ctx, const float* const* xyzi_in, float* const* xyzi_out, const uint64_t* n_points,

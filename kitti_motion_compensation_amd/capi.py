@@ -105,6 +105,12 @@ class KmcError(RuntimeError):
         super().__init__(msg)
 
 
+class CallTrace(C.Structure):
+    """kmc_call_trace (kmc_hip.h): stage times of the last in-place call, microseconds (host: steady_clock; device: its own 100 MHz clock)."""
+    _fields_ = [("issue_begin_us", C.c_double), ("issue_end_us", C.c_double), ("wait_begin_us", C.c_double), ("wait_end_us", C.c_double),
+                ("dev_first_wave_us", C.c_double), ("dev_last_store_us", C.c_double), ("waves", C.c_uint32), ("route", C.c_uint32)]
+
+
 _lib = None
 
 # every symbol include/kmc_hip.h declares: (restype, argtypes)
@@ -121,6 +127,8 @@ SIGNATURES = {
     "kmc_hip_enable_timing": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_last_error": (C.c_char_p, [_vp]),
     "kmc_hip_device_info": (C.c_int, [_vp, C.POINTER(DeviceInfo)]),
+    "kmc_hip_enable_call_trace": (C.c_int, [_vp, C.c_int]),
+    "kmc_hip_last_call_trace": (C.c_int, [_vp, C.POINTER(CallTrace)]),
     "kmc_hip_force_tier": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_timer_begin": (C.c_int, [_vp]),
     "kmc_hip_timer_end": (C.c_int, [_vp, C.POINTER(C.c_float)]),
@@ -139,6 +147,7 @@ SIGNATURES = {
     "kmc_hip_set_frame_queues": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_frame_queue_join": (C.c_int, [_vp]),
     "kmc_hip_any_order_launches": (C.c_uint64, [_vp]),
+    "kmc_hip_frame_queue_dropped": (C.c_uint64, [_vp]),
     "kmc_hip_set_frame_queue_order": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_deskew_frames_f32": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(FrameParams), C.c_uint32, C.POINTER(Stats)]),
     "kmc_hip_deskew_batch_f32": (
@@ -441,6 +450,18 @@ class Context:
 
     def frame_queue_join(self):
         self._check(lib().kmc_hip_frame_queue_join(self._h), "kmc_hip_frame_queue_join")
+
+    def enable_call_trace(self, on: bool = True):
+        self._check(lib().kmc_hip_enable_call_trace(self._h, 1 if on else 0), "kmc_hip_enable_call_trace")
+
+    def last_call_trace(self) -> "CallTrace":
+        t = CallTrace()
+        self._check(lib().kmc_hip_last_call_trace(self._h, C.byref(t)), "kmc_hip_last_call_trace")
+        return t
+
+    def frame_queue_dropped(self) -> int:
+        """Gathered frames lost to a failed join over the context's life (kmc_hip.h, "Gathered frames and errors")."""
+        return int(lib().kmc_hip_frame_queue_dropped(self._h))
 
     def any_order_launches(self) -> int:
         """Frames dispatched without the barrier bit so far (see kmc_hip_set_frame_queues in kmc_hip.h)."""

@@ -3,6 +3,7 @@
 // Everything per-point goes through the C-ABI (libkmc_hip.so).  No CPU fallback: without a HIP device the first call
 // throws std::runtime_error.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -20,6 +21,9 @@ struct CtxDeleter {
 };
 thread_local std::unique_ptr<kmc_ctx, CtxDeleter> t_ctx;
 thread_local int t_device = -1;
+thread_local bool t_trace = false;
+thread_local hip::FrameTrace t_last_trace;
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int default_device() {
   if (const char* e = std::getenv("KMC_DEVICE")) return std::atoi(e);
@@ -59,6 +63,13 @@ void SetDevice(int device_id) {
 }
 
 int GetDevice() { return detail::t_device < 0 ? detail::default_device() : detail::t_device; }
+
+void EnableFrameTrace(bool enabled) {
+  detail::t_trace = enabled;
+  detail::t_last_trace = FrameTrace{};
+  if (kmc_ctx* c = detail::thread_context()) (void)kmc_hip_enable_call_trace(c, enabled ? 1 : 0);
+}
+FrameTrace LastFrameTrace() { return detail::t_last_trace; }
 
 void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t n, Affine3d const& T_start, Affine3d const& T_end, Time stamp_start,
                                 Time stamp_end, Time requested_time, float* xyzi_out) {
@@ -130,13 +141,18 @@ void MotionCompensateKittiClouds(float const* xyzi_in, std::vector<std::uint64_t
 
 // motion_compensation.cpp:16-28
 Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time) {
+  bool const trace = detail::t_trace;
+  hip::FrameTrace tr;
+  if (trace) tr.enter_us = detail::now_us();
   Index const n = frame.scan.cloud.rows();
   if (frame.scan.timestamps.size() != n) throw std::invalid_argument("kmc::MotionCompensateFrame: timestamps.size() != cloud.rows()");
   kmc_frame_params const p = detail::frame_params(frame.T_start, frame.T_end, frame.scan.stamp_start, frame.scan.stamp_end, requested_time,
                                                   "kmc::MotionCompensateFrame");
+  if (trace) tr.params_us = detail::now_us();
   Pointcloud out{MatrixX4d::Uninitialized(n)};  // every element is written below
   if (n == 0) return out;
   kmc_ctx* c = detail::thread_context();
+  if (trace) tr.alloc_us = detail::now_us();
   kmc_stats st;
   Pointcloud const& in = frame.scan.cloud;
   // A cloud whose homogeneous column is KNOWN to be all ones (every cloud the loaders produce, data_io.cpp:130): the device neither
@@ -147,13 +163,25 @@ Pointcloud MotionCompensateFrame(Frame const& frame, Time const requested_time) 
   int rc = kmc_hip_deskew_f64cols_begin(c, in.col(0), in.col(1), in.col(2), ones ? nullptr : in.col(3), frame.scan.timestamps.data(),
                                         static_cast<std::uint64_t>(n), frame.scan.stamp_start, frame.scan.stamp_end, &p, ox, ox + n, ox + 2 * n,
                                         ones ? nullptr : ox + 3 * n, KMC_MEM_HOST);
+  if (trace) tr.begin_returned_us = detail::now_us();
   if (rc == KMC_OK) {
     if (ones) std::fill(ox + 3 * n, ox + 4 * n, 1.0);  // while the kernel works on the other three columns
+    if (trace) tr.fill_done_us = detail::now_us();
     rc = kmc_hip_deskew_f64cols_end(c, &st);
   }
+  if (trace) tr.end_returned_us = detail::now_us();
   if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::MotionCompensateFrame");
   if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_f64cols", c);
   detail::set_homogeneous(out, ones);
+  if (trace) {
+    kmc_call_trace ct;
+    if (kmc_hip_last_call_trace(c, &ct) == KMC_OK) {
+      tr.issue_begin_us = ct.issue_begin_us; tr.issue_end_us = ct.issue_end_us; tr.wait_begin_us = ct.wait_begin_us; tr.wait_end_us = ct.wait_end_us;
+      tr.dev_first_wave_us = ct.dev_first_wave_us; tr.dev_last_store_us = ct.dev_last_store_us; tr.waves = ct.waves; tr.route = ct.route;
+    }
+    tr.return_us = detail::now_us();
+    detail::t_last_trace = tr;
+  }
   return out;
 }
 

@@ -2,6 +2,8 @@
 // definitions of the helpers every other translation unit of libkmc_hip.so shares (kmc_internal.hip.h).
 #include "kmc_internal.hip.h"
 
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 
@@ -51,6 +53,42 @@ int ensure_events(kmc_ctx* c, size_t count) {
   return KMC_OK;
 }
 
+double trace_now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+DoneWord done_word_arm(kmc_ctx* c) {
+  DoneWord dw;
+  dw.ticket = c->d_ticket;
+  dw.word = c->h_done;
+  dw.stamps = c->trace ? c->h_stamps : nullptr;
+  dw.seq = ++c->done_seq;
+  if (dw.seq == 0) dw.seq = ++c->done_seq;  // (0 is the word's initial value)
+  dw.pad = 0;
+  c->done_armed = true;
+  return dw;
+}
+
+// The last armed launch has stored its sequence number <=> every wave's stores are in host memory (DoneWord, kmc_kernels.hip.h).
+// The stream is looked at every 16 Ki polls (~100 us): a launch that died never raises the word.
+int wait_done_word(kmc_ctx* c) {
+  if (!c->done_armed) return KMC_OK;
+  c->done_armed = false;
+  const uint32_t seq = c->done_seq;
+  volatile uint32_t* const word = c->h_done;
+  for (uint64_t spin = 1; *word != seq; ++spin) {
+    if ((spin & 0x3FFFu) != 0) continue;
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
+    if (q != hipSuccess) return fail_hip(c, q, "in-place kernel (hipStreamQuery while waiting for its completion word)");
+    if (*word == seq) break;  // the stream is idle: the word must be there
+    c->last_error = "in-place kernel finished without raising its completion word";
+    return KMC_ERR_HIP;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return KMC_OK;
+}
+
 int ensure_pipeline(kmc_ctx* c) {
   if (c->stage_cap) return KMC_OK;
   const size_t bytes = kHostChunkPoints * sizeof(v4f);
@@ -69,7 +107,7 @@ int ensure_pipeline(kmc_ctx* c) {
   return KMC_OK;
 }
 
-int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t count, int tier, uint32_t* launches_out) {
+int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t count, int tier, uint32_t* launches_out, bool inline_only) {
   if (launches_out) *launches_out = 0;
   if (count == 0) return KMC_OK;
   auto tiles_of = [&](uint32_t first, uint32_t n_recs) {
@@ -94,7 +132,7 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
     capturing = hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     (void)hipGetLastError();
   }
-  if (count <= (uint32_t)kInlineListFrames || capturing) {
+  if (count <= (uint32_t)kInlineListFrames || capturing || inline_only) {
     for (uint32_t first = 0; first < count; first += kInlineListFrames, ++launches) launch_inline(first, std::min<uint32_t>(kInlineListFrames, count - first));
     KMC_HIP_TRY(c, hipGetLastError());
   } else {
@@ -130,7 +168,27 @@ int fq_join(kmc_ctx* c) {
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t count = c->gather_count;
   c->gather_count = 0;  // (first: launch_list's table route may re-enter fq_join through slot_begin)
-  return launch_list(c, c->gather, c->gather64, count, c->gather_tier, nullptr);
+  int rc = launch_list(c, c->gather, c->gather64, count, c->gather_tier, nullptr);
+  if (rc != KMC_OK) {
+    // The table route failed (a slot could not grow, the upload did not go through).  The calls that queued these frames have already
+    // returned KMC_OK, so the frames must not be dropped on the floor: the records are still in c->gather -- issue them
+    // as kernel-argument launches of at most 16 frames, which need no table.  If even that fails the error is STICKY: it is what this
+    // join returns, and what kmc_hip_frame_queue_join / kmc_hip_synchronize keep returning until the caller has seen it once.
+    (void)hipGetLastError();
+    rc = launch_list(c, c->gather, c->gather64, count, c->gather_tier, nullptr, /*inline_only*/ true);
+    if (rc != KMC_OK) {
+      c->fq_error = rc;
+      c->fq_dropped += count;
+    }
+  }
+  return rc;
+}
+
+// the sticky error of a join that lost frames: reported once, by the next call whose job is to say "everything queued has been issued"
+int fq_take_error(kmc_ctx* c) {
+  const int rc = c->fq_error;
+  c->fq_error = KMC_OK;
+  return rc;
 }
 
 // May this frame start before the launches ahead of it on the context's stream have finished?  Yes if
@@ -176,7 +234,11 @@ bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool 
 //   before it AND sees everything they stored, from every XCD's L2.
 // Eight rounds of: A (ordinary) and B, B2 (barrier-free) each fill their own 4 MiB region with a pattern through plain stores from
 // 4096 workgroups (all XCDs); C (ordinary) re-reads the three regions through a reversed workgroup -> XCD mapping and counts what it
-// does not find; a D2H copy of B2's last KiB and an event follow; the host checks the copy right after the event.  Any miss: feature OFF.
+// does not find; a D2H copy of a barrier-free packet's last KiB and an event follow; the host checks the copy right after the event.
+// Every other round the copy follows a barrier-free packet DIRECTLY (no ordinary kernel in between): that packet, B3, fills a FOURTH
+// region that C never reads -- a barrier-free packet behind C need not wait for C, so it must not rewrite what C is still verifying
+// (the first version let B3 rewrite B2's region and could fail the probe on its own race).  Any miss: one more attempt
+// (a -1 is cached for the whole process, so a transient must not decide it), then feature OFF.
 // Verdict (kmc_device_info.any_order_dispatch): 1 = verified, on;  0 = switched off (KMC_ANY_ORDER=0);  -1 = an ordinary packet
 // overtook, or did not see, a barrier-free one;  -3 = the probe could not run (a HIP error).
 constexpr uint32_t kAoWords = 1u << 20;  // 4 MiB per region
@@ -200,7 +262,7 @@ static int ao_probe_run(kmc_ctx* c) {
   hipEvent_t ev = nullptr;
   const dim3 grid(kAoWords / 256), block(256);
   do {
-    if (hipMalloc((void**)&d, 3 * (size_t)kAoWords * 4) != hipSuccess) break;
+    if (hipMalloc((void**)&d, 4 * (size_t)kAoWords * 4) != hipSuccess) break;
     if (hipMalloc((void**)&d_bad, 8) != hipSuccess) break;
     if (hipHostMalloc((void**)&h, 1024, hipHostMallocDefault) != hipSuccess) break;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
@@ -213,13 +275,14 @@ static int ao_probe_run(kmc_ctx* c) {
       hipExtLaunchKernelGGL(ao_probe_fill, grid, block, 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d + 2 * kAoWords, sc);  // B2
       hipLaunchKernelGGL(ao_probe_verify, grid, block, 0, s, (const uint32_t*)d, sa, sb, sc, d_bad);                             // C: ordinary
       ran = hipGetLastError() == hipSuccess;
-      if (round & 1) {  // every other round the copy follows the barrier-free packets directly (no ordinary kernel in between)
-        hipExtLaunchKernelGGL(ao_probe_fill, grid, block, 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d + 2 * kAoWords, sc + 1);
+      const bool direct = (round & 1) != 0;  // the copy follows a barrier-free packet directly (no ordinary kernel in between)
+      if (direct) {  // B3: its own region -- C, still running, reads the other three
+        hipExtLaunchKernelGGL(ao_probe_fill, grid, block, 0, s, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, d + 3 * kAoWords, sc + 1);
         ran = ran && hipGetLastError() == hipSuccess;
       }
-      ran = ran && hipMemcpyAsync(h, d + 3 * kAoWords - 256, 1024, hipMemcpyDeviceToHost, s) == hipSuccess;
+      ran = ran && hipMemcpyAsync(h, d + (direct ? 4 : 3) * (size_t)kAoWords - 256, 1024, hipMemcpyDeviceToHost, s) == hipSuccess;
       ran = ran && hipEventRecord(ev, s) == hipSuccess && hipEventSynchronize(ev) == hipSuccess;
-      const uint32_t want = (round & 1) ? sc + 1 : sc;
+      const uint32_t want = direct ? sc + 1 : sc;
       for (uint32_t k = 0; ran && k < 256; ++k) host_ok = host_ok && h[k] == want + (kAoWords - 256 + k) * 2654435761u;
     }
     if (!ran) break;
@@ -236,20 +299,18 @@ static int ao_probe_run(kmc_ctx* c) {
   return verdict;
 }
 
-// one probe per device and process; KMC_ANY_ORDER=0 switches the feature off without probing.  KMC_ANY_ORDER_PROBE=fail is a TEST hook:
-// the probe's verdict is replaced by "order violated" so that the gate itself can be exercised on a runtime where the probe passes.
+// one probe per device and process; KMC_ANY_ORDER=0 switches the feature off without probing
 int ao_verdict_for(kmc_ctx* c) {
   if (const char* e = std::getenv("KMC_ANY_ORDER"))
     if (std::atoi(e) == 0) return 0;
-  if (const char* e = std::getenv("KMC_ANY_ORDER_PROBE"))
-    if (std::strcmp(e, "fail") == 0) return -1;
   static std::mutex mu;
   static int cached[64];
   static bool have[64] = {};
   std::lock_guard<std::mutex> lock(mu);
   const int d = c->device;
   if (d >= 0 && d < 64 && have[d]) return cached[d];
-  const int v = ao_probe_run(c);
+  int v = ao_probe_run(c);
+  if (v != 1) v = ao_probe_run(c);  // once more before a negative verdict is cached for the life of the process
   if (d >= 0 && d < 64) { cached[d] = v; have[d] = true; }
   return v;
 }
@@ -378,15 +439,25 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming);
   for (auto& ev : c->group_consumed)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocPortable | hipHostMallocMapped);
-  if (e == hipSuccess) *c->h_flag = 0;
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, 64);  // the out-of-range counter + (16 bytes on) the completion ticket
+  if (e == hipSuccess) e = hipMemset(c->d_counter, 0, 64);
+  if (e == hipSuccess) c->d_ticket = reinterpret_cast<uint32_t*>(c->d_counter + 2);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flag, 256, hipHostMallocPortable | hipHostMallocMapped);
+  if (e == hipSuccess) {
+    std::memset(c->h_flag, 0, 256);
+    c->h_done = c->h_flag + 16;
+    c->h_stamps = reinterpret_cast<uint64_t*>(c->h_flag + 32);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     kmc_hip_destroy(c);
     return KMC_ERR_NO_DEVICE;
   }
   c->stream = c->own_stream;
+  if (const char* e = std::getenv("KMC_MAPPED_WAVES")) {  // tuning knob: persistent waves of the in-place kernels (default 128; tools/link_probe)
+    const int w = std::atoi(e);
+    if (w >= 1 && w <= 65535) c->mapped_waves = w;
+  }
   c->ao_verdict = ao_verdict_for(c);  // barrier-free dispatch only where this device and runtime were SEEN to honour what it relies on
   c->ao_enabled = c->ao_verdict == 1;
   *out = c;
@@ -462,16 +533,22 @@ int kmc_hip_synchronize(kmc_ctx* c) {
   if (!c) return KMC_ERR_INVALID_ARG;
   KMC_ENTER(c);
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return KMC_OK;
+  return fq_take_error(c);  // frames an EARLIER join could not issue (its caller was some unrelated entry point)
 }
 
 int kmc_hip_set_frame_queues(kmc_ctx* c, int queues) {
   if (!c || queues < 1 || queues > kmc_ctx::kMaxFrameQueues) return KMC_ERR_INVALID_ARG;
   KMC_ENTER(c);  // issues what is pending
-  if (queues > 1 && !c->gather) {
-    c->gather = new (std::nothrow) ListRec[kmc_ctx::kGatherMax];
-    c->gather64 = new (std::nothrow) FrameRecD[kmc_ctx::kGatherMax];
-    if (!c->gather || !c->gather64) return KMC_ERR_ALLOC;
+  if (queues > 1 && (!c->gather || !c->gather64)) {
+    if (!c->gather) c->gather = new (std::nothrow) ListRec[kmc_ctx::kGatherMax];
+    if (!c->gather64) c->gather64 = new (std::nothrow) FrameRecD[kmc_ctx::kGatherMax];
+    if (!c->gather || !c->gather64) {  // both or neither: a retry must not find one array and skip the other
+      delete[] c->gather;
+      delete[] c->gather64;
+      c->gather = nullptr;
+      c->gather64 = nullptr;
+      return KMC_ERR_ALLOC;
+    }
   }
   c->fq_count = queues;
   return KMC_OK;
@@ -487,8 +564,12 @@ int kmc_hip_set_frame_queue_order(kmc_ctx* c, int after_producers) {
 int kmc_hip_frame_queue_join(kmc_ctx* c) {
   if (!c) return KMC_ERR_INVALID_ARG;
   KMC_HIP_TRY(c, hipSetDevice(c->device));
-  return fq_join(c);
+  const int rc = fq_join(c);
+  const int sticky = fq_take_error(c);
+  return rc != KMC_OK ? rc : sticky;
 }
+
+uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* c) { return c ? c->fq_dropped : 0; }
 
 uint64_t kmc_hip_any_order_launches(kmc_ctx* c) { return c ? c->ao_launches : 0; }
 
@@ -499,6 +580,19 @@ int kmc_hip_enable_timing(kmc_ctx* c, int enabled) {
 }
 
 const char* kmc_hip_last_error(kmc_ctx* c) { return c ? c->last_error.c_str() : "null ctx"; }
+
+int kmc_hip_enable_call_trace(kmc_ctx* c, int enabled) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  c->trace = enabled != 0;
+  c->last_trace = kmc_call_trace{};
+  return KMC_OK;
+}
+
+int kmc_hip_last_call_trace(kmc_ctx* c, kmc_call_trace* out) {
+  if (!c || !out) return KMC_ERR_INVALID_ARG;
+  *out = c->last_trace;
+  return c->trace ? KMC_OK : KMC_ERR_INVALID_ARG;
+}
 
 int kmc_hip_device_info(kmc_ctx* c, kmc_device_info* out) {
   if (!c || !out) return KMC_ERR_INVALID_ARG;

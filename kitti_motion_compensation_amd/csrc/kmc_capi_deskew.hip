@@ -16,19 +16,10 @@ namespace {
 
 // ---- template dispatch: the run-time choices of a call (tier, index output, kernel-argument tables, barrier bit) become template
 // arguments through with_tier / with_bool, every launch goes through launch_on (kmc_internal.hip.h) ----
-// The in-place routes end with "the results are in host memory".  A short busy wait first -- the kernel of a KITTI frame takes
-// ~100 us and an interrupt-driven wake-up adds several microseconds -- and then ALWAYS a hipStreamSynchronize: a successful
-// hipStreamQuery says the stream is idle, but only the synchronize carries the runtime's system-scope release / acquire (and is the
-// point at which HIP promises visibility for non-coherent pinned allocations, which host_in_place_ok() may have recognised); on an
-// idle stream it returns at once.
-int wait_results_in_host_memory(kmc_ctx* c) {
-  hipError_t q = hipErrorNotReady;
-  for (int spin = 0; spin < 20000 && (q = hipStreamQuery(c->stream)) == hipErrorNotReady; ++spin) {
-  }
-  if (q != hipSuccess) (void)hipGetLastError();
-  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return KMC_OK;
-}
+// The in-place routes end with "the results are in host memory": the kernel's last wave raises a page-locked completion word and the
+// host spins on it (wait_done_word, kmc_capi_core.hip) -- until round 4 a hipStreamQuery spin plus a hipStreamSynchronize, which
+// returned ~8.5 us after the last byte had landed (tools/link_probe).  Visibility does not rest on the runtime's wait any more: every
+// wave releases its stores at system scope before its ticket (DoneWord, kmc_kernels.hip.h).
 // in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of().
 // any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao_valid
 uint32_t launch_frame(hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0, bool any_order = false) {
@@ -164,7 +155,7 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
     if (e == hipSuccess) e = hipStreamWaitEvent(s_run, c->ev_pool[2 * k], 0);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(deskew_f64cols<false>, dim3((uint32_t)((m + 127) / 128)), dim3(64), 0, s_run, cols[0] + off, cols[1] + off, cols[2] + off, w ? cols[3] + off : nullptr,
-                         cols[4] + off, m, f, cols[5] + off, cols[6] + off, cols[7] + off, down_w ? cols[8] + off : nullptr, c->d_counter, (uint32_t*)nullptr, (uint64_t)0);
+                         cols[4] + off, m, f, cols[5] + off, cols[6] + off, cols[7] + off, down_w ? cols[8] + off : nullptr, c->d_counter, (uint32_t*)nullptr, (uint64_t)0, DoneWord{});
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(c->ev_pool[2 * k + 1], s_run);
@@ -290,16 +281,28 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     if (st) { st->n_points = n; st->variant = (uint32_t)tier; st->n_launches = n ? 1 : 0; }
     if (n == 0) return KMC_OK;
     CallTimer tm(c);
+    if (c->trace) { c->last_trace = kmc_call_trace{}; c->last_trace.issue_begin_us = trace_now_us(); }
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 63) / 64, (uint64_t)c->mapped_waves * 2));  // 16 B per lane here, 80 in the f64 kernel
+    // persistent waves: the link, not the wave count, sets the rate -- beyond ~128 KiB of reads in flight more waves only queue up
+    // behind each other (tools/link_probe: 128 waves 72 us per KITTI frame, 256 waves 82, one wave per tile 127)
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 63) / 64, (uint64_t)c->mapped_waves));
     const v4f* vin = (const v4f*)xyzi_in;
     v4f* vout = (v4f*)xyzi_out;
-    with_tier(tier, [&](auto T) { launch_on(deskew_frame_streamed_f32<decltype(T)::value>, grid, 64, c->stream, false, vin, vout, n, f, d); });
+    const DoneWord dw = done_word_arm(c);
+    with_tier(tier, [&](auto T) { launch_on(deskew_frame_streamed_f32<decltype(T)::value>, grid, 64, c->stream, false, vin, vout, n, f, dw, d); });
     KMC_HIP_TRY(c, hipGetLastError());
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    if (c->trace) c->last_trace.issue_end_us = c->last_trace.wait_begin_us = trace_now_us();
     {
-      const int rc_wait = wait_results_in_host_memory(c);
+      const int rc_wait = wait_done_word(c);
       if (rc_wait != KMC_OK) return rc_wait;
+    }
+    if (c->trace) {
+      c->last_trace.wait_end_us = trace_now_us();
+      c->last_trace.dev_first_wave_us = (double)c->h_stamps[0] * 0.01;
+      c->last_trace.dev_last_store_us = (double)c->h_stamps[1] * 0.01;
+      c->last_trace.waves = (uint32_t)grid;
+      c->last_trace.route = 1;
     }
     return tm.end_call(st);
   }
@@ -411,8 +414,16 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
     n_max = std::max<uint64_t>(n_max, n_points[f] + head_of(xyzi_out[f], KMC_MEM_DEVICE));
   }
   KMC_ENTER(c);
-  const int tier = pick_tier(c, params, n_frames);  // one launch runs its widest frame's tier, like a batch
-  if (st) { st->n_points = total; st->variant = (uint32_t)tier; }
+  // A frame's bits must not depend on its neighbours (gather_push keeps the same rule): every frame runs at ITS OWN
+  // coefficient tier, so a list of mixed tiers goes out as one launch per tier present (at most four; a drive is one tier).
+  std::vector<int> tiers(n_frames);
+  int tier_max = 0;
+  uint32_t tier_mask = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    tiers[f] = pick_tier(c, &params[f], 1);
+    if (n_points[f]) { tier_max = std::max(tier_max, tiers[f]); tier_mask |= 1u << tiers[f]; }
+  }
+  if (st) { st->n_points = total; st->variant = (uint32_t)tier_max; }
   if (total == 0) return KMC_OK;
   CallTimer tm(c);
   // Frames that depend on each other (one's output is another's input, or two write the same buffer) cannot share a launch: such a list
@@ -422,33 +433,47 @@ int kmc_hip_deskew_frames_f32(kmc_ctx* c, const float* const* xyzi_in, float* co
   const bool fits = n_frames <= 65535u && tiles_x * 64 * (uint64_t)n_frames < (1ull << 32);
   if (!fits || list_has_hazard(xyzi_in, xyzi_out, n_points, n_frames)) {
     if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
+    uint32_t launches = 0;
     for (uint32_t f = 0; f < n_frames; ++f) {
-      const int rc = issue_frame(c, c->stream, xyzi_in[f], xyzi_out[f], n_points[f], &params[f], nullptr, false);
+      uint32_t one = 0;
+      const int rc = issue_frame(c, c->stream, xyzi_in[f], xyzi_out[f], n_points[f], &params[f], nullptr, false, &one);
       if (rc != KMC_OK) return rc;
+      launches += one;  // (an empty frame launches nothing)
     }
     if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-    if (st) st->n_launches = n_frames;
+    if (st) st->n_launches = launches;
     return tm.end_call(st);
   }
-  std::vector<ListRec> recs(n_frames);
-  std::vector<FrameRecD> recd(n_frames);
-  for (uint32_t f = 0; f < n_frames; ++f) {
-    ListRec* r = &recs[f];
-    std::memset(r, 0, sizeof(*r));
-    fill_rec(params[f], &r->f);
-    r->f.pre2 = guard_pre2(params[f]);
-    fill_recd(params[f], &recd[f]);
-    const uint32_t head = n_points[f] ? head_of(xyzi_out[f], KMC_MEM_DEVICE) : 0u;
-    r->in = (const v4f*)xyzi_in[f] - head;
-    r->out = (v4f*)xyzi_out[f] - head;
-    r->n = n_points[f] ? n_points[f] + head : 0;
-    r->head = head;
-  }
+  std::vector<ListRec> recs;
+  std::vector<FrameRecD> recd;
+  recs.reserve(n_frames);
+  recd.reserve(n_frames);
   if (tm.begin_call() || tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   uint32_t launches = 0;
-  {
-    const int rc_list = launch_list(c, recs.data(), recd.data(), n_frames, tier, &launches);
+  for (int tier = 0; tier <= kTrig; ++tier) {
+    if (!(tier_mask & (1u << tier))) continue;
+    recs.clear();
+    recd.clear();
+    for (uint32_t f = 0; f < n_frames; ++f) {
+      if (tiers[f] != tier || !n_points[f]) continue;
+      ListRec r;
+      std::memset(&r, 0, sizeof(r));
+      fill_rec(params[f], &r.f);
+      r.f.pre2 = guard_pre2(params[f]);
+      FrameRecD d;
+      fill_recd(params[f], &d);
+      const uint32_t head = head_of(xyzi_out[f], KMC_MEM_DEVICE);
+      r.in = (const v4f*)xyzi_in[f] - head;
+      r.out = (v4f*)xyzi_out[f] - head;
+      r.n = n_points[f] + head;
+      r.head = head;
+      recs.push_back(r);
+      recd.push_back(d);
+    }
+    uint32_t one = 0;
+    const int rc_list = launch_list(c, recs.data(), recd.data(), (uint32_t)recs.size(), tier, &one);
     if (rc_list != KMC_OK) return rc_list;
+    launches += one;
   }
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (st) st->n_launches = launches;
@@ -684,23 +709,32 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
     dox = cols[5]; doy = cols[6]; doz = cols[7]; dow = ow ? cols[8] : nullptr;
   }
   CallTimer tm(c);
+  if (c->trace && !queued) { c->last_trace = kmc_call_trace{}; c->last_trace.issue_begin_us = trace_now_us(); }
   if (!queued) {
     if (tm.begin_call()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
     if (c->counter_dirty) KMC_HIP_TRY(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), c->stream));
     c->counter_dirty = true;
-    *c->h_flag = 0;  // the previous call has synchronized: nothing on the device still writes it
+    *c->h_flag = 0;  // the previous call has been waited for: nothing on the device still writes it
     if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   }
   if (mem_kind == KMC_MEM_HOST_MAPPED) {
-    // over the link: a few hundred persistent waves, each with its next tile's loads in flight while it stores the current one
-    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 127) / 128, (uint64_t)c->mapped_waves));
-    hipLaunchKernelGGL(deskew_f64cols<true>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, (uint64_t)0);
+    // over the link: ~a hundred persistent waves, each with its next tile's loads in flight while it stores the current one; the last
+    // wave raises the completion word f64cols_finish() spins on
+    // (a wave of this kernel keeps 4-5 KiB of loads in flight: half the f32 kernel's wave count carries a KITTI frame best -- 91 us per
+    // call with 64 waves, 94-118 with 96-192; frames of half a million points and more want the full count: tools/link_probe, 1 M points)
+    const uint64_t waves = n < (1ull << 19) ? std::max(1, c->mapped_waves / 2) : c->mapped_waves;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 127) / 128, waves));
+    const DoneWord done = done_word_arm(c);
+    hipLaunchKernelGGL(deskew_f64cols<true>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, (uint64_t)0, done);
+    if (c->trace) { c->last_trace.waves = (uint32_t)grid; c->last_trace.route = 2; }
   } else {  // one wave per workgroup, two points per lane
     launch_tiles((n + 127) / 128, [&](uint64_t t0, int grid) {
-      launch_on(deskew_f64cols<false>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, t0);
+      launch_on(deskew_f64cols<false>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, t0, DoneWord{});
     });
+    c->done_armed = false;  // resident or staged columns: this queue is waited for on the stream
   }
   KMC_HIP_TRY(c, hipGetLastError());
+  if (c->trace) c->last_trace.issue_end_us = trace_now_us();
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   if (mem_kind == KMC_MEM_HOST) {
     const bool down_w = ow != nullptr;
@@ -730,11 +764,21 @@ static int f64cols_finish(kmc_ctx* c, kmc_stats* st) {
   }
   if (c->f64_pending != 1) return KMC_ERR_INVALID_ARG;
   c->f64_pending = 0;
-  // The out-of-range verdict is part of the call's result: wait.  A short busy wait first -- the in-place kernel of a KITTI frame takes
-  // ~100 us and an interrupt-driven wake-up adds several microseconds to a call whose whole budget is ~130.
-  {
-    const int rc_wait = wait_results_in_host_memory(c);
+  // The out-of-range verdict is part of the call's result: wait.  In place over the link: for the completion word of the last kernel
+  // issued (kernels of one stream run in order, so the word of the last one covers a queue of _begin calls); resident and staged
+  // columns: for the stream.
+  if (c->trace) c->last_trace.wait_begin_us = trace_now_us();
+  if (c->done_armed) {
+    const int rc_wait = wait_done_word(c);
     if (rc_wait != KMC_OK) return rc_wait;
+    if (c->trace) {
+      c->last_trace.wait_end_us = trace_now_us();
+      c->last_trace.dev_first_wave_us = (double)c->h_stamps[0] * 0.01;
+      c->last_trace.dev_last_store_us = (double)c->h_stamps[1] * 0.01;
+    }
+  } else {
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->trace) { c->last_trace.wait_end_us = trace_now_us(); c->last_trace.route = 0; }
   }
   unsigned long long bad = 0;
   if (*(volatile uint32_t*)c->h_flag != 0) {  // cold: some stamp was out of range -> fetch the exact count

@@ -46,6 +46,15 @@ struct kmc_ctx {
   bool counter_dirty = true;   // d_counter may be non-zero: the f64 entry points clear it only then (a memset per call costs ~5 us)
   int mapped_waves = 128;      // persistent one-wave workgroups of the f64 kernel when it works on page-locked host memory (64 ... 1024 measured: profiles/r03_inplace_f64.txt)
   uint32_t* h_flag = nullptr;  // page-locked word the f64 kernels raise when a stamp is out of range (read by the host after the sync: no D2H copy on the good path)
+  // completion word of the in-place kernels (kmc_kernels.hip.h, DoneWord): the last wave stores the call's sequence number into h_done,
+  // the host spins on it instead of waiting for the stream (~8.5 us per call).  All in h_flag's page-locked block, one cache line each.
+  uint32_t* h_done = nullptr;    // h_flag + 16 words
+  uint64_t* h_stamps = nullptr;  // h_flag + 32 words: device clock at the first wave's start / at the last ticket (call trace)
+  uint32_t* d_ticket = nullptr;  // device word next to d_counter, 0 between kernels
+  uint32_t done_seq = 0;         // sequence number of the last launch that carries a completion word
+  bool done_armed = false;       // such a launch is in flight and nobody has waited for it yet
+  bool trace = false;            // kmc_hip_enable_call_trace
+  kmc_call_trace last_trace = {};
   // batch tables: a ring of slots, each one device buffer + one pinned staging buffer holding
   // [BatchRec x n_frames | coarse x (n_chunks + 1)], uploaded with ONE copy on a side stream so that the per-step host
   // preparation and the table H2D overlap the previous step's kernel.  The compute stream sees no event between two
@@ -102,6 +111,8 @@ struct kmc_ctx {
   int gather_tier = 0;
   uint64_t gather_tiles = 0;         // tiles of the largest pending frame = grid.x of the next list launch
   AoRange gather_reads[kGatherMax], gather_writes[kGatherMax];
+  int fq_error = 0;                  // sticky: a join failed to issue gathered frames whose calls had already returned KMC_OK (fq_join)
+  uint64_t fq_dropped = 0;           // how many frames that has cost so far (kmc_hip_frame_queue_dropped)
   // independent frames on ONE stream without the drain between them: a device-resident single-frame launch whose buffers overlap
   // nothing that was launched since (and including) the last ORDERED launch goes out with hipExtAnyOrderLaunch -- the dispatch packet
   // carries no barrier bit, the frame starts while the frame before it is still running.  Everything else the context puts on
@@ -158,7 +169,8 @@ int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n);
 int fq_join(kmc_ctx* c);
 // ONE launch of the frame-list kernel for `count` filled records on the context's stream: kernel-argument records for at most
 // kInlineListFrames frames, else one table upload (under stream capture: several kernel-argument launches).  -> launches_out
-int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t count, int tier, uint32_t* launches_out);
+int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t count, int tier, uint32_t* launches_out, bool inline_only = false);
+int fq_take_error(kmc_ctx* c);  // the sticky error of a join that could not issue its frames (reported once)
 
 // what every entry point that issues work on `stream` starts with
 #define KMC_ENTER(ctx)                                      \
@@ -259,6 +271,11 @@ int ensure_tmp(kmc_ctx* c, size_t bytes);  // grow-only device scratch of the ho
 int ensure_pipeline(kmc_ctx* c);           // streams, events and device slots of the three-stage host pipeline
 int ensure_pipe_streams(kmc_ctx* c);       // only its three streams
 int ensure_events(kmc_ctx* c, size_t count);  // at least `count` events in ev_pool
+// the in-place routes' completion word: done_word_arm() hands out the next launch's DoneWord, wait_done_word() returns when the last
+// armed launch has raised it (everything it stored is then in host memory) -- or when the stream reports an error
+DoneWord done_word_arm(kmc_ctx* c);
+int wait_done_word(kmc_ctx* c);
+double trace_now_us();
 
 // ---- ring of table slots (batch tables and trajectory segment tables) ---------------------------------------------------
 // slot_begin : picks the next slot, waits (host) until the kernels of its group from the previous lap are done, grows every

@@ -100,6 +100,48 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 }
 
 // ------------------------------------------------------------------------------------------------
+// completion word of the in-place kernels (round 5)
+// ------------------------------------------------------------------------------------------------
+// A call on page-locked host buffers ends with "the results are in host memory".  Waiting for the STREAM costs ~8.5 us after the last
+// byte has landed (the end-of-kernel release, the completion signal, the runtime's wait: tools/link_probe, profiles/r05_link_probe.json)
+// -- a tenth of a KITTI frame's call.  So the kernel says it itself: every wave, after its last store, makes its stores visible at
+// system scope (the fence writes back the L2 for cached mappings too: non-coherent page-locked memory is covered) and takes a ticket
+// (device scope); the wave that takes the last ticket re-arms the ticket word and stores the call's sequence number into a page-locked
+// word the host spins on.  What the host sees once the word shows the number: everything every wave stored (release by each wave ->
+// ticket -> acquire + release by the last wave -> the word; the same pattern RCCL's host proxies rest on).
+// `stamps` (optional, page-locked): the device clock (s_memrealtime, 100 MHz) at the first wave's start and at the last ticket --
+// the device half of kmc_hip_last_call_trace.
+struct DoneWord {
+  uint32_t* ticket;     // device memory, 0 between kernels
+  uint32_t* word;       // page-locked host memory; nullptr: no completion word (the caller waits for the stream)
+  uint64_t* stamps;     // page-locked host memory, [0] = first wave's start, [1] = last ticket; nullptr: no trace
+  uint32_t seq;
+  uint32_t pad;
+};
+// The kernels never NAME their DoneWord parameter (named, its 8 SGPRs are preloaded at entry and stay alive through the tile loop, which
+// pushed deskew_f64cols<true> into scratch): both halves read it through the kernel-argument segment, at the moment they need it.
+using done_cp = const DoneWord __attribute__((address_space(4)))*;
+__device__ __forceinline__ void done_word_start(done_cp dw) {
+  uint64_t* const stamps = dw->stamps;
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void done_word_finish(done_cp dw) {
+  uint32_t* const word = dw->word;
+  if (!word) return;       // wave-uniform
+  __threadfence_system();  // this wave's stores (the out-of-range flag included): visible at system scope before the ticket
+  if (threadIdx.x == 0) {
+    uint32_t* const ticket = dw->ticket;
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      uint64_t* const stamps = dw->stamps;
+      if (stamps) stamps[1] = __builtin_amdgcn_s_memrealtime();
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(word, dw->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // single-frame kernel for PAGE-LOCKED HOST buffers (KMC_MEM_HOST_MAPPED): the cloud is read and written IN PLACE over the link
 // ------------------------------------------------------------------------------------------------
 // Launched like deskew_frame_f32 -- every wave loads its tile, then stores it, all ~2 000 waves of a KITTI frame resident at
@@ -110,29 +152,38 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // line costs nothing on PCIe).
 template <int TIER>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_frame_streamed_f32(const v4f* __restrict__ in, v4f* __restrict__ out,
-                                                                                                     uint64_t n, FrameRec f, FrameRecD d) {
-  struct ArgLayout { const v4f* in; v4f* out; uint64_t n; FrameRec f; FrameRecD d; };  // == the parameter list; `d` is read through the segment only
-  const cdouble_p d_rec = (cdouble_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, d));
+                                                                                                     uint64_t n, FrameRec f, DoneWord dw, FrameRecD d) {
+  struct ArgLayout { const v4f* in; v4f* out; uint64_t n; FrameRec f; DoneWord dw; FrameRecD d; };  // == the parameter list; `d` is read through the segment only
+  const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  const cdouble_p d_rec = (cdouble_p)(kernarg + offsetof(ArgLayout, d));
+  const done_cp done = (done_cp)(kernarg + offsetof(ArgLayout, dw));  // read through the segment only, like `d`
+  done_word_start(done);
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + 63) / 64;
   uint64_t t = blockIdx.x;
-  if (t >= n_tiles) return;
-  const uint64_t last = n - 1;
-  v4f cur = __builtin_nontemporal_load(in + (t * 64 + tid <= last ? t * 64 + tid : last));  // dead lanes of the ragged tile re-read the last point
-  while (true) {
-    const uint64_t next = t + gridDim.x;
-    const bool more = next < n_tiles;
-    v4f nxt = cur;
-    if (more) nxt = __builtin_nontemporal_load(in + (next * 64 + tid <= last ? next * 64 + tid : last));  // in flight while `cur` is finished
-    const uint64_t i = t * 64 + tid;
-    const v4f o = deskew_point<TIER>(cur, f);
-    const bool redo = needs_redo(cur, o, f);
-    if (!redo && i < n) __builtin_nontemporal_store(o, out + i);
-    redo_lanes(redo && i < n, cur, d_rec, [&](v4f v) { __builtin_nontemporal_store(v, out + i); });
-    if (!more) break;
-    cur = nxt;
-    t = next;
+  if (t < n_tiles) {
+    const uint64_t last = n - 1;
+    v4f cur = __builtin_nontemporal_load(in + (t * 64 + tid <= last ? t * 64 + tid : last));  // dead lanes of the ragged tile re-read the last point
+    while (true) {
+      const uint64_t next = t + gridDim.x;
+      const bool more = next < n_tiles;
+      v4f nxt = cur;
+      if (more) nxt = __builtin_nontemporal_load(in + (next * 64 + tid <= last ? next * 64 + tid : last));  // in flight while `cur` is finished
+      const uint64_t i = t * 64 + tid;
+      const v4f o = deskew_point<TIER>(cur, f);
+      const bool redo = needs_redo(cur, o, f);
+      // sc1 on the store is what makes the link full duplex (round 5, tools/link_probe): the mapping of page-locked memory is cached
+      // in the L2, a store without it stays there until the end-of-kernel write-back -- the link then carries the whole upload first
+      // and the whole download afterwards (72 us per KITTI frame; 54 with sc1: the bytes leave while the next tile comes in)
+      const __amdgpu_buffer_rsrc_t rout = tile_rsrc(out + t * 64, (n - t * 64) * sizeof(v4f));  // ends with the frame: the ragged tile's dead lanes are clipped
+      if (!redo) tile_store(rout, (uint32_t)(tid * sizeof(v4f)), o);
+      redo_lanes(redo && i < n, cur, d_rec, [&](v4f v) { tile_store(rout, (uint32_t)(tid * sizeof(v4f)), v); });
+      if (!more) break;
+      cur = nxt;
+      t = next;
+    }
   }
+  done_word_finish(done);  // every wave of the grid takes its ticket, also one that found no tile
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,8 +489,21 @@ __device__ __forceinline__ F64Tile f64_tile_load(const double* __restrict__ x, c
   if (w) t.vw = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(w + i));
   return t;
 }
+// SYS (the in-place route over the link): the stores carry sc1 -- they leave for host memory at once instead of waiting in the L2
+// for the end-of-kernel write-back, which is what lets upload and download share the link IN TIME (see deskew_frame_streamed_f32).
+// Through one descriptor per column and tile (wave-uniform base): the global-store builtins have no cache-policy operand.
+template <bool SYS>
+__device__ __forceinline__ void f64_col_store(v2d_u v, double* __restrict__ col, uint64_t tile_first, uint32_t tid) {
+  if constexpr (SYS) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(col + tile_first), 0, 128 * sizeof(double), 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, tid * 16u, 0, /*nt | sc1*/ 2 | 16);
+  } else {
+    __builtin_nontemporal_store(v, reinterpret_cast<v2d_u*>(col + tile_first + 2 * (uint64_t)tid));
+  }
+}
+template <bool SYS = false>
 __device__ __forceinline__ uint32_t f64_tile_finish(const F64Tile& t, const FrameRec64& f, double* __restrict__ ox, double* __restrict__ oy,
-                                                    double* __restrict__ oz, double* __restrict__ ow, uint64_t i) {
+                                                    double* __restrict__ oz, double* __restrict__ ow, uint64_t tile_first, uint32_t tid) {
   v2d_u rx, ry, rz;
   bool ok0, ok1;
   double a, b, c;
@@ -447,10 +511,10 @@ __device__ __forceinline__ uint32_t f64_tile_finish(const F64Tile& t, const Fram
   rx.x = a; ry.x = b; rz.x = c;
   deskew_one_f64(t.vx.y, t.vy.y, t.vz.y, t.vw.y, t.ts.y, f, a, b, c, ok1);
   rx.y = a; ry.y = b; rz.y = c;
-  __builtin_nontemporal_store(rx, reinterpret_cast<v2d_u*>(ox + i));
-  __builtin_nontemporal_store(ry, reinterpret_cast<v2d_u*>(oy + i));
-  __builtin_nontemporal_store(rz, reinterpret_cast<v2d_u*>(oz + i));
-  if (ow) __builtin_nontemporal_store(t.vw, reinterpret_cast<v2d_u*>(ow + i));
+  f64_col_store<SYS>(rx, ox, tile_first, tid);
+  f64_col_store<SYS>(ry, oy, tile_first, tid);
+  f64_col_store<SYS>(rz, oz, tile_first, tid);
+  if (ow) f64_col_store<SYS>(t.vw, ow, tile_first, tid);
   return (ok0 ? 0u : 1u) + (ok1 ? 0u : 1u);
 }
 __device__ __forceinline__ void f64_report_bad(uint32_t bad_count, uint32_t tid, unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag) {
@@ -479,43 +543,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, KMC_F64_W
                                                      const double* __restrict__ stamps, uint64_t n, FrameRec64 f,
                                                      double* __restrict__ ox, double* __restrict__ oy,
                                                      double* __restrict__ oz, double* __restrict__ ow,
-                                                     unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base) {
+                                                     unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base, DoneWord dw) {
   constexpr uint64_t kTile64 = 128;  // points per wave HERE: two per lane
+  struct ArgLayout { const double *x, *y, *z, *w, *stamps; uint64_t n; FrameRec64 f; double *ox, *oy, *oz, *ow; unsigned long long* n_bad; uint32_t* bad_flag; uint64_t tile_base; DoneWord dw; };  // == the parameter list
+  const done_cp done = (done_cp)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, dw));  // `dw` is read through the segment only
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + kTile64 - 1) / kTile64;
   const uint64_t n_full = n / kTile64;  // tiles without a ragged end
   uint64_t t = tile_base + blockIdx.x;
   if constexpr (STREAMED) {  // persistent waves: the grid is the wave count, every wave walks its tiles (tile_base = 0)
+    done_word_start(done);
     F64Tile cur;
     if (t < n_full) cur = f64_tile_load(x, y, z, w, stamps, t * kTile64 + 2 * (uint64_t)tid);
     while (t < n_full) {
       const uint64_t next = t + gridDim.x;
       F64Tile nxt = cur;
       if (next < n_full) nxt = f64_tile_load(x, y, z, w, stamps, next * kTile64 + 2 * (uint64_t)tid);  // in flight while `cur` is finished
-      f64_report_bad(f64_tile_finish(cur, f, ox, oy, oz, ow, t * kTile64 + 2 * (uint64_t)tid), tid, n_bad, bad_flag);
+      f64_report_bad(f64_tile_finish<true>(cur, f, ox, oy, oz, ow, t * kTile64, tid), tid, n_bad, bad_flag);
       cur = nxt;
       t = next;
     }
     t = n_full + blockIdx.x;  // only the ragged last tile is left, for the first workgroup
   }
-  if (t >= n_tiles) return;
-  const uint64_t i = t * kTile64 + 2 * (uint64_t)tid;
-  uint32_t bad_count;
-  if (i + 1 < n) {
-    const F64Tile tl = f64_tile_load(x, y, z, w, stamps, i);
-    bad_count = f64_tile_finish(tl, f, ox, oy, oz, ow, i);
-  } else if (i < n) {  // the odd last point
-    const double pw = w ? w[i] : 1.0;
-    double a, b, c;
-    bool ok;
-    deskew_one_f64(x[i], y[i], z[i], pw, stamps[i], f, a, b, c, ok);
-    ox[i] = a; oy[i] = b; oz[i] = c;
-    if (ow) ow[i] = pw;
-    bad_count = ok ? 0u : 1u;
-  } else {
-    bad_count = 0;
+  if (t < n_tiles) {
+    const uint64_t i = t * kTile64 + 2 * (uint64_t)tid;
+    uint32_t bad_count;
+    if (i + 1 < n) {
+      const F64Tile tl = f64_tile_load(x, y, z, w, stamps, i);
+      bad_count = f64_tile_finish<false>(tl, f, ox, oy, oz, ow, t * kTile64, tid);
+    } else if (i < n) {  // the odd last point
+      const double pw = w ? w[i] : 1.0;
+      double a, b, c;
+      bool ok;
+      deskew_one_f64(x[i], y[i], z[i], pw, stamps[i], f, a, b, c, ok);
+      ox[i] = a; oy[i] = b; oz[i] = c;
+      if (ow) ow[i] = pw;
+      bad_count = ok ? 0u : 1u;
+    } else {
+      bad_count = 0;
+    }
+    f64_report_bad(bad_count, tid, n_bad, bad_flag);
   }
-  f64_report_bad(bad_count, tid, n_bad, bad_flag);
+  if constexpr (STREAMED) done_word_finish(done);  // the in-place route's completion word (see DoneWord); every wave of the grid takes its ticket
 }
 
 // GetPseudoTimeStamps (timestamp_mocking.cpp:46-63) in f64

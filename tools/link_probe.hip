@@ -70,10 +70,25 @@ __global__ __launch_bounds__(64) void k_flag(uint32_t* ticket, Sig* sig, uint32_
   wave_done(ticket, gridDim.x, sig, seq, dev + 1);
 }
 
+// store policies of the duplex kernel (round 5: the nt stores of a kernel over page-locked memory stay in the L2 until the end-of-kernel /
+// fence write-back -- the link then carries the reads first and the writes afterwards; a system-scope store goes out at once)
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+// `tile`: the wave's tile (wave-uniform base -> the descriptor lives in SGPRs), `bytes`: its extent, lane: 16-byte slot of the lane
+template <int POLICY>
+__device__ __forceinline__ void store_policy(v4f v, void* tile, uint32_t bytes, uint32_t lane) {
+  if constexpr (POLICY == 0) { if (lane * 16 < bytes) __builtin_nontemporal_store(v, (v4f*)tile + lane); }
+  else if constexpr (POLICY == 4) { if (lane * 16 < bytes) ((v4f*)tile)[lane] = v; }
+  else {
+    constexpr int aux = POLICY == 1 ? (1 | 16) : POLICY == 2 ? (1 | 16 | 2) : (16 | 2);  // 1 = sc0, 2 = nt, 16 = sc1
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(tile, 0, bytes, 0x00020000);  // lanes beyond `bytes` are clipped
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, lane * 16u, 0, aux);
+  }
+}
 // MODE 0: read + write (the product's streamed shape), 1: read only, 2: write only
-template <int MODE>
-__global__ __launch_bounds__(64) void k_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, uint32_t* ticket, Sig* sig, uint32_t seq, uint64_t* dev) {
+template <int MODE, int POLICY = 0>
+__global__ __launch_bounds__(64) void k_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, uint32_t* ticket, Sig* sig, uint32_t seq, uint64_t* dev, uint64_t* it_stamps) {
   wave_started(sig, seq, dev);
+  uint32_t it = 0;
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + 63) / 64, last = n - 1;
   uint64_t t = blockIdx.x;
@@ -89,19 +104,22 @@ __global__ __launch_bounds__(64) void k_f32(const v4f* __restrict__ in, v4f* __r
       const uint64_t i = t * 64 + tid;
       v4f o = cur * 1.0001f;
       o.w = cur.w;
-      if (MODE != 1) { if (i < n) __builtin_nontemporal_store(o, out + i); }
+      if (MODE != 1) store_policy<POLICY>(o, out + t * 64, (uint32_t)((n - t * 64 < 64 ? n - t * 64 : 64) * 16), tid);
       else acc += o;
+      if (it_stamps && blockIdx.x == 0 && tid == 0 && it < 62) it_stamps[2 + it++] = __builtin_amdgcn_s_memrealtime();  // wave 0: its tile `it` has been stored (issued)
       if (!more) break;
       cur = nxt;
       t = next;
     }
   }
   if (MODE == 1 && acc.x == 12345.678f) out[0] = acc;
+  if (it_stamps && blockIdx.x == 0 && tid == 0) { it_stamps[0] = it; it_stamps[1] = dev[0]; }
   wave_done(ticket, gridDim.x, sig, seq, dev + 1);
 }
 
 // Eigen layout: x y z stamps in, x y z out; 128 points per wave turn, two consecutive points per lane
 struct C64 { const double *x, *y, *z, *s; double *ox, *oy, *oz; };
+template <int POLICY>
 __global__ __launch_bounds__(64) void k_f64(C64 c, uint64_t n, uint32_t* ticket, Sig* sig, uint32_t seq, uint64_t* dev) {
   wave_started(sig, seq, dev);
   const uint32_t tid = threadIdx.x;
@@ -116,9 +134,9 @@ __global__ __launch_bounds__(64) void k_f64(C64 c, uint64_t n, uint32_t* ticket,
       const bool more = next < n_full;
       v2d nx = x, ny = y, nz = z, ns = s;
       if (more) { const uint64_t j = next * 128 + 2 * (uint64_t)tid; nx = ld(c.x, j); ny = ld(c.y, j); nz = ld(c.z, j); ns = ld(c.s, j); }
-      __builtin_nontemporal_store(x + s * 1e-9, reinterpret_cast<v2d*>(c.ox + i));
-      __builtin_nontemporal_store(y + s * 1e-9, reinterpret_cast<v2d*>(c.oy + i));
-      __builtin_nontemporal_store(z + s * 1e-9, reinterpret_cast<v2d*>(c.oz + i));
+      store_policy<POLICY>(__builtin_bit_cast(v4f, x + s * 1e-9), c.ox + t * 128, 1024, tid);
+      store_policy<POLICY>(__builtin_bit_cast(v4f, y + s * 1e-9), c.oy + t * 128, 1024, tid);
+      store_policy<POLICY>(__builtin_bit_cast(v4f, z + s * 1e-9), c.oz + t * 128, 1024, tid);
       if (!more) break;
       x = nx; y = ny; z = nz; s = ns;
       t = next;
@@ -212,18 +230,49 @@ int main(int argc, char** argv) {
   v4f* vout = (v4f*)h_out;
   for (int w : {64, 128, 256, 512, 1024, n_tiles}) {
     if (w > n_tiles) continue;
-    run("f32_rw", w, [&](int W, uint32_t q) { hipLaunchKernelGGL(k_f32<0>, dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev); }, 16.0 * n, 16.0 * n);
+    run("f32_rw", w, [&](int W, uint32_t q) { hipLaunchKernelGGL((k_f32<0, 0>), dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev, (uint64_t*)nullptr); }, 16.0 * n, 16.0 * n);
+  }
+  // store policies at W = 128 and 256: does the write go out while the reads are still coming in?
+  for (int w : {64, 128, 256}) {
+    run("f32_rw_store_sc0sc1", w, [&](int W, uint32_t q) { hipLaunchKernelGGL((k_f32<0, 1>), dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev, (uint64_t*)nullptr); }, 16.0 * n, 16.0 * n);
+    run("f32_rw_store_sc0sc1nt", w, [&](int W, uint32_t q) { hipLaunchKernelGGL((k_f32<0, 2>), dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev, (uint64_t*)nullptr); }, 16.0 * n, 16.0 * n);
+    run("f32_rw_store_sc1nt", w, [&](int W, uint32_t q) { hipLaunchKernelGGL((k_f32<0, 3>), dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev, (uint64_t*)nullptr); }, 16.0 * n, 16.0 * n);
+    run("f32_rw_store_plain", w, [&](int W, uint32_t q) { hipLaunchKernelGGL((k_f32<0, 4>), dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev, (uint64_t*)nullptr); }, 16.0 * n, 16.0 * n);
   }
   for (int w : {256, n_tiles}) {
     if (w > n_tiles) continue;
-    run("f32_read_only", w, [&](int W, uint32_t q) { hipLaunchKernelGGL(k_f32<1>, dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev); }, 16.0 * n, 0);
-    run("f32_write_only", w, [&](int W, uint32_t q) { hipLaunchKernelGGL(k_f32<2>, dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev); }, 0, 16.0 * n);
+    run("f32_read_only", w, [&](int W, uint32_t q) { hipLaunchKernelGGL((k_f32<1, 0>), dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev, (uint64_t*)nullptr); }, 16.0 * n, 0);
+    run("f32_write_only", w, [&](int W, uint32_t q) { hipLaunchKernelGGL((k_f32<2, 0>), dim3(W), dim3(64), 0, s, vin, vout, n, ticket, sig, q, dev, (uint64_t*)nullptr); }, 0, 16.0 * n);
+  }
+  {  // wave 0's own timeline at W = 128: when did each of its tiles go out (device clock, us after the wave started)?
+    uint64_t* its;
+    CHECK(hipHostMalloc((void**)&its, 64 * 8, hipHostMallocPortable | hipHostMallocMapped));
+    std::memset(its, 0, 64 * 8);
+    for (int rep = 0; rep < 20; ++rep) {
+      ++seq;
+      hipLaunchKernelGGL((k_f32<0, 0>), dim3(128), dim3(64), 0, s, vin, vout, n, ticket, sig, seq, dev, its);
+      while (sig->done != seq) {}
+      CHECK(hipStreamSynchronize(s));
+    }
+    std::printf(", \"f32_rw_w128_wave0_tile_stored_at_us\": [");
+    for (uint64_t k = 0; k < its[0] && k < 62; ++k) std::printf("%s%.2f", k ? ", " : "", (double)(its[2 + k] - its[1]) * 0.01);
+    std::printf("]");
+    for (int rep = 0; rep < 20; ++rep) {
+      ++seq;
+      hipLaunchKernelGGL((k_f32<0, 1>), dim3(128), dim3(64), 0, s, vin, vout, n, ticket, sig, seq, dev, its);
+      while (sig->done != seq) {}
+      CHECK(hipStreamSynchronize(s));
+    }
+    std::printf(", \"f32_rw_store_sc0sc1_w128_wave0_tile_stored_at_us\": [");
+    for (uint64_t k = 0; k < its[0] && k < 62; ++k) std::printf("%s%.2f", k ? ", " : "", (double)(its[2 + k] - its[1]) * 0.01);
+    std::printf("]");
   }
   C64 c64 = {h64, h64 + n, h64 + 2 * n, h64 + 3 * n, h64 + 4 * n, h64 + 5 * n, h64 + 6 * n};
   const int n_t128 = (int)(n / 128);
   for (int w : {64, 128, 256, 512, n_t128}) {
     if (w > n_t128) continue;
-    run("f64_rw", w, [&](int W, uint32_t q) { hipLaunchKernelGGL(k_f64, dim3(W), dim3(64), 0, s, c64, n, ticket, sig, q, dev); }, 32.0 * n, 24.0 * n);
+    run("f64_rw", w, [&](int W, uint32_t q) { hipLaunchKernelGGL(k_f64<0>, dim3(W), dim3(64), 0, s, c64, n, ticket, sig, q, dev); }, 32.0 * n, 24.0 * n);
+    run("f64_rw_store_sc0sc1", w, [&](int W, uint32_t q) { hipLaunchKernelGGL(k_f64<1>, dim3(W), dim3(64), 0, s, c64, n, ticket, sig, q, dev); }, 32.0 * n, 24.0 * n);
   }
 
   // ---- the same bytes through the copy engines (page-locked host buffers) ----

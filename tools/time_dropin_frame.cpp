@@ -7,6 +7,7 @@
 // Prints ONE JSON object.  With dump_prefix the frame's inputs and the clouds the two calls returned are written next to it
 // (<prefix>.cloud_in.f64 / .stamps.f64 / .cloud_out.f64: column-major N x 4 / N doubles; <prefix>.kitti_in.f32 / .kitti_out.f32: N x 4
 // floats), for bench.py's parity check against the oracle -- this tool itself never touches oracle/.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -72,12 +73,48 @@ int main(int argc, char** argv) {
     dump(prefix + ".kitti_in.f32", raw.data(), raw.size() * sizeof(float));
     dump(prefix + ".kitti_out.f32", out.data(), out.size() * sizeof(float));
   }
+  // ---- where the microseconds of one MotionCompensateFrame call go (hip::FrameTrace; medians over `iters` traced calls) ----
+  std::string trace_json = "null";
+  {
+    hip::EnableFrameTrace(true);
+    for (int i = 0; i < 10; ++i) checksum += MotionCompensateFrame(frame, scan.stamp_middle)(0, 0);
+    struct Row { double v[12]; };
+    std::vector<Row> rows;
+    for (int i = 0; i < iters; ++i) {
+      auto const a = std::chrono::duration<double, std::micro>(clk::now().time_since_epoch()).count();
+      checksum += MotionCompensateFrame(frame, scan.stamp_middle)(0, 0);
+      auto const b = std::chrono::duration<double, std::micro>(clk::now().time_since_epoch()).count();
+      hip::FrameTrace const t = hip::LastFrameTrace();
+      if (t.route != 2) continue;  // not the in-place route (pageable containers): no stage stamps
+      rows.push_back(Row{{t.enter_us - a, t.params_us - t.enter_us, t.alloc_us - t.params_us, t.begin_returned_us - t.alloc_us, t.fill_done_us - t.begin_returned_us,
+                          t.end_returned_us - t.fill_done_us, b - t.end_returned_us, b - a, t.issue_end_us - t.issue_begin_us, t.wait_end_us - t.issue_end_us,
+                          t.dev_last_store_us - t.dev_first_wave_us, static_cast<double>(t.waves)}});
+    }
+    hip::EnableFrameTrace(false);
+    if (!rows.empty()) {
+      auto med = [&](int k) {
+        std::vector<double> v;
+        for (Row const& r : rows) v.push_back(r.v[k]);
+        std::sort(v.begin(), v.end());
+        return v[v.size() / 2];
+      };
+      char buf[2048];
+      std::snprintf(buf, sizeof(buf),
+                    "{\"calls_traced\": %zu, \"medians_us\": {\"call_overhead_before_entry\": %.2f, \"host_prestep_Log_and_x_req\": %.2f, \"result_cloud_from_the_pool_and_context_lookup\": %.2f, "
+                    "\"f64cols_begin_checks_and_launch\": %.2f, \"host_fills_w_column_while_the_kernel_runs\": %.2f, \"f64cols_end_wait_for_the_completion_word\": %.2f, "
+                    "\"return_by_value_and_destructor\": %.2f, \"whole_call\": %.2f}, \"inside_the_c_abi_us\": {\"begin_entry_to_launch_enqueued\": %.2f, "
+                    "\"launch_enqueued_to_completion_word_seen\": %.2f, \"device_first_wave_to_last_store\": %.2f, \"persistent_waves\": %.0f}, "
+                    "\"derived_us\": {\"launch_enqueued_to_first_wave_plus_last_store_to_word_seen\": %.2f}}",
+                    rows.size(), med(0), med(1), med(2), med(3), med(4), med(5), med(6), med(7), med(8), med(9), med(10), med(11), med(9) - med(10));
+      trace_json = buf;
+    }
+  }
   std::printf(
       "{\"points\": %zu, \"iterations\": %d, \"containers\": \"%s\", \"route\": \"%s\", "
       "\"MotionCompensateFrame_f64_us_per_frame\": %.2f, \"MotionCompensateFrame_f64_us_best_call\": %.2f, \"MotionCompensateKittiCloud_f32_us_per_frame\": %.2f, "
-      "\"stamp_start\": %.9f, \"stamp_middle\": %.9f, \"stamp_end\": %.9f, \"T_end\": {\"yaw_z\": %.17g, \"t\": [%.17g, %.17g, %.17g]}, \"checksum\": %.6f}\n",
+      "\"stamp_start\": %.9f, \"stamp_middle\": %.9f, \"stamp_end\": %.9f, \"T_end\": {\"yaw_z\": %.17g, \"t\": [%.17g, %.17g, %.17g]}, \"trace\": %s, \"checksum\": %.6f}\n",
       n, iters, pooled ? "page-locked pool (the drop-in's default)" : "ordinary pageable memory (KMC_HOST_POOL=0 or no pool)",
       pooled ? "one kernel in place over the link" : "staged copies", us64, us64_min, us32, scan.stamp_start, scan.stamp_middle, scan.stamp_end, yaw, tx, ty, tz,
-      checksum + out[0]);
+      trace_json.c_str(), checksum + out[0]);
   return 0;
 }
