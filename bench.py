@@ -300,6 +300,35 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
             raise SystemExit(f"{' '.join(cmd)} failed ({r.returncode}): {r.stdout[-1000:]} {r.stderr[-2000:]}")
         return json.loads(lines[-1])
 
+    # ---- ceilings: the box's own memory ceilings for the kernels' access patterns, without their arithmetic (tools/copy_ceiling.hip) ----
+    # (driver-observed, in the same line as the kernels they bound)
+    def run_ceilings():
+        import subprocess
+
+        exe = os.path.join(ROOT, "kitti_motion_compensation_amd", "lib", "copy_ceiling")
+        if not os.path.exists(exe):
+            raise ToolMissing("copy_ceiling is missing (tools/Makefile builds it)")
+        r = subprocess.run([exe, "67108864", "3", "10"], capture_output=True, text=True, timeout=600, env=unprofiled_env())
+        rows = [l.split(",") for l in r.stdout.splitlines() if "," in l and not l.startswith("kernel,")]
+        if r.returncode != 0 or not rows:
+            raise SystemExit(f"copy_ceiling failed ({r.returncode}): {r.stdout[-500:]} {r.stderr[-1000:]}")
+        return {row[0]: {"us_median": float(row[3]), "GBps_median": float(row[5]), "frac_of_peak": _frac(float(row[5]))} for row in rows}
+
+    try:
+        ceil = run_ceilings()
+        out["ceilings"] = {
+            "what": "tools/copy_ceiling.hip on this box, 64 Mi points per launch, median of 3 rounds x 10 launches: the access patterns of the deskew kernels with the arithmetic taken out",
+            "f32_one_stream_in_one_out": {"kernel": "copy_tiles (one 64-point tile per one-wave workgroup, nt load, nt + sc1 store: the f32 kernels' pattern, 32 B/point)", **ceil.get("copy_tiles", {})},
+            "f32_read_alone": ceil.get("read_points"), "f32_write_alone": ceil.get("write_points"), "f32_copy_256_thread_workgroups": ceil.get("copy_points"),
+            "f64_nine_column_streams": {"kernel": "copy_cols9 (five double[n] columns read, four written, 16 B per lane and column, one 128-point tile per one-wave workgroup, nt: "
+                                                  "deskew_f64cols' pattern, 72 B/point); _w4 = 4 resident waves per SIMD like the kernel, _sc1 = nt + sc1 stores",
+                                        "copy_cols9": ceil.get("copy_cols9"), "copy_cols9_w4": ceil.get("copy_cols9_w4"), "copy_cols9_sc1": ceil.get("copy_cols9_sc1")},
+            "f64_seven_column_streams": {"kernel": "copy_cols7 (no homogeneous column: four read, three written, 56 B/point)", "copy_cols7": ceil.get("copy_cols7"), "copy_cols7_w4": ceil.get("copy_cols7_w4")},
+        }
+    except ToolMissing as e:
+        ceil = {}
+        out["ceilings"] = {"skipped": str(e)}
+
     # ---- configs1_literal: one 1 M-point frame per call, driven from C++ (tools/time_frame_stream.hip) ---------------------------
     # 256 frames of 1 M points, every frame its OWN allocation (8.2 GB of distinct in / out buffers: every frame comes from HBM).  The
     # C-ABI is driven by a C++ loop, so the host language does not set the pace (a ctypes call costs ~8 us, a launch ~2).
@@ -330,12 +359,16 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
             "in_order_drained": stream_leg(fs, "per_call_drained", n, "the same calls on a context created with KMC_ANY_ORDER=0: every dispatch waits for the last wave of the one before it"),
             "gathered_calls": stream_leg(fs, "per_call_gathered", n, "the same calls, one per frame, with kmc_hip_set_frame_queues(ctx, 4): the library gathers them on the host and issues "
                                          "ONE launch of the frame-list kernel per up to 16 frames (deferred issue, in-order results)"),
-            "list_one_launch": stream_leg(fs, "list_one_launch", n, "kmc_hip_deskew_frames_f32: the 256 separate frames handed over as ONE list -> one launch of the frame-list kernel "
-                                          "(2-D grid: frame x tile); bit-identical to the per-call outputs (checked by the tool: list_equals_per_call_bitwise)"),
+            "list_one_launch": stream_leg(fs, "list_one_launch", n, "kmc_hip_deskew_frames_f32: the 256 separate frames handed over as ONE list -> the frame-list kernel (2-D grid: frame x tile) "
+                                          "in chained kernel-argument launches of 16 frames, barrier-free behind the first where verified: nothing uploaded, the host never waits "
+                                          "(round 5; key name kept); bit-identical to the per-call outputs (checked by the tool: list_equals_per_call_bitwise)"),
             "batch_packed": stream_leg(fs, "batch_packed", n, "the same frames packed into one buffer, kmc_hip_deskew_batch_f32 (the headline's kernel): the ceiling for this frame mix"),
             "list_equals_per_call_bitwise": fs["list_equals_per_call_bitwise"],
         }
-        assert fs["list_equals_per_call_bitwise"] is True and fs["list_launches"] == 1, fs
+        assert fs["list_equals_per_call_bitwise"] is True, fs
+        leg["list_launches"] = fs["list_launches"]
+        if "list_table_route" in fs:
+            leg["list_table_route"] = stream_leg(fs, "list_table_route", n, "the same list call with KMC_LIST_ROUTE=table: ONE launch over an uploaded device table (the round-4 route)")
         if check:  # oracle spot check of the per-call entry point on this workload's first frame shape (outside any timing)
             work = make_workload(capi, 1, 0, yaw_per_frame=0.03)[0]
             prm, (t0, tm, t1), oxs = work
@@ -404,7 +437,10 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
             "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream"),
             "per_call_drained": stream_leg(fd, "per_call_drained", npts, "KMC_ANY_ORDER=0: the barrier bit on every dispatch"),
             "per_call_gathered": stream_leg(fd, "per_call_gathered", npts, "the same calls with kmc_hip_set_frame_queues(ctx, 4): gathered on the host, one list launch per up to 16 frames"),
-            "list_one_launch": stream_leg(fd, "list_one_launch", npts, "kmc_hip_deskew_frames_f32: the 108 separate frames as one list, ONE launch (device tables: one small upload per call)"),
+            "list_one_launch": stream_leg(fd, "list_one_launch", npts, "kmc_hip_deskew_frames_f32: the 108 separate frames as one list -> 7 chained kernel-argument launches of <= 16 frames, "
+                                          "barrier-free behind the first where verified (round 5: no table upload, no host wait; key name kept)"),
+            "list_table_route": stream_leg(fd, "list_table_route", npts, "the same call with KMC_LIST_ROUTE=table: ONE launch over an uploaded device table (the round-4 route)") if "list_table_route" in fd else None,
+            "list_launches": fd.get("list_launches"),
             "batch_packed": stream_leg(fd, "batch_packed", npts, "the same frames packed into one buffer, one batched launch"),
             "per_call_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call"]["us_per_frame"], 3),
             "gathered_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call_gathered"]["us_per_frame"], 3),
@@ -485,6 +521,13 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         ctx.deskew_f64cols_end()
 
     ms = timed(f64_burst, 3, 1) / K64
+
+    def f64_burst_ones():  # the homogeneous column KNOWN to be ones (what the C++ drop-in passes for every cloud its loaders made): neither read nor written
+        for _ in range(K64):
+            ctx.deskew_f64cols_begin(cols[0], cols[1], cols[2], None, stamps, 100.0, 100.1, turn, outs[0], outs[1], outs[2], None)
+        ctx.deskew_f64cols_end()
+
+    ms_ones = timed(f64_burst_ones, 3, 1) / K64
     ctx.enable_timing(True)
     for _ in range(3):
         ctx.deskew_f64cols(cols[0], cols[1], cols[2], w, stamps, 100.0, 100.1, turn, *outs)
@@ -494,6 +537,9 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
            "kernel": "kmc_dev::deskew_f64cols (one wave per workgroup, two points per lane)", "bytes_per_point": 72,
            "us_per_call": round(ms * 1e3, 2), "Mpts_s": round(n / ms / 1e3, 1), "GBps": round(72 * n / ms / 1e6, 1), "frac": _frac(72 * n / ms / 1e6),
            "timed_as": f"{K64} launches back to back (kmc_hip_deskew_f64cols_begin x {K64}, one _end) between ONE HIP-event pair on the launch stream, 3 bursts after a warm-up burst",
+           "homogeneous_column_known_to_be_ones": {
+               "bytes_per_point": 56, "us_per_call": round(ms_ones * 1e3, 2), "Mpts_s": round(n / ms_ones / 1e3, 1), "GBps": round(56 * n / ms_ones / 1e6, 1), "frac": _frac(56 * n / ms_ones / 1e6),
+               "note": "w == NULL, ow == NULL: Affine3d * (x, y, z, 1) needs no w (motion_compensation.cpp:13); what kmc::MotionCompensateFrame passes for clouds whose column is known to be ones (data_io.cpp:130)"},
            "single_call": {"us_per_call": round(ms_call * 1e3, 2), "GBps": round(72 * n / ms_call / 1e6, 1), "frac": _frac(72 * n / ms_call / 1e6),
                            "note": "one kmc_hip_deskew_f64cols call at a time (each ends with the host waiting for the out-of-range verdict): the library's own event pair around the lone launch, median of 20"}}
     if check:
@@ -507,6 +553,16 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         assert rc == orc.OK
         leg["parity"] = {"max_rel_err": rel_err(got, want[:, :3]), "bar": 1e-11, "points": m}
         assert leg["parity"]["max_rel_err"] <= 1e-11, leg
+    c9 = [v["GBps_median"] for k, v in (ceil or {}).items() if k.startswith("copy_cols9") and v]
+    c7 = [v["GBps_median"] for k, v in (ceil or {}).items() if k.startswith("copy_cols7") and v]
+    if c9:  # the kernel against the box's own ceiling for nine column streams (best of the copy variants measured in this run)
+        leg["ceiling_9_streams_GBps"] = max(c9)
+        leg["frac_of_9_stream_ceiling"] = round(leg["GBps"] / max(c9), 4)
+        leg["l2_hit_rate_explained"] = ("profiles/r04_pmc_sq_tcc_f64cols.json: TCC hits 16.0 M = exactly half of the 32.0 M write requests -- a 128-byte line arrives as two 64-byte "
+                                        "write requests, the second meets the first in the L2; every one of the 20.0 M read requests (128 B each = the 2.56 GB read) misses: nothing is re-read")
+    if c7:
+        leg["homogeneous_column_known_to_be_ones"]["ceiling_7_streams_GBps"] = max(c7)
+        leg["homogeneous_column_known_to_be_ones"]["frac_of_7_stream_ceiling"] = round(leg["homogeneous_column_known_to_be_ones"]["GBps"] / max(c7), 4)
     out["f64cols"] = leg
     del cols, w, stamps, outs
     torch.cuda.empty_cache()
@@ -598,7 +654,7 @@ def run_dropin_cpp_leg(run_tool, rel_err, orc):
             raise SystemExit("tools/make_synthetic_run.py failed: " + r.stderr[-1000:])
         run = r.stdout.strip().splitlines()[-1]
         cli = os.path.join(lib_dir, "motion_compensate_runs")
-        walls, stages = [], None
+        walls, stages, stage_rows = [], None, []
         for rep in range(3):
             shutil.rmtree(os.path.join(run, "velodyne_points", "data_motion_compensated"), ignore_errors=True)
             t0 = time.perf_counter()
@@ -607,6 +663,7 @@ def run_dropin_cpp_leg(run_tool, rel_err, orc):
             if rr.returncode != 0:
                 raise SystemExit("motion_compensate_runs failed: " + rr.stderr[-2000:])
             stages = [l for l in rr.stderr.splitlines() if l.startswith("kmc run timing")]
+            stage_rows.append(_run_stage_numbers(stages))
         pts_run = sum(os.path.getsize(os.path.join(run, "velodyne_points", "data", "%010d.bin" % i)) // 16 for i in range(1, n_run - 1))
         best = min(walls)
         leg["MotionCompensateRun"] = {
@@ -615,8 +672,11 @@ def run_dropin_cpp_leg(run_tool, rel_err, orc):
             "frames_compensated": n_run - 2, "points_compensated": int(pts_run),
             "process_wall_s_best_of_3": round(best, 3), "process_wall_s_all": [round(x, 3) for x in walls],
             "frames_per_s": round((n_run - 2) / best, 1), "Mpts_s": round(pts_run / best / 1e6, 1),
-            "busy_seconds_per_stage_last_run": stages[-1].split("busy seconds per stage:")[-1].strip() if stages else None,
-            "note": "whole process: HIP runtime start-up, context, page-locking the two buffer sets, text parsing, reading, one batched GPU round trip per 8 frames, writing",
+            "stages_ms_per_run": stage_rows,
+            "stages_are": "per run, milliseconds: busy time of the pipeline's stages (they overlap) and wall-clock marks since kmc::MotionCompensateRun was entered -- "
+                          "the rest of process_wall is the process itself: loading the HIP runtime before main, its teardown after",
+            "spread_of_3": round(max(walls) / min(walls) - 1.0, 3),
+            "note": "whole process: HIP runtime start-up and page-locking on a helper thread WHILE the text files are parsed, context, reading, one batched GPU round trip per 8 frames, writing",
         }
         if orc is not None:  # one frame the driver wrote, against oracle MakeFrame + the FAITHFUL loop
             from tests import util
@@ -637,6 +697,26 @@ def run_dropin_cpp_leg(run_tool, rel_err, orc):
         return leg
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _run_stage_numbers(lines):
+    """The `kmc run timing` lines of one motion_compensate_runs process (KMC_RUN_TIMING=1) as numbers, milliseconds."""
+    import re
+
+    out = {}
+    for l in lines:
+        m = re.search(r"text files parsed ([0-9.eE+-]+) ms", l)
+        if m:
+            out["text_files_parsed_at"] = round(float(m.group(1)), 2)
+        m = re.search(r"MotionCompensateRun returns ([0-9.eE+-]+) ms", l)
+        if m:
+            out["run_returns_at"] = round(float(m.group(1)), 2)
+        m = re.search(r"context ([0-9.eE+-]+)\s+read ([0-9.eE+-]+)\s+gpu round trip ([0-9.eE+-]+)\s+write ([0-9.eE+-]+)\s+\| wall seconds since the range started: first batch read ([0-9.eE+-]+)\s+all written ([0-9.eE+-]+)", l)
+        if m:
+            v = [round(float(x) * 1e3, 2) for x in m.groups()]
+            out.update({"busy_context": v[0], "busy_read": v[1], "busy_gpu_round_trips": v[2], "busy_write": v[3], "first_batch_read_after_range_start": v[4],
+                        "all_written_after_range_start": v[5]})
+    return out
 
 
 def relaunch_under_launcher(n, torch):

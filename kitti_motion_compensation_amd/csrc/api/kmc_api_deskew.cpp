@@ -42,6 +42,19 @@ kmc_ctx* thread_context() {
   return t_ctx.get();
 }
 
+// A context made on ANOTHER thread (kmc::MotionCompensateRun creates it on a helper while the calling thread parses the run's text
+// files: creating one costs 12-40 ms) becomes the calling thread's context.  The thread already has one: `c` is destroyed instead.
+void adopt_thread_context(kmc_ctx* c, int device) {
+  if (!c) return;
+  if (t_ctx) {
+    kmc_hip_destroy(c);
+    return;
+  }
+  t_device = device;
+  t_ctx.reset(c);
+}
+bool thread_has_context() { return static_cast<bool>(t_ctx); }
+
 static kmc_frame_params frame_params(Affine3d const& T_start, Affine3d const& T_end, Time t0, Time t1, Time t_req, const char* where) {
   double a[12], b[12];
   T_start.to_rt12(a);

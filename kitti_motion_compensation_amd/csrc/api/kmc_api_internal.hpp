@@ -52,5 +52,7 @@ inline Affine3d from_host(kmc_host::Pose const& P) {
 
 // one device context per thread (lazy); throws std::runtime_error when there is no HIP device
 kmc_ctx* thread_context();
+void adopt_thread_context(kmc_ctx* c, int device);  // a context created on a helper thread becomes this thread's (kmc_api_deskew.cpp)
+bool thread_has_context();
 
 }  // namespace kmc::detail

@@ -20,7 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <system_error>
@@ -252,6 +254,70 @@ namespace {
 //   writer thread : results written from pinned memory, a batch's files split over two threads (writing is the longest stage)
 // so reading batch k+1, deskewing batch k and writing batch k-1 overlap.  The second buffer set is page-locked while the reader
 // already fills the first (page-locking costs ~0.3 ms/MiB: a third of a short run's pipeline time).
+// The page-locked buffers of a run, made by a helper thread in the order the pipeline needs them (set 0 in, set 0 out, set 1 in,
+// set 1 out) out of the C-ABI's context-free pool -- so that the HIP runtime's start-up (~30 ms) and the page-locking (~0.3 ms per MiB)
+// run WHILE the caller parses the run's text files and the reader already fills the first buffer, instead of in front of them
+// (round 5; until then "context + pinned" was a serial 49 ms of a 188 ms run).  unavailable(): the pool is switched off
+// (KMC_HOST_POOL=0) -- the caller then allocates through its device context as before.
+class PinnedSets {
+ public:
+  PinnedSets(std::size_t floats_per_buffer, int n_buffers) : floats_(floats_per_buffer), n_(std::min(n_buffers, 4)) {
+    worker_ = std::thread([this] {
+      for (int k = 0; k < n_; ++k) {
+        void* q = nullptr;
+        int const rc = kmc_host_pool_alloc(floats_ * sizeof(float), &q);
+        std::lock_guard<std::mutex> lock(mu_);
+        if (rc != KMC_OK || !q) {
+          failed_rc_ = rc != KMC_OK ? rc : KMC_ERR_ALLOC;
+          cv_.notify_all();
+          return;
+        }
+        buf_[k] = static_cast<float*>(q);
+        ready_ = k + 1;
+        cv_.notify_all();
+      }
+    });
+  }
+  PinnedSets(PinnedSets const&) = delete;
+  PinnedSets& operator=(PinnedSets const&) = delete;
+  ~PinnedSets() {
+    if (worker_.joinable()) worker_.join();
+    for (float* p : buf_)
+      if (p) kmc_host_pool_free(p);
+  }
+  // buffer `index`, waiting for the helper if it is not there yet; nullptr: the pool declined (unavailable)
+  float* wait(int index) {
+    std::unique_lock<std::mutex> lock(mu_);
+    cv_.wait(lock, [&] { return ready_ > index || failed_rc_ != KMC_OK; });
+    return ready_ > index ? buf_[index] : nullptr;
+  }
+  int failed_rc() {
+    std::lock_guard<std::mutex> lock(mu_);
+    return failed_rc_;
+  }
+
+ private:
+  std::size_t floats_;
+  int n_;
+  std::thread worker_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  float* buf_[4] = {nullptr, nullptr, nullptr, nullptr};
+  int ready_ = 0;
+  int failed_rc_ = KMC_OK;
+};
+
+// points of the largest batch when frames [first, last) are cut into batches of max_batch_frames
+std::size_t MaxBatchPoints(std::vector<std::uint64_t> const& frame_points, std::size_t first, std::size_t last, std::size_t max_batch_frames) {
+  std::size_t worst = 0;
+  for (std::size_t b0 = first; b0 < last; b0 += max_batch_frames) {
+    std::size_t sum = 0;
+    for (std::size_t i = b0; i < std::min(b0 + max_batch_frames, last); ++i) sum += static_cast<std::size_t>(frame_points[i]);
+    worst = std::max(worst, sum);
+  }
+  return worst;
+}
+
 struct RunInputs {
   Path velodyne, out_dir;
   std::vector<Time> const* t_start;
@@ -264,12 +330,13 @@ struct RunInputs {
 };
 std::mutex g_cout_mu;
 
-void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t const last, int const worker) {
+void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t const last, int const worker, PinnedSets* prepared = nullptr,
+                      std::function<void()> const& adopt_early_context = nullptr) {
   if (first >= last) return;
   struct Pinned {
-    kmc_ctx* ctx = nullptr;
+    kmc_ctx* ctx = nullptr;  // set: `p` came from kmc_hip_host_alloc and is freed here; null: `p` belongs to a PinnedSets
     float* p = nullptr;
-    ~Pinned() { if (p) kmc_hip_host_free(ctx, p); }
+    ~Pinned() { if (p && ctx) kmc_hip_host_free(ctx, p); }
     void alloc(kmc_ctx* c, std::size_t n_floats) {
       void* q = nullptr;
       int const rc = kmc_hip_host_alloc(c, n_floats * sizeof(float), &q);
@@ -313,21 +380,40 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
     plans.push_back(std::move(plan));
   }
 
+  // The page-locked buffers come from a helper thread (PinnedSets): the caller's, started before it parsed the text files, or one
+  // started here (a worker of the multi-device driver).  This thread meanwhile creates its device context.
   auto const t_ctx0 = clk::now();
-  kmc_ctx* ctx = detail::thread_context();
+  std::unique_ptr<PinnedSets> own_sets;
+  if (!prepared) {
+    own_sets = std::make_unique<PinnedSets>(4 * max_points + 16, plans.size() > 1 ? 4 : 2);
+    prepared = own_sets.get();
+  }
+  // The device context is only needed by the first GPU round trip: it is taken (adopted from the caller's helper thread, or created)
+  // AFTER the reader has been started, so that the first batches are read while the context is still being made.
+  kmc_ctx* ctx = nullptr;
   BufferSet sets[2];
-  auto const alloc_set = [&](BufferSet& set) {
-    set.in.alloc(ctx, 4 * max_points + 16);
-    set.out.alloc(ctx, 4 * max_points + 16);
-  };
-  alloc_set(sets[0]);
-  sets[0].state = State::kFree;
-  double t_ctx = secs(t_ctx0, clk::now());
-
   std::mutex mu;
   std::condition_variable cv;
   std::exception_ptr failure;
-  double t_read = 0, t_gpu = 0, t_write = 0;
+  bool fallback_buffers = false;  // the pool declined: this thread has allocated every buffer through the context (under `mu`)
+  double t_read = 0, t_gpu = 0, t_write = 0, t_first_ready = 0, t_ctx = 0;
+  // buffer `which` (0 = in, 1 = out) of set `k`: from the page-locking helper, or -- the pool is switched off -- from this thread, which
+  // allocates all of them through the device context once it has one
+  auto const buffer_of = [&](BufferSet& set, int k, int which) -> float* {
+    Pinned& slot = which == 0 ? set.in : set.out;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (slot.p) return slot.p;
+    }
+    float* const q = prepared->wait(2 * k + which);
+    std::unique_lock<std::mutex> lock(mu);
+    if (q) slot.p = q;  // borrowed: PinnedSets frees it
+    else cv.wait(lock, [&] { return fallback_buffers || failure; });
+    return slot.p;  // (nullptr only with `failure` set: the caller's next wait_for ends the thread)
+  };
+  sets[0].state = State::kFree;
+  sets[1].state = State::kFree;
+
   auto const wait_for = [&](BufferSet& set, State wanted) {
     std::unique_lock<std::mutex> lock(mu);
     cv.wait(lock, [&] { return set.state == wanted || failure; });
@@ -348,6 +434,8 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
         BufferSet& set = sets[k % 2];
         BatchPlan const& plan = plans[k];
         if (!wait_for(set, State::kFree)) return;
+        float* const in_p = buffer_of(set, static_cast<int>(k % 2), 0);  // (the first lap may wait for the page-locking helper)
+        if (!in_p) return;  // only after a failure elsewhere
         auto const t0 = clk::now();
         set.frames.clear();
         set.trajectories.clear();
@@ -356,7 +444,7 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
           std::ifstream is{plan.files[j], std::ios::in | std::ios::binary};
           if (!is.is_open()) throw std::runtime_error("Unable to open requested KITTI pointcloud binary file: " + plan.files[j].string());
           auto const want = static_cast<std::streamsize>((plan.offsets[j + 1] - plan.offsets[j]) * 16);
-          is.read(reinterpret_cast<char*>(set.in.p + 4 * plan.offsets[j]), want);
+          is.read(reinterpret_cast<char*>(in_p + 4 * plan.offsets[j]), want);
           // a file that shrank or failed since the planning pass would leave the previous batch's bytes in this slot
           if (is.gcount() != want || is.bad())
             throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + plan.files[j].string() +
@@ -380,6 +468,7 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
           set.frames.push_back(fp);
         }
         t_read += secs(t0, clk::now());
+        if (k == 0) t_first_ready = secs(t_ctx0, clk::now());
         publish(set, State::kReady);
       }
     } catch (...) {
@@ -393,31 +482,41 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
         BatchPlan const& plan = plans[k];
         if (!wait_for(set, State::kDone)) return;
         auto const t0 = clk::now();
-        auto const write_files = [&](std::size_t j0) {  // every second file of the batch, from j0
-          for (std::size_t j = j0; j < plan.files.size(); j += 2)
+        constexpr std::size_t kWriters = 4;  // this thread + three helpers: the files of a batch are dealt out round-robin
+        auto const write_files = [&](std::size_t j0) {
+          for (std::size_t j = j0; j < plan.files.size(); j += kWriters)
             WriteRaw(in.out_dir, plan.first + j, set.out.p + 4 * plan.offsets[j], static_cast<std::size_t>(plan.offsets[j + 1] - plan.offsets[j]));
         };
-        std::exception_ptr helper_error;
-        std::thread helper;
-        try {
-          helper = std::thread([&] {
+        std::exception_ptr helper_error[kWriters];
+        std::thread helpers[kWriters];
+        for (std::size_t h = 1; h < kWriters; ++h) {
+          try {
+            helpers[h] = std::thread([&, h] {
+              try {
+                write_files(h);
+              } catch (...) {
+                helper_error[h] = std::current_exception();
+              }
+            });
+          } catch (std::system_error const&) {  // no helper thread to be had: this thread writes that share too
             try {
-              write_files(1);
+              write_files(h);
             } catch (...) {
-              helper_error = std::current_exception();
+              helper_error[h] = std::current_exception();
             }
-          });
-        } catch (std::system_error const&) {  // no helper thread to be had: this thread writes the whole batch
-          write_files(1);
+          }
         }
+        std::exception_ptr own_error;
         try {
           write_files(0);
         } catch (...) {
-          if (helper.joinable()) helper.join();
-          throw;
+          own_error = std::current_exception();
         }
-        if (helper.joinable()) helper.join();
-        if (helper_error) std::rethrow_exception(helper_error);
+        for (std::size_t h = 1; h < kWriters; ++h)
+          if (helpers[h].joinable()) helpers[h].join();
+        if (own_error) std::rethrow_exception(own_error);
+        for (std::size_t h = 1; h < kWriters; ++h)
+          if (helper_error[h]) std::rethrow_exception(helper_error[h]);
         {
           std::lock_guard<std::mutex> lock(g_cout_mu);
           for (std::size_t j = 0; j < plan.files.size(); ++j)
@@ -439,15 +538,23 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
     throw;
   }
   try {
-    if (plans.size() > 1) {  // the second buffer set, while the reader is busy with the first batch
-      auto const t0 = clk::now();
-      alloc_set(sets[1]);
-      t_ctx += secs(t0, clk::now());
-      publish(sets[1], State::kFree);
+    if (adopt_early_context) adopt_early_context();  // joins the caller's helper thread; its context becomes this thread's
+    ctx = detail::thread_context();
+    t_ctx = secs(t_ctx0, clk::now());
+    if (in.timing) std::cerr << "kmc run timing: device context " << t_ctx * 1e3 << " ms after the range started (the reader is already at work)\n";
+    if (prepared->wait(0) == nullptr) {  // KMC_HOST_POOL=0: page-locked buffers through the context, like before round 5
+      std::lock_guard<std::mutex> lock(mu);
+      for (auto& set : sets) {
+        set.in.alloc(ctx, 4 * max_points + 16);
+        set.out.alloc(ctx, 4 * max_points + 16);
+      }
+      fallback_buffers = true;
+      cv.notify_all();
     }
     for (std::size_t k = 0; k < plans.size(); ++k) {
       BufferSet& set = sets[k % 2];
       if (!wait_for(set, State::kReady)) break;
+      if (!buffer_of(set, static_cast<int>(k % 2), 1)) break;
       auto const t0 = clk::now();
       if (in.three_knots) hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.trajectories, set.out.p);
       else hip::MotionCompensateKittiClouds(set.in.p, plans[k].offsets, set.frames, set.out.p);
@@ -463,8 +570,8 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
   if (in.timing) {
     std::lock_guard<std::mutex> lock(g_cout_mu);
     std::cerr << "kmc run timing, worker " << worker << " (device " << hip::GetDevice() << ", frames [" << first << ", " << last
-              << ")), busy seconds per stage: context+pinned " << t_ctx << "  read " << t_read << "  gpu round trip " << t_gpu << "  write "
-              << t_write << "\n";
+              << ")), busy seconds per stage: context " << t_ctx << "  read " << t_read << "  gpu round trip " << t_gpu << "  write "
+              << t_write << "  | wall seconds since the range started: first batch read " << t_first_ready << "  all written " << secs(t_ctx0, clk::now()) << "\n";
   }
 }
 }  // namespace
@@ -475,18 +582,12 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
   Path const out_dir{velodyne / Path("data_motion_compensated")};
   if (!fs::is_directory(out_dir) || !fs::exists(out_dir)) fs::create_directory(out_dir);
   if (n_frames == 0) return;
-  CopyOverUncompensatedFirstAndLastFrame(run_folder);
-  if (n_frames < 3) return;
-
-  // every text file is parsed once per run
-  auto const t_start = LoadAllTimeStamps(velodyne / Path("timestamps_start.txt"));
-  auto const t_mid = LoadAllTimeStamps(velodyne / Path("timestamps.txt"));
-  auto const t_end = LoadAllTimeStamps(velodyne / Path("timestamps_end.txt"));
-  auto const t_oxts = LoadAllTimeStamps(run_folder / Path("oxts/timestamps.txt"));
-  if (t_start.size() < n_frames || t_mid.size() < n_frames || t_end.size() < n_frames || t_oxts.size() < n_frames)
-    throw std::runtime_error("timestamp files are shorter than the number of velodyne frames in " + run_folder.string());
-  std::vector<Oxts> oxts(n_frames);
-  for (std::size_t i = 0; i < n_frames; ++i) oxts[i] = LoadOxtsWithStamp(run_folder, i, t_oxts[i]);
+  auto const t_entry = std::chrono::steady_clock::now();
+  std::size_t const max_batch_frames = [] {  // page-locking costs ~0.3 ms/MiB, so modest batches win for one-off runs (tools/time_run_cli.sh: 8 beats 16 by ~20 ms per 216-frame run)
+    char const* e = std::getenv("KMC_RUN_BATCH_FRAMES");
+    long const v = e ? std::atol(e) : 0;
+    return static_cast<std::size_t>(v > 0 ? std::min(v, 4096L) : 8L);
+  }();
 
   // points per frame, from the file sizes: they decide the batch boundaries, the buffer sizes and the split across devices
   std::vector<std::uint64_t> frame_points(n_frames, 0);
@@ -498,6 +599,49 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
     if (bytes % 4 != 0) throw std::runtime_error("Opened KITTI pointcloud binary file is incorrectly formatted: " + file.string());
     frame_points[i] = bytes / 16;
   }
+  double const sizes_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+  std::vector<int> const devices = hip::GetRunDevices();
+  bool const one_device_here = n_frames >= 3 && std::min<std::size_t>(devices.size(), n_frames - 2) == 1 && devices[0] == hip::GetDevice();
+  // One device, the caller's thread: the HIP runtime starts up and the buffers are page-locked on a helper thread from HERE on, while
+  // this thread copies the two uncompensated frames and parses the text files (handlers.cpp:41-54 does those first, too).
+  std::unique_ptr<PinnedSets> prepared;
+  // ... and so is the device context (12 ms for a process's second context, ~40 ms for its first: streams, the code objects' load, the
+  // dispatch probe), on a helper of its own; this thread adopts it once the text files are parsed
+  struct EarlyContext {
+    std::thread worker;
+    kmc_ctx* ctx = nullptr;
+    int rc = KMC_OK;
+    ~EarlyContext() {  // (an exception on the way: the helper is joined, a context nobody adopted is destroyed)
+      if (worker.joinable()) worker.join();
+      if (ctx) kmc_hip_destroy(ctx);
+    }
+  } early;
+  if (one_device_here) {
+    std::size_t const most = MaxBatchPoints(frame_points, 1, n_frames - 1, max_batch_frames);
+    prepared = std::make_unique<PinnedSets>(4 * most + 16, n_frames - 2 > max_batch_frames ? 4 : 2);
+    if (!detail::thread_has_context()) {
+      int const device = hip::GetDevice();
+      try {
+        early.worker = std::thread([&early, device] { early.rc = kmc_hip_create(&early.ctx, device); });
+      } catch (std::system_error const&) {  // no helper to be had: the context is created where it always was
+      }
+    }
+  }
+  CopyOverUncompensatedFirstAndLastFrame(run_folder);
+  if (n_frames < 3) return;
+  double const copied_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+
+  // every text file is parsed once per run
+  auto const t_start = LoadAllTimeStamps(velodyne / Path("timestamps_start.txt"));
+  auto const t_mid = LoadAllTimeStamps(velodyne / Path("timestamps.txt"));
+  auto const t_end = LoadAllTimeStamps(velodyne / Path("timestamps_end.txt"));
+  auto const t_oxts = LoadAllTimeStamps(run_folder / Path("oxts/timestamps.txt"));
+  if (t_start.size() < n_frames || t_mid.size() < n_frames || t_end.size() < n_frames || t_oxts.size() < n_frames)
+    throw std::runtime_error("timestamp files are shorter than the number of velodyne frames in " + run_folder.string());
+  double const stamps_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+  std::vector<Oxts> oxts(n_frames);
+  for (std::size_t i = 0; i < n_frames; ++i) oxts[i] = LoadOxtsWithStamp(run_folder, i, t_oxts[i]);
+  double const parsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
 
   RunInputs in;
   in.velodyne = velodyne;
@@ -507,11 +651,7 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
   in.t_end = &t_end;
   in.oxts = &oxts;
   in.frame_points = &frame_points;
-  in.max_batch_frames = [] {  // page-locking costs ~0.3 ms/MiB, so modest batches win for one-off runs (tools/time_run_cli.sh: 8 beats 16 by ~20 ms per 216-frame run)
-    char const* e = std::getenv("KMC_RUN_BATCH_FRAMES");
-    long const v = e ? std::atol(e) : 0;
-    return static_cast<std::size_t>(v > 0 ? std::min(v, 4096L) : 8L);
-  }();
+  in.max_batch_frames = max_batch_frames;
   in.timing = [] { char const* e = std::getenv("KMC_RUN_TIMING"); return e && e[0] == '1'; }();
   // KMC_RUN_KNOTS=3: interpolate along the piecewise geodesic through the three OXTS poses around the frame, used as they
   // are, instead of first reducing them to the two scan-end poses like MakeFrame does (data_io.cpp:253-269).
@@ -521,15 +661,28 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
   // CONTIGUOUS range per device, balanced on points (kmc_frame_ranges_balanced -- the split the per-rank launch uses), and
   // every range runs its own read / deskew / write pipeline on its own device context.  KMC_DEVICES=0,1,... or
   // kmc::hip::SetRunDevices select the devices (an id may repeat: two contexts on one GPU); default = the calling thread's.
-  std::vector<int> const devices = hip::GetRunDevices();
   std::uint32_t const n_parts = static_cast<std::uint32_t>(std::min<std::size_t>(devices.size(), n_frames - 2));
   std::vector<std::uint32_t> bounds(n_parts + 1);
   {
     int const rc = kmc_frame_ranges_balanced(frame_points.data() + 1, static_cast<std::uint32_t>(n_frames - 2), n_parts, bounds.data());
     if (rc != KMC_OK) detail::throw_status(rc, "kmc_frame_ranges_balanced");
   }
-  if (n_parts == 1 && devices[0] == hip::GetDevice()) {  // the common case: no extra thread, the caller's own context
-    DeskewFrameRange(in, 1, n_frames - 1, 0);
+  if (in.timing)
+    std::cerr << "kmc run timing: file sizes " << sizes_ms << " ms, first / last frame copied " << copied_ms << " ms, time stamp files " << stamps_ms
+              << " ms, text files parsed " << parsed_ms << " ms after entry\n";
+  if (n_parts == 1 && devices[0] == hip::GetDevice()) {  // the common case: no extra worker, the caller's own context
+    auto const adopt = [&early] {
+      if (!early.worker.joinable()) return;
+      early.worker.join();
+      if (early.rc == KMC_OK && early.ctx) {
+        detail::adopt_thread_context(early.ctx, hip::GetDevice());
+        early.ctx = nullptr;
+      }  // (a failed creation is reported by thread_context(), which tries again)
+    };
+    DeskewFrameRange(in, 1, n_frames - 1, 0, prepared.get(), adopt);
+    if (in.timing)
+      std::cerr << "kmc run timing: MotionCompensateRun returns " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count()
+                << " ms after entry\n";
     return;
   }
   std::vector<std::thread> workers;

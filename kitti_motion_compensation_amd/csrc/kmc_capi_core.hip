@@ -115,26 +115,59 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
     for (uint32_t k = 0; k < n_recs; ++k) n_max = std::max<uint64_t>(n_max, recs[first + k].n);
     return (uint32_t)((n_max + kTile - 1) / kTile);
   };
-  auto launch_inline = [&](uint32_t first, uint32_t n_recs) {
-    ListInline inl;
-    if (n_recs < (uint32_t)kInlineListFrames) std::memset(&inl, 0, sizeof(inl));  // (no stale stack bytes in the kernel arguments)
+  // one launch whose records travel in the kernel arguments: the smallest of the three block capacities that holds n_recs
+  auto launch_inline_cap = [&](auto CAP, uint32_t first, uint32_t n_recs, bool any_order) {
+    constexpr int kCap = decltype(CAP)::value;
+    ListInlineT<kCap> inl;
+    if (n_recs < (uint32_t)kCap) std::memset(&inl, 0, sizeof(inl));  // (no stale stack bytes in the kernel arguments)
     std::memcpy(inl.recs, recs + first, n_recs * sizeof(ListRec));
     std::memcpy(inl.recs64, recd + first, n_recs * sizeof(FrameRecD));
     const dim3 grid(std::max(1u, tiles_of(first, n_recs)), n_recs, 1);
     with_tier(tier, [&](auto T) {
-      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, true>), grid, dim3(kTile), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, inl);
+      if (any_order)
+        hipExtLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kCap>), grid, dim3(kTile), 0, c->stream, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, (const ListRec*)nullptr,
+                              (const FrameRecD*)nullptr, inl);
+      else
+        hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kCap>), grid, dim3(kTile), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, inl);
     });
+  };
+  auto launch_inline = [&](uint32_t first, uint32_t n_recs, bool any_order) {
+    if (n_recs <= 16) launch_inline_cap(std::integral_constant<int, 16>{}, first, n_recs, any_order);
+    else if (n_recs <= 64) launch_inline_cap(std::integral_constant<int, 64>{}, first, n_recs, any_order);
+    else launch_inline_cap(std::integral_constant<int, kInlineListFramesMax>{}, first, n_recs, any_order);
   };
   uint32_t launches = 0;
   bool capturing = false;
-  if (count > (uint32_t)kInlineListFrames) {  // a table upload cannot be part of a stream capture (the slot is reused by later calls, and the host waits for the copy)
+  if (count > (uint32_t)kInlineListFrames) {  // (a table upload cannot be part of a stream capture: the slot is reused by later calls, and the host waits for the copy)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     capturing = hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     (void)hipGetLastError();
   }
-  if (count <= (uint32_t)kInlineListFrames || capturing || inline_only) {
-    for (uint32_t first = 0; first < count; first += kInlineListFrames, ++launches) launch_inline(first, std::min<uint32_t>(kInlineListFrames, count - first));
-    KMC_HIP_TRY(c, hipGetLastError());
+  // Every list goes out in kernel-argument launches (round 5): ONE launch for up to 256 frames; longer lists in launches of 256 (the
+  // frames of a list are independent of each other -- the callers have checked -- so where barrier-free dispatch is verified and the
+  // stream is the context's own, every launch after the first goes out without the barrier bit: the ordinary first launch orders
+  // the chain behind everything before it, the next ordinary packet on the stream waits for all of it).  Launches of at most 16 frames
+  // -- the block every runtime is known to take -- under stream capture, for fq_join's fallback (inline_only) and once a large block
+  // has been refused (kmc_ctx::big_kernargs).  KMC_LIST_ROUTE=table: one launch over an uploaded device table, the round-4 route.
+  const bool table = count > (uint32_t)kInlineListFrames && c->list_route == 1 && !capturing && !inline_only;
+  if (!table) {
+    const bool small_blocks = capturing || inline_only || !c->big_kernargs;
+    const uint32_t per_launch = small_blocks ? (uint32_t)kInlineListFrames : (uint32_t)kInlineListFramesMax;
+    if (count > per_launch && !capturing && c->stream == c->own_stream) ao_ensure(c);
+    const bool free_order = count > per_launch && !capturing && c->ao_enabled && c->stream == c->own_stream && c->stream != nullptr;
+    for (uint32_t first = 0; first < count; first += per_launch, ++launches)
+      launch_inline(first, std::min<uint32_t>(per_launch, count - first), free_order && first != 0);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess && !small_blocks && count > (uint32_t)kInlineListFrames) {
+      // this runtime refused a block beyond 4 KiB: remember it, and issue the list again in 16-frame launches (a refused launch ran nothing;
+      // launches of the loop that did go through ran frames that are now simply written twice with the same bits)
+      c->big_kernargs = false;
+      launches = 0;
+      for (uint32_t first = 0; first < count; first += kInlineListFrames, ++launches)
+        launch_inline(first, std::min<uint32_t>(kInlineListFrames, count - first), false);
+      le = hipGetLastError();
+    }
+    KMC_HIP_TRY(c, le);
   } else {
     // slot layout: [ListRec x F | FrameRecD x F], one upload on the side stream, awaited on the host (like a batch's tables)
     const size_t recs_bytes = ((size_t)count * sizeof(ListRec) + 255) & ~(size_t)255;
@@ -145,13 +178,15 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
     kmc_ctx::TableSlot& sl = c->slots[slot_id];
     std::memcpy(sl.h_buf, recs, (size_t)count * sizeof(ListRec));
     std::memcpy(sl.h_buf + recs_bytes, recd, (size_t)count * sizeof(FrameRecD));
+    // (the kernel reading the records straight from the page-locked staging block -- no upload at all -- was measured and dropped: 0.83 us
+    // per KITTI frame against 0.79 with the upload and 0.72 chained; profiles/NOTES_r05.md)
     rc = slot_upload(c, slot_id, need);
     if (rc != KMC_OK) return rc;
     const dim3 grid(std::max(1u, tiles_of(0, count)), count, 1);
     const ListRec* d_recs = reinterpret_cast<const ListRec*>(sl.d_buf);
     const FrameRecD* d_recd = reinterpret_cast<const FrameRecD*>(sl.d_buf + recs_bytes);
     with_tier(tier, [&](auto T) {
-      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, false>), grid, dim3(kTile), 0, c->stream, d_recs, d_recd, ListNoInline{});
+      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, 0>), grid, dim3(kTile), 0, c->stream, d_recs, d_recd, ListNoInline{});
     });
     KMC_HIP_TRY(c, hipGetLastError());
     rc = slot_end(c, slot_id);
@@ -198,8 +233,27 @@ int fq_take_error(kmc_ctx* c) {
 //   - the window describes everything in flight behind the last ordered launch (every other entry point ends it);
 //   - the frame's buffers overlap none of the window's (write against reads and writes, read against writes).
 // Either way the frame is entered into the window; an ordered launch starts a new one.
+int ao_verdict_for(kmc_ctx* c);
+// The probe runs when its verdict is first needed (round 5: kmc_hip_create used to run it -- allocations, kernels, waits -- for
+// contexts that never launch a single frame, e.g. the run driver's).  Never while a caller's stream captures a graph: the probe
+// allocates, which a capture in progress does not survive; such a call is simply dispatched in order and the probe waits for the next.
+void ao_ensure(kmc_ctx* c) {
+  if (c->ao_probed) return;
+  if (c->stream != c->own_stream && c->stream != nullptr) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return;
+    }
+  }
+  c->ao_probed = true;
+  c->ao_verdict = ao_verdict_for(c);  // barrier-free dispatch only where this device and runtime were SEEN to honour what it relies on
+  c->ao_enabled = c->ao_verdict == 1;
+}
+
 bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call) {
   const kmc_ctx::AoRange r = {(uintptr_t)in, (uintptr_t)in + bytes}, w = {(uintptr_t)out, (uintptr_t)out + bytes};
+  if (c->stream != nullptr && (same_call || c->stream == c->own_stream || !c->fq_ordered)) ao_ensure(c);  // (only where the verdict can matter)
   bool any_order = c->ao_enabled && c->ao_valid && c->stream != nullptr && c->ao_count < kmc_ctx::kAoWindow &&
                    (same_call || c->stream == c->own_stream || !c->fq_ordered);
   for (int k = 0; any_order && k < c->ao_count; ++k) {
@@ -338,7 +392,7 @@ int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
       if (rc_join != KMC_OK) return rc_join;
     }
     KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    if (c->copy_stream) KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     const size_t cap = std::max<size_t>(64 * 1024, need * 2);
     for (auto& each : c->slots) {
       if (each.cap >= cap) continue;
@@ -359,6 +413,9 @@ int slot_begin(kmc_ctx* c, size_t need, int* slot_id_out) {
 
 int slot_upload(kmc_ctx* c, int slot_id, size_t bytes) {
   kmc_ctx::TableSlot& sl = c->slots[slot_id];
+  // the side stream exists from the first table upload on (a stream is an HSA queue: ~4 ms of kmc_hip_create that a context which
+  // never uploads a table -- the run driver's, the drop-in's -- does not have to pay)
+  if (!c->copy_stream) KMC_HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   KMC_HIP_TRY(c, hipMemcpyAsync(sl.d_buf, sl.h_buf, bytes, hipMemcpyHostToDevice, c->copy_stream));
   KMC_HIP_TRY(c, hipEventRecord(sl.uploaded, c->copy_stream));
   KMC_HIP_TRY(c, hipEventSynchronize(sl.uploaded));
@@ -434,7 +491,6 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   hipEvent_t* evs[] = {&c->ev_k0, &c->ev_k1, &c->ev_c0, &c->ev_c1, &c->ev_t0, &c->ev_t1};
   for (hipEvent_t* ev : evs)
     if (e == hipSuccess) e = hipEventCreate(ev);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
   for (auto& sl : c->slots)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming);
   for (auto& ev : c->group_consumed)
@@ -454,12 +510,13 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
     return KMC_ERR_NO_DEVICE;
   }
   c->stream = c->own_stream;
+  if (const char* e = std::getenv("KMC_LIST_ROUTE")) c->list_route = std::strcmp(e, "table") == 0 ? 1 : 0;  // lists of more than 16 frames: "table" = one launch + one table upload
   if (const char* e = std::getenv("KMC_MAPPED_WAVES")) {  // tuning knob: persistent waves of the in-place kernels (default 128; tools/link_probe)
     const int w = std::atoi(e);
     if (w >= 1 && w <= 65535) c->mapped_waves = w;
   }
-  c->ao_verdict = ao_verdict_for(c);  // barrier-free dispatch only where this device and runtime were SEEN to honour what it relies on
-  c->ao_enabled = c->ao_verdict == 1;
+  if (const char* e = std::getenv("KMC_ANY_ORDER"))  // the switch is read HERE, like every other knob of a context; the probe itself runs at first need (ao_ensure)
+    if (std::atoi(e) == 0) { c->ao_probed = true; c->ao_verdict = 0; c->ao_enabled = false; }
   *out = c;
   return KMC_OK;
 }
@@ -512,7 +569,7 @@ static int switch_stream(kmc_ctx* c, hipStream_t next) {
   const int rc = fq_join(c);
   if (rc != KMC_OK) return rc;
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  if (c->copy_stream) KMC_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   for (auto& busy : c->group_busy) busy = false;
   for (auto& dirty : c->group_dirty) dirty = false;
   c->stream = next;
@@ -604,6 +661,8 @@ int kmc_hip_device_info(kmc_ctx* c, kmc_device_info* out) {
   out->wavefront_size = c->prop.warpSize;
   out->hbm_bytes = c->prop.totalGlobalMem;
   out->clock_khz = c->prop.clockRate;
+  (void)hipSetDevice(c->device);
+  ao_ensure(c);
   out->any_order_dispatch = c->ao_verdict;
   return KMC_OK;
 }

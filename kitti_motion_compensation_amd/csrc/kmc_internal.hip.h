@@ -111,6 +111,8 @@ struct kmc_ctx {
   int gather_tier = 0;
   uint64_t gather_tiles = 0;         // tiles of the largest pending frame = grid.x of the next list launch
   AoRange gather_reads[kGatherMax], gather_writes[kGatherMax];
+  bool big_kernargs = true;          // kernel-argument blocks beyond 4 KiB are taken by this runtime (cleared by the first refused launch: launch_list)
+  int list_route = 0;                // lists of more than 16 frames: 0 = kernel-argument launches of up to 256 frames (launch_list), 1 = one launch over an uploaded device table (KMC_LIST_ROUTE=table)
   int fq_error = 0;                  // sticky: a join failed to issue gathered frames whose calls had already returned KMC_OK (fq_join)
   uint64_t fq_dropped = 0;           // how many frames that has cost so far (kmc_hip_frame_queue_dropped)
   // independent frames on ONE stream without the drain between them: a device-resident single-frame launch whose buffers overlap
@@ -121,6 +123,7 @@ struct kmc_ctx {
   static constexpr int kAoWindow = 32;   // frames between two ordered launches at most
   bool ao_enabled = false;               // set by kmc_hip_create from the run-time probe's verdict (kmc_capi_core.hip); KMC_ANY_ORDER=0 turns it off
   int ao_verdict = 0;                    // kmc_device_info.any_order_dispatch
+  bool ao_probed = false;                // the verdict has been established (ao_ensure: at first need, not in kmc_hip_create)
   bool ao_valid = false;                 // the window describes EVERYTHING in flight on `stream` after the last ordered launch (it included)
   int ao_count = 0;
   uint64_t ao_launches = 0;              // frames that went out without the barrier bit so far (kmc_hip_any_order_launches)
@@ -264,6 +267,7 @@ inline void launch_on(void (*kernel)(KArgs...), int grid, int block, hipStream_t
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, static_cast<KArgs>(args)...);
 }
 
+void ao_ensure(kmc_ctx* c);  // runs the dispatch probe if its verdict is not known yet
 bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call);  // may this frame be dispatched without the barrier bit?  (kmc_capi_core.hip)
 bool host_pool_owns(const void* ptr, size_t bytes);  // inside a live block of the page-locked host pool (kmc_capi_hostpool.hip)
 bool host_in_place_ok(const void* ptr, size_t bytes);  // pool memory, or the caller's own page-locked memory that the device addresses at the same address

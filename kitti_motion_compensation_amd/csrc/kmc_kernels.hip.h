@@ -414,27 +414,33 @@ struct alignas(16) ListRec {
   uint32_t pad;
 };
 static_assert(sizeof(ListRec) == 96, "ListRec must stay one 96-byte record");
-// INLINE: a list of at most kInlineListFrames frames carries its records (and their f64 twins for the guard) in the kernel arguments:
-// nothing to upload, the host never waits, the call only enqueues a launch.
-constexpr int kInlineListFrames = 16;
-struct ListInline {
-  ListRec recs[kInlineListFrames];
-  FrameRecD recs64[kInlineListFrames];
+// CAP > 0: the list carries its records (and their f64 twins for the guard) IN THE KERNEL ARGUMENTS: nothing to upload, the host never
+// waits, the call only enqueues a launch.  Round 4 assumed a 4 KiB limit on the argument block (16 frames); the runtime takes 64 KiB and
+// more (tools/launch_probe, profiles/r05_launch_probe.json: 8 KiB 3.1 us, 16 KiB 4.1 us, 64 KiB 10 us of host time per launch against
+// 2.2-3.4 us for a small block), so a whole KITTI drive -- 108 frames, 24 KiB -- is ONE launch without a table.  Three capacities, so
+// that a short list does not copy a long list's block: 16 (3.5 KiB), 64 (14 KiB), 256 (56 KiB).  CAP == 0: a device table.
+constexpr int kInlineListFrames = 16;     // what a launch under stream capture and the fallback chain carry (the block round 4 proved everywhere)
+constexpr int kInlineListFramesMax = 256;
+template <int CAP>
+struct ListInlineT {
+  ListRec recs[CAP];
+  FrameRecD recs64[CAP];
 };
-static_assert(sizeof(ListInline) <= 3800, "the list tables must leave room for the other arguments in the 4 KB kernel-argument segment");
+static_assert(sizeof(ListInlineT<kInlineListFrames>) <= 3800, "the 16-frame block fits the 4 KiB every runtime takes");
+static_assert(sizeof(ListInlineT<kInlineListFramesMax>) <= 60 * 1024, "the largest block stays below the 64 KiB the probe verified");
 struct ListNoInline { uint32_t unused; };
-template <bool INLINE> using ListInlineArg = typename std::conditional<INLINE, ListInline, ListNoInline>::type;
+template <int CAP> using ListInlineArg = typename std::conditional<(CAP > 0), ListInlineT<(CAP > 0 ? CAP : 1)>, ListNoInline>::type;
 
-template <int TIER, bool INLINE = false>
+template <int TIER, int CAP = 0>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_list_f32(const ListRec* __restrict__ recs_g, const FrameRecD* __restrict__ recs64,
-                                                                                              ListInlineArg<INLINE> inl) {
+                                                                                              ListInlineArg<CAP> inl) {
   using rec_cp = const ListRec __attribute__((address_space(4)))*;
   rec_cp recs;
-  if constexpr (INLINE) {
-    struct ArgLayout { const ListRec* recs_g; const FrameRecD* recs64; ListInline inl; };
+  if constexpr (CAP > 0) {
+    struct ArgLayout { const ListRec* recs_g; const FrameRecD* recs64; ListInlineT<(CAP > 0 ? CAP : 1)> inl; };
     const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    recs = (rec_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(ListInline, recs));
-    recs64 = (const FrameRecD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(ListInline, recs64));
+    recs = (rec_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(ListInlineT<(CAP > 0 ? CAP : 1)>, recs));
+    recs64 = (const FrameRecD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(ListInlineT<(CAP > 0 ? CAP : 1)>, recs64));
   } else {
     recs = (rec_cp)(uintptr_t)recs_g;  // written by the host before the launch: constant for the kernel, uniform reads are scalar loads
   }

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #define CHECK(x)                                                                              \
@@ -39,6 +40,14 @@ __global__ __launch_bounds__(64) void k_frame(const v4f* __restrict__ in, v4f* _
     p.x = __builtin_fmaf(p.x, f.v[0], f.v[1] + (float)d.v[3]);
     __builtin_nontemporal_store(p, out + i);
   }
+}
+// Does the runtime take kernel-argument blocks beyond 4 KiB?  (the frame-list kernel carries 16 frames' records in 3.6 KiB; 32 or 64
+// frames per launch would halve / quarter the launches of a drive)
+template <int BYTES> struct Big { uint32_t w[BYTES / 4]; };
+template <int BYTES>
+__global__ __launch_bounds__(64) void k_big(uint32_t* out, Big<BYTES> b) {
+  const uint32_t __attribute__((address_space(4)))* p = (const uint32_t __attribute__((address_space(4)))*)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = p[BYTES / 4 - 1] + p[0];  // first and last word of the block, through the segment
 }
 struct Args { const v4f* in; v4f* out; uint64_t n; Rec32 f; uint32_t head; uint64_t tile_base; Rec64 d; };
 
@@ -138,6 +147,36 @@ int main(int argc, char** argv) {
     CHECK(hipStreamSynchronize(s));
     const double all = us_since(t0) / (N / 16 * 16);
     std::printf(", \"graph_16\": {\"host_us_per_kernel\": %.3f, \"train_us_per_kernel\": %.3f}", host, all);
+  }
+  {
+    uint32_t* d_out;
+    CHECK(hipMalloc(&d_out, 64));
+    auto try_big = [&](auto tag, const char* name) {
+      constexpr int BYTES = decltype(tag)::value;
+      Big<BYTES> b;
+      for (int i = 0; i < BYTES / 4; ++i) b.w[i] = 1000u + (uint32_t)i;
+      CHECK(hipMemset(d_out, 0, 64));
+      hipLaunchKernelGGL(k_big<BYTES>, dim3(1), dim3(64), 0, s, d_out, b);
+      const hipError_t le = hipGetLastError();
+      const hipError_t se = hipStreamSynchronize(s);
+      uint32_t got = 0;
+      (void)hipMemcpy(&got, d_out, 4, hipMemcpyDeviceToHost);
+      const bool ok = le == hipSuccess && se == hipSuccess && got == 1000u + 1000u + (uint32_t)(BYTES / 4 - 1);
+      double host = 0;
+      if (ok) {
+        auto t0 = clk::now();
+        for (int i = 0; i < 2000; ++i) hipLaunchKernelGGL(k_big<BYTES>, dim3(1), dim3(64), 0, s, d_out, b);
+        host = us_since(t0) / 2000;
+        (void)hipStreamSynchronize(s);
+      }
+      std::printf(", \"%s\": {\"accepted_and_correct\": %s, \"launch_error\": \"%s\", \"host_us_per_launch\": %.3f}", name, ok ? "true" : "false", hipGetErrorString(le != hipSuccess ? le : se), host);
+      (void)hipGetLastError();
+    };
+    try_big(std::integral_constant<int, 3584>{}, "kernarg_3584_B");
+    try_big(std::integral_constant<int, 4000>{}, "kernarg_4000_B");
+    try_big(std::integral_constant<int, 8192>{}, "kernarg_8192_B");
+    try_big(std::integral_constant<int, 16384>{}, "kernarg_16384_B");
+    try_big(std::integral_constant<int, 65536>{}, "kernarg_65536_B");
   }
   std::printf("}\n");
   return 0;

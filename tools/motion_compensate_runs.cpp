@@ -3,6 +3,7 @@
 // With no RUN arguments every "*_sync" directory under DATA_DIR is processed.  Thin argv wrapper around
 // kmc::MotionCompensateRun (handlers.cpp:41-65); the frames are deskewed on the GPU in batches.
 #include <algorithm>
+#include <cstdlib>
 #include <filesystem>
 #include <iostream>
 #include <string>
@@ -33,5 +34,11 @@ int main(int argc, char** argv) {
       return 1;
     }
   }
-  return 0;
+  // Everything is written and closed.  Leaving through exit() would now tear the HIP runtime down, unpin the buffer pool and destroy the
+  // device context -- 20-30 ms of a 0.15 s process that produces nothing; the streams are flushed and the process ends here instead.
+  // KMC_CLI_FULL_TEARDOWN=1 takes the long way out (leak checkers, sanitizers).
+  std::cout.flush();
+  std::cerr.flush();
+  if (char const* e = std::getenv("KMC_CLI_FULL_TEARDOWN"); e && e[0] == '1') return 0;
+  std::_Exit(0);
 }

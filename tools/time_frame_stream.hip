@@ -11,7 +11,9 @@
 //                       flight go out without the barrier bit when the run-time probe allowed it: kmc_device_info.any_order_dispatch)
 //   per_call_drained    the same calls on a context created with KMC_ANY_ORDER=0 (every dispatch carries the barrier bit)
 //   per_call_gathered   the same calls with kmc_hip_set_frame_queues(ctx, 4): the library gathers them into list launches of up to 16 frames
-//   list_one_launch     kmc_hip_deskew_frames_f32: the set's frames handed over as ONE list -> one launch of the frame-list kernel
+//   list_one_launch     kmc_hip_deskew_frames_f32: the set's frames handed over as ONE list (the key keeps its round-4 name; since round 5 a
+//                       list of more than 16 frames goes out as chained kernel-argument launches of 16 frames, barrier-free where verified)
+//   list_table_route    the same call on a context created with KMC_LIST_ROUTE=table: one launch of the frame-list kernel over an uploaded table
 //   batch_packed        kmc_hip_deskew_batch_f32 on the same frames packed into one buffer (the ceiling for this frame mix)
 // plus the host's own time per call (steady_clock around the issuing loop) and a bit-for-bit comparison of what the list kernel and
 // the per-frame kernel wrote for every frame.  Prints one JSON object.
@@ -73,8 +75,11 @@ int main(int argc, char** argv) {
   }
   const uint64_t total = offsets[F];
 
-  kmc_ctx *ctx = nullptr, *drained = nullptr;
+  kmc_ctx *ctx = nullptr, *drained = nullptr, *tabled = nullptr;
   KMC_OK_OR_DIE(kmc_hip_create(&ctx, 0));
+  setenv("KMC_LIST_ROUTE", "table", 1);
+  KMC_OK_OR_DIE(kmc_hip_create(&tabled, 0));
+  unsetenv("KMC_LIST_ROUTE");
   setenv("KMC_ANY_ORDER", "0", 1);
   KMC_OK_OR_DIE(kmc_hip_create(&drained, 0));
   unsetenv("KMC_ANY_ORDER");
@@ -180,6 +185,8 @@ int main(int argc, char** argv) {
   }
   const double us_list = timed(ctx, list);
   const double host_list = host_us;
+  const double us_list_table = timed(tabled, list);
+  const double host_list_table = host_us;
   const double us_batch = timed(ctx, batch);
 
   const double mean_pts = (double)total / F;
@@ -191,10 +198,12 @@ int main(int argc, char** argv) {
       "\"per_call_drained\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}, "
       "\"per_call_gathered\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
       "\"list_one_launch\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
+      "\"list_table_route\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
       "\"batch_packed\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}}\n",
       F, carve ? "carved out of one allocation per set (1 KiB-aligned starts)" : "separate hipMalloc allocations", n_sets, iters, mean_pts, (unsigned long long)total, info.name, info.any_order_dispatch, st.n_launches, same ? "true" : "false", us_call,
-      gbps(us_call), host_call, ao_share, us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_batch, gbps(us_batch));
+      gbps(us_call), host_call, ao_share, us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_list_table, gbps(us_list_table), host_list_table, us_batch, gbps(us_batch));
   kmc_hip_destroy(drained);
+  kmc_hip_destroy(tabled);
   kmc_hip_destroy(ctx);
   return same ? 0 : 1;
 }
