@@ -216,8 +216,8 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  * One launch per frame is bound by the launch, not by HBM: the host pays 2.5-5 us per launch and the chip drains and refills between
  * two launches -- 6.1-7.0 us call to call for a 1 M-point frame whose kernel takes 4.7, 2.4-5 us for a KITTI frame whose kernel takes
  * 0.6.  The frames of this path are independent (motion_compensation.cpp:22-25 reads nothing a previous frame wrote).  Three ways out:
- *   (1) hand a LIST of ready frames to kmc_hip_deskew_frames_f32: one launch of the frame-list kernel for all of them (84 % of the HBM
- *       peak on 1 M-point frames, 0.66 us per KITTI frame; gathered calls, (2), reach 83-84 % and 0.70 us);
+ *   (1) hand a LIST of ready frames to kmc_hip_deskew_frames_f32: one launch of the frame-list kernel for all of them (85 % of the HBM
+ *       peak on 1 M-point frames -- the packed batch's rate --, 0.62 us per KITTI frame; gathered calls, (2), reach 84 % and 0.68 us);
  *   (2) kmc_hip_set_frame_queues(ctx, q > 1): keep calling kmc_hip_deskew_f32(KMC_MEM_DEVICE) once per frame and let the library GATHER
  *       the calls -- a call only adds its frame to a pending list (~0.1 us); the list goes out as ONE launch of the same frame-list
  *       kernel when the context's stream has run dry (looked at for the first frame and then every fourth: an idle device is not kept
@@ -244,6 +244,13 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  *       (from every XCD); only then is the feature on (kmc_device_info.any_order_dispatch == 1), otherwise every launch is an
  *       ordinary one.  KMC_ANY_ORDER=0 switches it off unprobed.  Measured (bench.py's configs1_literal leg): 7.0 -> 6.1 us per
  *       1 M-point frame.
+ * ALIASES.  Both (2) and (3) decide "these two frames are independent" by comparing the VIRTUAL ADDRESS RANGES of their buffers.  Two
+ * mappings of one physical buffer (hipMemCreate + hipMemMap twice, an imported IPC handle next to the original allocation) are two
+ * unrelated ranges to the library: it cannot see that they alias.  A caller who hands frames that communicate through an alias (one
+ * writes through mapping m1 what the next reads through mapping m2) has to order them itself: kmc_hip_frame_queue_join() or
+ * kmc_hip_synchronize() between the two calls, or a context created with KMC_ANY_ORDER=0 and queues = 1.  Without that the second frame
+ * may read memory the first has not written yet.  tools/alias_probe.hip builds exactly that chain and counts the wrong results per
+ * configuration (profiles/r05_alias_probe.json); tests/test_alias_contract.py holds the ordered configurations to zero.
  * kmc_hip_set_frame_queue_order(ctx, after_producers): what the library may assume about a CALLER's stream (kmc_hip_set_stream) --
  * 1 (default): the caller may have put a producer of the next frame on the stream since the last call; 0: every frame was produced
  * before the first call.  Only (3)'s barrier-free dispatch on a caller's stream depends on it. */
@@ -260,8 +267,11 @@ uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* ctx);
 uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
  * (HOST arrays of device pointers / sizes / params), each frame in its own buffer (any 16-byte-aligned addresses).  ONE launch of the
- * frame-list kernel (2-D grid: frame x tile) on the context's stream; lists of at most 16 frames carry their records in the kernel
- * arguments (the call only enqueues a launch and can be captured into a HIP graph), longer ones upload one small table.  Per-point results
+ * frame-list kernel (2-D grid: frame x tile) on the context's stream with the frames' records IN ITS KERNEL ARGUMENTS -- up to 256 frames
+ * per launch (a 56 KiB argument block; a KITTI drive of 108 frames is one launch of 24 KiB), longer lists in launches of 256: nothing is
+ * uploaded, the host never waits, the call only enqueues.  Under stream capture the launches carry 16 frames each (the block every
+ * runtime is known to take; so does everything after a runtime has refused a larger one).  KMC_LIST_ROUTE=table selects the round-4
+ * route for lists beyond 16 frames: one launch over an uploaded table, the host waits for the copy.  Per-point results
  * are bit-identical to kmc_hip_deskew_f32 on the same frame: every frame runs at its own coefficient tier (a list that mixes tiers goes
  * out as one launch per tier present -- at most four; out_stats->variant reports the widest).  The frames must
  * be independent of each other (in == out of ONE frame is fine): a list in which one frame's output overlaps another frame's input or

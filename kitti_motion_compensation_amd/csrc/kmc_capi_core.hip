@@ -198,19 +198,19 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
 }
 
 int fq_join(kmc_ctx* c) {
-  c->ao_valid = false;  // whoever joins is about to put ordinary work on the stream: the any-order window ends here
-  if (c->gather_count == 0) return KMC_OK;
+  c->ao.invalidate();  // whoever joins is about to put ordinary work on the stream: the any-order window ends here
+  if (c->gl.count == 0) return KMC_OK;
   KMC_HIP_TRY(c, hipSetDevice(c->device));
-  const uint32_t count = c->gather_count;
-  c->gather_count = 0;  // (first: launch_list's table route may re-enter fq_join through slot_begin)
-  int rc = launch_list(c, c->gather, c->gather64, count, c->gather_tier, nullptr);
+  const uint32_t count = c->gl.count;
+  c->gl.flushed();  // (first: launch_list's table route may re-enter fq_join through slot_begin)
+  int rc = launch_list(c, c->gather, c->gather64, count, c->gl.tier, nullptr);
   if (rc != KMC_OK) {
     // The table route failed (a slot could not grow, the upload did not go through).  The calls that queued these frames have already
     // returned KMC_OK, so the frames must not be dropped on the floor: the records are still in c->gather -- issue them
     // as kernel-argument launches of at most 16 frames, which need no table.  If even that fails the error is STICKY: it is what this
     // join returns, and what kmc_hip_frame_queue_join / kmc_hip_synchronize keep returning until the caller has seen it once.
     (void)hipGetLastError();
-    rc = launch_list(c, c->gather, c->gather64, count, c->gather_tier, nullptr, /*inline_only*/ true);
+    rc = launch_list(c, c->gather, c->gather64, count, c->gl.tier, nullptr, /*inline_only*/ true);
     if (rc != KMC_OK) {
       c->fq_error = rc;
       c->fq_dropped += count;
@@ -254,25 +254,16 @@ void ao_ensure(kmc_ctx* c) {
 bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call) {
   const kmc_ctx::AoRange r = {(uintptr_t)in, (uintptr_t)in + bytes}, w = {(uintptr_t)out, (uintptr_t)out + bytes};
   if (c->stream != nullptr && (same_call || c->stream == c->own_stream || !c->fq_ordered)) ao_ensure(c);  // (only where the verdict can matter)
-  bool any_order = c->ao_enabled && c->ao_valid && c->stream != nullptr && c->ao_count < kmc_ctx::kAoWindow &&
-                   (same_call || c->stream == c->own_stream || !c->fq_ordered);
-  for (int k = 0; any_order && k < c->ao_count; ++k) {
-    const kmc_ctx::AoRange &pr = c->ao_reads[k], &pw = c->ao_writes[k];
-    if ((w.lo < pr.hi && pr.lo < w.hi) || (w.lo < pw.hi && pw.lo < w.hi) || (r.lo < pw.hi && pw.lo < r.hi)) any_order = false;
-  }
+  const bool stream_ok = c->stream != nullptr && (same_call || c->stream == c->own_stream || !c->fq_ordered);
+  bool any_order = c->ao.admit(r, w, c->ao_enabled, stream_ok);  // the rule itself: kmc_dispatch_book.hpp (unit-tested on the CPU)
   if (any_order && c->stream != c->own_stream) {  // a caller's stream may be capturing a graph: plain launches there
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
       (void)hipGetLastError();
+      c->ao.demote_last(true);
       any_order = false;
     }
   }
-  if (!any_order) c->ao_count = 0;
-  c->ao_reads[c->ao_count] = r;
-  c->ao_writes[c->ao_count] = w;
-  ++c->ao_count;
-  c->ao_valid = c->ao_enabled;
-  c->ao_launches += any_order ? 1 : 0;
   return any_order;
 }
 
@@ -628,7 +619,7 @@ int kmc_hip_frame_queue_join(kmc_ctx* c) {
 
 uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* c) { return c ? c->fq_dropped : 0; }
 
-uint64_t kmc_hip_any_order_launches(kmc_ctx* c) { return c ? c->ao_launches : 0; }
+uint64_t kmc_hip_any_order_launches(kmc_ctx* c) { return c ? c->ao.launches : 0; }
 
 int kmc_hip_enable_timing(kmc_ctx* c, int enabled) {
   if (!c) return KMC_ERR_INVALID_ARG;

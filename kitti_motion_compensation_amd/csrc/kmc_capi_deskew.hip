@@ -21,7 +21,7 @@ namespace {
 // returned ~8.5 us after the last byte had landed (tools/link_probe).  Visibility does not rest on the runtime's wait any more: every
 // wave releases its stores at system scope before its ticket (DoneWord, kmc_kernels.hip.h).
 // in / out / n are the caller's; `head` dead points are put in front (pointers moved back, n grown) -- see head_of().
-// any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao_valid
+// any_order: the dispatch packet carries no barrier bit (hipExtAnyOrderLaunch) -- see kmc_ctx::ao
 uint32_t launch_frame(hipStream_t s, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head = 0, bool any_order = false) {
   in -= head;
   out -= head;
@@ -204,34 +204,26 @@ int gather_push(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64_t n, c
   const int tier = pick_tier(c, params, 1);
   const uintptr_t bytes = (uintptr_t)n * sizeof(v4f);
   const kmc_ctx::AoRange r = {(uintptr_t)xyzi_in, (uintptr_t)xyzi_in + bytes}, w = {(uintptr_t)xyzi_out, (uintptr_t)xyzi_out + bytes};
-  bool flush_first = c->gather_count && tier != c->gather_tier;
-  for (uint32_t k = 0; !flush_first && k < c->gather_count; ++k) {
-    const kmc_ctx::AoRange &pr = c->gather_reads[k], &pw = c->gather_writes[k];
-    flush_first = (w.lo < pr.hi && pr.lo < w.hi) || (w.lo < pw.hi && pw.lo < w.hi) || (r.lo < pw.hi && pw.lo < r.hi);
-  }
   uint32_t launches = 0;
-  if (flush_first) {
+  if (c->gl.must_flush_first(r, w, tier)) {  // the decisions: kmc_dispatch_book.hpp (unit-tested on the CPU); the runtime calls: here
     const int rc = fq_join(c);
     if (rc != KMC_OK) return rc;
     ++launches;
   }
-  c->ao_valid = false;  // a pending frame is work the any-order window does not describe
-  const uint32_t k = c->gather_count++;
+  c->ao.invalidate();  // a pending frame is work the any-order window does not describe
+  const auto verdict = c->gl.commit(r, w, tier);
   const uint32_t head = head_of(xyzi_out, KMC_MEM_DEVICE);
-  ListRec& rec = c->gather[k];
+  ListRec& rec = c->gather[verdict.slot];
   std::memset(&rec, 0, sizeof(rec));
   fill_rec(*params, &rec.f);
   rec.f.pre2 = guard_pre2(*params);
-  fill_recd(*params, &c->gather64[k]);
+  fill_recd(*params, &c->gather64[verdict.slot]);
   rec.in = (const v4f*)xyzi_in - head;
   rec.out = (v4f*)xyzi_out - head;
   rec.n = n + head;
   rec.head = head;
-  c->gather_reads[k] = r;
-  c->gather_writes[k] = w;
-  c->gather_tier = tier;
-  bool go = c->gather_count == (uint32_t)kmc_ctx::kGatherMax;
-  if (!go && (c->gather_count == 1 || (c->gather_count & 3u) == 0)) {
+  bool go = verdict.issue_now;
+  if (verdict.ask_stream) {
     bool may_query = true;
     if (c->stream != c->own_stream) {  // a caller's stream may be capturing a graph: a query is not allowed there (it would invalidate the capture)
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -319,7 +311,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   if (mem_kind == KMC_MEM_DEVICE) {
     hipStream_t s = c->stream;
     bool any_order = false;
-    if (c->gather_count || c->timing) {  // a list launch, event records: ordinary work on the stream, the any-order window ends
+    if (c->gl.count || c->timing) {  // a list launch, event records: ordinary work on the stream, the any-order window ends
       const int rc_j = fq_join(c);
       if (rc_j != KMC_OK) return rc_j;
     }

@@ -168,8 +168,8 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (!(requested_time >= stamp_start && requested_time <= stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   const bool inline_records = mem_kind == KMC_MEM_DEVICE && th.n_seg <= (uint32_t)kInlineSegments;
-  // in order on the context's stream, but -- like kmc_hip_deskew_f32 -- not behind frames it shares no buffer with (kmc_ctx::ao_valid)
-  const bool window = inline_records && !c->timing && c->gather_count == 0 && !bracket_idx_out && n;
+  // in order on the context's stream, but -- like kmc_hip_deskew_f32 -- not behind frames it shares no buffer with (kmc_ctx::ao)
+  const bool window = inline_records && !c->timing && c->gl.count == 0 && !bracket_idx_out && n;
   if (!window) {
     rc = fq_join(c);  // (also issues two-pose frames that are still being gathered: the N-knot kernel is launched per call)
     if (rc != KMC_OK) return rc;
@@ -437,10 +437,19 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
   c->counter_dirty = true;
   *c->h_flag = 0;
   if (tm.begin_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
-  launch_tiles((n + 127) / 128, [&](uint64_t t0, int grid) {  // one wave per workgroup, two points per lane
-    launch_on(deskew_traj_f64cols<0>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, (const TrajSeg64*)d_segs, th.n_seg, knot_times[0], knot_times[n_knots - 1], dox, doy,
-              doz, dow, d_idx, c->d_counter, c->h_flag, t0);
-  });
+  if (mem_kind == KMC_MEM_HOST_MAPPED) {
+    // over the link: persistent waves, sc1 stores, completion word (like kmc_hip_deskew_f64cols; half the wave count for a KITTI-sized frame)
+    const uint64_t waves = n < (1ull << 19) ? std::max(1, c->mapped_waves / 2) : c->mapped_waves;
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + 127) / 128, waves));
+    const DoneWord done = done_word_arm(c);
+    launch_on(deskew_traj_f64cols<true>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, (const TrajSeg64*)d_segs, th.n_seg, knot_times[0], knot_times[n_knots - 1], dox, doy, doz,
+              dow, d_idx, c->d_counter, c->h_flag, (uint64_t)0, done);
+  } else {
+    launch_tiles((n + 127) / 128, [&](uint64_t t0, int grid) {  // one wave per workgroup, two points per lane
+      launch_on(deskew_traj_f64cols<false>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, (const TrajSeg64*)d_segs, th.n_seg, knot_times[0], knot_times[n_knots - 1], dox, doy,
+                doz, dow, d_idx, c->d_counter, c->h_flag, t0, DoneWord{});
+    });
+  }
   KMC_HIP_TRY(c, hipGetLastError());
   if (tm.end_kernel()) return fail_hip(c, hipGetLastError(), "hipEventRecord");
   unsigned long long bad = 0;
@@ -455,7 +464,12 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
     }
     if (bracket_idx_out) KMC_HIP_TRY(c, hipMemcpyAsync(bracket_idx_out, d_idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   }
-  KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (mem_kind == KMC_MEM_HOST_MAPPED) {  // in place: the kernel's completion word says "everything is in host memory"
+    const int rc_wait = wait_done_word(c);
+    if (rc_wait != KMC_OK) return rc_wait;
+  } else {
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   if (*(volatile uint32_t*)c->h_flag != 0) KMC_HIP_TRY(c, hipMemcpy(&bad, c->d_counter, sizeof(bad), hipMemcpyDeviceToHost));  // cold
   else c->counter_dirty = false;  // nobody touched the counter
   if (st) { st->n_launches = 1; st->n_out_of_range = bad; }

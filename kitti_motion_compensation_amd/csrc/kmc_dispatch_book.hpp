@@ -1,0 +1,102 @@
+// kmc_dispatch_book.hpp -- the BOOKKEEPING of the two ways a context lets independent frames overlap, free of HIP so that it can be
+// unit-tested on a CPU (tests/cpp/test_dispatch_book.cpp; VERDICT r04 #7: this logic used to be spread over kmc_capi_core.hip and
+// kmc_capi_deskew.hip between the runtime calls it steers).
+//
+//   AnyOrderWindow   the frames launched since (and including) the last ORDERED launch on the context's stream.  A new frame may be
+//                    dispatched without the AQL barrier bit iff the window is valid (it describes everything in flight behind the last
+//                    ordinary packet), it has room, and the frame's buffers overlap none of the window's: its write range against every
+//                    read and write range, its read range against every write range.  Either way the frame enters the window; a frame
+//                    that had to be ordered starts a new one.
+//   GatherList       the frames a context with gathering on (kmc_hip_set_frame_queues(ctx, q > 1)) holds back to issue as ONE list
+//                    launch.  push() says what has to happen around the new frame: flush the pending frames FIRST (the new frame
+//                    touches a pending frame's buffers, or needs another coefficient tier: in-order results, and a frame's bits never
+//                    depend on its neighbours), and/or issue the list NOW (it is full), and/or ask the stream whether it has run dry
+//                    (first frame of a list and then every fourth: an idle device is not kept waiting, a busy one gathers).
+//
+// Hazards are judged on VIRTUAL ADDRESS RANGES.  Two mappings of one physical buffer (hipMemMap aliases, an IPC import next to the
+// original) are two unrelated ranges here: the library cannot see that they alias, and a caller who passes aliased buffers to frames
+// of one window / one list has to order them itself (kmc_hip_synchronize() or kmc_hip_frame_queue_join() between them, or
+// KMC_ANY_ORDER=0 together with queues = 1).  include/kmc_hip.h states this contract; tools/alias_probe.hip demonstrates it.
+#pragma once
+
+#include <cstdint>
+
+namespace kmc_book {
+
+struct Range {
+  uintptr_t lo, hi;  // [lo, hi)
+};
+inline bool overlap(const Range& a, const Range& b) { return a.lo < b.hi && b.lo < a.hi; }
+// may a frame reading `r` and writing `w` run next to one that reads `pr` and writes `pw`?
+inline bool independent(const Range& r, const Range& w, const Range& pr, const Range& pw) { return !(overlap(w, pr) || overlap(w, pw) || overlap(r, pw)); }
+
+template <int CAPACITY>
+struct AnyOrderWindow {
+  Range reads[CAPACITY], writes[CAPACITY];
+  int count = 0;
+  bool valid = false;      // the window describes EVERYTHING in flight on the stream after the last ordered launch (it included)
+  uint64_t launches = 0;   // frames admitted without the barrier bit so far
+
+  // every other entry point: ordinary work goes on the stream, the window no longer describes what is in flight
+  void invalidate() { valid = false; }
+
+  // -> may the frame go out without the barrier bit?  `enabled`: the feature is on (verified by the probe, not switched off);
+  // `stream_ok`: nothing the library cannot see may sit between the previous frame and this one (own stream / caller's word / same call).
+  // Either way the frame is entered; an ordered frame starts a new window.
+  bool admit(const Range& r, const Range& w, bool enabled, bool stream_ok) {
+    bool any_order = enabled && valid && stream_ok && count < CAPACITY;
+    for (int k = 0; any_order && k < count; ++k) any_order = independent(r, w, reads[k], writes[k]);
+    if (!any_order) count = 0;
+    reads[count] = r;
+    writes[count] = w;
+    ++count;
+    valid = enabled;
+    launches += any_order ? 1 : 0;
+    return any_order;
+  }
+  // the caller found out after admit() that the launch has to be ordered after all (a capturing stream): same effect as a refusal
+  void demote_last(bool was_any_order) {
+    if (!was_any_order) return;
+    reads[0] = reads[count - 1];
+    writes[0] = writes[count - 1];
+    count = 1;
+    --launches;
+  }
+};
+
+template <int CAPACITY>
+struct GatherList {
+  Range reads[CAPACITY], writes[CAPACITY];
+  uint32_t count = 0;
+  int tier = 0;
+
+  struct Verdict {
+    bool flush_first;   // issue the pending frames before this one is added
+    bool issue_now;     // after adding: the list is full
+    bool ask_stream;    // after adding (and not full): look whether the stream has run dry -- if so, issue
+    uint32_t slot;      // where the new frame's record goes
+  };
+  // The caller flushes (if told to) and then calls commit(); split in two because the flush is a runtime call that can fail.
+  bool must_flush_first(const Range& r, const Range& w, int frame_tier) const {
+    if (count == 0) return false;
+    if (frame_tier != tier) return true;
+    for (uint32_t k = 0; k < count; ++k)
+      if (!independent(r, w, reads[k], writes[k])) return true;
+    return false;
+  }
+  void flushed() { count = 0; }
+  Verdict commit(const Range& r, const Range& w, int frame_tier) {
+    Verdict v;
+    v.flush_first = false;
+    v.slot = count;
+    reads[count] = r;
+    writes[count] = w;
+    tier = frame_tier;
+    ++count;
+    v.issue_now = count == (uint32_t)CAPACITY;
+    v.ask_stream = !v.issue_now && (count == 1 || (count & 3u) == 0);
+    return v;
+  }
+};
+
+}  // namespace kmc_book

@@ -24,6 +24,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "kmc_dispatch_book.hpp"
 #include "kmc_host_math.hpp"
 #include "kmc_kernels.hip.h"
 
@@ -99,18 +100,14 @@ struct kmc_ctx {
   // frames), before a frame that touches a pending frame's buffers or needs another coefficient tier, and before anything else the
   // context puts on its stream (fq_join, which every other entry point starts with).
   static constexpr int kMaxFrameQueues = 4;              // the API's range of `queues`; any value > 1 switches gathering on
-  static constexpr int kGatherMax = 64;                  // pending frames at most: 16 travel in the kernel arguments, a longer list -- it only grows
-                                                         // that long while the device is busy -- uploads one small table
+  static constexpr int kGatherMax = 64;                  // pending frames at most (a list only grows that long while the device is busy); their records travel in the list launch's kernel arguments
   static constexpr uint64_t kGatherMaxPoints = 1ull << 24;  // larger frames gain nothing from sharing a launch (and a 2-D grid of kGatherMax such frames stays below 2^32 work-items)
-  struct AoRange { uintptr_t lo, hi; };
+  using AoRange = kmc_book::Range;
   int fq_count = 1;                  // 1 = off: every call launches on `stream`
   bool fq_ordered = true;            // kmc_hip_set_frame_queue_order: on a CALLER's stream, producers may sit between two calls
   ListRec* gather = nullptr;         // the pending frames' records (kGatherMax of each)
   FrameRecD* gather64 = nullptr;
-  uint32_t gather_count = 0;
-  int gather_tier = 0;
-  uint64_t gather_tiles = 0;         // tiles of the largest pending frame = grid.x of the next list launch
-  AoRange gather_reads[kGatherMax], gather_writes[kGatherMax];
+  kmc_book::GatherList<kGatherMax> gl;  // how many are pending, their tier and address ranges, and the decisions around a new frame (kmc_dispatch_book.hpp)
   bool big_kernargs = true;          // kernel-argument blocks beyond 4 KiB are taken by this runtime (cleared by the first refused launch: launch_list)
   int list_route = 0;                // lists of more than 16 frames: 0 = kernel-argument launches of up to 256 frames (launch_list), 1 = one launch over an uploaded device table (KMC_LIST_ROUTE=table)
   int fq_error = 0;                  // sticky: a join failed to issue gathered frames whose calls had already returned KMC_OK (fq_join)
@@ -124,10 +121,7 @@ struct kmc_ctx {
   bool ao_enabled = false;               // set by kmc_hip_create from the run-time probe's verdict (kmc_capi_core.hip); KMC_ANY_ORDER=0 turns it off
   int ao_verdict = 0;                    // kmc_device_info.any_order_dispatch
   bool ao_probed = false;                // the verdict has been established (ao_ensure: at first need, not in kmc_hip_create)
-  bool ao_valid = false;                 // the window describes EVERYTHING in flight on `stream` after the last ordered launch (it included)
-  int ao_count = 0;
-  uint64_t ao_launches = 0;              // frames that went out without the barrier bit so far (kmc_hip_any_order_launches)
-  AoRange ao_reads[kAoWindow], ao_writes[kAoWindow];
+  kmc_book::AnyOrderWindow<kAoWindow> ao;  // the frames in flight behind the last ordered launch, and the admission rule (kmc_dispatch_book.hpp)
 };
 
 namespace kmc_impl {
@@ -171,14 +165,14 @@ int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n);
 // point that puts other work on the stream starts with; gather_push() adds a frame (kmc_capi_deskew.hip)
 int fq_join(kmc_ctx* c);
 // ONE launch of the frame-list kernel for `count` filled records on the context's stream: kernel-argument records for at most
-// kInlineListFrames frames, else one table upload (under stream capture: several kernel-argument launches).  -> launches_out
+// up to kInlineListFramesMax (256) frames per launch (16 under stream capture and for `inline_only`; KMC_LIST_ROUTE=table: one table upload).  -> launches_out
 int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t count, int tier, uint32_t* launches_out, bool inline_only = false);
 int fq_take_error(kmc_ctx* c);  // the sticky error of a join that could not issue its frames (reported once)
 
 // what every entry point that issues work on `stream` starts with
 #define KMC_ENTER(ctx)                                      \
   do {                                                      \
-    (ctx)->ao_valid = false;                                \
+    (ctx)->ao.invalidate();                                 \
     KMC_HIP_TRY(ctx, hipSetDevice((ctx)->device));          \
     const int rc_join_ = fq_join(ctx);                      \
     if (rc_join_ != KMC_OK) return rc_join_;                \
@@ -257,7 +251,7 @@ inline void with_tier(int tier, F&& f) {
     default: f(std::integral_constant<int, kTrig>{}); break;
   }
 }
-// `any_order`: dispatch without the AQL barrier bit (hipExtAnyOrderLaunch), see kmc_ctx::ao_valid
+// `any_order`: dispatch without the AQL barrier bit (hipExtAnyOrderLaunch), see kmc_ctx::ao
 template <typename... KArgs, typename... Args>
 inline void launch_on(void (*kernel)(KArgs...), int grid, int block, hipStream_t s, bool any_order, Args&&... args) {
   static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");

@@ -947,8 +947,12 @@ __device__ __forceinline__ void traj_one_f64(double px, double py, double pz, do
   k_out = k;
 }
 
-// same geometry as deskew_f64cols: one wave per workgroup, two consecutive points per lane, 16-byte column accesses
-template <int kInstance = 0>  // a template only so that the header can be included by several translation units
+// same geometry as deskew_f64cols: one wave per workgroup, two consecutive points per lane, 16-byte column accesses.
+// STREAMED (round 5): the columns are PAGE-LOCKED HOST memory and the kernel works on them over the link (the 3-argument
+// MotionCompensateFrame(Frame, Trajectory, Time) on the drop-in's own containers): the grid is a few dozen persistent waves that walk the
+// tiles -- one wave per tile over the link runs at a third of the rate (tools/link_probe) --, the stores carry sc1 so that they leave
+// for host memory while the next tile's loads come in, and the last wave raises the completion word (DoneWord).
+template <bool STREAMED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, const double* __restrict__ w,
                                                           const double* __restrict__ stamps, uint64_t n,
@@ -956,10 +960,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
                                                           double t_first, double t_last, double* __restrict__ ox,
                                                           double* __restrict__ oy, double* __restrict__ oz,
                                                           double* __restrict__ ow, uint32_t* __restrict__ bracket_out,
-                                                          unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base) {
+                                                          unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base, DoneWord dw) {
+  struct ArgLayout { const double *x, *y, *z, *w, *stamps; uint64_t n; const TrajSeg64* segs; uint32_t n_seg; double t_first, t_last; double *ox, *oy, *oz, *ow; uint32_t* bracket_out;
+                     unsigned long long* n_bad; uint32_t* bad_flag; uint64_t tile_base; DoneWord dw; };  // == the parameter list; `dw` is read through the segment only
+  const done_cp done = (done_cp)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, dw));
   const uint32_t tid = threadIdx.x;
-  {
-    const uint64_t i = (tile_base + blockIdx.x) * 128 + 2 * (uint64_t)tid;
+  const uint64_t n_tiles = (n + 127) / 128;
+  uint64_t t = tile_base + blockIdx.x;
+  if constexpr (STREAMED) done_word_start(done);
+  while (t < n_tiles) {
+    const uint64_t i = t * 128 + 2 * (uint64_t)tid;
     uint32_t bad_count = 0;
     if (i + 1 < n) {
       const v2d_u ts = __builtin_nontemporal_load(reinterpret_cast<const v2d_u*>(stamps + i));
@@ -976,10 +986,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
       rx.x = a; ry.x = b; rz.x = c;
       traj_one_f64(vx.y, vy.y, vz.y, vw.y, ts.y, segs, n_seg, t_first, t_last, a, b, c, k1, ok1);
       rx.y = a; ry.y = b; rz.y = c;
-      __builtin_nontemporal_store(rx, reinterpret_cast<v2d_u*>(ox + i));
-      __builtin_nontemporal_store(ry, reinterpret_cast<v2d_u*>(oy + i));
-      __builtin_nontemporal_store(rz, reinterpret_cast<v2d_u*>(oz + i));
-      if (ow) __builtin_nontemporal_store(vw, reinterpret_cast<v2d_u*>(ow + i));
+      if (STREAMED && (t + 1) * 128 <= n) {  // a full tile over the link: descriptor stores with sc1 (f64_col_store)
+        f64_col_store<true>(rx, ox, t * 128, tid);
+        f64_col_store<true>(ry, oy, t * 128, tid);
+        f64_col_store<true>(rz, oz, t * 128, tid);
+        if (ow) f64_col_store<true>(vw, ow, t * 128, tid);
+      } else {
+        __builtin_nontemporal_store(rx, reinterpret_cast<v2d_u*>(ox + i));
+        __builtin_nontemporal_store(ry, reinterpret_cast<v2d_u*>(oy + i));
+        __builtin_nontemporal_store(rz, reinterpret_cast<v2d_u*>(oz + i));
+        if (ow) __builtin_nontemporal_store(vw, reinterpret_cast<v2d_u*>(ow + i));
+      }
       if (bracket_out) {
         bracket_out[i] = k0;
         bracket_out[i + 1] = k1;
@@ -997,7 +1014,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
       bad_count = ok ? 0u : 1u;
     }
     f64_report_bad(bad_count, tid, n_bad, bad_flag);
+    if constexpr (!STREAMED) break;  // device-resident columns: one tile per workgroup, the hardware dispatcher streams the tiles
+    t += gridDim.x;
   }
+  if constexpr (STREAMED) done_word_finish(done);
 }
 
 // ------------------------------------------------------------------------------------------------

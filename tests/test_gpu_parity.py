@@ -42,9 +42,26 @@ def torch_mod():
     return torch
 
 
-@pytest.fixture(scope="module")
-def ctx(torch_mod):
-    c = capi.Context(0)
+@pytest.fixture(scope="module", params=["default", "barrier_bit_on_every_dispatch"])
+def ctx(request, torch_mod):
+    """Every test of this module that takes the shared context runs twice: on a default context -- independent frames may go
+    out without the AQL barrier bit where kmc_hip_create's probe verified it -- and on one created with KMC_ANY_ORDER=0, every dispatch
+    ordered.  Same assertions, same bits.  (Gathering changes WHEN results become visible -- a deferred issue -- so it cannot be swapped in
+    under tests that read results right after a call; tests/test_dispatch_modes.py replays one script under every configuration, gathering
+    included.)"""
+    if request.param == "default":
+        c = capi.Context(0)
+    else:
+        saved = os.environ.get("KMC_ANY_ORDER")
+        os.environ["KMC_ANY_ORDER"] = "0"
+        try:
+            c = capi.Context(0)
+        finally:
+            if saved is None:
+                os.environ.pop("KMC_ANY_ORDER", None)
+            else:
+                os.environ["KMC_ANY_ORDER"] = saved
+        assert c.device_info()["any_order_dispatch"] == 0
     yield c
     c.close()
 

@@ -144,6 +144,28 @@ def test_gpu_project_f32_host_bit_exact(ctx, calib, kitti_xyzi, n):
 
 
 @pytest.mark.gpu
+def test_gpu_project_f32_against_numpy_alone_no_oracle(ctx, golden_dir, kitti_xyzi):
+    """the HIP projection against an INDEPENDENT second implementation -- numpy f64 straight from the shipped calibration
+    text files (tests/golden/calib_*.txt) and the shipped scan, camera_model.cpp:5-36's operations one rounded step at a time -- with
+    nothing of oracle/ in the loop.  It does not pin the row (the reference holds no vector for camera_model.cpp) but it removes the
+    "oracle against itself" structure: two implementations that share no code agree on every integer."""
+    from kitti_motion_compensation_amd import capi
+
+    tf, R_rect, P = util.load_kitti_calibration(golden_dir)  # parses the calibration text, no oracle
+    for max_range in (15.0, 40.0):
+        rig = capi.CameraRig.make(tf, R_rect, P, max_range)
+        n = kitti_xyzi.shape[0]
+        uv = np.zeros((n, 4, 2), dtype=np.int32)
+        bgrv = np.zeros((n, 4), dtype=np.uint8)
+        ctx.project_f32(kitti_xyzi, rig, uv, bgrv)
+        uv_np, bgrv_np = util.project_numpy(kitti_xyzi[:, :3].astype(np.float64), tf, R_rect, P, max_range)
+        drawn = bgrv_np[:, 3] == 1
+        in_view = drawn & (uv_np[:, 0, 0] >= 0) & (uv_np[:, 0, 0] < 1242) & (uv_np[:, 0, 1] >= 0) & (uv_np[:, 0, 1] < 375)
+        assert in_view.sum() >= 1000, in_view.sum()  # thousands of points of the shipped scan land inside camera 00's image
+        assert np.array_equal(uv, uv_np) and np.array_equal(bgrv, bgrv_np)
+
+
+@pytest.mark.gpu
 def test_gpu_project_f32_device_and_f64cols(ctx, calib, kitti_xyzi):
     import torch
 

@@ -54,6 +54,20 @@ int main(int argc, char** argv) {
   double us64_min = per_call.empty() ? 0.0 : per_call[0];
   for (double v : per_call) us64_min = std::min(us64_min, v);
 
+  // the 3-argument form north_star names: three knots (start, middle, end of the scan), the frame's own stamps
+  Trajectory traj;
+  {
+    Affine3d T_mid;
+    T_mid.rotate(AngleAxisd{0.4 * yaw, Vector3d{0, 0, 1}});
+    T_mid.translation() = Vector3d{0.48 * tx, 0.5 * ty, 0.5 * tz};
+    traj.times = {scan.stamp_start, scan.stamp_middle, scan.stamp_end};
+    traj.poses = {Affine3d::Identity(), T_mid, T_end};
+  }
+  for (int i = 0; i < 10; ++i) checksum += MotionCompensateFrame(frame, traj, scan.stamp_middle)(0, 0);
+  t0 = clk::now();
+  for (int i = 0; i < iters; ++i) checksum += MotionCompensateFrame(frame, traj, scan.stamp_middle)(0, 0);
+  double const us64_traj = std::chrono::duration<double, std::micro>(clk::now() - t0).count() / iters;
+
   KittiCloudF32 const raw = KittiPclLoader::LoadRaw(run / "velodyne_points/data/0000000000.bin");  // page-locked when the pool is on
   KittiCloudF32 out(raw.size());
   std::size_t const n = raw.size() / 4;
@@ -111,10 +125,10 @@ int main(int argc, char** argv) {
   }
   std::printf(
       "{\"points\": %zu, \"iterations\": %d, \"containers\": \"%s\", \"route\": \"%s\", "
-      "\"MotionCompensateFrame_f64_us_per_frame\": %.2f, \"MotionCompensateFrame_f64_us_best_call\": %.2f, \"MotionCompensateKittiCloud_f32_us_per_frame\": %.2f, "
+      "\"MotionCompensateFrame_f64_us_per_frame\": %.2f, \"MotionCompensateFrame_f64_us_best_call\": %.2f, \"MotionCompensateFrame_3arg_3knots_f64_us_per_frame\": %.2f, \"MotionCompensateKittiCloud_f32_us_per_frame\": %.2f, "
       "\"stamp_start\": %.9f, \"stamp_middle\": %.9f, \"stamp_end\": %.9f, \"T_end\": {\"yaw_z\": %.17g, \"t\": [%.17g, %.17g, %.17g]}, \"trace\": %s, \"checksum\": %.6f}\n",
       n, iters, pooled ? "page-locked pool (the drop-in's default)" : "ordinary pageable memory (KMC_HOST_POOL=0 or no pool)",
-      pooled ? "one kernel in place over the link" : "staged copies", us64, us64_min, us32, scan.stamp_start, scan.stamp_middle, scan.stamp_end, yaw, tx, ty, tz,
+      pooled ? "one kernel in place over the link" : "staged copies", us64, us64_min, us64_traj, us32, scan.stamp_start, scan.stamp_middle, scan.stamp_end, yaw, tx, ty, tz,
       trace_json.c_str(), checksum + out[0]);
   return 0;
 }
