@@ -570,6 +570,16 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         out["dropin_cpp"] = run_dropin_cpp_leg(run_tool, rel_err, orc if check else None)
     except ToolMissing as e:
         out["dropin_cpp"] = {"skipped": str(e)}
+    # ---- sharded_cpp: north_star's multi-GPU shape driven from C++ in one process (tools/run_sharded.hip): frame ranges per device, ONE native
+    # RCCL reduction of the counters (ncclCommInitAll + ncclAllReduce sum / max).  At N = 1 a world of one; the driver's 8-GPU box can run
+    # `run_sharded 0,1,2,3,4,5,6,7` -- unmeasured on hardware so far (SCALE was skipped in every round).
+    try:
+        sh = run_tool([os.path.join(ROOT, "kitti_motion_compensation_amd", "lib", "run_sharded"), "0", "64", "1000000", "8"])
+        out["sharded_cpp"] = {"what": "tools/run_sharded.hip: 64 synthetic 1 M-point frames in contiguous frame ranges per rank (kmc_frame_ranges_balanced), one device context per rank, "
+                                      "8 frames per batched launch; counters reduced by ONE RCCL group (librccl dlopen'ed by the tool only)", **sh}
+        assert sh["reduction_agrees_with_host_arithmetic"] is True, sh
+    except ToolMissing as e:
+        out["sharded_cpp"] = {"skipped": str(e)}
     return out
 
 
@@ -688,6 +698,8 @@ def run_dropin_cpp_leg(run_tool, rel_err, orc):
             "stages_are": "per run, milliseconds: busy time of the pipeline's stages (they overlap) and wall-clock marks since kmc::MotionCompensateRun was entered -- "
                           "the rest of process_wall is the process itself: loading the HIP runtime before main, its teardown after",
             "spread_of_3": round(max(walls) / min(walls) - 1.0, 3),
+            "spread_is": "the HIP runtime's own start-up differs from run to run and box to box (stages_ms_per_run.hip_runtime_up_and_first_buffer_page_locked_at: 55-235 ms observed); "
+                         "everything after it (run_after_the_hip_runtime_is_up) is this library's and steady",
             "note": "whole process: HIP runtime start-up and page-locking on a helper thread WHILE the text files are parsed, context, reading, one batched GPU round trip per 8 frames, writing",
         }
         if orc is not None:  # one frame the driver wrote, against oracle MakeFrame + the FAITHFUL loop
@@ -720,9 +732,11 @@ def _run_stage_numbers(lines):
         m = re.search(r"text files parsed ([0-9.eE+-]+) ms", l)
         if m:
             out["text_files_parsed_at"] = round(float(m.group(1)), 2)
-        m = re.search(r"MotionCompensateRun returns ([0-9.eE+-]+) ms", l)
+        m = re.search(r"MotionCompensateRun returns ([0-9.eE+-]+) ms after entry; HIP runtime up and first buffer page-locked ([0-9.eE+-]+) ms", l)
         if m:
             out["run_returns_at"] = round(float(m.group(1)), 2)
+            out["hip_runtime_up_and_first_buffer_page_locked_at"] = round(float(m.group(2)), 2)
+            out["run_after_the_hip_runtime_is_up"] = round(float(m.group(1)) - float(m.group(2)), 2)
         m = re.search(r"context ([0-9.eE+-]+)\s+read ([0-9.eE+-]+)\s+gpu round trip ([0-9.eE+-]+)\s+write ([0-9.eE+-]+)\s+\| wall seconds since the range started: first batch read ([0-9.eE+-]+)\s+all written ([0-9.eE+-]+)", l)
         if m:
             v = [round(float(x) * 1e3, 2) for x in m.groups()]
