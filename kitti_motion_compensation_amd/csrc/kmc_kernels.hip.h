@@ -541,7 +541,7 @@ __device__ __forceinline__ void f64_report_bad(uint32_t bad_count, uint32_t tid,
 // ~1000 waves of a KITTI frame at once) the link is used one direction after the other -- 148 us per 123 k-point frame against
 // ~110 us pipelined (profiles/NOTES_r03.md).
 #ifndef KMC_F64_WAVES
-#define KMC_F64_WAVES 4  // waves per SIMD of the f64 column kernels (2 / 6 / 8 measured: profiles/NOTES.md)
+#define KMC_F64_WAVES 4  // waves per SIMD of the f64 column kernels (2 / 6 / 8 measured: profiles/NOTES_r04.md)
 #endif
 template <bool STREAMED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, KMC_F64_WAVES))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,

@@ -1,0 +1,191 @@
+// aql_probe.hip -- what would a frame cost BELOW the HIP runtime?  (follow-up of tools/launch_probe)
+// Every HIP launch API costs the host 2.2-3.5 us per launch; a KITTI frame's kernel takes 0.6 us.  This probe dispatches the same
+// stand-in kernel by writing AQL kernel-dispatch packets into an HSA queue of its own (hsa_queue_create; the code object loaded through
+// the HSA loader; kernel arguments in a ring of kernarg memory; one doorbell per packet), with and without the barrier bit, and reports
+// the host's time per dispatch and the train's time per dispatch (the device's side).  Device buffers come from hipMalloc (one process,
+// one HSA runtime: the addresses are valid on both sides).  Every wait has a timeout: a queue that hangs ends the probe, not the box.
+//   aql_probe [dispatches=20000] [points=123397]   -> one JSON object
+#include <hip/hip_runtime_api.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include <unistd.h>
+
+#define HSA_OK(x)                                                                       \
+  do {                                                                                  \
+    hsa_status_t s_ = (x);                                                              \
+    if (s_ != HSA_STATUS_SUCCESS) {                                                     \
+      const char* m_ = nullptr;                                                         \
+      hsa_status_string(s_, &m_);                                                       \
+      std::printf("{\"failed\": \"%s: %s\"}\n", #x, m_ ? m_ : "?");                    \
+      std::_Exit(3);                                                                    \
+    }                                                                                   \
+  } while (0)
+#define HIP_OK(x)                                                                       \
+  do {                                                                                  \
+    hipError_t e_ = (x);                                                                \
+    if (e_ != hipSuccess) {                                                             \
+      std::printf("{\"failed\": \"%s: %s\"}\n", #x, hipGetErrorString(e_));            \
+      std::_Exit(3);                                                                    \
+    }                                                                                   \
+  } while (0)
+
+struct Rec32 { float v[16]; };
+struct Rec64 { double v[16]; };
+struct Args { const void* in; void* out; uint64_t n; Rec32 f; uint32_t head; uint32_t pad; uint64_t tile_base; Rec64 d; };
+static_assert(sizeof(Args) == 232, "the kernel's kernarg segment");
+
+static hsa_agent_t g_gpu, g_cpu;
+static bool g_have_gpu = false, g_have_cpu = false;
+static hsa_status_t on_agent(hsa_agent_t a, void*) {
+  hsa_device_type_t t;
+  hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t);
+  if (t == HSA_DEVICE_TYPE_GPU && !g_have_gpu) { g_gpu = a; g_have_gpu = true; }
+  if (t == HSA_DEVICE_TYPE_CPU && !g_have_cpu) { g_cpu = a; g_have_cpu = true; }
+  return HSA_STATUS_SUCCESS;
+}
+static hsa_amd_memory_pool_t g_kernarg_pool;
+static bool g_have_pool = false;
+static hsa_status_t on_pool(hsa_amd_memory_pool_t p, void*) {
+  hsa_amd_segment_t seg;
+  hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+  if (seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+  uint32_t flags = 0;
+  hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+  if ((flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_KERNARG_INIT) && !g_have_pool) { g_kernarg_pool = p; g_have_pool = true; }
+  return HSA_STATUS_SUCCESS;
+}
+using clk = std::chrono::steady_clock;
+static double us_since(clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); }
+
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? std::atoi(argv[1]) : 20000;
+  const uint64_t n = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 123397ull;
+  HIP_OK(hipSetDevice(0));  // HIP first: it initialises the HSA runtime this process shares
+  HSA_OK(hsa_init());
+  HSA_OK(hsa_iterate_agents(on_agent, nullptr));
+  if (!g_have_gpu || !g_have_cpu) { std::printf("{\"failed\": \"no GPU / CPU agent\"}\n"); return 3; }
+  HSA_OK(hsa_amd_agent_iterate_memory_pools(g_cpu, on_pool, nullptr));
+  if (!g_have_pool) { std::printf("{\"failed\": \"no kernarg pool\"}\n"); return 3; }
+  // the code object, next to this binary
+  std::string path = argc > 3 ? argv[3] : "";
+  if (path.empty()) {
+    char self[4096];
+    const ssize_t len = readlink("/proc/self/exe", self, sizeof(self) - 1);
+    self[len > 0 ? len : 0] = 0;
+    path = std::string(self);
+    path = path.substr(0, path.rfind('/')) + "/aql_kernel.hsaco";
+  }
+  std::ifstream is(path, std::ios::binary);
+  std::vector<char> image((std::istreambuf_iterator<char>(is)), std::istreambuf_iterator<char>());
+  if (image.empty()) { std::printf("{\"failed\": \"cannot read %s\"}\n", path.c_str()); return 3; }
+  hsa_code_object_reader_t reader;
+  HSA_OK(hsa_code_object_reader_create_from_memory(image.data(), image.size(), &reader));
+  hsa_executable_t exe;
+  HSA_OK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &exe));
+  HSA_OK(hsa_executable_load_agent_code_object(exe, g_gpu, reader, nullptr, nullptr));
+  HSA_OK(hsa_executable_freeze(exe, nullptr));
+  hsa_executable_symbol_t sym;
+  HSA_OK(hsa_executable_get_symbol_by_name(exe, "k_frame.kd", &g_gpu, &sym));
+  uint64_t kobj = 0;
+  uint32_t karg = 0, group = 0, priv = 0;
+  HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &kobj));
+  HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &karg));
+  HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &group));
+  HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv));
+  if (karg != sizeof(Args)) { std::printf("{\"failed\": \"kernarg segment is %u bytes\"}\n", karg); return 3; }
+  const uint32_t kQueue = 4096;
+  hsa_queue_t* q = nullptr;
+  HSA_OK(hsa_queue_create(g_gpu, kQueue, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+  Args* ring = nullptr;
+  HSA_OK(hsa_amd_memory_pool_allocate(g_kernarg_pool, sizeof(Args) * kQueue, 0, (void**)&ring));
+  HSA_OK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, ring));
+  hsa_signal_t done;
+  HSA_OK(hsa_signal_create(1, 0, nullptr, &done));
+
+  const int kBufs = 8;
+  void *in[kBufs], *out[kBufs];
+  for (int b = 0; b < kBufs; ++b) { HIP_OK(hipMalloc(&in[b], n * 16)); HIP_OK(hipMalloc(&out[b], n * 16)); HIP_OK(hipMemset(in[b], 0, n * 16)); HIP_OK(hipMemset(out[b], 0xFF, n * 16)); }
+  {  // in[0]: x = 1.0 everywhere, so that out.x = 1 * f.v[0] + f.v[1] + d.v[3] is checkable
+    std::vector<float> h(4 * n, 1.0f);
+    HIP_OK(hipMemcpy(in[0], h.data(), n * 16, hipMemcpyHostToDevice));
+  }
+  HIP_OK(hipDeviceSynchronize());
+  Args proto;
+  std::memset(&proto, 0, sizeof(proto));
+  proto.n = n;
+  for (int i = 0; i < 16; ++i) { proto.f.v[i] = 1.0f + i; proto.d.v[i] = 0.5 * i; }
+  const uint32_t grid = (uint32_t)((n + 63) / 64) * 64;
+  auto* packets = (hsa_kernel_dispatch_packet_t*)q->base_address;
+  uint64_t widx = hsa_queue_load_write_index_relaxed(q);
+  auto wait_for_room = [&](uint64_t idx) {  // never more than kQueue - 64 packets ahead of the packet processor
+    const auto t0 = clk::now();
+    while (idx - hsa_queue_load_read_index_scacquire(q) >= kQueue - 64) {
+      if (us_since(t0) > 5e6) { std::printf("{\"failed\": \"the queue stopped consuming packets\"}\n"); std::_Exit(4); }
+    }
+  };
+  auto dispatch = [&](int i, bool barrier, hsa_signal_t completion) {
+    wait_for_room(widx);
+    Args* a = ring + (widx % kQueue);
+    *a = proto;
+    a->in = in[i % kBufs];
+    a->out = out[i % kBufs];
+    hsa_kernel_dispatch_packet_t* p = packets + (widx % kQueue);
+    p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+    p->workgroup_size_x = 64; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
+    p->grid_size_x = grid; p->grid_size_y = 1; p->grid_size_z = 1;
+    p->private_segment_size = priv; p->group_segment_size = group;
+    p->kernel_object = kobj;
+    p->kernarg_address = a;
+    p->completion_signal = completion;
+    uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
+                      (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    __atomic_store_n((uint16_t*)&p->header, header, __ATOMIC_RELEASE);
+    hsa_queue_store_write_index_relaxed(q, widx + 1);
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)widx);
+    ++widx;
+  };
+  auto drain = [&] {  // a last packet with the barrier bit and a completion signal; waited for with a timeout
+    hsa_signal_store_relaxed(done, 1);
+    dispatch(0, true, done);
+    const auto t0 = clk::now();
+    while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 100000, HSA_WAIT_STATE_ACTIVE) >= 1) {  // short waits, the wall clock decides
+      if (us_since(t0) > 5e6) { std::printf("{\"failed\": \"a dispatched kernel did not complete within 5 s\"}\n"); std::_Exit(4); }
+    }
+  };
+  hsa_signal_t none;
+  none.handle = 0;
+  // correctness first: one frame, checked
+  dispatch(0, true, none);
+  drain();
+  {
+    std::vector<float> h(4 * n);
+    HIP_OK(hipMemcpy(h.data(), out[0], n * 16, hipMemcpyDeviceToHost));
+    const float want = 1.0f * proto.f.v[0] + (proto.f.v[1] + (float)proto.d.v[3]);
+    bool ok = true;
+    for (uint64_t i = 0; i < n && ok; ++i) ok = h[4 * i] == want && h[4 * i + 1] == 1.0f;
+    if (!ok) { std::printf("{\"failed\": \"the AQL-dispatched kernel wrote %g, expected %g\"}\n", (double)h[0], (double)want); return 1; }
+  }
+  std::printf("{\"dispatches\": %d, \"points\": %llu, \"kernarg_bytes\": %u, \"first_frame_checked\": true", N, (unsigned long long)n, karg);
+  for (int barrier = 1; barrier >= 0; --barrier) {
+    for (int i = 0; i < 2000; ++i) dispatch(i, barrier != 0, none);
+    drain();
+    const auto t0 = clk::now();
+    for (int i = 0; i < N; ++i) dispatch(i, barrier != 0, none);
+    const double host = us_since(t0) / N;
+    drain();
+    const double train = us_since(t0) / N;
+    std::printf(", \"%s\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", barrier ? "aql_with_barrier_bit" : "aql_without_barrier_bit", host, train);
+  }
+  std::printf(", \"note\": \"host = packet + 232-byte kernarg block + doorbell per frame, including the back-pressure of a 4096-packet queue when the device is the slower side\"}\n");
+  hsa_queue_destroy(q);
+  return 0;
+}
