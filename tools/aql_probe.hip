@@ -4,7 +4,7 @@
 // the HSA loader; kernel arguments in a ring of kernarg memory; one doorbell per packet), with and without the barrier bit, and reports
 // the host's time per dispatch and the train's time per dispatch (the device's side).  Device buffers come from hipMalloc (one process,
 // one HSA runtime: the addresses are valid on both sides).  Every wait has a timeout: a queue that hangs ends the probe, not the box.
-//   aql_probe [dispatches=20000] [points=123397]   -> one JSON object
+//   aql_probe [dispatches=20000] [points=123397] [code_object=<next to the binary>] [kernargs=device|host]   -> one JSON object
 #include <hip/hip_runtime_api.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -26,7 +26,7 @@
       const char* m_ = nullptr;                                                         \
       hsa_status_string(s_, &m_);                                                       \
       std::printf("{\"failed\": \"%s: %s\"}\n", #x, m_ ? m_ : "?");                    \
-      std::_Exit(3);                                                                    \
+      die(3);                                                                    \
     }                                                                                   \
   } while (0)
 #define HIP_OK(x)                                                                       \
@@ -34,10 +34,14 @@
     hipError_t e_ = (x);                                                                \
     if (e_ != hipSuccess) {                                                             \
       std::printf("{\"failed\": \"%s: %s\"}\n", #x, hipGetErrorString(e_));            \
-      std::_Exit(3);                                                                    \
+      die(3);                                                                    \
     }                                                                                   \
   } while (0)
 
+[[noreturn]] static void die(int code) {  // the failure paths leave without tearing the runtimes down -- but not without their message
+  std::fflush(stdout);
+  std::_Exit(code);
+}
 struct Rec32 { float v[16]; };
 struct Rec64 { double v[16]; };
 struct Args { const void* in; void* out; uint64_t n; Rec32 f; uint32_t head; uint32_t pad; uint64_t tile_base; Rec64 d; };
@@ -61,6 +65,21 @@ static hsa_status_t on_pool(hsa_amd_memory_pool_t p, void*) {
   uint32_t flags = 0;
   hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
   if ((flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_KERNARG_INIT) && !g_have_pool) { g_kernarg_pool = p; g_have_pool = true; }
+  return HSA_STATUS_SUCCESS;
+}
+// device-local memory the host can write (large BAR): where the HIP runtime itself keeps kernel arguments on this class of device --
+// a wave's scalar loads of its arguments then stay on the device instead of crossing the link
+static hsa_amd_memory_pool_t g_dev_pool;
+static bool g_have_dev_pool = false;
+static hsa_status_t on_gpu_pool(hsa_amd_memory_pool_t p, void*) {
+  hsa_amd_segment_t seg;
+  hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+  if (seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+  bool alloc_ok = false;
+  hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc_ok);
+  uint32_t flags = 0;
+  hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+  if (alloc_ok && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !g_have_dev_pool) { g_dev_pool = p; g_have_dev_pool = true; }
   return HSA_STATUS_SUCCESS;
 }
 using clk = std::chrono::steady_clock;
@@ -105,15 +124,30 @@ int main(int argc, char** argv) {
   const uint32_t kQueue = 4096;
   hsa_queue_t* q = nullptr;
   HSA_OK(hsa_queue_create(g_gpu, kQueue, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+  const bool device_kernargs = argc > 4 ? std::strcmp(argv[4], "host") != 0 : true;
+  // "device_noreadback": the block is only fenced (sfence) in front of the HDP flush and the doorbell -- three posted writes to one device --
+  // without the read over the link that proves they landed.  Every dispatch of the timed trains then carries its own number, and the
+  // last frames' outputs are checked: a stale argument block would show.
+  const bool readback = !(argc > 4 && std::strcmp(argv[4], "device_noreadback") == 0);
   Args* ring = nullptr;
-  HSA_OK(hsa_amd_memory_pool_allocate(g_kernarg_pool, sizeof(Args) * kQueue, 0, (void**)&ring));
-  HSA_OK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, ring));
+  hsa_amd_hdp_flush_t hdp = {nullptr, nullptr};
+  if (device_kernargs) {
+    HSA_OK(hsa_amd_agent_iterate_memory_pools(g_gpu, on_gpu_pool, nullptr));
+    if (!g_have_dev_pool) { std::printf("{\"failed\": \"no device-local pool\"}\n"); return 3; }
+    HSA_OK(hsa_amd_memory_pool_allocate(g_dev_pool, sizeof(Args) * kQueue, 0, (void**)&ring));
+    const hsa_status_t acc = hsa_amd_agents_allow_access(1, &g_cpu, nullptr, ring);
+    if (acc != HSA_STATUS_SUCCESS) { std::printf("{\"failed\": \"the host cannot map device memory (no large BAR?)\"}\n"); return 3; }
+    HSA_OK(hsa_agent_get_info(g_gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp));
+  } else {
+    HSA_OK(hsa_amd_memory_pool_allocate(g_kernarg_pool, sizeof(Args) * kQueue, 0, (void**)&ring));
+    HSA_OK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, ring));
+  }
   hsa_signal_t done;
   HSA_OK(hsa_signal_create(1, 0, nullptr, &done));
 
   const int kBufs = 8;
-  void *in[kBufs], *out[kBufs];
-  for (int b = 0; b < kBufs; ++b) { HIP_OK(hipMalloc(&in[b], n * 16)); HIP_OK(hipMalloc(&out[b], n * 16)); HIP_OK(hipMemset(in[b], 0, n * 16)); HIP_OK(hipMemset(out[b], 0xFF, n * 16)); }
+  void *in[kBufs + 1], *out[kBufs + 1];  // (the extra pair belongs to the drain's own dispatch)
+  for (int b = 0; b <= kBufs; ++b) { HIP_OK(hipMalloc(&in[b], n * 16)); HIP_OK(hipMalloc(&out[b], n * 16)); HIP_OK(hipMemset(in[b], 0, n * 16)); HIP_OK(hipMemset(out[b], 0xFF, n * 16)); }
   {  // in[0]: x = 1.0 everywhere, so that out.x = 1 * f.v[0] + f.v[1] + d.v[3] is checkable
     std::vector<float> h(4 * n, 1.0f);
     HIP_OK(hipMemcpy(in[0], h.data(), n * 16, hipMemcpyHostToDevice));
@@ -129,15 +163,22 @@ int main(int argc, char** argv) {
   auto wait_for_room = [&](uint64_t idx) {  // never more than kQueue - 64 packets ahead of the packet processor
     const auto t0 = clk::now();
     while (idx - hsa_queue_load_read_index_scacquire(q) >= kQueue - 64) {
-      if (us_since(t0) > 5e6) { std::printf("{\"failed\": \"the queue stopped consuming packets\"}\n"); std::_Exit(4); }
+      if (us_since(t0) > 5e6) { std::printf("{\"failed\": \"the queue stopped consuming packets\"}\n"); die(4); }
     }
   };
   auto dispatch = [&](int i, bool barrier, hsa_signal_t completion) {
     wait_for_room(widx);
     Args* a = ring + (widx % kQueue);
-    *a = proto;
-    a->in = in[i % kBufs];
-    a->out = out[i % kBufs];
+    Args mine = proto;
+    mine.in = in[0];               // x = 1 everywhere
+    mine.out = i < 0 ? out[kBufs] : out[i % kBufs];
+    mine.f.v[1] = i < 0 ? 0.0f : (float)(i % 4096);  // this dispatch's own number: out.x = f.v[0] + f.v[1] + d.v[3]
+    *a = mine;
+    if (device_kernargs) {  // the block went over the BAR: make it land before the packet can be seen (what the HIP runtime does for device kernargs)
+      __atomic_thread_fence(__ATOMIC_SEQ_CST);
+      if (hdp.HDP_MEM_FLUSH_CNTL) *(volatile uint32_t*)hdp.HDP_MEM_FLUSH_CNTL = 1u;
+      if (readback) (void)*(volatile uint32_t*)&a->head;  // read back: the posted writes before it have reached the device
+    }
     hsa_kernel_dispatch_packet_t* p = packets + (widx % kQueue);
     p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
     p->workgroup_size_x = 64; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
@@ -155,10 +196,10 @@ int main(int argc, char** argv) {
   };
   auto drain = [&] {  // a last packet with the barrier bit and a completion signal; waited for with a timeout
     hsa_signal_store_relaxed(done, 1);
-    dispatch(0, true, done);
+    dispatch(-1, true, done);
     const auto t0 = clk::now();
     while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 100000, HSA_WAIT_STATE_ACTIVE) >= 1) {  // short waits, the wall clock decides
-      if (us_since(t0) > 5e6) { std::printf("{\"failed\": \"a dispatched kernel did not complete within 5 s\"}\n"); std::_Exit(4); }
+      if (us_since(t0) > 5e6) { std::printf("{\"failed\": \"a dispatched kernel did not complete within 5 s\"}\n"); die(4); }
     }
   };
   hsa_signal_t none;
@@ -169,12 +210,14 @@ int main(int argc, char** argv) {
   {
     std::vector<float> h(4 * n);
     HIP_OK(hipMemcpy(h.data(), out[0], n * 16, hipMemcpyDeviceToHost));
-    const float want = 1.0f * proto.f.v[0] + (proto.f.v[1] + (float)proto.d.v[3]);
+    const float want = 1.0f * proto.f.v[0] + (0.0f + (float)proto.d.v[3]);
     bool ok = true;
     for (uint64_t i = 0; i < n && ok; ++i) ok = h[4 * i] == want && h[4 * i + 1] == 1.0f;
     if (!ok) { std::printf("{\"failed\": \"the AQL-dispatched kernel wrote %g, expected %g\"}\n", (double)h[0], (double)want); return 1; }
   }
-  std::printf("{\"dispatches\": %d, \"points\": %llu, \"kernarg_bytes\": %u, \"first_frame_checked\": true", N, (unsigned long long)n, karg);
+  std::printf("{\"dispatches\": %d, \"points\": %llu, \"kernarg_bytes\": %u, \"kernargs_in\": \"%s\", \"first_frame_checked\": true", N, (unsigned long long)n, karg,
+              !device_kernargs ? "host memory (the kernarg pool): every wave's scalar loads cross the link"
+                               : readback ? "device memory written by the host over the BAR (+ HDP flush, read-back)" : "device memory written by the host over the BAR (+ HDP flush, NO read-back)");
   for (int barrier = 1; barrier >= 0; --barrier) {
     for (int i = 0; i < 2000; ++i) dispatch(i, barrier != 0, none);
     drain();
@@ -183,6 +226,16 @@ int main(int argc, char** argv) {
     const double host = us_since(t0) / N;
     drain();
     const double train = us_since(t0) / N;
+    {  // the last kBufs dispatches each wrote their own number into their own buffer
+      std::vector<float> h(4 * n);
+      for (int b = 0; b < kBufs && N >= kBufs; ++b) {
+        const int i = N - kBufs + b;
+        HIP_OK(hipMemcpy(h.data(), out[i % kBufs], n * 16, hipMemcpyDeviceToHost));
+        const float want = proto.f.v[0] + ((float)(i % 4096) + (float)proto.d.v[3]);
+        for (uint64_t k = 0; k < n; k += 997)
+          if (h[4 * k] != want) { std::printf(", \"failed\": \"dispatch %d wrote %g, expected %g (a stale argument block?)\"}\n", i, (double)h[4 * k], (double)want); die(1); }
+      }
+    }
     std::printf(", \"%s\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", barrier ? "aql_with_barrier_bit" : "aql_without_barrier_bit", host, train);
   }
   std::printf(", \"note\": \"host = packet + 232-byte kernarg block + doorbell per frame, including the back-pressure of a 4096-packet queue when the device is the slower side\"}\n");
