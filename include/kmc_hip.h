@@ -265,6 +265,20 @@ int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* ctx);
 /* How many frames of this context have been dispatched without the barrier bit so far (a counter for tests and tuning). */
 uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
+/* THE DIRECT QUEUE (ABI 5).  On the context's OWN stream (the state after kmc_hip_create) a device-resident kmc_hip_deskew_f32 call does
+ * not go through a HIP launch: the library writes the frame's AQL dispatch packet into an HSA queue of the context's own, with the
+ * argument block in device memory -- 2.1 us of host time per call instead of the 3.6-4.7 us of the HIP runtime's launch path (which costs
+ * 2.2-3.5 us through every launch API).  Same kernel body, same bits (checked on the device when the queue is opened, at the first such
+ * call).  The barrier bit of a packet is decided like before: a frame that shares no buffer with the frames in flight goes out without
+ * it (KMC_ANY_ORDER=0: every packet carries it).  ORDER: the queue and the context's HIP stream are two queues; the library keeps
+ * them in the order of the calls -- a frame waits for what the context put on its stream before it, every other entry point waits for
+ * the frames before it (host waits, at such transitions only).  What a caller must know: the frames are not in a HIP stream, so
+ * hipDeviceSynchronize() or a synchronize of some stream of the caller's does not wait for them -- kmc_hip_synchronize(ctx) does, and so
+ * does every other call on the context.  Not used on a caller's stream (kmc_hip_set_stream), with gathering on, with per-call timing
+ * on, or with KMC_DIRECT_DISPATCH=0; not available (HIP launches instead) where the host cannot map device memory.  A wait on the queue
+ * that exceeds ten seconds turns into KMC_ERR_HIP, and the context goes back to HIP launches.
+ * kmc_hip_direct_frames: frames this context has dispatched through its direct queue so far (0: the queue is not in use). */
+uint64_t kmc_hip_direct_frames(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
  * (HOST arrays of device pointers / sizes / params), each frame in its own buffer (any 16-byte-aligned addresses).  ONE launch of the
  * frame-list kernel (2-D grid: frame x tile) on the context's stream with the frames' records IN ITS KERNEL ARGUMENTS -- up to 256 frames

@@ -148,6 +148,7 @@ SIGNATURES = {
     "kmc_hip_frame_queue_join": (C.c_int, [_vp]),
     "kmc_hip_any_order_launches": (C.c_uint64, [_vp]),
     "kmc_hip_frame_queue_dropped": (C.c_uint64, [_vp]),
+    "kmc_hip_direct_frames": (C.c_uint64, [_vp]),
     "kmc_hip_set_frame_queue_order": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_deskew_frames_f32": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(FrameParams), C.c_uint32, C.POINTER(Stats)]),
     "kmc_hip_deskew_batch_f32": (
@@ -458,6 +459,10 @@ class Context:
         t = CallTrace()
         self._check(lib().kmc_hip_last_call_trace(self._h, C.byref(t)), "kmc_hip_last_call_trace")
         return t
+
+    def direct_frames(self) -> int:
+        """Frames dispatched through the context's direct queue (kmc_hip.h, "THE DIRECT QUEUE"); 0: HIP launches."""
+        return int(lib().kmc_hip_direct_frames(self._h))
 
     def frame_queue_dropped(self) -> int:
         """Gathered frames lost to a failed join over the context's life (kmc_hip.h, "Gathered frames and errors")."""

@@ -199,10 +199,15 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
 
 int fq_join(kmc_ctx* c) {
   c->ao.invalidate();  // whoever joins is about to put ordinary work on the stream: the any-order window ends here
+  if (c->dd_pending) {  // ... and that work is ordered behind the frames in the direct queue: wait for them (kmc_capi_direct.hip)
+    const int rc_direct = direct_join(c);
+    if (rc_direct != KMC_OK) return rc_direct;
+  }
   if (c->gl.count == 0) return KMC_OK;
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t count = c->gl.count;
   c->gl.flushed();  // (first: launch_list's table route may re-enter fq_join through slot_begin)
+  c->stream_dirty = true;  // the list launch goes to the HIP stream
   int rc = launch_list(c, c->gather, c->gather64, count, c->gl.tier, nullptr);
   if (rc != KMC_OK) {
     // The table route failed (a slot could not grow, the upload did not go through).  The calls that queued these frames have already
@@ -507,7 +512,9 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
     if (w >= 1 && w <= 65535) c->mapped_waves = w;
   }
   if (const char* e = std::getenv("KMC_ANY_ORDER"))  // the switch is read HERE, like every other knob of a context; the probe itself runs at first need (ao_ensure)
-    if (std::atoi(e) == 0) { c->ao_probed = true; c->ao_verdict = 0; c->ao_enabled = false; }
+    if (std::atoi(e) == 0) { c->ao_probed = true; c->ao_verdict = 0; c->ao_enabled = false; c->dd_free_order = false; }
+  if (const char* e = std::getenv("KMC_DIRECT_DISPATCH"))
+    if (std::atoi(e) == 0) c->dd_tried = true;  // (never opened: every frame is a HIP launch)
   *out = c;
   return KMC_OK;
 }
@@ -515,7 +522,8 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
 void kmc_hip_destroy(kmc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream || c->own_stream) (void)fq_join(c);  // frames still being gathered are issued, not dropped
+  if (c->stream || c->own_stream) (void)fq_join(c);  // frames still being gathered are issued, not dropped; the direct queue is waited for
+  direct_close(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (int b = 0; b < 3; ++b)
@@ -581,6 +589,7 @@ int kmc_hip_synchronize(kmc_ctx* c) {
   if (!c) return KMC_ERR_INVALID_ARG;
   KMC_ENTER(c);
   KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream_dirty = false;  // nothing of this context is in flight any more, on either queue
   return fq_take_error(c);  // frames an EARLIER join could not issue (its caller was some unrelated entry point)
 }
 

@@ -1,0 +1,326 @@
+// kmc_capi_direct.hip -- the DIRECT QUEUE: device-resident single-frame calls dispatched below the HIP runtime (round 5).
+//
+// kmc_hip_deskew_f32(KMC_MEM_DEVICE) is the reference's calling pattern -- one frame per call (handlers.cpp:55-64) -- and its cost on
+// KITTI-sized frames is the HIP runtime's launch path: 2.2-3.5 us per launch through every launch API (tools/launch_probe), 3.6-4.7 us
+// per call, against 0.6 us of kernel.  What a launch IS on this hardware: a 64-byte AQL kernel-dispatch packet in a user-mode queue, the
+// kernel's argument block somewhere the waves' scalar loads can reach, a doorbell.  tools/aql_probe measured exactly that: 2.1 us per
+// frame with the argument block in DEVICE memory (written by the host over the BAR; in host memory every wave's scalar loads would
+// cross the link: 38 us per frame).  So a context on its OWN stream dispatches its frames itself:
+//   * an HSA queue of its own (hsa_queue_create, 4096 packets) next to the HIP stream's;
+//   * the frame kernels as a raw gfx950 code object (kmc_direct_kernels.hip, embedded below) loaded once per process through the HSA
+//     loader -- same tile body, same argument layout, same bits as the HIP code object's deskew_frame_f32 (self-test at open);
+//   * a ring of 240-byte argument blocks in device-local memory that the host maps (large BAR), written with ordinary stores, an
+//     sfence, the HDP flush register and one read-back -- what the HIP runtime itself does for device-resident kernel arguments;
+//   * the AQL barrier bit per packet decided by the same bookkeeping as before (kmc_dispatch_book.hpp): a frame that shares no buffer
+//     with the frames in flight goes out without it -- here that is plain AQL semantics, not a launch flag;
+//   * ORDER against everything else: the HIP stream and the direct queue are two queues.  A frame waits (on the host) for work the
+//     context put on its HIP stream before it (only at such a transition: `stream_dirty`); every other entry point waits for the
+//     direct queue to drain first (direct_join: a barrier packet with a completion signal).  A stream of frames pays neither.
+// What changes for a caller: on the context's own stream the frames no longer sit in a HIP stream, so a hipDeviceSynchronize() of the
+// caller's does not cover them -- kmc_hip_synchronize(ctx) does (include/kmc_hip.h).  A caller's stream (kmc_hip_set_stream), gathered
+// calls, per-call timing and KMC_DIRECT_DISPATCH=0 keep the HIP launches.
+// Every wait on the queue is bounded: a queue that stops consuming packets or a kernel that does not complete within ten seconds
+// turns into KMC_ERR_HIP and the context falls back to HIP launches.
+#include "kmc_internal.hip.h"
+
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include <chrono>
+#include <mutex>
+
+// the code object (Makefile: hipcc --genco --no-gpu-bundle-output kmc_direct_kernels.hip -> obj/kmc_direct.hsaco)
+__asm__(
+    ".section .rodata\n"
+    ".balign 4096\n"
+    ".global kmc_direct_hsaco_begin\n"
+    "kmc_direct_hsaco_begin:\n"
+    ".incbin \"" KMC_DIRECT_HSACO_PATH "\"\n"
+    ".global kmc_direct_hsaco_end\n"
+    "kmc_direct_hsaco_end:\n"
+    ".previous\n");
+extern "C" const char kmc_direct_hsaco_begin[];
+extern "C" const char kmc_direct_hsaco_end[];
+
+namespace kmc_impl {
+
+struct DirectArgs {  // == the kernels' parameter list (kmc_direct_kernels.hip; deskew_frame_f32 in kmc_kernels.hip.h)
+  const v4f* in;
+  v4f* out;
+  uint64_t n;
+  FrameRec f;
+  uint32_t head;
+  uint64_t tile_base;
+  FrameRecD d;
+};
+static_assert(sizeof(DirectArgs) == 240 && offsetof(DirectArgs, f) == 32 && offsetof(DirectArgs, head) == 96 && offsetof(DirectArgs, tile_base) == 104 && offsetof(DirectArgs, d) == 112,
+              "the argument block the code object expects");
+
+namespace {
+constexpr uint32_t kQueuePackets = 4096;
+constexpr double kWaitSeconds = 10.0;
+
+struct AgentCode {  // per HSA agent, once per process
+  bool tried = false, ok = false;
+  hsa_agent_t gpu{}, cpu{};
+  hsa_executable_t exe{};
+  uint64_t kernel_object[4] = {0, 0, 0, 0};
+  uint32_t group_size = 0, private_size = 0;
+  hsa_amd_memory_pool_t device_pool{};
+  hsa_amd_hdp_flush_t hdp = {nullptr, nullptr};
+};
+std::mutex g_code_mu;
+AgentCode g_code[64];
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct FindAgents {
+  uint32_t want_bdf = 0, want_domain = 0;
+  bool have_gpu = false, have_cpu = false;
+  hsa_agent_t gpu{}, cpu{};
+};
+hsa_status_t on_agent(hsa_agent_t a, void* data) {
+  auto* f = static_cast<FindAgents*>(data);
+  hsa_device_type_t t;
+  if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+  if (t == HSA_DEVICE_TYPE_CPU && !f->have_cpu) { f->cpu = a; f->have_cpu = true; }
+  if (t == HSA_DEVICE_TYPE_GPU && !f->have_gpu) {
+    uint32_t bdf = 0, domain = 0;
+    (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+    (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+    if (bdf == f->want_bdf && domain == f->want_domain) { f->gpu = a; f->have_gpu = true; }
+  }
+  return HSA_STATUS_SUCCESS;
+}
+struct FindPool { bool have = false; hsa_amd_memory_pool_t pool{}; };
+hsa_status_t on_gpu_pool(hsa_amd_memory_pool_t p, void* data) {
+  auto* f = static_cast<FindPool*>(data);
+  hsa_amd_segment_t seg;
+  if (hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL) return HSA_STATUS_SUCCESS;
+  bool alloc_ok = false;
+  (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc_ok);
+  uint32_t flags = 0;
+  (void)hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+  if (alloc_ok && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !f->have) { f->pool = p; f->have = true; }
+  return HSA_STATUS_SUCCESS;
+}
+
+// the code object on HIP device `device`'s agent (matched by PCI address), loaded once per process
+AgentCode* agent_code(int device) {
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_code_mu);
+  AgentCode& ac = g_code[device];
+  if (ac.tried) return ac.ok ? &ac : nullptr;
+  ac.tried = true;
+  int bus = 0, dev = 0, domain = 0;
+  if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess || hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess ||
+      hipDeviceGetAttribute(&domain, hipDeviceAttributePciDomainID, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (hsa_init() != HSA_STATUS_SUCCESS) return nullptr;  // (reference-counted: HIP holds the runtime already)
+  FindAgents fa;
+  fa.want_bdf = ((uint32_t)bus << 8) | ((uint32_t)dev << 3);  // function 0
+  fa.want_domain = (uint32_t)domain;
+  if (hsa_iterate_agents(on_agent, &fa) != HSA_STATUS_SUCCESS || !fa.have_gpu || !fa.have_cpu) return nullptr;
+  ac.gpu = fa.gpu;
+  ac.cpu = fa.cpu;
+  FindPool fp;
+  if (hsa_amd_agent_iterate_memory_pools(ac.gpu, on_gpu_pool, &fp) != HSA_STATUS_SUCCESS || !fp.have) return nullptr;
+  ac.device_pool = fp.pool;
+  if (hsa_agent_get_info(ac.gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &ac.hdp) != HSA_STATUS_SUCCESS) return nullptr;
+  hsa_code_object_reader_t reader;
+  const size_t image_bytes = (size_t)(kmc_direct_hsaco_end - kmc_direct_hsaco_begin);
+  if (hsa_code_object_reader_create_from_memory(kmc_direct_hsaco_begin, image_bytes, &reader) != HSA_STATUS_SUCCESS) return nullptr;
+  if (hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &ac.exe) != HSA_STATUS_SUCCESS) return nullptr;
+  if (hsa_executable_load_agent_code_object(ac.exe, ac.gpu, reader, nullptr, nullptr) != HSA_STATUS_SUCCESS) return nullptr;
+  if (hsa_executable_freeze(ac.exe, nullptr) != HSA_STATUS_SUCCESS) return nullptr;
+  static const char* const names[4] = {"kmc_direct_frame_t0.kd", "kmc_direct_frame_t1.kd", "kmc_direct_frame_t2.kd", "kmc_direct_frame_t3.kd"};
+  for (int t = 0; t < 4; ++t) {
+    hsa_executable_symbol_t sym;
+    uint32_t karg = 0, group = 0, priv = 0;
+    if (hsa_executable_get_symbol_by_name(ac.exe, names[t], &ac.gpu, &sym) != HSA_STATUS_SUCCESS) return nullptr;
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &ac.kernel_object[t]) != HSA_STATUS_SUCCESS) return nullptr;
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &karg);
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &group);
+    (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv);
+    if (karg != sizeof(DirectArgs) || priv != 0) return nullptr;  // (a kernel that needs scratch would need the queue's scratch set up: not this one)
+    ac.group_size = std::max(ac.group_size, group);
+    ac.private_size = std::max(ac.private_size, priv);
+  }
+  ac.ok = true;
+  return &ac;
+}
+}  // namespace
+
+struct DirectQueue {
+  AgentCode* code = nullptr;
+  hsa_queue_t* q = nullptr;
+  DirectArgs* ring = nullptr;  // device-local memory, host-mapped
+  hsa_signal_t done{};
+  uint64_t widx = 0;           // next packet slot (single producer: the context's calling thread)
+  bool first_after_transition = true;
+  bool readback = true;
+  uint64_t frames = 0;
+};
+
+namespace {
+// room for one more packet?  (never more than kQueuePackets - 64 ahead of the packet processor)  false: the queue stopped consuming
+bool wait_for_room(DirectQueue* d) {
+  if (d->widx - hsa_queue_load_read_index_relaxed(d->q) < kQueuePackets - 64) return true;
+  const double t0 = now_s();
+  while (d->widx - hsa_queue_load_read_index_scacquire(d->q) >= kQueuePackets - 64)
+    if (now_s() - t0 > kWaitSeconds) return false;
+  return true;
+}
+void ring_doorbell(DirectQueue* d, void* packet, uint16_t header, uint16_t setup_or_rest) {
+  // header and the following 16 bits are published together, last, with release semantics: the packet processor may look at the slot at any time
+  const uint32_t word = (uint32_t)header | ((uint32_t)setup_or_rest << 16);
+  __atomic_store_n(reinterpret_cast<uint32_t*>(packet), word, __ATOMIC_RELEASE);
+  hsa_queue_store_write_index_relaxed(d->q, d->widx + 1);
+  hsa_signal_store_screlease(d->q->doorbell_signal, (hsa_signal_value_t)d->widx);
+  ++d->widx;
+}
+}  // namespace
+
+void direct_close(kmc_ctx* c) {
+  DirectQueue* d = c->dd;
+  if (!d) return;
+  c->dd = nullptr;
+  if (d->q) (void)hsa_queue_destroy(d->q);
+  if (d->ring) (void)hsa_amd_memory_pool_free(d->ring);
+  if (d->done.handle) (void)hsa_signal_destroy(d->done);
+  delete d;
+}
+
+// the queue has drained: every frame dispatched so far has completed and released its stores (bounded wait)
+int direct_join(kmc_ctx* c) {
+  DirectQueue* d = c->dd;
+  if (!d || !c->dd_pending) return KMC_OK;
+  if (!wait_for_room(d)) { c->last_error = "direct queue: the packet processor stopped consuming packets"; c->dd_broken = true; return KMC_ERR_HIP; }
+  hsa_signal_store_relaxed(d->done, 1);
+  auto* p = reinterpret_cast<hsa_barrier_and_packet_t*>(d->q->base_address) + (d->widx % kQueuePackets);
+  std::memset(reinterpret_cast<char*>(p) + 4, 0, sizeof(*p) - 4);
+  p->completion_signal = d->done;
+  const uint16_t header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                          (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+  ring_doorbell(d, p, header, 0);
+  const double t0 = now_s();
+  while (hsa_signal_wait_scacquire(d->done, HSA_SIGNAL_CONDITION_LT, 1, 200000, HSA_WAIT_STATE_ACTIVE) >= 1) {
+    if (now_s() - t0 > kWaitSeconds) {
+      c->last_error = "direct queue: a dispatched frame did not complete within the timeout";
+      c->dd_broken = true;
+      return KMC_ERR_HIP;
+    }
+  }
+  c->dd_pending = false;
+  d->first_after_transition = true;  // whatever comes next on the HIP stream may rewrite the frames' buffers: the next frame re-acquires at system scope
+  return KMC_OK;
+}
+
+// one frame = one packet (frames beyond 2^26 - 1 tiles: several, told their first tile).  `barrier`: the AQL barrier bit.
+int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& rd, uint32_t head, bool barrier, uint32_t* launches_out) {
+  DirectQueue* d = c->dd;
+  in -= head;
+  out -= head;
+  n += head;
+  const uint64_t n_tiles = (n + kTile - 1) / kTile;
+  uint32_t launches = 0;
+  for (uint64_t t0 = 0; t0 < n_tiles; t0 += kMaxTilesPerLaunch, ++launches) {
+    if (!wait_for_room(d)) { c->last_error = "direct queue: the packet processor stopped consuming packets"; c->dd_broken = true; return KMC_ERR_HIP; }
+    const uint32_t tiles = (uint32_t)std::min<uint64_t>(kMaxTilesPerLaunch, n_tiles - t0);
+    DirectArgs* a = d->ring + (d->widx % kQueuePackets);
+    alignas(64) DirectArgs mine;
+    mine.in = in; mine.out = out; mine.n = n; mine.f = f; mine.head = head; mine.tile_base = t0; mine.d = rd;
+    std::memcpy((void*)a, &mine, sizeof(mine));  // over the BAR, write-combined: one sequential pass over the 240 bytes
+    // the block must have landed in device memory before the packet processor can see the packet: fence, HDP flush, one read back over the
+    // link (what the HIP runtime does for device-resident kernel arguments; tools/aql_probe: without the read-back 1.5 us per frame instead
+    // of 2.1 and no stale block in 40 000 dispatches -- kept all the same: a stale argument block is a silently wrong frame)
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    if (d->code->hdp.HDP_MEM_FLUSH_CNTL) *(volatile uint32_t*)d->code->hdp.HDP_MEM_FLUSH_CNTL = 1u;
+    if (d->readback) (void)*(volatile uint32_t*)&a->head;  // (KMC_DIRECT_READBACK=0, a measurement knob: the three posted writes alone)
+    auto* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(d->q->base_address) + (d->widx % kQueuePackets);
+    p->workgroup_size_x = kTile; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
+    p->reserved0 = 0;
+    p->grid_size_x = tiles * (uint32_t)kTile; p->grid_size_y = 1; p->grid_size_z = 1;
+    p->private_segment_size = d->code->private_size;
+    p->group_segment_size = d->code->group_size;
+    p->kernel_object = d->code->kernel_object[tier];
+    p->kernarg_address = a;
+    p->reserved2 = 0;
+    p->completion_signal.handle = 0;
+    // ordered packets acquire at agent scope (the frame before them may have written what they read), the first one behind HIP-stream work
+    // at system scope (copies, host writes); every frame releases at agent scope, direct_join's barrier packet at system scope
+    const bool ordered = barrier || d->first_after_transition || t0 != 0;
+    const uint16_t acquire = d->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+    const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((ordered ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
+                            (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    ring_doorbell(d, p, header, (uint16_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS));
+    d->first_after_transition = false;
+  }
+  c->dd_pending = true;
+  ++d->frames;
+  if (launches_out) *launches_out = launches;
+  return KMC_OK;
+}
+
+// Opens the context's direct queue (once; nullptr afterwards if this device / runtime cannot: no large BAR, no HDP flush register, the
+// self-test differs).  The self-test runs one 1000-point frame through the direct queue and through a HIP launch and compares the bits.
+bool direct_open(kmc_ctx* c) {
+  if (c->dd) return true;
+  if (c->dd_tried) return false;
+  c->dd_tried = true;
+  if (const char* e = std::getenv("KMC_DIRECT_DISPATCH"))
+    if (std::atoi(e) == 0) return false;
+  AgentCode* code = agent_code(c->device);
+  if (!code) return false;
+  DirectQueue* d = new (std::nothrow) DirectQueue();
+  if (!d) return false;
+  d->code = code;
+  if (const char* e = std::getenv("KMC_DIRECT_READBACK")) d->readback = std::atoi(e) != 0;
+  c->dd = d;
+  bool ok = hsa_queue_create(code->gpu, kQueuePackets, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &d->q) == HSA_STATUS_SUCCESS;
+  ok = ok && hsa_amd_memory_pool_allocate(code->device_pool, sizeof(DirectArgs) * kQueuePackets, 0, (void**)&d->ring) == HSA_STATUS_SUCCESS;
+  ok = ok && hsa_amd_agents_allow_access(1, &code->cpu, nullptr, d->ring) == HSA_STATUS_SUCCESS;  // fails without a large BAR
+  ok = ok && hsa_signal_create(1, 0, nullptr, &d->done) == HSA_STATUS_SUCCESS;
+  if (ok) d->widx = hsa_queue_load_write_index_relaxed(d->q);
+  // ---- self-test: the direct queue's frame against the HIP launch's, bit for bit ----
+  float *t_in = nullptr, *t_a = nullptr, *t_b = nullptr;
+  constexpr uint64_t kN = 1000;
+  if (ok) {
+    ok = hipMalloc((void**)&t_in, kN * 16) == hipSuccess && hipMalloc((void**)&t_a, kN * 16) == hipSuccess && hipMalloc((void**)&t_b, kN * 16) == hipSuccess;
+    std::vector<float> h(4 * kN), ha(4 * kN), hb(4 * kN);
+    if (ok) ok = kmc_synth_points_host(h.data(), kN, 0xD1EC7) == KMC_OK && hipMemcpy(t_in, h.data(), kN * 16, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemset(t_a, 0xFF, kN * 16) == hipSuccess && hipMemset(t_b, 0, kN * 16) == hipSuccess;
+    kmc_frame_params prm;
+    std::memset(&prm, 0, sizeof(prm));
+    prm.twist[0] = 1.3; prm.twist[1] = 0.05; prm.twist[2] = -0.02; prm.twist[3] = 0.002; prm.twist[4] = -0.004; prm.twist[5] = 0.03; prm.x_req = 0.4;
+    FrameRec f;
+    std::memset(&f, 0, sizeof(f));
+    fill_rec(prm, &f);
+    f.pre2 = guard_pre2(prm);
+    FrameRecD rd;
+    fill_recd(prm, &rd);
+    if (ok) {
+      hipLaunchKernelGGL(deskew_frame_f32<kSeries3>, dim3((unsigned)((kN + kTile - 1) / kTile)), dim3(kTile), 0, c->own_stream, (const v4f*)t_in, (v4f*)t_a, kN, f, 0u, (uint64_t)0, rd);
+      ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->own_stream) == hipSuccess;
+    }
+    if (ok) ok = direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, kN, f, rd, 0, true, nullptr) == KMC_OK && direct_join(c) == KMC_OK;
+    if (ok) ok = hipMemcpy(ha.data(), t_a, kN * 16, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(hb.data(), t_b, kN * 16, hipMemcpyDeviceToHost) == hipSuccess &&
+                 std::memcmp(ha.data(), hb.data(), kN * 16) == 0;
+  }
+  if (t_in) (void)hipFree(t_in);
+  if (t_a) (void)hipFree(t_a);
+  if (t_b) (void)hipFree(t_b);
+  (void)hipGetLastError();
+  if (!ok) {
+    direct_close(c);
+    return false;
+  }
+  c->dd->frames = 0;
+  return true;
+}
+
+}  // namespace kmc_impl
+
+extern "C" uint64_t kmc_hip_direct_frames(kmc_ctx* c) { return (c && c->dd) ? c->dd->frames : 0; }

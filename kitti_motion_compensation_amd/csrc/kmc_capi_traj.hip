@@ -173,7 +173,11 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   if (!window) {
     rc = fq_join(c);  // (also issues two-pose frames that are still being gathered: the N-knot kernel is launched per call)
     if (rc != KMC_OK) return rc;
+  } else if (c->dd_pending) {  // a HIP launch behind two-pose frames in the direct queue: wait for them (kmc_capi_direct.hip)
+    rc = direct_join(c);
+    if (rc != KMC_OK) return rc;
   }
+  c->stream_dirty = true;
   const int tier = traj_tier(c, th, stamp_start, stamp_end);
   if (st) { st->n_points = n; st->variant = (uint32_t)tier; }
   if (n == 0) return KMC_OK;

@@ -30,6 +30,8 @@
 
 using namespace kmc_dev;
 
+namespace kmc_impl { struct DirectQueue; }
+
 struct kmc_ctx {
   int device = -1;
   hipStream_t own_stream = nullptr;
@@ -108,6 +110,14 @@ struct kmc_ctx {
   ListRec* gather = nullptr;         // the pending frames' records (kGatherMax of each)
   FrameRecD* gather64 = nullptr;
   kmc_book::GatherList<kGatherMax> gl;  // how many are pending, their tier and address ranges, and the decisions around a new frame (kmc_dispatch_book.hpp)
+  // the direct queue (kmc_capi_direct.hip): device-resident single-frame calls on the context's OWN stream are dispatched as AQL packets in an
+  // HSA queue of the context's, below the HIP runtime's launch path
+  kmc_impl::DirectQueue* dd = nullptr;
+  bool dd_tried = false;             // direct_open() has been attempted
+  bool dd_pending = false;           // frames are in the direct queue that nobody has waited for (direct_join)
+  bool dd_broken = false;            // a wait on the queue timed out: HIP launches from here on
+  bool dd_free_order = true;         // independent frames go out without the AQL barrier bit (KMC_ANY_ORDER=0: every packet carries it)
+  bool stream_dirty = true;          // the context has put work on its HIP stream since the last host wait for it: a direct frame waits first
   bool big_kernargs = true;          // kernel-argument blocks beyond 4 KiB are taken by this runtime (cleared by the first refused launch: launch_list)
   int list_route = 0;                // lists of more than 16 frames: 0 = kernel-argument launches of up to 256 frames (launch_list), 1 = one launch over an uploaded device table (KMC_LIST_ROUTE=table)
   int fq_error = 0;                  // sticky: a join failed to issue gathered frames whose calls had already returned KMC_OK (fq_join)
@@ -173,6 +183,7 @@ int fq_take_error(kmc_ctx* c);  // the sticky error of a join that could not iss
 #define KMC_ENTER(ctx)                                      \
   do {                                                      \
     (ctx)->ao.invalidate();                                 \
+    (ctx)->stream_dirty = true;                             \
     KMC_HIP_TRY(ctx, hipSetDevice((ctx)->device));          \
     const int rc_join_ = fq_join(ctx);                      \
     if (rc_join_ != KMC_OK) return rc_join_;                \
@@ -261,6 +272,11 @@ inline void launch_on(void (*kernel)(KArgs...), int grid, int block, hipStream_t
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, static_cast<KArgs>(args)...);
 }
 
+// the direct queue (kmc_capi_direct.hip)
+bool direct_open(kmc_ctx* c);   // the context's queue exists (opened at first need; false: not on this device / runtime, or KMC_DIRECT_DISPATCH=0)
+void direct_close(kmc_ctx* c);
+int direct_join(kmc_ctx* c);    // every frame dispatched through the queue has completed (bounded wait)
+int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head, bool barrier, uint32_t* launches_out);
 void ao_ensure(kmc_ctx* c);  // runs the dispatch probe if its verdict is not known yet
 bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call);  // may this frame be dispatched without the barrier bit?  (kmc_capi_core.hip)
 bool host_pool_owns(const void* ptr, size_t bytes);  // inside a live block of the page-locked host pool (kmc_capi_hostpool.hip)
