@@ -344,7 +344,7 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     def stream_leg(d, key, npts, note):
         us = d[key]["us_per_frame"]
         o = {"us_per_frame": round(us, 3), "Mpts_s": round(npts / us, 1), "GBps": round(32 * npts / us / 1e3, 1), "frac": _frac(32 * npts / us / 1e3), "note": note}
-        for k in ("host_us_per_call", "host_us_per_frame", "dispatched_without_barrier_bit"):
+        for k in ("host_us_per_call", "host_us_per_frame", "dispatched_without_barrier_bit", "through_the_direct_queue"):
             if k in d[key]:
                 o[k] = d[key][k]
         return o
@@ -354,8 +354,9 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
             "workload": "configs[1] literally: synthetic 1 M-point frames, each in its own allocation (256 distinct frames, 8.2 GB), per-frame twists; driven from C++ through the C-ABI (tools/time_frame_stream.hip), HIP events on the context's stream, 8 timed sweeps",
             "kernel": "kmc_dev::deskew_frame_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64> per call; kmc_dev::deskew_list_f32 for the list",
             "any_order_dispatch_verdict": fs["any_order_dispatch"],
-            "in_order": stream_leg(fs, "per_call", n, "ONE kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream; frames that share no buffer with one in flight "
-                                   "go out without the barrier bit where kmc_hip_create's probe verified it (any_order_dispatch_verdict == 1)"),
+            "in_order": stream_leg(fs, "per_call", n, "ONE kmc_hip_deskew_f32 call per frame, in order on the context's own stream: since round 5 an AQL packet in the context's direct queue "
+                                   "(through_the_direct_queue = share of the frames; below the HIP runtime's launch path); frames that share no buffer with one in flight go out without the barrier bit"),
+            "in_order_hip_launches": stream_leg(fs, "per_call_hip_launches", n, "the same calls with KMC_DIRECT_DISPATCH=0: one HIP launch per frame (round 4's route), barrier-free where the run-time probe verified it") if "per_call_hip_launches" in fs else None,
             "in_order_drained": stream_leg(fs, "per_call_drained", n, "the same calls on a context created with KMC_ANY_ORDER=0: every dispatch waits for the last wave of the one before it"),
             "gathered_calls": stream_leg(fs, "per_call_gathered", n, "the same calls, one per frame, with kmc_hip_set_frame_queues(ctx, 4): the library gathers them on the host and issues "
                                          "ONE launch of the frame-list kernel per up to 16 frames (deferred issue, in-order results)"),
@@ -434,7 +435,8 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         leg["frame_by_frame_from_c"] = {
             "workload": "108 separate frames ~N(121 k, 3 k) points, each in its own allocation, 3 rotating sets, per-frame twists; tools/time_frame_stream.hip, 50 timed sweeps",
             "mean_points_per_frame": npts, "any_order_dispatch_verdict": fd["any_order_dispatch"],
-            "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call (one launch) per frame, in order on the context's stream"),
+            "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call per frame, in order on the context's own stream: an AQL packet in the context's direct queue (round 5)"),
+            "per_call_hip_launches": stream_leg(fd, "per_call_hip_launches", npts, "KMC_DIRECT_DISPATCH=0: one HIP launch per frame (the runtime's launch path, 2.2-3.5 us through every launch API)") if "per_call_hip_launches" in fd else None,
             "per_call_drained": stream_leg(fd, "per_call_drained", npts, "KMC_ANY_ORDER=0: the barrier bit on every dispatch"),
             "per_call_gathered": stream_leg(fd, "per_call_gathered", npts, "the same calls with kmc_hip_set_frame_queues(ctx, 4): gathered on the host, one list launch per up to 16 frames"),
             "list_one_launch": stream_leg(fd, "list_one_launch", npts, "kmc_hip_deskew_frames_f32: the 108 separate frames as one list -> 7 chained kernel-argument launches of <= 16 frames, "

@@ -161,6 +161,7 @@ struct DirectQueue {
   uint64_t widx = 0;           // next packet slot (single producer: the context's calling thread)
   bool first_after_transition = true;
   bool readback = true;
+  bool light = false;  // KMC_DIRECT_LIGHT=1 (measurement knob): packets without the barrier bit acquire nothing
   uint64_t frames = 0;
 };
 
@@ -252,7 +253,7 @@ int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, cons
     // ordered packets acquire at agent scope (the frame before them may have written what they read), the first one behind HIP-stream work
     // at system scope (copies, host writes); every frame releases at agent scope, direct_join's barrier packet at system scope
     const bool ordered = barrier || d->first_after_transition || t0 != 0;
-    const uint16_t acquire = d->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+    const uint16_t acquire = d->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : (!ordered && d->light) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((ordered ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                             (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     ring_doorbell(d, p, header, (uint16_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS));
@@ -278,6 +279,7 @@ bool direct_open(kmc_ctx* c) {
   if (!d) return false;
   d->code = code;
   if (const char* e = std::getenv("KMC_DIRECT_READBACK")) d->readback = std::atoi(e) != 0;
+  if (const char* e = std::getenv("KMC_DIRECT_LIGHT")) d->light = std::atoi(e) != 0;
   c->dd = d;
   bool ok = hsa_queue_create(code->gpu, kQueuePackets, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &d->q) == HSA_STATUS_SUCCESS;
   ok = ok && hsa_amd_memory_pool_allocate(code->device_pool, sizeof(DirectArgs) * kQueuePackets, 0, (void**)&d->ring) == HSA_STATUS_SUCCESS;

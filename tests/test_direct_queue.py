@@ -1,0 +1,186 @@
+"""THE DIRECT QUEUE (include/kmc_hip.h, kmc_capi_direct.hip): on a context's own stream a device-resident kmc_hip_deskew_f32 call is an
+AQL packet the library writes into an HSA queue of its own, not a HIP launch.  Same bits as the HIP launch; ordered against everything
+else the context does (HIP-stream work before it, other entry points after it); never used on a caller's stream, with per-call timing,
+or with KMC_DIRECT_DISPATCH=0.  tests/test_dispatch_modes.py replays a whole script of calls under both dispatch paths."""
+import os
+
+import numpy as np
+import pytest
+
+from kitti_motion_compensation_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(**env):
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return capi.Context(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _params(k):
+    return capi.FrameParams.make([1.0 + 0.01 * k, 0.02, -0.01, 0.001, -0.002, 0.03 + 0.3 * (k % 3 == 2)], (k * 37 % 100) / 100.0)
+
+
+def test_direct_frames_write_the_hip_launch_bits_and_keep_the_call_order():
+    import torch
+
+    direct, hip = _ctx(), _ctx(KMC_DIRECT_DISPATCH="0")
+    try:
+        sizes = [123_397, 1, 63, 64, 65, 4097, 200_003, 0, 77_777]
+        ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for n in sizes]
+        for k, a in enumerate(ins):
+            if a.shape[0]:
+                direct.synth_points(a, a.shape[0], 900 + k)      # HIP-stream work of the SAME context right before the frames: a transition
+        outs = {name: [torch.zeros_like(a) for a in ins] for name in ("direct", "hip")}
+        for k, a in enumerate(ins):
+            st = direct.deskew_f32(a, outs["direct"][k], _params(k))
+            assert st.n_points == a.shape[0] and st.n_launches == (1 if a.shape[0] else 0)
+        # another entry point of the context right behind the frames: a batch over the biggest frame's OUTPUT (must see it)
+        copy = torch.zeros_like(outs["direct"][6])
+        ident = capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5)
+        direct.deskew_batch_f32(outs["direct"][6], copy, np.array([0, sizes[6]], dtype=np.uint64), [ident], None)
+        direct.synchronize()
+        hip.synchronize()
+        for k, a in enumerate(ins):
+            hip.deskew_f32(a, outs["hip"][k], _params(k))
+        hip.synchronize()
+        if direct.direct_frames() == 0:
+            pytest.skip("this device / runtime offers no direct queue (the host cannot map device memory): HIP launches were used")
+        assert direct.direct_frames() == sum(1 for n in sizes if n) and hip.direct_frames() == 0
+        for k in range(len(sizes)):
+            assert torch.equal(outs["direct"][k].view(torch.int32), outs["hip"][k].view(torch.int32)), k
+        assert torch.equal(copy.view(torch.int32), outs["hip"][6].view(torch.int32))
+        # a chain and an in-place repeat through the queue: the barrier bit keeps the order of the calls
+        n = 150_001
+        bufs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(5)]
+        hip.synth_points(bufs[0], n, 77)
+        hip.synchronize()
+        want = [bufs[0]]
+        for k in range(4):
+            w = torch.empty_like(bufs[0])
+            hip.deskew_f32(want[-1], w, _params(k))
+            want.append(w)
+        hip.synchronize()
+        before = direct.any_order_launches()
+        for k in range(4):
+            direct.deskew_f32(bufs[k], bufs[k + 1], _params(k))
+        y = want[0].clone()
+        torch.cuda.synchronize()
+        for k in range(3):
+            direct.deskew_f32(y, y, _params(k))
+        direct.synchronize()
+        assert torch.equal(bufs[4].view(torch.int32), want[4].view(torch.int32))
+        assert torch.equal(y.view(torch.int32), want[3].view(torch.int32))
+        assert direct.any_order_launches() - before <= 1  # every frame of the chain and of the repeat depends on the one before it
+    finally:
+        direct.close()
+        hip.close()
+
+
+def test_direct_queue_is_not_used_where_the_contract_says_so():
+    import torch
+
+    n = 50_000
+    a = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    prm = _params(1)
+    c = _ctx()
+    try:
+        c.synth_points(a, n, 5)
+        c.synchronize()
+        c.set_stream(torch.cuda.current_stream().cuda_stream)   # a caller's stream: HIP launches (the caller's own work on it must stay ordered)
+        c.deskew_f32(a, b, prm)
+        torch.cuda.synchronize()
+        assert c.direct_frames() == 0
+        on_stream = b.clone()
+        c.set_stream(None)
+        c.enable_timing(True)                                     # per-call timing brackets the launch with HIP events
+        st = c.deskew_f32(a, b, prm)
+        assert c.direct_frames() == 0 and st.kernel_ms > 0
+        c.enable_timing(False)
+        c.set_frame_queues(4)                                     # gathered calls go out as list launches
+        c.deskew_f32(a, b, prm)
+        c.synchronize()
+        assert c.direct_frames() == 0
+        c.set_frame_queues(1)
+        b.zero_()
+        c.deskew_f32(a, b, prm)                                   # and now the queue, if this device has one
+        c.synchronize()
+        assert torch.equal(b.view(torch.int32), on_stream.view(torch.int32))
+        assert c.direct_frames() in (0, 1)
+    finally:
+        c.close()
+    off = _ctx(KMC_DIRECT_DISPATCH="0")
+    try:
+        off.deskew_f32(a, b, prm)
+        off.synchronize()
+        assert off.direct_frames() == 0
+    finally:
+        off.close()
+
+
+def test_every_packet_carries_the_barrier_bit_with_kmc_any_order_0():
+    import torch
+
+    n, nf = 30_000, 10
+    ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for _ in range(nf)]
+    outs = [torch.zeros_like(x) for x in ins]
+    free, ordered = _ctx(), _ctx(KMC_ANY_ORDER="0")
+    try:
+        for k, x in enumerate(ins):
+            free.synth_points(x, n, 300 + k)
+        free.synchronize()
+        for k in range(nf):
+            ordered.deskew_f32(ins[k], outs[k], _params(k))
+        ordered.synchronize()
+        assert ordered.any_order_launches() == 0
+        outs2 = [torch.zeros_like(x) for x in ins]
+        for k in range(nf):
+            free.deskew_f32(ins[k], outs2[k], _params(k))
+        free.synchronize()
+        if free.direct_frames():
+            assert free.any_order_launches() == nf - 1  # the first frame opens the window, the independent rest follow without the bit
+        for k in range(nf):
+            assert torch.equal(outs[k].view(torch.int32), outs2[k].view(torch.int32)), k
+    finally:
+        free.close()
+        ordered.close()
+
+
+def test_the_argument_ring_wraps_without_a_stale_block():
+    """The queue's argument blocks live in a ring of 4096 slots in device memory, written by the host over the BAR.  Three laps of TINY frames
+    (so little traffic that nothing is evicted from the device's caches by accident), every frame with its own buffers and its own twist:
+    a wave that read a previous lap's block from a cache would read the wrong pointers or the wrong twist.  Against HIP launches, bit for bit."""
+    import torch
+
+    n, nf = 64, 3 * 4096 + 100
+    direct, hip = _ctx(), _ctx(KMC_DIRECT_DISPATCH="0")
+    try:
+        src = torch.empty((nf * n, 4), dtype=torch.float32, device="cuda")
+        direct.synth_points(src, nf * n, 4242)
+        direct.synchronize()
+        got = torch.zeros_like(src)
+        want = torch.zeros_like(src)
+        params = [capi.FrameParams.make([1.0 + 1e-4 * k, 0.02, -0.01, 0.001, -0.002, 0.03 + 1e-5 * k], (k % 97) / 96.0) for k in range(nf)]
+        for k in range(nf):
+            direct.deskew_f32(src[k * n:(k + 1) * n], got[k * n:(k + 1) * n], params[k])
+        direct.synchronize()
+        if direct.direct_frames() == 0:
+            pytest.skip("no direct queue on this device / runtime")
+        for k in range(nf):
+            hip.deskew_f32(src[k * n:(k + 1) * n], want[k * n:(k + 1) * n], params[k])
+        hip.synchronize()
+        diff = (got.view(torch.int32) != want.view(torch.int32)).any(dim=1).view(nf, n).any(dim=1)
+        assert not bool(diff.any()), ("frames with wrong bits", diff.nonzero().flatten()[:10].tolist())
+        assert direct.direct_frames() == nf
+    finally:
+        direct.close()
+        hip.close()

@@ -2,8 +2,11 @@
 repeats, an overwritten input, shared inputs, mixed coefficient tiers, empty and ragged frames, other entry points (a list, a batch, an
 N-knot frame, a host in-place call) in between -- replayed under every dispatch configuration a context can be in:
 
-    default                          frames that share no buffer with one in flight go out without the AQL barrier bit (where probed)
-    barrier_bit_on_every_dispatch    KMC_ANY_ORDER=0
+    default                          the context's own stream: frames go out through the DIRECT QUEUE (AQL packets the library writes itself),
+                                     without the barrier bit when they share no buffer with a frame in flight
+    hip_launches_only                KMC_DIRECT_DISPATCH=0: every frame a HIP launch, barrier-free (hipExtAnyOrderLaunch) where probed
+    barrier_bit_on_every_dispatch    KMC_ANY_ORDER=0 (direct queue, every packet ordered)
+    hip_launches_with_the_barrier_bit  KMC_DIRECT_DISPATCH=0 and KMC_ANY_ORDER=0
     gathered_calls                   kmc_hip_set_frame_queues(ctx, 4): calls gathered into list launches
     gathered_on_a_callers_stream     the same on torch's stream, with the caller's word that nothing is produced between calls
     list_table_route                 KMC_LIST_ROUTE=table: lists beyond 16 frames over an uploaded table
@@ -23,11 +26,13 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-MODES = ["serial", "default", "barrier_bit_on_every_dispatch", "gathered_calls", "gathered_on_a_callers_stream", "list_table_route"]
+MODES = ["serial", "default", "hip_launches_only", "barrier_bit_on_every_dispatch", "hip_launches_with_the_barrier_bit", "gathered_calls", "gathered_on_a_callers_stream",
+         "list_table_route"]
 
 
 def _make_ctx(mode, torch):
-    env = {"serial": {"KMC_ANY_ORDER": "0"}, "barrier_bit_on_every_dispatch": {"KMC_ANY_ORDER": "0"}, "list_table_route": {"KMC_LIST_ROUTE": "table"}}.get(mode, {})
+    env = {"serial": {"KMC_ANY_ORDER": "0"}, "barrier_bit_on_every_dispatch": {"KMC_ANY_ORDER": "0"}, "list_table_route": {"KMC_LIST_ROUTE": "table"},
+           "hip_launches_only": {"KMC_DIRECT_DISPATCH": "0"}, "hip_launches_with_the_barrier_bit": {"KMC_DIRECT_DISPATCH": "0", "KMC_ANY_ORDER": "0"}}.get(mode, {})
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -126,6 +131,7 @@ def replay(golden_dir):
             torch.cuda.synchronize()
             results[mode] = {k: v.cpu().numpy() for k, v in dev.items() if not k.startswith("_")}
             results[mode]["_any_order_launches"] = ctx.any_order_launches()
+            results[mode]["_direct_frames"] = ctx.direct_frames()
             results[mode]["_verdict"] = ctx.device_info()["any_order_dispatch"]
         finally:
             ctx.close()
@@ -145,9 +151,15 @@ def test_the_configurations_really_differ(replay):
     results, _ = replay
     assert results["serial"]["_any_order_launches"] == 0 and results["barrier_bit_on_every_dispatch"]["_any_order_launches"] == 0
     assert results["barrier_bit_on_every_dispatch"]["_verdict"] == 0
-    if results["default"]["_verdict"] == 1:
-        assert results["default"]["_any_order_launches"] >= 8, results["default"]["_any_order_launches"]  # the independent frames of the script
     assert results["gathered_calls"]["_any_order_launches"] == 0  # gathered frames go out as list launches
+    # the direct queue carries the frames of the own-stream configurations (where this device offers it), never those of the others
+    assert results["hip_launches_only"]["_direct_frames"] == 0 and results["hip_launches_with_the_barrier_bit"]["_direct_frames"] == 0
+    assert results["gathered_calls"]["_direct_frames"] == 0 and results["gathered_on_a_callers_stream"]["_direct_frames"] == 0
+    if results["default"]["_direct_frames"]:
+        assert results["default"]["_direct_frames"] >= 20 and results["serial"]["_direct_frames"] >= 20
+        assert results["default"]["_any_order_launches"] >= 8  # plain AQL semantics: no probe needed for packets without the barrier bit
+    if results["hip_launches_only"]["_verdict"] == 1:
+        assert results["hip_launches_only"]["_any_order_launches"] >= 8
 
 
 def test_the_serial_bits_are_within_the_bar_of_the_oracle(replay):

@@ -60,13 +60,26 @@ def test_bench_prints_one_contract_line():
     fb = d["configs2_drive"]["frame_by_frame_from_c"]  # the reference's calling pattern on KITTI-sized frames, from C++
     assert fb["list_equals_per_call_bitwise"] is True and fb["per_call"]["us_per_frame"] > 0 and fb["list_rate_vs_batched"] > 0.5, fb
     assert fb["gathered_rate_vs_batched"] > 0.25, fb  # KITTI-sized per-frame calls at >= 25 % of the batched rate, from C
+    # round 5: the direct queue carries the per-call frames (where the device offers it); its HIP-launch twin is measured beside it
+    if lit["in_order"].get("through_the_direct_queue", 0) > 0:
+        assert lit["in_order"]["through_the_direct_queue"] > 0.99 and fb["per_call"]["through_the_direct_queue"] > 0.99
+        assert fb["per_call"]["us_per_frame"] < fb["per_call_hip_launches"]["us_per_frame"], fb  # below the HIP runtime's launch path
+    assert fb["list_launches"] == 1 and fb["list_rate_vs_batched"] > 0.85, fb  # a drive's list: ONE launch, its records in the kernel arguments
+    ce = d["ceilings"]  # the box's own ceilings for the kernels' access patterns, measured in this run
+    assert ce["f32_one_stream_in_one_out"]["GBps_median"] > 5000 and ce["f64_nine_column_streams"]["copy_cols9"]["GBps_median"] > 4500
     f64 = d["f64cols"]  # K launches between one event pair; the single-call figure beside it
+    assert 0.85 < f64["frac_of_9_stream_ceiling"] < 1.25 and f64["homogeneous_column_known_to_be_ones"]["frac"] > 0.6, f64
     assert "back to back" in f64["timed_as"] and f64["single_call"]["us_per_call"] > 0
     dc = d["dropin_cpp"]  # the API north_star names, through the C++ library
     assert dc["MotionCompensateFrame_f64"]["page_locked_containers"]["us_per_frame"] > 0 and dc["MotionCompensateFrame_f64"]["pageable_containers"]["us_per_frame"] > 0
     assert dc["MotionCompensateKittiCloud_f32"]["page_locked_containers"]["us_per_frame"] > 0
     assert dc["parity"]["MotionCompensateFrame_f64_max_rel_err"] <= 1e-11 and dc["parity"]["MotionCompensateKittiCloud_f32_max_rel_err"] <= 1e-5
     assert dc["oracle_faithful_1_thread_ms_per_frame"] > 1.0
+    tr = dc["trace_of_MotionCompensateFrame_f64"]  # where the microseconds of the literal call go
+    assert tr["calls_traced"] > 100 and 0 < tr["inside_the_c_abi_us"]["device_first_wave_to_last_store"] < tr["medians_us"]["whole_call"]
+    assert dc["MotionCompensateFrame_3arg_f64"]["page_locked_containers"]["us_per_frame"] > 0
+    sh = d["sharded_cpp"]  # frame ranges per rank from C++, counters reduced by one native RCCL group
+    assert sh["world"] == 1 and sh["reduced_by"].startswith("rccl") and sh["reduction_agrees_with_host_arithmetic"] is True
     run = dc["MotionCompensateRun"]
     assert run["frames_compensated"] == 214 and run["frames_per_s"] > 50 and run["parity"]["max_rel_err"] <= 1e-5
     rk = d["ranks"]

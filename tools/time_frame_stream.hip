@@ -7,8 +7,9 @@
 // N(121 000, 3 000) clipped to [90 000, 140 000] like bench.py's configs2_drive leg; `sets` rotating sets of such frames (so that a
 // sweep's working set exceeds the 256 MiB Infinity Cache when the frames are small).  Timed with HIP events on the context's stream
 // (kmc_hip_timer_begin / _end, which also join the frame queues), `iters` sweeps over all sets' frames after two warm-up sweeps:
-//   per_call            one kmc_hip_deskew_f32 call per frame, in order on the context's stream (frames that share no buffer with one in
-//                       flight go out without the barrier bit when the run-time probe allowed it: kmc_device_info.any_order_dispatch)
+//   per_call            one kmc_hip_deskew_f32 call per frame, in order on the context's own stream: since round 5 through the context's DIRECT
+//                       QUEUE (AQL packets the library writes itself; frames that share no buffer with one in flight without the barrier bit)
+//   per_call_hip_launches   the same calls on a context created with KMC_DIRECT_DISPATCH=0: one HIP launch per frame (round 4's route)
 //   per_call_drained    the same calls on a context created with KMC_ANY_ORDER=0 (every dispatch carries the barrier bit)
 //   per_call_gathered   the same calls with kmc_hip_set_frame_queues(ctx, 4): the library gathers them into list launches of up to 16 frames
 //   list_one_launch     kmc_hip_deskew_frames_f32: the set's frames handed over as ONE list (the key keeps its round-4 name; since round 5 a
@@ -125,6 +126,7 @@ int main(int argc, char** argv) {
 
   double host_us = 0;      // the issuing loop's own time per frame, last mode measured
   double ao_share_last = 0;  // share of the timed region's frames that went out without the barrier bit, last mode measured
+  double dd_share_last = 0;  // share of the timed region's frames that went out through the context's direct queue (AQL packets below the HIP runtime)
   auto timed = [&](kmc_ctx* c, auto&& sweep) {
     // warm-up: at least two sweeps AND ~40 ms of device work -- an idle MI355X needs ~10 ms of launches to ramp its clocks, and every
     // mode here follows a pause (allocation, the bitwise comparison's copies)
@@ -136,12 +138,14 @@ int main(int argc, char** argv) {
       }
     }
     const uint64_t ao_before = kmc_hip_any_order_launches(c);
+    const uint64_t dd_before = kmc_hip_direct_frames(c);
     KMC_OK_OR_DIE(kmc_hip_timer_begin(c));
     const double t0 = now_us();
     for (int it = 0; it < iters; ++it)
       for (int s = 0; s < n_sets; ++s) sweep(c, sets[s]);
     host_us = (now_us() - t0) / ((double)iters * n_sets * F);
     ao_share_last = (double)(kmc_hip_any_order_launches(c) - ao_before) / ((double)iters * n_sets * F);
+    dd_share_last = (double)(kmc_hip_direct_frames(c) - dd_before) / ((double)iters * n_sets * F);
     float ms = 0;
     KMC_OK_OR_DIE(kmc_hip_timer_end(c, &ms));
     return (double)ms * 1e3 / ((double)iters * n_sets * F);  // us per frame
@@ -157,7 +161,15 @@ int main(int argc, char** argv) {
   };
 
   const double us_call = timed(ctx, per_call);
-  const double host_call = host_us, ao_share = ao_share_last;
+  const double host_call = host_us, ao_share = ao_share_last, dd_share = dd_share_last;
+  // the same calls as HIP launches (KMC_DIRECT_DISPATCH=0): what the runtime's launch path costs per frame
+  setenv("KMC_DIRECT_DISPATCH", "0", 1);
+  kmc_ctx* hip_only = nullptr;
+  KMC_OK_OR_DIE(kmc_hip_create(&hip_only, 0));
+  unsetenv("KMC_DIRECT_DISPATCH");
+  const double us_call_hip = timed(hip_only, per_call);
+  const double host_call_hip = host_us;
+  kmc_hip_destroy(hip_only);
   const double us_drained = timed(drained, per_call);
   KMC_OK_OR_DIE(kmc_hip_set_frame_queues(ctx, 4));
   const double us_q4 = timed(ctx, per_call);
@@ -194,14 +206,15 @@ int main(int argc, char** argv) {
   std::printf(
       "{\"frames_per_set\": %u, \"frames_are\": \"%s\", \"sets\": %d, \"iters\": %d, \"mean_points_per_frame\": %.1f, \"points_per_set\": %llu, \"device\": \"%s\", "
       "\"any_order_dispatch\": %d, \"list_launches\": %u, \"list_equals_per_call_bitwise\": %s, "
-      "\"per_call\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"dispatched_without_barrier_bit\": %.3f}, "
+      "\"per_call\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"dispatched_without_barrier_bit\": %.3f, \"through_the_direct_queue\": %.3f}, "
+      "\"per_call_hip_launches\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
       "\"per_call_drained\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}, "
       "\"per_call_gathered\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
       "\"list_one_launch\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
       "\"list_table_route\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
       "\"batch_packed\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}}\n",
       F, carve ? "carved out of one allocation per set (1 KiB-aligned starts)" : "separate hipMalloc allocations", n_sets, iters, mean_pts, (unsigned long long)total, info.name, info.any_order_dispatch, st.n_launches, same ? "true" : "false", us_call,
-      gbps(us_call), host_call, ao_share, us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_list_table, gbps(us_list_table), host_list_table, us_batch, gbps(us_batch));
+      gbps(us_call), host_call, ao_share, dd_share, us_call_hip, gbps(us_call_hip), host_call_hip, us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_list_table, gbps(us_list_table), host_list_table, us_batch, gbps(us_batch));
   kmc_hip_destroy(drained);
   kmc_hip_destroy(tabled);
   kmc_hip_destroy(ctx);
