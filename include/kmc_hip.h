@@ -237,7 +237,7 @@ int kmc_hip_deskew_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint
  *       frame, and everything the context or the caller puts on the stream afterwards (copies, events, other kernels: ordinary
  *       packets, which wait for all of them), are the same as before.  It applies (a) on the context's own stream, (b) on a caller's
  *       stream after kmc_hip_set_frame_queue_order(ctx, 0) -- the caller's word that nothing is produced between two calls --, never
- *       on HIP's legacy default stream (handle NULL), never while the stream captures a graph; at most 32 frames go out between two
+ *       on HIP's legacy default stream (handle NULL), never while the stream captures a graph; at most 128 frames go out between two
  *       ordinary launches.  CONTRACT: the flag is documented as unsupported on gfx9, so the library does not take it on trust --
  *       kmc_hip_create runs a probe (< 1 ms, once per device and process) that must SEE, on this device and runtime, an ordinary
  *       kernel, a device-to-host copy and an event behind barrier-free kernels wait for all of them and read every word they stored

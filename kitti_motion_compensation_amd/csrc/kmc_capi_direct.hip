@@ -153,13 +153,47 @@ AgentCode* agent_code(int device) {
 }
 }  // namespace
 
-struct DirectQueue {
-  AgentCode* code = nullptr;
+// TWO LANES.  One AQL queue processes its packets one after the other: between the last workgroup of one frame's dispatch and the first
+// of the next the packet processor spends ~1.4 us in which nothing is dispatched (tools/aql_probe: 5.9 us per 1 M-point frame through
+// one queue, 4.5 us with independent frames alternating between two).  So the context has two queues ("lanes"):
+//   * a frame that is INDEPENDENT of every frame in flight (the window of kmc_dispatch_book.hpp says so) goes to the lane the previous
+//     independent frame did not take, without the barrier bit;
+//   * an ORDERED frame -- it touches a buffer of a frame in flight, or the window is full, or KMC_ANY_ORDER=0 -- goes to lane 0 with the
+//     barrier bit (it waits for everything before it on lane 0).  If lane 1 has taken frames since the last synchronisation point, a
+//     barrier packet on lane 1 first signals "lane 1 done up to here" and a barrier packet on lane 0 waits for that signal.  The
+//     ordered frame carries a completion signal; the next packet that goes to lane 1 is preceded by a barrier packet that waits for it
+//     (that frame may depend on ANYTHING before the ordered frame -- those frames have left the window --, and "the ordered frame has
+//     completed" implies all of them have).  The signals come in records of three (the frame's, lane 1's "done up to here", the lane-1
+//     barrier packet's own) out of a ring; a record is re-armed only when its frame AND the lane-1 barrier packet that referenced it have
+//     completed -- a barrier packet still queued must never find its signal re-armed for a later frame (that later frame would wait for
+//     lane 1, which waits for the packet: a deadlock the first two-lane version ran into).
+// A chain of dependent frames therefore stays on lane 0, one packet each, like on a single queue; a stream of independent frames
+// alternates and overlaps.  direct_join drains both lanes.
+constexpr int kLanes = 2;
+constexpr int kOrderRecords = 64;
+struct OrderRec {
+  hsa_signal_t s{};  // completion of the ordered frame
+  hsa_signal_t x{};  // completion of lane 1's "done up to here" barrier packet (lane 0 waits for it in front of the frame)
+  hsa_signal_t w{};  // completion of the lane-1 barrier packet that waits for `s`
+  bool w_used = false;
+};
+
+struct Lane {
   hsa_queue_t* q = nullptr;
   DirectArgs* ring = nullptr;  // device-local memory, host-mapped
-  hsa_signal_t done{};
+  hsa_signal_t done{};         // direct_join's completion signal
   uint64_t widx = 0;           // next packet slot (single producer: the context's calling thread)
   bool first_after_transition = true;
+};
+struct DirectQueue {
+  AgentCode* code = nullptr;
+  Lane lane[kLanes];
+  OrderRec order[kOrderRecords];           // used round-robin, one per ordered frame
+  uint32_t next_record = 0;
+  OrderRec* lane1_must_wait_for = nullptr; // the last ordered frame's record, if lane 1 has not been told to wait for that frame yet
+  bool lane1_dirty = false;                // lane 1 has taken packets since the last point at which lane 0 waited for it
+  int next_free_lane = 1;                  // where the next independent frame goes
+  bool two_lanes = true;                   // KMC_DIRECT_LANES=1: everything on lane 0 (measurement knob)
   bool readback = true;
   bool light = false;  // KMC_DIRECT_LIGHT=1 (measurement knob): packets without the barrier bit acquire nothing
   uint64_t frames = 0;
@@ -167,20 +201,50 @@ struct DirectQueue {
 
 namespace {
 // room for one more packet?  (never more than kQueuePackets - 64 ahead of the packet processor)  false: the queue stopped consuming
-bool wait_for_room(DirectQueue* d) {
-  if (d->widx - hsa_queue_load_read_index_relaxed(d->q) < kQueuePackets - 64) return true;
+bool wait_for_room(Lane* l) {
+  if (l->widx - hsa_queue_load_read_index_relaxed(l->q) < kQueuePackets - 64) return true;
   const double t0 = now_s();
-  while (d->widx - hsa_queue_load_read_index_scacquire(d->q) >= kQueuePackets - 64)
+  while (l->widx - hsa_queue_load_read_index_scacquire(l->q) >= kQueuePackets - 64)
     if (now_s() - t0 > kWaitSeconds) return false;
   return true;
 }
-void ring_doorbell(DirectQueue* d, void* packet, uint16_t header, uint16_t setup_or_rest) {
+void ring_doorbell(Lane* l, void* packet, uint16_t header, uint16_t setup_or_rest) {
   // header and the following 16 bits are published together, last, with release semantics: the packet processor may look at the slot at any time
   const uint32_t word = (uint32_t)header | ((uint32_t)setup_or_rest << 16);
   __atomic_store_n(reinterpret_cast<uint32_t*>(packet), word, __ATOMIC_RELEASE);
-  hsa_queue_store_write_index_relaxed(d->q, d->widx + 1);
-  hsa_signal_store_screlease(d->q->doorbell_signal, (hsa_signal_value_t)d->widx);
-  ++d->widx;
+  hsa_queue_store_write_index_relaxed(l->q, l->widx + 1);
+  hsa_signal_store_screlease(l->q->doorbell_signal, (hsa_signal_value_t)l->widx);
+  ++l->widx;
+}
+int queue_stuck(kmc_ctx* c, const char* what) {
+  c->last_error = what;
+  c->dd_broken = true;
+  return KMC_ERR_HIP;
+}
+// a barrier packet on lane `l`: waits for every packet before it on that lane (barrier bit) and for `dep` (handle 0: none); signals `completion` (handle 0: none)
+int barrier_packet(kmc_ctx* c, Lane* l, hsa_signal_t dep, hsa_signal_t completion, uint16_t scope) {
+  if (!wait_for_room(l)) return queue_stuck(c, "direct queue: the packet processor stopped consuming packets");
+  auto* p = reinterpret_cast<hsa_barrier_and_packet_t*>(l->q->base_address) + (l->widx % kQueuePackets);
+  std::memset(reinterpret_cast<char*>(p) + 4, 0, sizeof(*p) - 4);
+  p->dep_signal[0] = dep;
+  p->completion_signal = completion;
+  const uint16_t header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) | (scope << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                          (scope << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+  ring_doorbell(l, p, header, 0);
+  return KMC_OK;
+}
+// the next record of the ring.  Its previous user -- 64 ordered frames ago -- and the lane-1 barrier packet that waited for that frame must
+// have completed (bounded waits on device progress that depends on nothing the host has yet to do).
+int take_order_record(kmc_ctx* c, DirectQueue* d, OrderRec** out) {
+  OrderRec* r = &d->order[d->next_record];
+  d->next_record = (d->next_record + 1) % kOrderRecords;
+  const double t0 = now_s();
+  while (hsa_signal_load_scacquire(r->s) > 0 || hsa_signal_load_scacquire(r->x) > 0 || (r->w_used && hsa_signal_load_scacquire(r->w) > 0))
+    if (now_s() - t0 > kWaitSeconds) return queue_stuck(c, "direct queue: an ordered frame did not complete within the timeout");
+  r->w_used = false;
+  if (d->lane1_must_wait_for == r) d->lane1_must_wait_for = nullptr;  // (it has completed: nothing to wait for)
+  *out = r;
+  return KMC_OK;
 }
 }  // namespace
 
@@ -188,49 +252,83 @@ void direct_close(kmc_ctx* c) {
   DirectQueue* d = c->dd;
   if (!d) return;
   c->dd = nullptr;
-  if (d->q) (void)hsa_queue_destroy(d->q);
-  if (d->ring) (void)hsa_amd_memory_pool_free(d->ring);
-  if (d->done.handle) (void)hsa_signal_destroy(d->done);
+  for (Lane& l : d->lane) {
+    if (l.q) (void)hsa_queue_destroy(l.q);
+    if (l.ring) (void)hsa_amd_memory_pool_free(l.ring);
+    if (l.done.handle) (void)hsa_signal_destroy(l.done);
+  }
+  for (OrderRec& r : d->order)
+    for (hsa_signal_t* sg : {&r.s, &r.x, &r.w})
+      if (sg->handle) (void)hsa_signal_destroy(*sg);
   delete d;
 }
 
-// the queue has drained: every frame dispatched so far has completed and released its stores (bounded wait)
+// both lanes have drained: every frame dispatched so far has completed and released its stores (bounded wait)
 int direct_join(kmc_ctx* c) {
   DirectQueue* d = c->dd;
   if (!d || !c->dd_pending) return KMC_OK;
-  if (!wait_for_room(d)) { c->last_error = "direct queue: the packet processor stopped consuming packets"; c->dd_broken = true; return KMC_ERR_HIP; }
-  hsa_signal_store_relaxed(d->done, 1);
-  auto* p = reinterpret_cast<hsa_barrier_and_packet_t*>(d->q->base_address) + (d->widx % kQueuePackets);
-  std::memset(reinterpret_cast<char*>(p) + 4, 0, sizeof(*p) - 4);
-  p->completion_signal = d->done;
-  const uint16_t header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
-                          (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_SYSTEM << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
-  ring_doorbell(d, p, header, 0);
-  const double t0 = now_s();
-  while (hsa_signal_wait_scacquire(d->done, HSA_SIGNAL_CONDITION_LT, 1, 200000, HSA_WAIT_STATE_ACTIVE) >= 1) {
-    if (now_s() - t0 > kWaitSeconds) {
-      c->last_error = "direct queue: a dispatched frame did not complete within the timeout";
-      c->dd_broken = true;
-      return KMC_ERR_HIP;
-    }
+  for (Lane& l : d->lane) {
+    hsa_signal_store_relaxed(l.done, 1);
+    const int rc = barrier_packet(c, &l, hsa_signal_t{0}, l.done, HSA_FENCE_SCOPE_SYSTEM);
+    if (rc != KMC_OK) return rc;
+  }
+  for (Lane& l : d->lane) {
+    const double t0 = now_s();
+    while (hsa_signal_wait_scacquire(l.done, HSA_SIGNAL_CONDITION_LT, 1, 200000, HSA_WAIT_STATE_ACTIVE) >= 1)
+      if (now_s() - t0 > kWaitSeconds) return queue_stuck(c, "direct queue: a dispatched frame did not complete within the timeout");
+    l.first_after_transition = true;  // whatever comes next on the HIP stream may rewrite the frames' buffers: the lane's next frame re-acquires at system scope
   }
   c->dd_pending = false;
-  d->first_after_transition = true;  // whatever comes next on the HIP stream may rewrite the frames' buffers: the next frame re-acquires at system scope
+  d->lane1_dirty = false;
+  d->lane1_must_wait_for = nullptr;
   return KMC_OK;
 }
 
-// one frame = one packet (frames beyond 2^26 - 1 tiles: several, told their first tile).  `barrier`: the AQL barrier bit.
+// one frame = one packet (frames beyond 2^26 - 1 tiles: several, told their first tile).  `barrier`: the frame is ORDERED behind every
+// frame dispatched before it; false: it is independent of every frame in flight.
 int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& rd, uint32_t head, bool barrier, uint32_t* launches_out) {
   DirectQueue* d = c->dd;
   in -= head;
   out -= head;
   n += head;
   const uint64_t n_tiles = (n + kTile - 1) / kTile;
+  const bool ordered_frame = barrier || n_tiles > kMaxTilesPerLaunch;  // (a frame of several packets keeps to lane 0, its packets ordered)
+  int li = 0;
+  hsa_signal_t completion{0};
+  OrderRec* rec = nullptr;
+  if (ordered_frame && d->two_lanes) {
+    int rc = take_order_record(c, d, &rec);
+    if (rc != KMC_OK) return rc;
+    if (d->lane1_dirty) {  // lane 0 waits for what lane 1 has taken so far
+      hsa_signal_store_relaxed(rec->x, 1);
+      rc = barrier_packet(c, &d->lane[1], hsa_signal_t{0}, rec->x, HSA_FENCE_SCOPE_AGENT);
+      if (rc == KMC_OK) rc = barrier_packet(c, &d->lane[0], rec->x, hsa_signal_t{0}, HSA_FENCE_SCOPE_AGENT);
+      if (rc != KMC_OK) return rc;
+      d->lane1_dirty = false;
+    }
+    hsa_signal_store_relaxed(rec->s, 1);
+    completion = rec->s;
+  } else if (!ordered_frame && d->two_lanes) {
+    li = d->next_free_lane;
+    d->next_free_lane ^= 1;
+    if (li == 1) {
+      if (OrderRec* r = d->lane1_must_wait_for) {  // everything before the last ordered frame must be over before lane 1 goes on
+        hsa_signal_store_relaxed(r->w, 1);
+        r->w_used = true;
+        const int rc = barrier_packet(c, &d->lane[1], r->s, r->w, HSA_FENCE_SCOPE_AGENT);
+        if (rc != KMC_OK) return rc;
+        d->lane1_must_wait_for = nullptr;
+      }
+      d->lane1_dirty = true;
+    }
+  }
+  Lane* l = &d->lane[li];
   uint32_t launches = 0;
   for (uint64_t t0 = 0; t0 < n_tiles; t0 += kMaxTilesPerLaunch, ++launches) {
-    if (!wait_for_room(d)) { c->last_error = "direct queue: the packet processor stopped consuming packets"; c->dd_broken = true; return KMC_ERR_HIP; }
+    if (!wait_for_room(l)) return queue_stuck(c, "direct queue: the packet processor stopped consuming packets");
     const uint32_t tiles = (uint32_t)std::min<uint64_t>(kMaxTilesPerLaunch, n_tiles - t0);
-    DirectArgs* a = d->ring + (d->widx % kQueuePackets);
+    const bool last_packet = t0 + kMaxTilesPerLaunch >= n_tiles;
+    DirectArgs* a = l->ring + (l->widx % kQueuePackets);
     alignas(64) DirectArgs mine;
     mine.in = in; mine.out = out; mine.n = n; mine.f = f; mine.head = head; mine.tile_base = t0; mine.d = rd;
     std::memcpy((void*)a, &mine, sizeof(mine));  // over the BAR, write-combined: one sequential pass over the 240 bytes
@@ -240,7 +338,7 @@ int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, cons
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     if (d->code->hdp.HDP_MEM_FLUSH_CNTL) *(volatile uint32_t*)d->code->hdp.HDP_MEM_FLUSH_CNTL = 1u;
     if (d->readback) (void)*(volatile uint32_t*)&a->head;  // (KMC_DIRECT_READBACK=0, a measurement knob: the three posted writes alone)
-    auto* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(d->q->base_address) + (d->widx % kQueuePackets);
+    auto* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(l->q->base_address) + (l->widx % kQueuePackets);
     p->workgroup_size_x = kTile; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
     p->reserved0 = 0;
     p->grid_size_x = tiles * (uint32_t)kTile; p->grid_size_y = 1; p->grid_size_z = 1;
@@ -249,16 +347,17 @@ int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, cons
     p->kernel_object = d->code->kernel_object[tier];
     p->kernarg_address = a;
     p->reserved2 = 0;
-    p->completion_signal.handle = 0;
-    // ordered packets acquire at agent scope (the frame before them may have written what they read), the first one behind HIP-stream work
-    // at system scope (copies, host writes); every frame releases at agent scope, direct_join's barrier packet at system scope
-    const bool ordered = barrier || d->first_after_transition || t0 != 0;
-    const uint16_t acquire = d->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : (!ordered && d->light) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
+    p->completion_signal.handle = last_packet ? completion.handle : 0;
+    // ordered packets acquire at agent scope (the frame before them may have written what they read), a lane's first one behind HIP-stream
+    // work at system scope (copies, host writes); every frame releases at agent scope, direct_join's barrier packets at system scope
+    const bool ordered = ordered_frame || l->first_after_transition || t0 != 0;
+    const uint16_t acquire = l->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : (!ordered && d->light) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((ordered ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                             (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
-    ring_doorbell(d, p, header, (uint16_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS));
-    d->first_after_transition = false;
+    ring_doorbell(l, p, header, (uint16_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS));
+    l->first_after_transition = false;
   }
+  if (rec) d->lane1_must_wait_for = rec;  // (the latest ordered frame: its completion implies that of everything before it)
   c->dd_pending = true;
   ++d->frames;
   if (launches_out) *launches_out = launches;
@@ -281,11 +380,21 @@ bool direct_open(kmc_ctx* c) {
   if (const char* e = std::getenv("KMC_DIRECT_READBACK")) d->readback = std::atoi(e) != 0;
   if (const char* e = std::getenv("KMC_DIRECT_LIGHT")) d->light = std::atoi(e) != 0;
   c->dd = d;
-  bool ok = hsa_queue_create(code->gpu, kQueuePackets, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &d->q) == HSA_STATUS_SUCCESS;
-  ok = ok && hsa_amd_memory_pool_allocate(code->device_pool, sizeof(DirectArgs) * kQueuePackets, 0, (void**)&d->ring) == HSA_STATUS_SUCCESS;
-  ok = ok && hsa_amd_agents_allow_access(1, &code->cpu, nullptr, d->ring) == HSA_STATUS_SUCCESS;  // fails without a large BAR
-  ok = ok && hsa_signal_create(1, 0, nullptr, &d->done) == HSA_STATUS_SUCCESS;
-  if (ok) d->widx = hsa_queue_load_write_index_relaxed(d->q);
+  if (const char* e = std::getenv("KMC_DIRECT_LANES")) d->two_lanes = std::atoi(e) != 1;
+  if (!c->dd_free_order) d->two_lanes = false;  // every frame ordered (KMC_ANY_ORDER=0): nothing for a second lane to overlap
+  bool ok = true;
+  for (Lane& l : d->lane) {
+    ok = ok && hsa_queue_create(code->gpu, kQueuePackets, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &l.q) == HSA_STATUS_SUCCESS;
+    ok = ok && hsa_amd_memory_pool_allocate(code->device_pool, sizeof(DirectArgs) * kQueuePackets, 0, (void**)&l.ring) == HSA_STATUS_SUCCESS;
+    ok = ok && hsa_amd_agents_allow_access(1, &code->cpu, nullptr, l.ring) == HSA_STATUS_SUCCESS;  // fails without a large BAR
+    ok = ok && hsa_signal_create(1, 0, nullptr, &l.done) == HSA_STATUS_SUCCESS;
+    if (ok) l.widx = hsa_queue_load_write_index_relaxed(l.q);
+  }
+  for (OrderRec& r : d->order)
+    for (hsa_signal_t* sg : {&r.s, &r.x, &r.w})  // waited for by barrier packets only (the host polls their values, it never sleeps on them): no interrupt per completion
+      ok = ok && hsa_amd_signal_create(0, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, sg) == HSA_STATUS_SUCCESS;
+  const bool debug = std::getenv("KMC_DIRECT_DEBUG") != nullptr;
+  if (debug) std::fprintf(stderr, "kmc direct queue: lanes, rings and signals %s\n", ok ? "ok" : "FAILED");
   // ---- self-test: the direct queue's frame against the HIP launch's, bit for bit ----
   float *t_in = nullptr, *t_a = nullptr, *t_b = nullptr;
   constexpr uint64_t kN = 1000;
@@ -293,7 +402,7 @@ bool direct_open(kmc_ctx* c) {
     ok = hipMalloc((void**)&t_in, kN * 16) == hipSuccess && hipMalloc((void**)&t_a, kN * 16) == hipSuccess && hipMalloc((void**)&t_b, kN * 16) == hipSuccess;
     std::vector<float> h(4 * kN), ha(4 * kN), hb(4 * kN);
     if (ok) ok = kmc_synth_points_host(h.data(), kN, 0xD1EC7) == KMC_OK && hipMemcpy(t_in, h.data(), kN * 16, hipMemcpyHostToDevice) == hipSuccess &&
-                 hipMemset(t_a, 0xFF, kN * 16) == hipSuccess && hipMemset(t_b, 0, kN * 16) == hipSuccess;
+                 hipMemset(t_a, 0xFF, kN * 16) == hipSuccess && hipMemset(t_b, 0, kN * 16) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     kmc_frame_params prm;
     std::memset(&prm, 0, sizeof(prm));
     prm.twist[0] = 1.3; prm.twist[1] = 0.05; prm.twist[2] = -0.02; prm.twist[3] = 0.002; prm.twist[4] = -0.004; prm.twist[5] = 0.03; prm.x_req = 0.4;
@@ -307,6 +416,11 @@ bool direct_open(kmc_ctx* c) {
       hipLaunchKernelGGL(deskew_frame_f32<kSeries3>, dim3((unsigned)((kN + kTile - 1) / kTile)), dim3(kTile), 0, c->own_stream, (const v4f*)t_in, (v4f*)t_a, kN, f, 0u, (uint64_t)0, rd);
       ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->own_stream) == hipSuccess;
     }
+    // through lane 1 (an independent frame behind an ordered one: the cross-lane wait is exercised too), then through lane 0
+    if (ok) ok = direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, 64, f, rd, 0, true, nullptr) == KMC_OK &&
+                 direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, kN, f, rd, 0, false, nullptr) == KMC_OK && direct_join(c) == KMC_OK;
+    if (ok) ok = hipMemcpy(ha.data(), t_a, kN * 16, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(hb.data(), t_b, kN * 16, hipMemcpyDeviceToHost) == hipSuccess &&
+                 std::memcmp(ha.data(), hb.data(), kN * 16) == 0 && hipMemset(t_b, 0, kN * 16) == hipSuccess && hipDeviceSynchronize() == hipSuccess;  // (a memset is asynchronous)
     if (ok) ok = direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, kN, f, rd, 0, true, nullptr) == KMC_OK && direct_join(c) == KMC_OK;
     if (ok) ok = hipMemcpy(ha.data(), t_a, kN * 16, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(hb.data(), t_b, kN * 16, hipMemcpyDeviceToHost) == hipSuccess &&
                  std::memcmp(ha.data(), hb.data(), kN * 16) == 0;
@@ -315,8 +429,11 @@ bool direct_open(kmc_ctx* c) {
   if (t_a) (void)hipFree(t_a);
   if (t_b) (void)hipFree(t_b);
   (void)hipGetLastError();
+  if (debug) std::fprintf(stderr, "kmc direct queue: self-test %s (%s)\n", ok ? "ok" : "FAILED", c->last_error.c_str());
   if (!ok) {
     direct_close(c);
+    c->dd_broken = false;  // (not broken: absent -- HIP launches from the start)
+    c->dd_pending = false;
     return false;
   }
   c->dd->frames = 0;

@@ -127,7 +127,7 @@ struct kmc_ctx {
   // carries no barrier bit, the frame starts while the frame before it is still running.  Everything else the context puts on
   // its stream is an ordinary (barrier) packet and waits for all of them (tools/anyorder_probe.hip measures both facts).  Only on the
   // context's OWN stream: a caller's stream may hold producers the library does not see.
-  static constexpr int kAoWindow = 32;   // frames between two ordered launches at most
+  static constexpr int kAoWindow = 128;  // frames between two ordered launches at most
   bool ao_enabled = false;               // set by kmc_hip_create from the run-time probe's verdict (kmc_capi_core.hip); KMC_ANY_ORDER=0 turns it off
   int ao_verdict = 0;                    // kmc_device_info.any_order_dispatch
   bool ao_probed = false;                // the verdict has been established (ao_ensure: at first need, not in kmc_hip_create)

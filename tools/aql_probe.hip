@@ -122,8 +122,10 @@ int main(int argc, char** argv) {
   HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv));
   if (karg != sizeof(Args)) { std::printf("{\"failed\": \"kernarg segment is %u bytes\"}\n", karg); return 3; }
   const uint32_t kQueue = 4096;
-  hsa_queue_t* q = nullptr;
-  HSA_OK(hsa_queue_create(g_gpu, kQueue, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+  hsa_queue_t* qs[2] = {nullptr, nullptr};  // [1]: the second queue of the two-queue trains (independent frames alternate between them)
+  for (auto& qq : qs) HSA_OK(hsa_queue_create(g_gpu, kQueue, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &qq));
+  int cur = 0;  // the queue dispatch() writes to
+  hsa_queue_t* q = qs[0];
   const bool device_kernargs = argc > 4 ? std::strcmp(argv[4], "host") != 0 : true;
   // "device_noreadback": the block is only fenced (sfence) in front of the HDP flush and the doorbell -- three posted writes to one device --
   // without the read over the link that proves they landed.  Every dispatch of the timed trains then carries its own number, and the
@@ -134,12 +136,12 @@ int main(int argc, char** argv) {
   if (device_kernargs) {
     HSA_OK(hsa_amd_agent_iterate_memory_pools(g_gpu, on_gpu_pool, nullptr));
     if (!g_have_dev_pool) { std::printf("{\"failed\": \"no device-local pool\"}\n"); return 3; }
-    HSA_OK(hsa_amd_memory_pool_allocate(g_dev_pool, sizeof(Args) * kQueue, 0, (void**)&ring));
+    HSA_OK(hsa_amd_memory_pool_allocate(g_dev_pool, sizeof(Args) * kQueue * 2, 0, (void**)&ring));
     const hsa_status_t acc = hsa_amd_agents_allow_access(1, &g_cpu, nullptr, ring);
     if (acc != HSA_STATUS_SUCCESS) { std::printf("{\"failed\": \"the host cannot map device memory (no large BAR?)\"}\n"); return 3; }
     HSA_OK(hsa_agent_get_info(g_gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp));
   } else {
-    HSA_OK(hsa_amd_memory_pool_allocate(g_kernarg_pool, sizeof(Args) * kQueue, 0, (void**)&ring));
+    HSA_OK(hsa_amd_memory_pool_allocate(g_kernarg_pool, sizeof(Args) * kQueue * 2, 0, (void**)&ring));
     HSA_OK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, ring));
   }
   hsa_signal_t done;
@@ -158,8 +160,8 @@ int main(int argc, char** argv) {
   proto.n = n;
   for (int i = 0; i < 16; ++i) { proto.f.v[i] = 1.0f + i; proto.d.v[i] = 0.5 * i; }
   const uint32_t grid = (uint32_t)((n + 63) / 64) * 64;
-  auto* packets = (hsa_kernel_dispatch_packet_t*)q->base_address;
-  uint64_t widx = hsa_queue_load_write_index_relaxed(q);
+  uint64_t widxs[2] = {hsa_queue_load_write_index_relaxed(qs[0]), hsa_queue_load_write_index_relaxed(qs[1])};
+  Args* const ring0 = ring;
   auto wait_for_room = [&](uint64_t idx) {  // never more than kQueue - 64 packets ahead of the packet processor
     const auto t0 = clk::now();
     while (idx - hsa_queue_load_read_index_scacquire(q) >= kQueue - 64) {
@@ -167,6 +169,10 @@ int main(int argc, char** argv) {
     }
   };
   auto dispatch = [&](int i, bool barrier, hsa_signal_t completion) {
+    q = qs[cur];
+    uint64_t& widx = widxs[cur];
+    auto* packets = (hsa_kernel_dispatch_packet_t*)q->base_address;
+    ring = ring0 + (size_t)cur * kQueue;
     wait_for_room(widx);
     Args* a = ring + (widx % kQueue);
     Args mine = proto;
@@ -194,13 +200,17 @@ int main(int argc, char** argv) {
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)widx);
     ++widx;
   };
-  auto drain = [&] {  // a last packet with the barrier bit and a completion signal; waited for with a timeout
-    hsa_signal_store_relaxed(done, 1);
-    dispatch(-1, true, done);
-    const auto t0 = clk::now();
-    while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 100000, HSA_WAIT_STATE_ACTIVE) >= 1) {  // short waits, the wall clock decides
-      if (us_since(t0) > 5e6) { std::printf("{\"failed\": \"a dispatched kernel did not complete within 5 s\"}\n"); die(4); }
+  auto drain = [&] {  // per queue: a last packet with the barrier bit and a completion signal; waited for with a timeout
+    for (int qi = 0; qi < 2; ++qi) {
+      cur = qi;
+      hsa_signal_store_relaxed(done, 1);
+      dispatch(-1, true, done);
+      const auto t0 = clk::now();
+      while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 100000, HSA_WAIT_STATE_ACTIVE) >= 1) {  // short waits, the wall clock decides
+        if (us_since(t0) > 5e6) { std::printf("{\"failed\": \"a dispatched kernel did not complete within 5 s\"}\n"); die(4); }
+      }
     }
+    cur = 0;
   };
   hsa_signal_t none;
   none.handle = 0;
@@ -238,7 +248,17 @@ int main(int argc, char** argv) {
     }
     std::printf(", \"%s\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", barrier ? "aql_with_barrier_bit" : "aql_without_barrier_bit", host, train);
   }
+  {  // independent frames alternating between TWO queues (no barrier bit): does the packet processor overlap what it serialises in one queue?
+    for (int i = 0; i < 2000; ++i) { cur = i & 1; dispatch(i, false, none); }
+    drain();
+    const auto t0 = clk::now();
+    for (int i = 0; i < N; ++i) { cur = i & 1; dispatch(i, false, none); }
+    const double host = us_since(t0) / N;
+    drain();
+    const double train = us_since(t0) / N;
+    std::printf(", \"aql_two_queues_alternating_without_barrier_bit\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", host, train);
+  }
   std::printf(", \"note\": \"host = packet + 232-byte kernarg block + doorbell per frame, including the back-pressure of a 4096-packet queue when the device is the slower side\"}\n");
-  hsa_queue_destroy(q);
+  for (auto& qq : qs) hsa_queue_destroy(qq);
   return 0;
 }
