@@ -184,3 +184,52 @@ def test_the_argument_ring_wraps_without_a_stale_block():
     finally:
         direct.close()
         hip.close()
+
+
+def test_a_frame_behind_an_ordered_frame_still_sees_what_was_written_before_it():
+    """Two lanes: independent frames alternate between two HSA queues, an ORDERED frame F waits for both.  A frame N behind F that is
+    independent of F may run beside F on either lane -- but it may read what a frame G BEFORE F wrote (the any-order window only holds the
+    frames since F).  G is big and slow, F and N are tiny, both lane parities are exercised; against HIP launches bit for bit."""
+    import torch
+
+    big, small = 1_500_000, 4_000
+    direct, hip = _ctx(), _ctx(KMC_DIRECT_DISPATCH="0")
+    try:
+        src_big = torch.empty((big, 4), dtype=torch.float32, device="cuda")
+        src_small = [torch.empty((small, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+        direct.synth_points(src_big, big, 11)
+        for k, s in enumerate(src_small):
+            direct.synth_points(s, small, 20 + k)
+        direct.synchronize()
+
+        def script(ctx, pad):
+            """pad = number of independent small frames ahead of G: it decides which lane G and N land on"""
+            made = []
+            def frame(a, k):
+                o = torch.zeros_like(a)
+                ctx.deskew_f32(a, o, _params(k))
+                made.append(o)
+                return o
+            a0 = frame(src_small[0], 0)                      # opens the window
+            for j in range(pad):
+                frame(src_small[1 + j % 2], 1 + j)
+            g = frame(src_big, 7)                            # G: slow, independent
+            f = frame(a0, 8)                                 # F: reads a0 -> ordered behind everything
+            n1 = frame(g[:small], 9)                         # N: independent of F, reads the head of G's output
+            n2 = frame(g[big - small:], 10)                  # and its tail (the last tiles G writes), on the other lane
+            f2 = frame(n2, 11)                               # ordered again (reads n2) ...
+            n3 = frame(g[big // 2: big // 2 + small], 12)    # ... and a frame behind it that reads G once more
+            ctx.synchronize()
+            return [f, n1, n2, f2, n3]
+
+        for pad in range(4):
+            want = script(hip, pad)
+            for rep in range(3):
+                got = script(direct, pad)
+                for k, (w, g_) in enumerate(zip(want, got)):
+                    assert torch.equal(w.view(torch.int32), g_.view(torch.int32)), (pad, rep, k)
+        if direct.direct_frames() == 0:
+            pytest.skip("no direct queue on this device / runtime")
+    finally:
+        direct.close()
+        hip.close()

@@ -1238,15 +1238,28 @@ def test_any_order_frames_same_bits_and_hazards_kept(torch_mod, monkeypatch):
             plain.deskew_f32(ins[f], want[f], params[f])
         plain.synchronize()
         assert plain.any_order_launches() == 0
-        # (1) independent frames: one ordinary launch opens a window, at most 31 frames follow it without the barrier bit
+        # (1) independent frames: one ordinary launch opens a window, at most 127 frames follow it without the barrier bit
+        window = 128
         outs = [torch.zeros_like(x) for x in ins]
         torch.cuda.synchronize()
         for f in range(nf):
             fast.deskew_f32(ins[f], outs[f], params[f])
-        assert fast.any_order_launches() == nf - 2, fast.any_order_launches()
+        assert fast.any_order_launches() == nf - (nf + window - 1) // window, fast.any_order_launches()
         fast.synchronize()
         for f in range(nf):
             assert torch.equal(outs[f].view(torch.int32), want[f].view(torch.int32)), f
+        # ... and the window closes and re-opens: 300 small independent frames -> ordinary launches at 0, 128 and 256
+        small, many = 1_000, 300
+        s_out, s_want = torch.zeros((many * small, 4), dtype=torch.float32, device="cuda"), torch.zeros((many * small, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        before = fast.any_order_launches()
+        for f in range(many):
+            fast.deskew_f32(ins[f % nf][f * small:(f + 1) * small], s_out[f * small:(f + 1) * small], params[f % nf])
+            plain.deskew_f32(ins[f % nf][f * small:(f + 1) * small], s_want[f * small:(f + 1) * small], params[f % nf])
+        assert fast.any_order_launches() - before == many - (many + window - 1) // window, fast.any_order_launches() - before
+        fast.synchronize()
+        plain.synchronize()
+        assert torch.equal(s_out.view(torch.int32), s_want.view(torch.int32))
         # (2) a chain: every frame reads what the one before it wrote -> none of them may overtake
         before = fast.any_order_launches()
         chain_ref = [ins[0]]
