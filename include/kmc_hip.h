@@ -267,10 +267,14 @@ uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* ctx);
 uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
 /* THE DIRECT QUEUE (ABI 5).  On the context's OWN stream (the state after kmc_hip_create) a device-resident kmc_hip_deskew_f32 call does
  * not go through a HIP launch: the library writes the frame's AQL dispatch packet into an HSA queue of the context's own, with the
- * argument block in device memory -- 2.1 us of host time per call instead of the 3.6-4.7 us of the HIP runtime's launch path (which costs
- * 2.2-3.5 us through every launch API).  Same kernel body, same bits (checked on the device when the queue is opened, at the first such
- * call).  The barrier bit of a packet is decided like before: a frame that shares no buffer with the frames in flight goes out without
- * it (KMC_ANY_ORDER=0: every packet carries it).  ORDER: the queue and the context's HIP stream are two queues; the library keeps
+ * argument block in device memory -- 1.7-2.0 us per KITTI frame per call instead of the 3.5-4.7 us of the HIP runtime's launch path
+ * (which costs 2.2-3.5 us through every launch API).  Same kernel body, same bits (checked on the device when the queue is opened, at the
+ * first such call).  The barrier bit of a packet is decided like before: a frame that shares no buffer with the frames in flight goes out
+ * without it (KMC_ANY_ORDER=0: every packet carries it).  TWO LANES: the direct queue is two HSA queues; independent frames alternate
+ * between them (two packet processors fetch argument blocks and launch waves side by side), a frame that must stay ordered goes to lane 0
+ * behind a barrier packet that waits for lane 1, and lane 1's next frame waits for that ordered frame -- so a frame always sees what
+ * every frame called before it wrote, on whichever lane either ran (KMC_DIRECT_LANES=1: one lane; with KMC_ANY_ORDER=0 one lane as
+ * well, every packet ordered).  ORDER: the direct queue and the context's HIP stream are separate queues; the library keeps
  * them in the order of the calls -- a frame waits for what the context put on its stream before it, every other entry point waits for
  * the frames before it (host waits, at such transitions only).  What a caller must know: the frames are not in a HIP stream, so
  * hipDeviceSynchronize() or a synchronize of some stream of the caller's does not wait for them -- kmc_hip_synchronize(ctx) does, and so
