@@ -78,22 +78,38 @@ static bool float_eq(double a, double b) {  // gtest's AlmostEquals: 4 ULP as fl
 #define ASSERT_EQ(a, b) ASSERT_TRUE((a) == (b))
 #define CASE(name) g_case = name
 
-// ---- fixtures (test_motion_compensation.cpp:12-49 / test_timestamp_mocking.cpp:10-46) -----------------------
-static Frame MakeMotionCompensationTestFrame() {
-  Oxts const odometry_0{Time(0.05), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  Oxts const odometry_1{Time(0.15), 0.0, 0.00001, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  Oxts const odometry_2{Time(0.25), 0.0, 0.00002, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  Pointcloud cloud_1 = MatrixX4d(3, 4);
-  cloud_1.row(0) = Vector4d{0.0, 5.0, 0.0, 1.0};
-  cloud_1.row(1) = Vector4d{5.0, 0.0, 0.0, 1.0};
-  cloud_1.row(2) = Vector4d{0.0, -5.0, 0.0, 1.0};
-  Time const stamp_start{Time(0.1)};
-  Time const stamp_middle{Time(0.15)};
-  Time const stamp_end{Time(0.2)};
-  VectorXd const intensities_1{VectorXd(3)};
-  VectorXd const timestamps_1{GetPseudoTimeStamps(cloud_1, stamp_start, stamp_end)};
-  LidarScan const scan_1{stamp_start, stamp_middle, stamp_end, cloud_1, intensities_1, timestamps_1};
-  return MakeFrame(odometry_0, odometry_1, odometry_2, scan_1);
+// ---- the reference's three-point frame, as data (the vectors test_motion_compensation.cpp:12-49 and test_timestamp_mocking.cpp:10-46
+// hold): three OXTS packets 0.1 s apart that differ in longitude only (the vehicle drives due east), three points at radius 5 on
+// +y / +x / -y (a quarter, a half and three quarters of the sweep), a sweep from 0.1 s to 0.2 s with the camera trigger in the middle.
+namespace three_point_frame {
+constexpr double kPacketStamp[3] = {0.05, 0.15, 0.25};
+constexpr double kPacketLongitudeDeg[3] = {0.0, 1e-5, 2e-5};
+constexpr double kPoint[3][4] = {{0.0, 5.0, 0.0, 1.0}, {5.0, 0.0, 0.0, 1.0}, {0.0, -5.0, 0.0, 1.0}};
+constexpr double kSweep[3] = {0.1, 0.15, 0.2};  // start, camera trigger, end
+// what the reference's tests expect of it
+constexpr double kSweepFraction[3] = {0.25, 0.5, 0.75};       // test_timestamp_mocking.cpp:48-58
+constexpr double kPseudoStamp[3] = {0.125, 0.15, 0.175};      // :60-87
+constexpr double kDeskewedX[3] = {-0.27829874, 5.0, 0.27829874};  // test_motion_compensation.cpp:54-76 (y, z, w: unchanged)
+}  // namespace three_point_frame
+
+static Frame ThreePointFrame() {
+  namespace v = three_point_frame;
+  Oxts packet[3];
+  for (int k = 0; k < 3; ++k) {
+    packet[k] = Oxts{};
+    packet[k].stamp = Time(v::kPacketStamp[k]);
+    packet[k].lon = v::kPacketLongitudeDeg[k];
+  }
+  LidarScan scan;
+  scan.stamp_start = Time(v::kSweep[0]);
+  scan.stamp_middle = Time(v::kSweep[1]);
+  scan.stamp_end = Time(v::kSweep[2]);
+  scan.cloud = MatrixX4d(3, 4);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) scan.cloud(i, j) = v::kPoint[i][j];
+  scan.intensities = VectorXd(3);
+  scan.timestamps = GetPseudoTimeStamps(scan.cloud, scan.stamp_start, scan.stamp_end);
+  return MakeFrame(packet[0], packet[1], packet[2], scan);
 }
 
 static Affine3d ArtificialPose(double const x_rotation, double const x_translation) {  // test_trajectory_interpolation.cpp:24-30
@@ -151,10 +167,9 @@ static void host_cases(std::string const& golden) {
   {
     Oxts const oxts{LoadOxts(data_folder, 0)};
     auto const pose{OxtsToPose(oxts, 1.0)};
+    double const mercator_xyz[3] = {937631.25, 6276764, 112.83492};  // the vector the reference's test holds for packet 0 at scale 1
     ASSERT_FLOAT_EQ(pose.rotation().determinant(), 1.0);
-    ASSERT_FLOAT_EQ(pose.translation().x(), 937631.25);
-    ASSERT_FLOAT_EQ(pose.translation().y(), 6276764);
-    ASSERT_FLOAT_EQ(pose.translation().z(), 112.83492);
+    for (int j = 0; j < 3; ++j) ASSERT_FLOAT_EQ(pose.translation()(j), mercator_xyz[j]);
   }
   CASE("DataIoTest.LoadOdometryProperly");  // test_data_io.cpp:10-30
   {
@@ -365,43 +380,29 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
 
   CASE("FractionOfScanCompletedTest");  // test_timestamp_mocking.cpp:48-58
   {
-    Frame const test_frame{MakeMotionCompensationTestFrame()};
-    Pointcloud const& c{test_frame.scan.cloud};
-    ASSERT_FLOAT_EQ(FractionOfScanCompleted(c.row(0)), 0.25);
-    ASSERT_FLOAT_EQ(FractionOfScanCompleted(c.row(1)), 0.5);
-    ASSERT_FLOAT_EQ(FractionOfScanCompleted(c.row(2)), 0.75);
+    Frame const f{ThreePointFrame()};
+    for (Index i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(FractionOfScanCompleted(f.scan.cloud.row(i)), three_point_frame::kSweepFraction[i]);
   }
   CASE("PsuedoTimeStampTest");  // :60-74
   {
-    Frame const f{MakeMotionCompensationTestFrame()};
-    ASSERT_FLOAT_EQ(GetPseudoTimeStamp(f.scan.cloud.row(0), f.scan.stamp_start, f.scan.stamp_end), 0.125);
-    ASSERT_FLOAT_EQ(GetPseudoTimeStamp(f.scan.cloud.row(1), f.scan.stamp_start, f.scan.stamp_end), 0.15);
-    ASSERT_FLOAT_EQ(GetPseudoTimeStamp(f.scan.cloud.row(2), f.scan.stamp_start, f.scan.stamp_end), 0.175);
+    Frame const f{ThreePointFrame()};
+    for (Index i = 0; i < 3; ++i)
+      ASSERT_FLOAT_EQ(GetPseudoTimeStamp(f.scan.cloud.row(i), f.scan.stamp_start, f.scan.stamp_end), three_point_frame::kPseudoStamp[i]);
   }
   CASE("PsuedoTimeStampFrameInitializationTest");  // :76-87 (GetPseudoTimeStamps ran on the GPU inside the fixture)
   {
-    Frame const f{MakeMotionCompensationTestFrame()};
-    ASSERT_FLOAT_EQ(f.scan.timestamps(0), 0.125);
-    ASSERT_FLOAT_EQ(f.scan.timestamps(1), 0.15);
-    ASSERT_FLOAT_EQ(f.scan.timestamps(2), 0.175);
+    Frame const f{ThreePointFrame()};
+    for (Index i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(f.scan.timestamps(i), three_point_frame::kPseudoStamp[i]);
   }
   CASE("TestFrameFixture.MotionCompensateFrame");  // test_motion_compensation.cpp:54-76
   {
-    Frame const frame{MakeMotionCompensationTestFrame()};
+    Frame const frame{ThreePointFrame()};
     Time const requested_time{frame.scan.stamp_middle};
     Pointcloud const mc{MotionCompensateFrame(frame, requested_time)};
-    Vector4d const point_1{mc.row(0)};
-    ASSERT_FLOAT_EQ(point_1(0), -0.27829874);
-    ASSERT_FLOAT_EQ(point_1(1), 5.0);
-    ASSERT_FLOAT_EQ(point_1(2), 0.0);
-    ASSERT_FLOAT_EQ(point_1(3), 1.0);
-    Vector4d const point_2{mc.row(1)};
-    for (int j = 0; j < 4; ++j) ASSERT_FLOAT_EQ(point_2(j), frame.scan.cloud(1, j));
-    Vector4d const point_3{mc.row(2)};
-    ASSERT_FLOAT_EQ(point_3(0), 0.27829874);
-    ASSERT_FLOAT_EQ(point_3(1), -5.0);
-    ASSERT_FLOAT_EQ(point_3(2), 0.0);
-    ASSERT_FLOAT_EQ(point_3(3), 1.0);
+    for (Index i = 0; i < 3; ++i) {  // x moves by what the vehicle drove between the point's stamp and the trigger; y, z, w stay
+      ASSERT_FLOAT_EQ(mc(i, 0), three_point_frame::kDeskewedX[i]);
+      for (int j = 1; j < 4; ++j) ASSERT_FLOAT_EQ(mc(i, j), three_point_frame::kPoint[i][j]);
+    }
     // inputs are never mutated; MotionCompensatePoint agrees with the frame call
     ASSERT_FLOAT_EQ(frame.scan.cloud(0, 1), 5.0);
     TrajectoryInterpolator const ti(frame.scan.stamp_start, frame.T_start, frame.scan.stamp_end, frame.T_end);
@@ -472,7 +473,7 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
   }
   CASE("MotionCompensateFrame(Frame, Trajectory, Time): 2 knots == the 2-argument function, bit for bit");
   {
-    Frame const frame{MakeMotionCompensationTestFrame()};
+    Frame const frame{ThreePointFrame()};
     Trajectory const two{{frame.scan.stamp_start, frame.scan.stamp_end}, {frame.T_start, frame.T_end}};
     Pointcloud const a{MotionCompensateFrame(frame, frame.scan.stamp_middle)};
     Pointcloud const b{MotionCompensateFrame(frame, two, frame.scan.stamp_middle)};
@@ -488,7 +489,7 @@ static void gpu_cases(std::string const& golden, std::string const& tmp) {
     Oxts const o0{Time(0.05), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     Oxts const o1{Time(0.15), 0.0, 0.00001, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     Oxts const o2{Time(0.25), 0.0, 0.00002, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    Frame const frame{MakeMotionCompensationTestFrame()};
+    Frame const frame{ThreePointFrame()};
     Trajectory const three{{o0.stamp, o1.stamp, o2.stamp}, {OxtsToPose(o0), OxtsToPose(o1), OxtsToPose(o2)}};
     Pointcloud const mc{MotionCompensateFrame(frame, three, frame.scan.stamp_middle)};
     ASSERT_FLOAT_EQ(mc(0, 0), -0.27829874);
@@ -759,12 +760,12 @@ int main(int argc, char** argv) {
     (void)ti.GetPoseAtTime(0);
     return 0;  // not reached
   } else if (mode == "death_frame") {  // a point stamp outside the scan: MotionCompensateFrame must abort
-    Frame frame{MakeMotionCompensationTestFrame()};
+    Frame frame{ThreePointFrame()};
     frame.scan.timestamps(1) = 0.25;
     (void)MotionCompensateFrame(frame, frame.scan.stamp_middle);
     return 0;
   } else if (mode == "death_point") {  // requested_time outside the trajectory
-    Frame const frame{MakeMotionCompensationTestFrame()};
+    Frame const frame{ThreePointFrame()};
     TrajectoryInterpolator const ti(frame.scan.stamp_start, frame.T_start, frame.scan.stamp_end, frame.T_end);
     (void)MotionCompensatePoint(ti, 0.15, Vector4d{1, 2, 3, 1}, 0.5);
     return 0;
