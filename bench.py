@@ -480,9 +480,9 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
 
     torch.cuda.synchronize()
     ctx.set_stream(None)  # the context's own stream, like configs1_literal
-    ao_before = ctx.any_order_launches()
+    ao_before, calls_before = ctx.any_order_launches(), state["k"]
     ms = timed(traj, 120, 12)
-    ao_share = (ctx.any_order_launches() - ao_before) / 132
+    ao_share = (ctx.any_order_launches() - ao_before) / max(1, state["k"] - calls_before)  # (the warm-up runs for at least 40 ms: count the calls made)
     ctx.synchronize()
     ctx.set_stream(caller_stream)
     leg = {"workload": "north_star's three bracketing poses used directly (piecewise geodesic, 2 segments): one synthetic 10 M-point frame per kmc_hip_deskew_traj_f32 call, 3 rotating buffer pairs",
