@@ -265,8 +265,9 @@ int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* ctx);
 /* How many frames of this context have been dispatched without the barrier bit so far (a counter for tests and tuning). */
 uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
-/* THE DIRECT QUEUE (ABI 5).  On the context's OWN stream (the state after kmc_hip_create) a device-resident kmc_hip_deskew_f32 call does
- * not go through a HIP launch: the library writes the frame's AQL dispatch packet into an HSA queue of the context's own, with the
+/* THE DIRECT QUEUE (ABI 5).  On the context's OWN stream (the state after kmc_hip_create) a device-resident kmc_hip_deskew_f32 call -- and a
+ * device-resident kmc_hip_deskew_traj_f32 call of up to four knots without an index output (north_star's three bracketing poses: the segment
+ * records ride in the argument block, 2.7 us per KITTI frame instead of 5.5) -- does not go through a HIP launch: the library writes the frame's AQL dispatch packet into an HSA queue of the context's own, with the
  * argument block in device memory -- 1.7-2.0 us per KITTI frame per call instead of the 3.5-4.7 us of the HIP runtime's launch path
  * (which costs 2.2-3.5 us through every launch API).  Same kernel body, same bits (checked on the device when the queue is opened, at the
  * first such call).  The barrier bit of a packet is decided like before: a frame that shares no buffer with the frames in flight goes out

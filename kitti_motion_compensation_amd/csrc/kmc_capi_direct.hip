@@ -56,6 +56,19 @@ struct DirectArgs {  // == the kernels' parameter list (kmc_direct_kernels.hip; 
 static_assert(sizeof(DirectArgs) == 240 && offsetof(DirectArgs, f) == 32 && offsetof(DirectArgs, head) == 96 && offsetof(DirectArgs, tile_base) == 104 && offsetof(DirectArgs, d) == 112,
               "the argument block the code object expects");
 
+struct TrajDirectArgs {  // == kmc_direct_traj_t*'s parameter list: an N-knot frame with its segment records in the block
+  const v4f* in;
+  v4f* out;
+  uint64_t n;
+  uint32_t n_seg;
+  uint32_t head;
+  uint64_t tile_base;
+  kmc_dev::TrajInline inl;
+};
+static_assert(sizeof(TrajDirectArgs) == 1152 && offsetof(TrajDirectArgs, tile_base) == 32 && offsetof(TrajDirectArgs, inl) == 48, "the argument block the code object expects");
+constexpr size_t kSlotBytes = sizeof(TrajDirectArgs);  // one ring slot holds the larger of the two blocks
+static_assert(kSlotBytes % 64 == 0 && sizeof(DirectArgs) <= kSlotBytes, "ring slots are 64-byte aligned");
+
 namespace {
 constexpr uint32_t kQueuePackets = 4096;
 constexpr double kWaitSeconds = 10.0;
@@ -64,7 +77,8 @@ struct AgentCode {  // per HSA agent, once per process
   bool tried = false, ok = false;
   hsa_agent_t gpu{}, cpu{};
   hsa_executable_t exe{};
-  uint64_t kernel_object[4] = {0, 0, 0, 0};
+  uint64_t kernel_object[4] = {0, 0, 0, 0};       // kmc_direct_frame_t<tier>
+  uint64_t kernel_object_traj[4] = {0, 0, 0, 0};  // kmc_direct_traj_t<tier>
   uint32_t group_size = 0, private_size = 0;
   hsa_amd_memory_pool_t device_pool{};
   hsa_amd_hdp_flush_t hdp = {nullptr, nullptr};
@@ -135,16 +149,18 @@ AgentCode* agent_code(int device) {
   if (hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &ac.exe) != HSA_STATUS_SUCCESS) return nullptr;
   if (hsa_executable_load_agent_code_object(ac.exe, ac.gpu, reader, nullptr, nullptr) != HSA_STATUS_SUCCESS) return nullptr;
   if (hsa_executable_freeze(ac.exe, nullptr) != HSA_STATUS_SUCCESS) return nullptr;
-  static const char* const names[4] = {"kmc_direct_frame_t0.kd", "kmc_direct_frame_t1.kd", "kmc_direct_frame_t2.kd", "kmc_direct_frame_t3.kd"};
-  for (int t = 0; t < 4; ++t) {
+  static const char* const names[8] = {"kmc_direct_frame_t0.kd", "kmc_direct_frame_t1.kd", "kmc_direct_frame_t2.kd", "kmc_direct_frame_t3.kd",
+                                       "kmc_direct_traj_t0.kd",  "kmc_direct_traj_t1.kd",  "kmc_direct_traj_t2.kd",  "kmc_direct_traj_t3.kd"};
+  for (int t = 0; t < 8; ++t) {
     hsa_executable_symbol_t sym;
     uint32_t karg = 0, group = 0, priv = 0;
+    uint64_t* object = t < 4 ? &ac.kernel_object[t] : &ac.kernel_object_traj[t - 4];
     if (hsa_executable_get_symbol_by_name(ac.exe, names[t], &ac.gpu, &sym) != HSA_STATUS_SUCCESS) return nullptr;
-    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &ac.kernel_object[t]) != HSA_STATUS_SUCCESS) return nullptr;
+    if (hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, object) != HSA_STATUS_SUCCESS) return nullptr;
     (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &karg);
     (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &group);
     (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv);
-    if (karg != sizeof(DirectArgs) || priv != 0) return nullptr;  // (a kernel that needs scratch would need the queue's scratch set up: not this one)
+    if (karg != (t < 4 ? sizeof(DirectArgs) : sizeof(TrajDirectArgs)) || priv != 0) return nullptr;  // (a kernel that needs scratch would need the queue's scratch set up: not these)
     ac.group_size = std::max(ac.group_size, group);
     ac.private_size = std::max(ac.private_size, priv);
   }
@@ -180,7 +196,7 @@ struct OrderRec {
 
 struct Lane {
   hsa_queue_t* q = nullptr;
-  DirectArgs* ring = nullptr;  // device-local memory, host-mapped
+  char* ring = nullptr;        // kQueuePackets slots of kSlotBytes: device-local memory, host-mapped
   hsa_signal_t done{};         // direct_join's completion signal
   uint64_t widx = 0;           // next packet slot (single producer: the context's calling thread)
   bool first_after_transition = true;
@@ -285,13 +301,11 @@ int direct_join(kmc_ctx* c) {
 }
 
 // one frame = one packet (frames beyond 2^26 - 1 tiles: several, told their first tile).  `barrier`: the frame is ORDERED behind every
-// frame dispatched before it; false: it is independent of every frame in flight.
-int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& rd, uint32_t head, bool barrier, uint32_t* launches_out) {
+// frame dispatched before it; false: it is independent of every frame in flight.  `args`: the kernel's argument block (arg_bytes of it,
+// <= kSlotBytes, 16-byte aligned), `tile_base_at`: where its first-tile field sits.
+namespace {
+int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_bytes, size_t tile_base_at, uint64_t n_tiles, bool barrier, uint32_t* launches_out) {
   DirectQueue* d = c->dd;
-  in -= head;
-  out -= head;
-  n += head;
-  const uint64_t n_tiles = (n + kTile - 1) / kTile;
   const bool ordered_frame = barrier || n_tiles > kMaxTilesPerLaunch;  // (a frame of several packets keeps to lane 0, its packets ordered)
   int li = 0;
   hsa_signal_t completion{0};
@@ -328,23 +342,22 @@ int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, cons
     if (!wait_for_room(l)) return queue_stuck(c, "direct queue: the packet processor stopped consuming packets");
     const uint32_t tiles = (uint32_t)std::min<uint64_t>(kMaxTilesPerLaunch, n_tiles - t0);
     const bool last_packet = t0 + kMaxTilesPerLaunch >= n_tiles;
-    DirectArgs* a = l->ring + (l->widx % kQueuePackets);
-    alignas(64) DirectArgs mine;
-    mine.in = in; mine.out = out; mine.n = n; mine.f = f; mine.head = head; mine.tile_base = t0; mine.d = rd;
-    std::memcpy((void*)a, &mine, sizeof(mine));  // over the BAR, write-combined: one sequential pass over the 240 bytes
+    char* a = l->ring + (size_t)(l->widx % kQueuePackets) * kSlotBytes;
+    std::memcpy(static_cast<char*>(args) + tile_base_at, &t0, sizeof(t0));
+    std::memcpy(a, args, arg_bytes);  // over the BAR, write-combined: one sequential pass over the block
     // the block must have landed in device memory before the packet processor can see the packet: fence, HDP flush, one read back over the
     // link (what the HIP runtime does for device-resident kernel arguments; tools/aql_probe: without the read-back 1.5 us per frame instead
     // of 2.1 and no stale block in 40 000 dispatches -- kept all the same: a stale argument block is a silently wrong frame)
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     if (d->code->hdp.HDP_MEM_FLUSH_CNTL) *(volatile uint32_t*)d->code->hdp.HDP_MEM_FLUSH_CNTL = 1u;
-    if (d->readback) (void)*(volatile uint32_t*)&a->head;  // (KMC_DIRECT_READBACK=0, a measurement knob: the three posted writes alone)
+    if (d->readback) (void)*(volatile uint32_t*)(a + arg_bytes - 4);  // (KMC_DIRECT_READBACK=0, a measurement knob: the posted writes alone)
     auto* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(l->q->base_address) + (l->widx % kQueuePackets);
     p->workgroup_size_x = kTile; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
     p->reserved0 = 0;
     p->grid_size_x = tiles * (uint32_t)kTile; p->grid_size_y = 1; p->grid_size_z = 1;
     p->private_segment_size = d->code->private_size;
     p->group_segment_size = d->code->group_size;
-    p->kernel_object = d->code->kernel_object[tier];
+    p->kernel_object = kernel_object;
     p->kernarg_address = a;
     p->reserved2 = 0;
     p->completion_signal.handle = last_packet ? completion.handle : 0;
@@ -362,6 +375,20 @@ int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, cons
   ++d->frames;
   if (launches_out) *launches_out = launches;
   return KMC_OK;
+}
+}  // namespace
+
+int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& rd, uint32_t head, bool barrier, uint32_t* launches_out) {
+  alignas(64) DirectArgs mine;
+  mine.in = in - head; mine.out = out - head; mine.n = n + head; mine.f = f; mine.head = head; mine.tile_base = 0; mine.d = rd;
+  return dispatch_frame(c, c->dd->code->kernel_object[tier], &mine, sizeof(mine), offsetof(DirectArgs, tile_base), (mine.n + kTile - 1) / kTile, barrier, launches_out);
+}
+
+// an N-knot frame whose segment records (<= kInlineSegments) travel in the argument block: deskew_traj_f32<tier, false, true>'s twin
+int direct_traj_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, uint32_t n_seg, uint32_t head, const kmc_dev::TrajInline& inl, bool barrier, uint32_t* launches_out) {
+  alignas(64) TrajDirectArgs mine;
+  mine.in = in - head; mine.out = out - head; mine.n = n + head; mine.n_seg = n_seg; mine.head = head; mine.tile_base = 0; mine.inl = inl;
+  return dispatch_frame(c, c->dd->code->kernel_object_traj[tier], &mine, sizeof(mine), offsetof(TrajDirectArgs, tile_base), (mine.n + kTile - 1) / kTile, barrier, launches_out);
 }
 
 // Opens the context's direct queue (once; nullptr afterwards if this device / runtime cannot: no large BAR, no HDP flush register, the
@@ -385,7 +412,7 @@ bool direct_open(kmc_ctx* c) {
   bool ok = true;
   for (Lane& l : d->lane) {
     ok = ok && hsa_queue_create(code->gpu, kQueuePackets, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &l.q) == HSA_STATUS_SUCCESS;
-    ok = ok && hsa_amd_memory_pool_allocate(code->device_pool, sizeof(DirectArgs) * kQueuePackets, 0, (void**)&l.ring) == HSA_STATUS_SUCCESS;
+    ok = ok && hsa_amd_memory_pool_allocate(code->device_pool, kSlotBytes * kQueuePackets, 0, (void**)&l.ring) == HSA_STATUS_SUCCESS;
     ok = ok && hsa_amd_agents_allow_access(1, &code->cpu, nullptr, l.ring) == HSA_STATUS_SUCCESS;  // fails without a large BAR
     ok = ok && hsa_signal_create(1, 0, nullptr, &l.done) == HSA_STATUS_SUCCESS;
     if (ok) l.widx = hsa_queue_load_write_index_relaxed(l.q);

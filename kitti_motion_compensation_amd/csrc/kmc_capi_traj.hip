@@ -166,14 +166,35 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   // every point stamp lies in [stamp_start, stamp_end]: the trajectory has to cover the scan
   if (!(knot_times[0] <= stamp_start && stamp_end <= knot_times[n_knots - 1])) return KMC_ERR_TIME_OUT_OF_RANGE;
   if (!(requested_time >= stamp_start && requested_time <= stamp_end)) return KMC_ERR_TIME_OUT_OF_RANGE;
-  KMC_HIP_TRY(c, hipSetDevice(c->device));
   const bool inline_records = mem_kind == KMC_MEM_DEVICE && th.n_seg <= (uint32_t)kInlineSegments;
   // in order on the context's stream, but -- like kmc_hip_deskew_f32 -- not behind frames it shares no buffer with (kmc_ctx::ao)
   const bool window = inline_records && !c->timing && c->gl.count == 0 && !bracket_idx_out && n;
+  // The context's OWN stream: such a frame goes out through the direct queue like a two-pose frame (kmc_capi_direct.hip) -- its records
+  // ride in the packet's argument block, no HIP call on the way.  Same tile body as the HIP launch below, same bits.
+  const bool direct = window && c->stream == c->own_stream && c->fq_count <= 1 && !c->dd_broken && (c->dd || direct_open(c));  // (not with gathering on: kmc_hip.h)
+  if (!(direct && !c->stream_dirty)) KMC_HIP_TRY(c, hipSetDevice(c->device));
+  if (direct) {
+    if (c->stream_dirty) {
+      KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->stream_dirty = false;
+    }
+    const int tier_d = traj_tier(c, th, stamp_start, stamp_end);
+    TrajInline inl;
+    std::memset(&inl, 0, sizeof(inl));
+    fill_traj_segs(th, stamp_start, stamp_end, inl.s, inl.d);
+    const uintptr_t bytes = (uintptr_t)n * sizeof(v4f);
+    const kmc_ctx::AoRange r = {(uintptr_t)xyzi_in, (uintptr_t)xyzi_in + bytes}, w = {(uintptr_t)xyzi_out, (uintptr_t)xyzi_out + bytes};
+    const bool free_order = c->ao.admit(r, w, c->dd_free_order, true);
+    uint32_t launches = 0;
+    rc = direct_traj_frame(c, tier_d, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, th.n_seg, head_of(xyzi_out, KMC_MEM_DEVICE), inl, !free_order, &launches);
+    if (rc != KMC_OK) return rc;
+    if (st) { st->n_points = n; st->variant = (uint32_t)tier_d; st->n_launches = launches; }
+    return KMC_OK;
+  }
   if (!window) {
     rc = fq_join(c);  // (also issues two-pose frames that are still being gathered: the N-knot kernel is launched per call)
     if (rc != KMC_OK) return rc;
-  } else if (c->dd_pending) {  // a HIP launch behind two-pose frames in the direct queue: wait for them (kmc_capi_direct.hip)
+  } else if (c->dd_pending) {  // a HIP launch behind frames in the direct queue: wait for them (kmc_capi_direct.hip)
     rc = direct_join(c);
     if (rc != KMC_OK) return rc;
   }

@@ -277,6 +277,7 @@ bool direct_open(kmc_ctx* c);   // the context's queue exists (opened at first n
 void direct_close(kmc_ctx* c);
 int direct_join(kmc_ctx* c);    // every frame dispatched through the queue has completed (bounded wait)
 int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head, bool barrier, uint32_t* launches_out);
+int direct_traj_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, uint32_t n_seg, uint32_t head, const kmc_dev::TrajInline& inl, bool barrier, uint32_t* launches_out);
 void ao_ensure(kmc_ctx* c);  // runs the dispatch probe if its verdict is not known yet
 bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call);  // may this frame be dispatched without the barrier bit?  (kmc_capi_core.hip)
 bool host_pool_owns(const void* ptr, size_t bytes);  // inside a live block of the page-locked host pool (kmc_capi_hostpool.hip)

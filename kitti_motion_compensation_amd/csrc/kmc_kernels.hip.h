@@ -768,23 +768,11 @@ struct TrajInline {
   TrajSeg32 s[kInlineSegments];
   TrajSegD d[kInlineSegments];
 };
-template <int TIER, bool WRITE_IDX, bool INLINE = false>
-__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
-                                                     const TrajSeg32* __restrict__ segs, uint32_t n_seg,
-                                                     uint32_t* __restrict__ bracket_out, uint32_t head,
-                                                     const TrajSegD* __restrict__ segs64, uint64_t tile_base, TrajInline inl) {
-  // `head`: dead leading indices, see frame_tile; `tile_base`: first tile of this launch
-  seg_cp segs_c;
-  if constexpr (INLINE) {
-    struct ArgLayout { const v4f* in; v4f* out; uint64_t n; const TrajSeg32* segs; uint32_t n_seg; uint32_t* bracket_out; uint32_t head; const TrajSegD* segs64; uint64_t tile_base; TrajInline inl; };
-    const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    segs_c = (seg_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, s));
-    segs64 = (const TrajSegD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, d));
-  } else {
-    segs_c = (seg_cp)(uintptr_t)segs;  // written by the host before the launch: constant for the kernel
-  }
+// one 64-point tile of an N-knot frame (the body of deskew_traj_f32 and of the direct queue's kmc_direct_traj_t* kernels)
+template <int TIER, bool WRITE_IDX>
+__device__ __forceinline__ void traj_tile(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n, seg_cp segs_c, uint32_t n_seg, uint32_t* __restrict__ bracket_out,
+                                          uint32_t head, const TrajSegD* __restrict__ segs64, uint64_t t) {
   const uint32_t tid = threadIdx.x;
-  const uint64_t t = tile_base + blockIdx.x;
   const uint64_t base = t * kTile;
   if (base >= n) return;
   const uint64_t i = base + tid;
@@ -807,6 +795,24 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if (alive) __builtin_nontemporal_store(k, bracket_out + i);
   }
   traj_redo_lanes(redo_any && alive, p, segs64, redo_seg, [&](v4f v) { tile_store(rout, (uint32_t)(tid * sizeof(v4f)), v); });
+}
+
+template <int TIER, bool WRITE_IDX, bool INLINE = false>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_traj_f32(const v4f* __restrict__ in, v4f* __restrict__ out, uint64_t n,
+                                                     const TrajSeg32* __restrict__ segs, uint32_t n_seg,
+                                                     uint32_t* __restrict__ bracket_out, uint32_t head,
+                                                     const TrajSegD* __restrict__ segs64, uint64_t tile_base, TrajInline inl) {
+  // `head`: dead leading indices, see frame_tile; `tile_base`: first tile of this launch
+  seg_cp segs_c;
+  if constexpr (INLINE) {
+    struct ArgLayout { const v4f* in; v4f* out; uint64_t n; const TrajSeg32* segs; uint32_t n_seg; uint32_t* bracket_out; uint32_t head; const TrajSegD* segs64; uint64_t tile_base; TrajInline inl; };
+    const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    segs_c = (seg_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, s));
+    segs64 = (const TrajSegD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(TrajInline, d));
+  } else {
+    segs_c = (seg_cp)(uintptr_t)segs;  // written by the host before the launch: constant for the kernel
+  }
+  traj_tile<TIER, WRITE_IDX>(in, out, n, segs_c, n_seg, bracket_out, head, segs64, tile_base + blockIdx.x);
 }
 
 // Batched N-knot kernel: many frames in one launch, every frame with its own trajectory (its own segment records).

@@ -233,3 +233,85 @@ def test_a_frame_behind_an_ordered_frame_still_sees_what_was_written_before_it()
     finally:
         direct.close()
         hip.close()
+
+
+def _knots(k, n_knots):
+    """n_knots stamped poses along a gentle curve; frame k gets its own speeds"""
+    t0 = 47072.0
+    times = [t0 + 0.05 + 0.1 * j for j in range(n_knots)]
+    poses = []
+    for j in range(n_knots):
+        yaw = (0.02 + 0.003 * k) * j
+        c, s = np.cos(yaw), np.sin(yaw)
+        M = np.eye(4)[:3].copy()
+        M[:2, :2] = [[c, -s], [s, c]]
+        M[:, 3] = [(1.2 + 0.01 * k) * j, 0.02 * j * j, 0.001 * j]
+        poses.append(M)
+    return times, np.stack(poses), t0 + 0.10, t0 + 0.05 + 0.1 * (n_knots - 1) - 0.05, t0 + 0.12
+
+
+def test_n_knot_frames_with_their_records_in_the_argument_block_go_through_the_direct_queue():
+    """north_star's three bracketing poses on a device-resident frame (kmc_hip_deskew_traj_f32, up to four knots, no index output): on the
+    context's own stream an AQL packet like the two-pose frame, its segment records in the packet's argument block.  Same bits as the HIP
+    launch; mixed with two-pose frames, a chain and an in-place repeat keep their order; five knots (a record table) and an index output
+    take the HIP launch, behind the queue."""
+    import torch
+
+    direct, hip = _ctx(), _ctx(KMC_DIRECT_DISPATCH="0")
+    try:
+        sizes = [123_397, 65, 64, 1, 200_003, 4097]
+        ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for n in sizes]
+        for k, a in enumerate(ins):
+            direct.synth_points(a, a.shape[0], 500 + k)
+        direct.synchronize()
+
+        def script(ctx):
+            outs = []
+            for k, a in enumerate(ins):                        # independent frames, 3 and 4 knots alternating with two-pose frames
+                o = torch.zeros_like(a)
+                tk, P, ts, te, tr = _knots(k, 3 + k % 2)
+                st = ctx.deskew_traj_f32(a, o, tk, P, ts, te, tr)
+                assert st.n_points == a.shape[0] and st.n_launches == 1
+                outs.append(o)
+                o2 = torch.zeros_like(a)
+                ctx.deskew_f32(a, o2, _params(k))
+                outs.append(o2)
+            chain = [ins[0]]                                     # a chain: N-knot -> two-pose -> N-knot, then in place twice
+            for k in range(3):
+                o = torch.zeros_like(ins[0])
+                if k % 2 == 0:
+                    tk, P, ts, te, tr = _knots(10 + k, 3)
+                    ctx.deskew_traj_f32(chain[-1], o, tk, P, ts, te, tr)
+                else:
+                    ctx.deskew_f32(chain[-1], o, _params(k))
+                chain.append(o)
+            y = chain[-1]
+            for k in range(2):
+                tk, P, ts, te, tr = _knots(20 + k, 4)
+                ctx.deskew_traj_f32(y, y, tk, P, ts, te, tr)
+            outs.append(y)
+            five = torch.zeros_like(ins[0])                      # five knots: four segments do not fit the block -> HIP launch behind the queue
+            tk, P, ts, te, tr = _knots(30, 5)
+            ctx.deskew_traj_f32(y, five, tk, P, ts, te, tr)
+            outs.append(five)
+            idx = torch.zeros((sizes[0],), dtype=torch.int32, device="cuda")
+            with_idx = torch.zeros_like(ins[0])
+            tk, P, ts, te, tr = _knots(31, 3)
+            ctx.deskew_traj_f32(five, with_idx, tk, P, ts, te, tr, bracket_idx_out=idx)
+            outs += [with_idx, idx.view(torch.float32).reshape(-1, 1)]
+            ctx.synchronize()
+            return outs
+
+        want = script(hip)
+        before = direct.direct_frames()
+        got = script(direct)
+        if direct.direct_frames() == 0:
+            pytest.skip("no direct queue on this device / runtime")
+        # 6 N-knot + 6 two-pose + 3 chain links + 2 in-place repeats through the queue; the five-knot frame and the one with an index output not
+        assert direct.direct_frames() - before == 17, direct.direct_frames() - before
+        assert hip.direct_frames() == 0
+        for k, (w, g) in enumerate(zip(want, got)):
+            assert torch.equal(w.view(torch.int32), g.view(torch.int32)), k
+    finally:
+        direct.close()
+        hip.close()

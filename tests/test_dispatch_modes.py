@@ -4,6 +4,7 @@ N-knot frame, a host in-place call) in between -- replayed under every dispatch 
 
     default                          the context's own stream: frames go out through the DIRECT QUEUE (AQL packets the library writes itself),
                                      without the barrier bit when they share no buffer with a frame in flight
+    direct_queue_on_one_lane         KMC_DIRECT_LANES=1: the direct queue on ONE HSA queue (by default independent frames alternate between two)
     hip_launches_only                KMC_DIRECT_DISPATCH=0: every frame a HIP launch, barrier-free (hipExtAnyOrderLaunch) where probed
     barrier_bit_on_every_dispatch    KMC_ANY_ORDER=0 (direct queue, every packet ordered)
     hip_launches_with_the_barrier_bit  KMC_DIRECT_DISPATCH=0 and KMC_ANY_ORDER=0
@@ -26,13 +27,13 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-MODES = ["serial", "default", "hip_launches_only", "barrier_bit_on_every_dispatch", "hip_launches_with_the_barrier_bit", "gathered_calls", "gathered_on_a_callers_stream",
+MODES = ["serial", "default", "direct_queue_on_one_lane", "hip_launches_only", "barrier_bit_on_every_dispatch", "hip_launches_with_the_barrier_bit", "gathered_calls", "gathered_on_a_callers_stream",
          "list_table_route"]
 
 
 def _make_ctx(mode, torch):
     env = {"serial": {"KMC_ANY_ORDER": "0"}, "barrier_bit_on_every_dispatch": {"KMC_ANY_ORDER": "0"}, "list_table_route": {"KMC_LIST_ROUTE": "table"},
-           "hip_launches_only": {"KMC_DIRECT_DISPATCH": "0"}, "hip_launches_with_the_barrier_bit": {"KMC_DIRECT_DISPATCH": "0", "KMC_ANY_ORDER": "0"}}.get(mode, {})
+           "direct_queue_on_one_lane": {"KMC_DIRECT_LANES": "1"}, "hip_launches_only": {"KMC_DIRECT_DISPATCH": "0"}, "hip_launches_with_the_barrier_bit": {"KMC_DIRECT_DISPATCH": "0", "KMC_ANY_ORDER": "0"}}.get(mode, {})
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -157,6 +158,7 @@ def test_the_configurations_really_differ(replay):
     assert results["gathered_calls"]["_direct_frames"] == 0 and results["gathered_on_a_callers_stream"]["_direct_frames"] == 0
     if results["default"]["_direct_frames"]:
         assert results["default"]["_direct_frames"] >= 20 and results["serial"]["_direct_frames"] >= 20
+        assert results["direct_queue_on_one_lane"]["_direct_frames"] == results["default"]["_direct_frames"]
         assert results["default"]["_any_order_launches"] >= 8  # plain AQL semantics: no probe needed for packets without the barrier bit
     if results["hip_launches_only"]["_verdict"] == 1:
         assert results["hip_launches_only"]["_any_order_launches"] >= 8

@@ -10,7 +10,7 @@ ROOT=$PWD
 O=$ROOT/gpurun_out/$TAG
 mkdir -p "$O"
 export TMPDIR=/tmp
-run() { echo "== $*" >&2; "$@"; }
+run() { echo "== $*" >&2; timeout 600 "$@"; }
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -o bench -- python bench.py --no-cpu-baseline --no-live-traffic --no-configs3 --no-legs --sustained-seconds 0 > "$O/bench_kt.log" 2>&1
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-configs3 --no-legs --sustained-seconds 0 > "$O/bench_fetch.log" 2>&1
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-live-traffic --no-configs3 --no-legs --sustained-seconds 0 > "$O/bench_write.log" 2>&1
@@ -25,6 +25,6 @@ KMC_ANY_ORDER=0 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_stream" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 4 > "$O/stream_kt.json" 2> "$O/stream_kt.err"
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_stream_fetch" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 2 > /dev/null 2>&1
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_stream_write" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 2 > /dev/null 2>&1
-python bench.py > "$O/bench_plain.json" 2> "$O/bench_plain.err"
+timeout 600 python bench.py > "$O/bench_plain.json" 2> "$O/bench_plain.err"
 tail -1 "$O/bench_plain.json" | cut -c1-200
 grep -h "deskew_batch_f32" "$O"/kt/bench_kernel_stats.csv | cut -c1-60,200-320

@@ -10,6 +10,7 @@
 //   per_call            one kmc_hip_deskew_f32 call per frame, in order on the context's own stream: since round 5 through the context's DIRECT
 //                       QUEUE (AQL packets the library writes itself; frames that share no buffer with one in flight without the barrier bit)
 //   per_call_hip_launches   the same calls on a context created with KMC_DIRECT_DISPATCH=0: one HIP launch per frame (round 4's route)
+//   per_call_nknot3     one kmc_hip_deskew_traj_f32 call per frame (three knots, the records in the argument block): direct queue; _hip_launches: its twin
 //   per_call_drained    the same calls on a context created with KMC_ANY_ORDER=0 (every dispatch carries the barrier bit)
 //   per_call_gathered   the same calls with kmc_hip_set_frame_queues(ctx, 4): the library gathers them into list launches of up to 16 frames
 //   list_one_launch     kmc_hip_deskew_frames_f32: the set's frames handed over as ONE list (the key keeps its round-4 name; since round 5 a
@@ -21,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -160,6 +162,30 @@ int main(int argc, char** argv) {
     KMC_OK_OR_DIE(kmc_hip_deskew_batch_f32(c, S.packed_in, S.packed_out, offsets.data(), F, params.data(), nullptr, KMC_MEM_DEVICE, nullptr));
   };
 
+  // north_star's three bracketing poses, one kmc_hip_deskew_traj_f32 call per frame (every frame its own knots): the records ride in the
+  // dispatch's argument block -- through the direct queue on `ctx`, as HIP launches on `hip_only`
+  std::vector<double> knot_times((size_t)F * 3), knot_poses((size_t)F * 36);
+  const double T0 = 47072.0;
+  for (uint32_t f = 0; f < F; ++f)
+    for (int j = 0; j < 3; ++j) {
+      knot_times[(size_t)f * 3 + j] = T0 + 0.05 + 0.1 * j;
+      const double yaw = (0.02 + 0.0003 * (f % 31)) * j, cy = std::cos(yaw), sy = std::sin(yaw);
+      const double P[12] = {cy, -sy, 0, (1.2 + 0.001 * (f % 17)) * j, sy, cy, 0, 0.02 * j * j, 0, 0, 1, 0.001 * j};
+      std::memcpy(&knot_poses[((size_t)f * 3 + j) * 12], P, sizeof(P));
+    }
+  auto per_call_nknot = [&](kmc_ctx* c, Set& S) {
+    for (uint32_t f = 0; f < F; ++f)
+      KMC_OK_OR_DIE(kmc_hip_deskew_traj_f32(c, S.in[f], S.out[f], sizes[f], &knot_times[(size_t)f * 3], &knot_poses[(size_t)f * 36], 3, T0 + 0.10, T0 + 0.20, T0 + 0.13 + 0.0005 * (f % 40), nullptr,
+                                            KMC_MEM_DEVICE, nullptr));
+  };
+  const double us_nknot = timed(ctx, per_call_nknot);
+  const double host_nknot = host_us, dd_share_nknot = dd_share_last;
+  std::vector<std::vector<float>> want_nknot(F);
+  KMC_OK_OR_DIE(kmc_hip_synchronize(ctx));
+  for (uint32_t f = 0; f < F; ++f) {
+    want_nknot[f].resize(4 * sizes[f]);
+    HIP_OK(hipMemcpy(want_nknot[f].data(), sets[n_sets - 1].out[f], sizes[f] * 16, hipMemcpyDeviceToHost));
+  }
   const double us_call = timed(ctx, per_call);
   const double host_call = host_us, ao_share = ao_share_last, dd_share = dd_share_last;
   // the same calls as HIP launches (KMC_DIRECT_DISPATCH=0): what the runtime's launch path costs per frame
@@ -169,6 +195,18 @@ int main(int argc, char** argv) {
   unsetenv("KMC_DIRECT_DISPATCH");
   const double us_call_hip = timed(hip_only, per_call);
   const double host_call_hip = host_us;
+  const double us_nknot_hip = timed(hip_only, per_call_nknot);
+  const double host_nknot_hip = host_us;
+  bool same_nknot = true;  // the direct queue's N-knot frames against the HIP launches', bit for bit
+  KMC_OK_OR_DIE(kmc_hip_synchronize(hip_only));
+  {
+    std::vector<float> got;
+    for (uint32_t f = 0; f < F; ++f) {
+      got.resize(4 * sizes[f]);
+      HIP_OK(hipMemcpy(got.data(), sets[n_sets - 1].out[f], sizes[f] * 16, hipMemcpyDeviceToHost));
+      same_nknot = same_nknot && std::memcmp(got.data(), want_nknot[f].data(), sizes[f] * 16) == 0;
+    }
+  }
   kmc_hip_destroy(hip_only);
   const double us_drained = timed(drained, per_call);
   KMC_OK_OR_DIE(kmc_hip_set_frame_queues(ctx, 4));
@@ -208,15 +246,17 @@ int main(int argc, char** argv) {
       "\"any_order_dispatch\": %d, \"list_launches\": %u, \"list_equals_per_call_bitwise\": %s, "
       "\"per_call\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"dispatched_without_barrier_bit\": %.3f, \"through_the_direct_queue\": %.3f}, "
       "\"per_call_hip_launches\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
+      "\"per_call_nknot3\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"through_the_direct_queue\": %.3f, \"same_bits_as_hip_launches\": %s}, "
+      "\"per_call_nknot3_hip_launches\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
       "\"per_call_drained\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}, "
       "\"per_call_gathered\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
       "\"list_one_launch\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
       "\"list_table_route\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
       "\"batch_packed\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}}\n",
       F, carve ? "carved out of one allocation per set (1 KiB-aligned starts)" : "separate hipMalloc allocations", n_sets, iters, mean_pts, (unsigned long long)total, info.name, info.any_order_dispatch, st.n_launches, same ? "true" : "false", us_call,
-      gbps(us_call), host_call, ao_share, dd_share, us_call_hip, gbps(us_call_hip), host_call_hip, us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_list_table, gbps(us_list_table), host_list_table, us_batch, gbps(us_batch));
+      gbps(us_call), host_call, ao_share, dd_share, us_call_hip, gbps(us_call_hip), host_call_hip, us_nknot, gbps(us_nknot), host_nknot, dd_share_nknot, same_nknot ? "true" : "false", us_nknot_hip, gbps(us_nknot_hip), host_nknot_hip, us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_list_table, gbps(us_list_table), host_list_table, us_batch, gbps(us_batch));
   kmc_hip_destroy(drained);
   kmc_hip_destroy(tabled);
   kmc_hip_destroy(ctx);
-  return same ? 0 : 1;
+  return same && same_nknot ? 0 : 1;
 }
