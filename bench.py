@@ -344,7 +344,7 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     def stream_leg(d, key, npts, note):
         us = d[key]["us_per_frame"]
         o = {"us_per_frame": round(us, 3), "Mpts_s": round(npts / us, 1), "GBps": round(32 * npts / us / 1e3, 1), "frac": _frac(32 * npts / us / 1e3), "note": note}
-        for k in ("host_us_per_call", "host_us_per_frame", "dispatched_without_barrier_bit", "through_the_direct_queue"):
+        for k in ("host_us_per_call", "host_us_per_frame", "dispatched_without_barrier_bit", "through_the_direct_queue", "same_bits_as_hip_launches"):
             if k in d[key]:
                 o[k] = d[key][k]
         return o
@@ -357,6 +357,9 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
             "in_order": stream_leg(fs, "per_call", n, "ONE kmc_hip_deskew_f32 call per frame, in order on the context's own stream: since round 5 an AQL packet in the context's direct queue "
                                    "(through_the_direct_queue = share of the frames; below the HIP runtime's launch path); frames that share no buffer with one in flight go out without the barrier bit"),
             "in_order_hip_launches": stream_leg(fs, "per_call_hip_launches", n, "the same calls with KMC_DIRECT_DISPATCH=0: one HIP launch per frame (round 4's route), barrier-free where the run-time probe verified it") if "per_call_hip_launches" in fs else None,
+            "in_order_nknot3": stream_leg(fs, "per_call_nknot3", n, "ONE kmc_hip_deskew_traj_f32 call per frame (north_star's three bracketing poses, every frame its own knots): the segment records ride in the "
+                                          "direct queue's argument block") if "per_call_nknot3" in fs else None,
+            "in_order_nknot3_hip_launches": stream_leg(fs, "per_call_nknot3_hip_launches", n, "the same calls with KMC_DIRECT_DISPATCH=0") if "per_call_nknot3_hip_launches" in fs else None,
             "in_order_drained": stream_leg(fs, "per_call_drained", n, "the same calls on a context created with KMC_ANY_ORDER=0: every dispatch waits for the last wave of the one before it"),
             "gathered_calls": stream_leg(fs, "per_call_gathered", n, "the same calls, one per frame, with kmc_hip_set_frame_queues(ctx, 4): the library gathers them on the host and issues "
                                          "ONE launch of the frame-list kernel per up to 16 frames (deferred issue, in-order results)"),
@@ -437,6 +440,8 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
             "mean_points_per_frame": npts, "any_order_dispatch_verdict": fd["any_order_dispatch"],
             "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call per frame, in order on the context's own stream: an AQL packet in the context's direct queue (round 5)"),
             "per_call_hip_launches": stream_leg(fd, "per_call_hip_launches", npts, "KMC_DIRECT_DISPATCH=0: one HIP launch per frame (the runtime's launch path, 2.2-3.5 us through every launch API)") if "per_call_hip_launches" in fd else None,
+            "per_call_nknot3": stream_leg(fd, "per_call_nknot3", npts, "one kmc_hip_deskew_traj_f32 call per frame (three knots, the records in the direct queue's argument block)") if "per_call_nknot3" in fd else None,
+            "per_call_nknot3_hip_launches": stream_leg(fd, "per_call_nknot3_hip_launches", npts, "the same calls with KMC_DIRECT_DISPATCH=0") if "per_call_nknot3_hip_launches" in fd else None,
             "per_call_drained": stream_leg(fd, "per_call_drained", npts, "KMC_ANY_ORDER=0: the barrier bit on every dispatch"),
             "per_call_gathered": stream_leg(fd, "per_call_gathered", npts, "the same calls with kmc_hip_set_frame_queues(ctx, 4): gathered on the host, one list launch per up to 16 frames"),
             "list_one_launch": stream_leg(fd, "list_one_launch", npts, "kmc_hip_deskew_frames_f32: the 108 separate frames as one list -> 7 chained kernel-argument launches of <= 16 frames, "

@@ -64,6 +64,9 @@ def test_bench_prints_one_contract_line():
     if lit["in_order"].get("through_the_direct_queue", 0) > 0:
         assert lit["in_order"]["through_the_direct_queue"] > 0.99 and fb["per_call"]["through_the_direct_queue"] > 0.99
         assert fb["per_call"]["us_per_frame"] < fb["per_call_hip_launches"]["us_per_frame"], fb  # below the HIP runtime's launch path
+        nk = fb["per_call_nknot3"]  # north_star's three bracketing poses, one call per frame: the same queue, the records in the argument block
+        assert nk["through_the_direct_queue"] > 0.99 and nk["same_bits_as_hip_launches"] is True and nk["us_per_frame"] < fb["per_call_nknot3_hip_launches"]["us_per_frame"], fb
+        assert lit["in_order_nknot3"]["same_bits_as_hip_launches"] is True and lit["in_order_nknot3"]["frac"] > 0.5, lit["in_order_nknot3"]
     assert fb["list_launches"] == 1 and fb["list_rate_vs_batched"] > 0.85, fb  # a drive's list: ONE launch, its records in the kernel arguments
     ce = d["ceilings"]  # the box's own ceilings for the kernels' access patterns, measured in this run
     assert ce["f32_one_stream_in_one_out"]["GBps_median"] > 5000 and ce["f64_nine_column_streams"]["copy_cols9"]["GBps_median"] > 4500
