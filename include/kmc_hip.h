@@ -349,7 +349,10 @@ int kmc_hip_deskew_f64cols_end(kmc_ctx* ctx, kmc_stats* out_stats);
  * kmc_hip_deskew_f32 calls, under the same conditions -- a frame that shares no buffer with the frames in flight is dispatched without
  * the barrier bit.  (N-knot calls are launched one per call; with gathering on, kmc_hip_set_frame_queues, they first issue the
  * two-pose frames that are pending.)  Longer trajectories and host buffers go through a device table (same kernel body, same bits)
- * on the context's stream. */
+ * on the context's stream.  kmc_hip_deskew_traj_f64cols with n_knots <= 4 carries its records in the kernel arguments as well (no
+ * table upload in front of the kernel).  w == NULL means "the homogeneous column is all ones" (like kmc_hip_deskew_f64cols); if ow is
+ * wanted all the same and the columns are host memory, the HOST fills it with ones while the kernel runs -- the column crosses the
+ * link in neither direction. */
 int kmc_hip_deskew_traj_f32(kmc_ctx* ctx, const float* xyzi_in, float* xyzi_out, uint64_t n, const double* knot_times,
                             const double* knot_poses, uint32_t n_knots, double stamp_start, double stamp_end,
                             double requested_time, uint32_t* bracket_idx_out, int mem_kind, kmc_stats* out_stats);

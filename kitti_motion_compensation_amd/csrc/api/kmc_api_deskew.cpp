@@ -208,12 +208,16 @@ Pointcloud MotionCompensateFrame(Frame const& frame, Trajectory const& tr, Time 
   Pointcloud out{MatrixX4d::Uninitialized(n)};  // every element is written by the download below
   kmc_ctx* c = detail::thread_context();
   Pointcloud const& in = frame.scan.cloud;
-  int const rc = kmc_hip_deskew_traj_f64cols(c, in.col(0), in.col(1), in.col(2), in.col(3), frame.scan.timestamps.data(),
+  // (a cloud whose homogeneous column is known to be all ones -- see the 2-argument form: the column stays off the link, the C-ABI
+  // fills the result's column on the host while the kernel runs)
+  bool const ones = in.is_homogeneous();
+  int const rc = kmc_hip_deskew_traj_f64cols(c, in.col(0), in.col(1), in.col(2), ones ? nullptr : in.col(3), frame.scan.timestamps.data(),
                                              static_cast<std::uint64_t>(n), tr.times.data(), poses.data(),
                                              static_cast<std::uint32_t>(tr.times.size()), requested_time, out.col(0), out.col(1), out.col(2),
                                              out.col(3), nullptr, KMC_MEM_HOST, nullptr);
   if (rc == KMC_ERR_TIME_OUT_OF_RANGE) detail::die_time_out_of_range("kmc::MotionCompensateFrame(Frame, Trajectory, Time)");
   if (rc != KMC_OK) detail::throw_status(rc, "kmc_hip_deskew_traj_f64cols", c);
+  detail::set_homogeneous(out, ones);
   return out;
 }
 

@@ -958,6 +958,11 @@ __device__ __forceinline__ void traj_one_f64(double px, double py, double pz, do
 // MotionCompensateFrame(Frame, Trajectory, Time) on the drop-in's own containers): the grid is a few dozen persistent waves that walk the
 // tiles -- one wave per tile over the link runs at a third of the rate (tools/link_probe) --, the stores carry sc1 so that they leave
 // for host memory while the next tile's loads come in, and the last wave raises the completion word (DoneWord).
+// The segment records of a short trajectory (<= kInlineSegments: up to four knots, north_star's three bracketing poses) travel in the
+// kernel arguments (`inl`, read through the argument segment only; `segs` == nullptr says so): no table upload in front of the kernel.
+struct TrajInline64 {
+  TrajSeg64 s[kInlineSegments];
+};
 template <bool STREAMED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void deskew_traj_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, const double* __restrict__ w,
@@ -966,10 +971,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 4))) void
                                                           double t_first, double t_last, double* __restrict__ ox,
                                                           double* __restrict__ oy, double* __restrict__ oz,
                                                           double* __restrict__ ow, uint32_t* __restrict__ bracket_out,
-                                                          unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base, DoneWord dw) {
+                                                          unsigned long long* __restrict__ n_bad, uint32_t* __restrict__ bad_flag, uint64_t tile_base, DoneWord dw,
+                                                          TrajInline64 inl) {
   struct ArgLayout { const double *x, *y, *z, *w, *stamps; uint64_t n; const TrajSeg64* segs; uint32_t n_seg; double t_first, t_last; double *ox, *oy, *oz, *ow; uint32_t* bracket_out;
-                     unsigned long long* n_bad; uint32_t* bad_flag; uint64_t tile_base; DoneWord dw; };  // == the parameter list; `dw` is read through the segment only
-  const done_cp done = (done_cp)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, dw));
+                     unsigned long long* n_bad; uint32_t* bad_flag; uint64_t tile_base; DoneWord dw; TrajInline64 inl; };  // == the parameter list; `dw` and `inl` are read through the segment only
+  const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  const done_cp done = (done_cp)(kernarg + offsetof(ArgLayout, dw));
+  if (!segs) segs = (const TrajSeg64*)(const char*)(kernarg + offsetof(ArgLayout, inl));  // (wave-uniform)
   const uint32_t tid = threadIdx.x;
   const uint64_t n_tiles = (n + 127) / 128;
   uint64_t t = tile_base + blockIdx.x;

@@ -292,6 +292,64 @@ def test_f64_trajectory_vs_oracle(ctx, kitti):
 
 
 @pytest.mark.gpu
+def test_f64_trajectory_long_table_and_the_ones_column(ctx, kitti):
+    """(a) More than four knots: the records go through the device table instead of the kernel arguments -- same oracle bar.
+    (b) w = None says "the homogeneous column is all ones": same XYZ bits as an explicit column of ones; an output column that is
+    wanted all the same comes back as ones on every route -- staged (pageable numpy), in place (the page-locked pool: the HOST fills
+    it while the kernel runs, the column never crosses the link) and device-resident (the kernel writes it)."""
+    import torch
+
+    xyzi, _ = kitti
+    xyzi = xyzi[::5]
+    n = xyzi.shape[0]
+    P_local = orc.Affine.from_Rt(orc.so3_exp([0.01, -0.02, 0.7]), [12.5, -3.0, 0.4])
+    cloud = np.concatenate([xyzi[:, :3].astype(np.float64), np.ones((n, 1))], axis=1)
+    stamps = orc.pseudo_timestamps(cloud, T0, T1)
+    cols = [np.ascontiguousarray(cloud[:, j]) for j in range(4)]
+    for n_knots in (3, 7):
+        times = list(np.linspace(T0 - 0.05, T1 + 0.05, n_knots))
+        poses = _chain(P_local, [[0.4 + 0.01 * k, 0.01, -0.005, 0.001, -0.002, 0.012 + 0.001 * k] for k in range(n_knots - 1)])
+        rc_o, nbad, want, br_o = orc.motion_compensate_frame_traj(cloud, stamps, times, poses, TREQ)
+        assert rc_o == orc.OK
+        full = [np.empty(n) for _ in range(4)]
+        br = np.empty(n, dtype=np.uint32)
+        rc, st = ctx.deskew_traj_f64cols(*cols, stamps, times, _rt(poses), TREQ, *full, bracket_idx_out=br)
+        assert rc == capi.OK and st.n_out_of_range == 0 and np.array_equal(br, br_o)
+        assert util.rel_point_error(np.stack(full, axis=1)[:, :3], want[:, :3]).max() <= 1e-11
+        assert np.array_equal(full[3], cols[3])
+        # staged, no w
+        outs = [np.full(n, -7.0) for _ in range(4)]
+        ctx.deskew_traj_f64cols(cols[0], cols[1], cols[2], None, stamps, times, _rt(poses), TREQ, *outs)
+        for j in range(3):
+            assert np.array_equal(outs[j].view(np.uint64), full[j].view(np.uint64)), (n_knots, "staged", j)
+        assert np.all(outs[3] == 1.0)
+        outs3 = [np.full(n, -7.0) for _ in range(3)]  # ... and no output column either
+        ctx.deskew_traj_f64cols(cols[0], cols[1], cols[2], None, stamps, times, _rt(poses), TREQ, *outs3)
+        assert np.array_equal(outs3[0].view(np.uint64), full[0].view(np.uint64))
+        # in place on the page-locked pool
+        pin, pst, pout = capi.PooledArray((3, n)), capi.PooledArray((n,)), capi.PooledArray((4, n))
+        try:
+            pin.a[:] = np.stack(cols[:3])
+            pst.a[:] = stamps
+            pout.a[:] = -7.0
+            rc, st = ctx.deskew_traj_f64cols(pin.a[0], pin.a[1], pin.a[2], None, pst.a, times, _rt(poses), TREQ, pout.a[0], pout.a[1], pout.a[2], pout.a[3])
+            assert rc == capi.OK and st.n_launches == 1
+            for j in range(3):
+                assert np.array_equal(pout.a[j].view(np.uint64), full[j].view(np.uint64)), (n_knots, "in place", j)
+            assert np.all(pout.a[3] == 1.0)
+        finally:
+            pin.close(), pst.close(), pout.close()
+        # device-resident
+        d = [torch.from_numpy(c).cuda() for c in cols[:3]] + [torch.from_numpy(stamps).cuda()]
+        do = [torch.full((n,), -7.0, dtype=torch.float64, device="cuda") for _ in range(4)]
+        ctx.deskew_traj_f64cols(d[0], d[1], d[2], None, d[3], times, _rt(poses), TREQ, *do)
+        ctx.synchronize()
+        for j in range(3):
+            assert np.array_equal(do[j].cpu().numpy().view(np.uint64), full[j].view(np.uint64)), (n_knots, "device", j)
+        assert bool((do[3] == 1.0).all())
+
+
+@pytest.mark.gpu
 def test_trajectory_argument_checks(ctx, kitti):
     xyzi, P1 = kitti
     pts = np.ascontiguousarray(xyzi[:64])

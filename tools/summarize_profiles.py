@@ -100,12 +100,20 @@ def main():
     lf_path, lw_path = (os.path.join(src, d, "stream_counter_collection.csv") for d in ("pmc_stream_fetch", "pmc_stream_write"))
     if os.path.exists(lf_path) and os.path.exists(lw_path):
         lf, lw = counters(lf_path, "FETCH_SIZE"), counters(lw_path, "WRITE_SIZE")
-        pick_list = lambda d: [v for (k, grid, wg), v in d.items() if "deskew_list_f32<0, false>" in k and grid == 256000000]
+        # (round 5: the list's records ride in the kernel arguments -- deskew_list_f32<0, 256>; round 4: a device table -- <0, false>)
+        pick_list = lambda d: [v for (k, grid, wg), v in d.items() if ("deskew_list_f32<0, 256>" in k or "deskew_list_f32<0, false>" in k) and grid == 256000000]
         if pick_list(lf) and pick_list(lw):
             fv2, wv2 = pick_list(lf)[0], pick_list(lw)[0]
             b = (sum(fv2) / len(fv2) * fetch_factor + sum(wv2) / len(wv2) * write_factor) * 1024.0
-            list_traffic = {"kernel": "deskew_list_f32<0, false>, 2-D grid 15625 x 256 (256 separate 1 M-point frames, device tables)", "launches": len(fv2),
+            list_traffic = {"kernel": "deskew_list_f32<0, 256>, 2-D grid 15625 x 256 (256 separate 1 M-point frames, records in the kernel arguments)", "launches": len(fv2),
                             "hbm_bytes_per_launch": b, "traffic_over_algorithmic": b / (32.0 * 256000000)}
+        # the direct queue's per-frame kernels (AQL packets the library writes itself; rocprofv3 sees the HSA queue): traffic per 1 M-point frame
+        for kern, key in (("kmc_direct_frame_t0", "direct_queue_frame"), ("kmc_direct_traj_t0", "direct_queue_nknot_frame")):
+            pick = lambda d: [v for (k, grid, wg), v in d.items() if kern in k and grid == 1000000]
+            if pick(lf) and pick(lw):
+                fv3, wv3 = pick(lf)[0], pick(lw)[0]
+                b = (sum(fv3) / len(fv3) * fetch_factor + sum(wv3) / len(wv3) * write_factor) * 1024.0
+                list_traffic[key] = {"kernel": kern + " (one 1 M-point frame per AQL packet)", "dispatches": len(fv3), "hbm_bytes_per_dispatch": b, "traffic_over_algorithmic": b / 32.0e6}
     summary = {
         "tag": tag,
         "kernel": kname,
