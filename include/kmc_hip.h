@@ -272,9 +272,10 @@ uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
  * (which costs 2.2-3.5 us through every launch API).  Same kernel body, same bits (checked on the device when the queue is opened, at the
  * first such call).  The barrier bit of a packet is decided like before: a frame that shares no buffer with the frames in flight goes out
  * without it (KMC_ANY_ORDER=0: every packet carries it).  TWO LANES: the direct queue is two HSA queues; independent frames alternate
- * between them (two packet processors fetch argument blocks and launch waves side by side), a frame that must stay ordered goes to lane 0
- * behind a barrier packet that waits for lane 1, and lane 1's next frame waits for that ordered frame -- so a frame always sees what
- * every frame called before it wrote, on whichever lane either ran (KMC_DIRECT_LANES=1: one lane; with KMC_ANY_ORDER=0 one lane as
+ * between them (two packet processors fetch argument blocks and launch waves side by side); a frame that shares a buffer with frames in
+ * flight in ONE lane follows them in that lane (barrier bit, nothing crosses lanes: a chain stays in its lane, buffer pairs used in
+ * rotation keep both lanes busy); a frame with conflicts in both lanes goes to lane 0 behind a barrier packet that waits for lane 1, and
+ * lane 1's next frame waits for that frame -- so a frame always sees what every frame called before it wrote, on whichever lane either ran (KMC_DIRECT_LANES=1: one lane; with KMC_ANY_ORDER=0 one lane as
  * well, every packet ordered).  ORDER: the direct queue and the context's HIP stream are separate queues; the library keeps
  * them in the order of the calls -- a frame waits for what the context put on its stream before it, every other entry point waits for
  * the frames before it (host waits, at such transitions only).  What a caller must know: the frames are not in a HIP stream, so

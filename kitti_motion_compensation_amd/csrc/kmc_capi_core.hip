@@ -628,7 +628,7 @@ int kmc_hip_frame_queue_join(kmc_ctx* c) {
 
 uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* c) { return c ? c->fq_dropped : 0; }
 
-uint64_t kmc_hip_any_order_launches(kmc_ctx* c) { return c ? c->ao.launches : 0; }
+uint64_t kmc_hip_any_order_launches(kmc_ctx* c) { return c ? c->ao.launches + c->lw.launches : 0; }
 
 int kmc_hip_enable_timing(kmc_ctx* c, int enabled) {
   if (!c) return KMC_ERR_INVALID_ARG;

@@ -328,7 +328,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
       }
       const uintptr_t bytes = (uintptr_t)n * sizeof(v4f);
       const kmc_ctx::AoRange r = {(uintptr_t)xyzi_in, (uintptr_t)xyzi_in + bytes}, w = {(uintptr_t)xyzi_out, (uintptr_t)xyzi_out + bytes};
-      const bool free_order = c->ao.admit(r, w, c->dd_free_order, true);
+      const kmc_book::LaneVerdict lane = c->lw.admit(r, w, c->dd_free_order, direct_frame_is_huge(n));
       const int tier = pick_tier(c, params, 1);
       FrameRec f;
       std::memset(&f, 0, sizeof(f));
@@ -337,7 +337,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
       FrameRecD d;
       fill_recd(*params, &d);
       uint32_t launches = 0;
-      const int rc_direct = direct_frame(c, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, KMC_MEM_DEVICE), !free_order, &launches);
+      const int rc_direct = direct_frame(c, tier, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, f, d, head_of(xyzi_out, KMC_MEM_DEVICE), lane, &launches);
       if (rc_direct != KMC_OK) return rc_direct;
       if (st) { st->n_points = n; st->variant = (uint32_t)tier; st->n_launches = launches; }
       return KMC_OK;

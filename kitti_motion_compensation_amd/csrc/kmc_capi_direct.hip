@@ -172,19 +172,21 @@ AgentCode* agent_code(int device) {
 // TWO LANES.  One AQL queue processes its packets one after the other: between the last workgroup of one frame's dispatch and the first
 // of the next the packet processor spends ~1.4 us in which nothing is dispatched (tools/aql_probe: 5.9 us per 1 M-point frame through
 // one queue, 4.5 us with independent frames alternating between two).  So the context has two queues ("lanes"):
-//   * a frame that is INDEPENDENT of every frame in flight (the window of kmc_dispatch_book.hpp says so) goes to the lane the previous
+//   * a frame that is INDEPENDENT of every frame in flight (kmc_dispatch_book.hpp's LaneWindow says so) goes to the lane the previous
 //     independent frame did not take, without the barrier bit;
-//   * an ORDERED frame -- it touches a buffer of a frame in flight, or the window is full, or KMC_ANY_ORDER=0 -- goes to lane 0 with the
-//     barrier bit (it waits for everything before it on lane 0).  If lane 1 has taken frames since the last synchronisation point, a
-//     barrier packet on lane 1 first signals "lane 1 done up to here" and a barrier packet on lane 0 waits for that signal.  The
-//     ordered frame carries a completion signal; the next packet that goes to lane 1 is preceded by a barrier packet that waits for it
-//     (that frame may depend on ANYTHING before the ordered frame -- those frames have left the window --, and "the ordered frame has
-//     completed" implies all of them have).  The signals come in records of three (the frame's, lane 1's "done up to here", the lane-1
-//     barrier packet's own) out of a ring; a record is re-armed only when its frame AND the lane-1 barrier packet that referenced it have
+//   * a frame whose conflicts -- a buffer shared with a frame in flight -- all sit in ONE lane goes to THAT lane with the barrier bit: it
+//     waits for that lane's packets and runs beside the other lane's; nothing crosses lanes (a chain of dependent frames stays in its
+//     lane, three buffer pairs used in rotation keep both lanes busy);
+//   * a FULLY ORDERED frame -- conflicts in both lanes, the window full or invalid, KMC_ANY_ORDER=0 -- goes to lane 0 with the barrier
+//     bit.  If lane 1 has taken frames since the last synchronisation point, a barrier packet on lane 1 first signals "lane 1 done up
+//     to here" and a barrier packet on lane 0 waits for that signal.  The frame carries a completion signal; the next packet that goes
+//     to lane 1 is preceded by a barrier packet that waits for it (that frame may depend on ANYTHING before the fully ordered frame --
+//     those frames have left the window --, and "the ordered frame has completed" implies all of them have).  The signals come in
+//     records of three (the frame's, lane 1's "done up to here", the lane-1 barrier packet's own) out of a ring; a record is re-armed
+//     only when its frame AND the lane-1 barrier packet that referenced it have
 //     completed -- a barrier packet still queued must never find its signal re-armed for a later frame (that later frame would wait for
 //     lane 1, which waits for the packet: a deadlock the first two-lane version ran into).
-// A chain of dependent frames therefore stays on lane 0, one packet each, like on a single queue; a stream of independent frames
-// alternates and overlaps.  direct_join drains both lanes.
+// direct_join drains both lanes and ends the window.
 constexpr int kLanes = 2;
 constexpr int kOrderRecords = 64;
 struct OrderRec {
@@ -208,7 +210,6 @@ struct DirectQueue {
   uint32_t next_record = 0;
   OrderRec* lane1_must_wait_for = nullptr; // the last ordered frame's record, if lane 1 has not been told to wait for that frame yet
   bool lane1_dirty = false;                // lane 1 has taken packets since the last point at which lane 0 waited for it
-  int next_free_lane = 1;                  // where the next independent frame goes
   bool two_lanes = true;                   // KMC_DIRECT_LANES=1: everything on lane 0 (measurement knob)
   bool readback = true;
   bool light = false;  // KMC_DIRECT_LIGHT=1 (measurement knob): packets without the barrier bit acquire nothing
@@ -295,6 +296,7 @@ int direct_join(kmc_ctx* c) {
     l.first_after_transition = true;  // whatever comes next on the HIP stream may rewrite the frames' buffers: the lane's next frame re-acquires at system scope
   }
   c->dd_pending = false;
+  c->lw.invalidate();  // nothing in flight; the next frame re-acquires at system scope, fully ordered
   d->lane1_dirty = false;
   d->lane1_must_wait_for = nullptr;
   return KMC_OK;
@@ -304,9 +306,11 @@ int direct_join(kmc_ctx* c) {
 // frame dispatched before it; false: it is independent of every frame in flight.  `args`: the kernel's argument block (arg_bytes of it,
 // <= kSlotBytes, 16-byte aligned), `tile_base_at`: where its first-tile field sits.
 namespace {
-int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_bytes, size_t tile_base_at, uint64_t n_tiles, bool barrier, uint32_t* launches_out) {
+int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_bytes, size_t tile_base_at, uint64_t n_tiles, kmc_book::LaneVerdict v, uint32_t* launches_out) {
   DirectQueue* d = c->dd;
-  const bool ordered_frame = barrier || n_tiles > kMaxTilesPerLaunch;  // (a frame of several packets keeps to lane 0, its packets ordered)
+  // (a frame of several packets must have been admitted as fully ordered: direct_frame_is_huge)
+  const bool ordered_frame = v.kind == kmc_book::LaneVerdict::kFullyOrdered || n_tiles > kMaxTilesPerLaunch;
+  const bool lane_ordered = v.kind == kmc_book::LaneVerdict::kLaneOrdered;
   int li = 0;
   hsa_signal_t completion{0};
   OrderRec* rec = nullptr;
@@ -323,10 +327,9 @@ int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_by
     hsa_signal_store_relaxed(rec->s, 1);
     completion = rec->s;
   } else if (!ordered_frame && d->two_lanes) {
-    li = d->next_free_lane;
-    d->next_free_lane ^= 1;
+    li = v.lane;  // the window's choice: the next lane in turn (independent of everything in flight) or the lane its conflicts sit in
     if (li == 1) {
-      if (OrderRec* r = d->lane1_must_wait_for) {  // everything before the last ordered frame must be over before lane 1 goes on
+      if (OrderRec* r = d->lane1_must_wait_for) {  // everything before the last fully ordered frame must be over before lane 1 goes on
         hsa_signal_store_relaxed(r->w, 1);
         r->w_used = true;
         const int rc = barrier_packet(c, &d->lane[1], r->s, r->w, HSA_FENCE_SCOPE_AGENT);
@@ -363,7 +366,7 @@ int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_by
     p->completion_signal.handle = last_packet ? completion.handle : 0;
     // ordered packets acquire at agent scope (the frame before them may have written what they read), a lane's first one behind HIP-stream
     // work at system scope (copies, host writes); every frame releases at agent scope, direct_join's barrier packets at system scope
-    const bool ordered = ordered_frame || l->first_after_transition || t0 != 0;
+    const bool ordered = ordered_frame || lane_ordered || l->first_after_transition || t0 != 0;
     const uint16_t acquire = l->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : (!ordered && d->light) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((ordered ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                             (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
@@ -378,17 +381,21 @@ int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_by
 }
 }  // namespace
 
-int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& rd, uint32_t head, bool barrier, uint32_t* launches_out) {
+// a frame that takes several packets (beyond 2^26 - 1 tiles): the caller has the window admit it as fully ordered
+bool direct_frame_is_huge(uint64_t n) { return (n + 2 * kTile - 1) / kTile > kMaxTilesPerLaunch; }
+
+int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& rd, uint32_t head, kmc_book::LaneVerdict v, uint32_t* launches_out) {
   alignas(64) DirectArgs mine;
   mine.in = in - head; mine.out = out - head; mine.n = n + head; mine.f = f; mine.head = head; mine.tile_base = 0; mine.d = rd;
-  return dispatch_frame(c, c->dd->code->kernel_object[tier], &mine, sizeof(mine), offsetof(DirectArgs, tile_base), (mine.n + kTile - 1) / kTile, barrier, launches_out);
+  return dispatch_frame(c, c->dd->code->kernel_object[tier], &mine, sizeof(mine), offsetof(DirectArgs, tile_base), (mine.n + kTile - 1) / kTile, v, launches_out);
 }
 
 // an N-knot frame whose segment records (<= kInlineSegments) travel in the argument block: deskew_traj_f32<tier, false, true>'s twin
-int direct_traj_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, uint32_t n_seg, uint32_t head, const kmc_dev::TrajInline& inl, bool barrier, uint32_t* launches_out) {
+int direct_traj_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, uint32_t n_seg, uint32_t head, const kmc_dev::TrajInline& inl, kmc_book::LaneVerdict v,
+                      uint32_t* launches_out) {
   alignas(64) TrajDirectArgs mine;
   mine.in = in - head; mine.out = out - head; mine.n = n + head; mine.n_seg = n_seg; mine.head = head; mine.tile_base = 0; mine.inl = inl;
-  return dispatch_frame(c, c->dd->code->kernel_object_traj[tier], &mine, sizeof(mine), offsetof(TrajDirectArgs, tile_base), (mine.n + kTile - 1) / kTile, barrier, launches_out);
+  return dispatch_frame(c, c->dd->code->kernel_object_traj[tier], &mine, sizeof(mine), offsetof(TrajDirectArgs, tile_base), (mine.n + kTile - 1) / kTile, v, launches_out);
 }
 
 // Opens the context's direct queue (once; nullptr afterwards if this device / runtime cannot: no large BAR, no HDP flush register, the
@@ -409,6 +416,8 @@ bool direct_open(kmc_ctx* c) {
   c->dd = d;
   if (const char* e = std::getenv("KMC_DIRECT_LANES")) d->two_lanes = std::atoi(e) != 1;
   if (!c->dd_free_order) d->two_lanes = false;  // every frame ordered (KMC_ANY_ORDER=0): nothing for a second lane to overlap
+  c->lw.lanes = d->two_lanes ? 2 : 1;
+  c->lw.invalidate();
   bool ok = true;
   for (Lane& l : d->lane) {
     ok = ok && hsa_queue_create(code->gpu, kQueuePackets, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &l.q) == HSA_STATUS_SUCCESS;
@@ -444,11 +453,11 @@ bool direct_open(kmc_ctx* c) {
       ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->own_stream) == hipSuccess;
     }
     // through lane 1 (an independent frame behind an ordered one: the cross-lane wait is exercised too), then through lane 0
-    if (ok) ok = direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, 64, f, rd, 0, true, nullptr) == KMC_OK &&
-                 direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, kN, f, rd, 0, false, nullptr) == KMC_OK && direct_join(c) == KMC_OK;
+    if (ok) ok = direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, 64, f, rd, 0, {kmc_book::LaneVerdict::kFullyOrdered, 0}, nullptr) == KMC_OK &&
+                 direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, kN, f, rd, 0, {kmc_book::LaneVerdict::kLaneOrdered, d->two_lanes ? 1 : 0}, nullptr) == KMC_OK && direct_join(c) == KMC_OK;
     if (ok) ok = hipMemcpy(ha.data(), t_a, kN * 16, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(hb.data(), t_b, kN * 16, hipMemcpyDeviceToHost) == hipSuccess &&
                  std::memcmp(ha.data(), hb.data(), kN * 16) == 0 && hipMemset(t_b, 0, kN * 16) == hipSuccess && hipDeviceSynchronize() == hipSuccess;  // (a memset is asynchronous)
-    if (ok) ok = direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, kN, f, rd, 0, true, nullptr) == KMC_OK && direct_join(c) == KMC_OK;
+    if (ok) ok = direct_frame(c, kSeries3, (const v4f*)t_in, (v4f*)t_b, kN, f, rd, 0, {kmc_book::LaneVerdict::kFullyOrdered, 0}, nullptr) == KMC_OK && direct_join(c) == KMC_OK;
     if (ok) ok = hipMemcpy(ha.data(), t_a, kN * 16, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(hb.data(), t_b, kN * 16, hipMemcpyDeviceToHost) == hipSuccess &&
                  std::memcmp(ha.data(), hb.data(), kN * 16) == 0;
   }

@@ -184,9 +184,9 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
     fill_traj_segs(th, stamp_start, stamp_end, inl.s, inl.d);
     const uintptr_t bytes = (uintptr_t)n * sizeof(v4f);
     const kmc_ctx::AoRange r = {(uintptr_t)xyzi_in, (uintptr_t)xyzi_in + bytes}, w = {(uintptr_t)xyzi_out, (uintptr_t)xyzi_out + bytes};
-    const bool free_order = c->ao.admit(r, w, c->dd_free_order, true);
+    const kmc_book::LaneVerdict lane = c->lw.admit(r, w, c->dd_free_order, direct_frame_is_huge(n));
     uint32_t launches = 0;
-    rc = direct_traj_frame(c, tier_d, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, th.n_seg, head_of(xyzi_out, KMC_MEM_DEVICE), inl, !free_order, &launches);
+    rc = direct_traj_frame(c, tier_d, (const v4f*)xyzi_in, (v4f*)xyzi_out, n, th.n_seg, head_of(xyzi_out, KMC_MEM_DEVICE), inl, lane, &launches);
     if (rc != KMC_OK) return rc;
     if (st) { st->n_points = n; st->variant = (uint32_t)tier_d; st->n_launches = launches; }
     return KMC_OK;

@@ -7,6 +7,11 @@
 //                    ordinary packet), it has room, and the frame's buffers overlap none of the window's: its write range against every
 //                    read and write range, its read range against every write range.  Either way the frame enters the window; a frame
 //                    that had to be ordered starts a new one.
+//   LaneWindow       the same question for the DIRECT QUEUE's two lanes (kmc_capi_direct.hip): the frames in flight since the last FULLY
+//                    ordered frame, each with the lane it went to.  A new frame that conflicts with nothing goes to the next lane in turn
+//                    without the barrier bit; one whose conflicts all sit in ONE lane goes to THAT lane with the barrier bit (a lane runs
+//                    its barrier-bit packets in order: nothing crosses lanes, the window lives on); only a frame with conflicts in both
+//                    lanes, a full window or an invalid one costs the cross-lane synchronisation and starts a new window.
 //   GatherList       the frames a context with gathering on (kmc_hip_set_frame_queues(ctx, q > 1)) holds back to issue as ONE list
 //                    launch.  push() says what has to happen around the new frame: flush the pending frames FIRST (the new frame
 //                    touches a pending frame's buffers, or needs another coefficient tier: in-order results, and a frame's bits never
@@ -61,6 +66,72 @@ struct AnyOrderWindow {
     writes[0] = writes[count - 1];
     count = 1;
     --launches;
+  }
+};
+
+struct LaneVerdict {
+  enum Kind { kFree = 0, kLaneOrdered = 1, kFullyOrdered = 2 } kind;
+  int lane;
+};
+inline bool contains(const Range& outer, const Range& inner) { return inner.lo >= inner.hi || (outer.lo <= inner.lo && inner.hi <= outer.hi); }
+
+template <int CAPACITY>
+struct LaneWindow {
+  Range reads[CAPACITY], writes[CAPACITY];
+  uint8_t lane[CAPACITY];
+  int count = 0;
+  int lanes = 2;          // 1: everything on lane 0 (KMC_DIRECT_LANES=1)
+  int next_free_lane = 1;
+  bool valid = false;     // the window describes everything in flight in the lanes (false after a join: the next frame is fully ordered)
+  uint64_t launches = 0;  // frames dispatched without the barrier bit so far
+
+  void invalidate() { valid = false; }
+
+  // `enabled`: frames may overlap at all (KMC_ANY_ORDER=0: never); `force_full`: the caller needs this frame fully ordered whatever its
+  // buffers (a frame of several packets).  The frame is entered either way.
+  LaneVerdict admit(const Range& r, const Range& w, bool enabled, bool force_full) {
+    unsigned conflict_lanes = 0;
+    bool full = !enabled || !valid || force_full || count >= CAPACITY;
+    for (int k = 0; !full && k < count; ++k)
+      if (!independent(r, w, reads[k], writes[k])) conflict_lanes |= 1u << lane[k];
+    if (conflict_lanes == 3u) full = true;
+    if (full) {  // behind everything in both lanes: a new window
+      count = 0;
+      push(r, w, 0);
+      valid = enabled;
+      return {LaneVerdict::kFullyOrdered, 0};
+    }
+    if (conflict_lanes == 0) {
+      const int l = lanes > 1 ? next_free_lane : 0;
+      next_free_lane ^= 1;
+      push(r, w, l);
+      ++launches;
+      return {LaneVerdict::kFree, l};
+    }
+    // every conflict sits in ONE lane: behind that lane's packets (barrier bit), beside the other lane's.  Entries of that lane whose
+    // ranges the new frame's ranges contain are superseded: whatever conflicts with them conflicts with the new frame, which is behind them
+    const int l = conflict_lanes == 2u ? 1 : 0;
+    int kept = 0;
+    for (int k = 0; k < count; ++k) {
+      const bool superseded = lane[k] == l && contains(r, reads[k]) && contains(w, writes[k]);
+      if (!superseded) {
+        reads[kept] = reads[k];
+        writes[kept] = writes[k];
+        lane[kept] = lane[k];
+        ++kept;
+      }
+    }
+    count = kept;
+    push(r, w, l);
+    return {LaneVerdict::kLaneOrdered, l};
+  }
+
+ private:
+  void push(const Range& r, const Range& w, int l) {
+    reads[count] = r;
+    writes[count] = w;
+    lane[count] = (uint8_t)l;
+    ++count;
   }
 };
 

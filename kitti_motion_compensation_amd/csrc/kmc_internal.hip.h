@@ -131,6 +131,7 @@ struct kmc_ctx {
   bool ao_enabled = false;               // set by kmc_hip_create from the run-time probe's verdict (kmc_capi_core.hip); KMC_ANY_ORDER=0 turns it off
   int ao_verdict = 0;                    // kmc_device_info.any_order_dispatch
   bool ao_probed = false;                // the verdict has been established (ao_ensure: at first need, not in kmc_hip_create)
+  kmc_book::LaneWindow<kAoWindow> lw;      // the direct queue's frames in flight, with their lanes (kmc_capi_direct.hip)
   kmc_book::AnyOrderWindow<kAoWindow> ao;  // the frames in flight behind the last ordered launch, and the admission rule (kmc_dispatch_book.hpp)
 };
 
@@ -276,8 +277,9 @@ inline void launch_on(void (*kernel)(KArgs...), int grid, int block, hipStream_t
 bool direct_open(kmc_ctx* c);   // the context's queue exists (opened at first need; false: not on this device / runtime, or KMC_DIRECT_DISPATCH=0)
 void direct_close(kmc_ctx* c);
 int direct_join(kmc_ctx* c);    // every frame dispatched through the queue has completed (bounded wait)
-int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head, bool barrier, uint32_t* launches_out);
-int direct_traj_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, uint32_t n_seg, uint32_t head, const kmc_dev::TrajInline& inl, bool barrier, uint32_t* launches_out);
+bool direct_frame_is_huge(uint64_t n);
+int direct_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, const FrameRec& f, const FrameRecD& d, uint32_t head, kmc_book::LaneVerdict v, uint32_t* launches_out);
+int direct_traj_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n, uint32_t n_seg, uint32_t head, const kmc_dev::TrajInline& inl, kmc_book::LaneVerdict v, uint32_t* launches_out);
 void ao_ensure(kmc_ctx* c);  // runs the dispatch probe if its verdict is not known yet
 bool ao_admit(kmc_ctx* c, const void* in, const void* out, uint64_t bytes, bool same_call);  // may this frame be dispatched without the barrier bit?  (kmc_capi_core.hip)
 bool host_pool_owns(const void* ptr, size_t bytes);  // inside a live block of the page-locked host pool (kmc_capi_hostpool.hip)

@@ -144,9 +144,73 @@ static void test_gather_list() {
   CHECK(s.asked - asked_before == 2);  // frames 1 and 4 asked; frame 8 filled the list and did not
 }
 
+static void test_lane_window() {
+  using kmc_book::LaneVerdict;
+  kmc_book::LaneWindow<6> w;
+  const Range a_in = buf(0x1000, 64), a_out = buf(0x2000, 64), b_in = buf(0x3000, 64), b_out = buf(0x4000, 64), c_in = buf(0x5000, 64), c_out = buf(0x6000, 64);
+  // switched off (KMC_ANY_ORDER=0): every frame fully ordered, lane 0, the window never becomes valid
+  LaneVerdict v = w.admit(a_in, a_out, /*enabled*/ false, false);
+  CHECK(v.kind == LaneVerdict::kFullyOrdered && v.lane == 0 && !w.valid && w.launches == 0);
+  // the first frame after a join is fully ordered (it opens the window); independent frames behind it alternate between the lanes
+  v = w.admit(a_in, a_out, true, false);
+  CHECK(v.kind == LaneVerdict::kFullyOrdered && v.lane == 0 && w.valid && w.count == 1);
+  v = w.admit(b_in, b_out, true, false);
+  CHECK(v.kind == LaneVerdict::kFree && v.lane == 1);
+  v = w.admit(c_in, c_out, true, false);
+  CHECK(v.kind == LaneVerdict::kFree && v.lane == 0 && w.launches == 2 && w.count == 3);
+  // a frame that reads what the lane-1 frame writes: behind lane 1's packets, in lane 1 -- no new window
+  v = w.admit(b_out, buf(0x7000, 64), true, false);
+  CHECK(v.kind == LaneVerdict::kLaneOrdered && v.lane == 1 && w.count == 4 && w.launches == 2);
+  // the same buffers again (a rotation of buffer pairs): the lane of the frame that used them; the entry it supersedes is dropped
+  v = w.admit(a_in, a_out, true, false);
+  CHECK(v.kind == LaneVerdict::kLaneOrdered && v.lane == 0 && w.count == 4);
+  // an in-place chain stays in its lane and never grows the window
+  const Range y = buf(0x9000, 64);
+  v = w.admit(y, y, true, false);
+  CHECK(v.kind == LaneVerdict::kFree && w.count == 5);
+  const int y_lane = v.lane;
+  for (int k = 0; k < 10; ++k) {
+    v = w.admit(y, y, true, false);
+    CHECK(v.kind == LaneVerdict::kLaneOrdered && v.lane == y_lane && w.count == 5);
+  }
+  // conflicts in BOTH lanes (reads lane 1's output, overwrites lane 0's): fully ordered, a new window
+  v = w.admit(buf(0x7000, 64), a_out, true, false);
+  CHECK(v.kind == LaneVerdict::kFullyOrdered && v.lane == 0 && w.count == 1);
+  // a frame of several packets is fully ordered whatever its buffers
+  v = w.admit(buf(0xA000, 64), buf(0xB000, 64), true, /*force_full*/ true);
+  CHECK(v.kind == LaneVerdict::kFullyOrdered && w.count == 1);
+  // capacity: a full window orders the next frame fully
+  for (int k = 0; k < 5; ++k) CHECK(w.admit(buf(0x10000 + 0x1000 * k, 64), buf(0x20000 + 0x1000 * k, 64), true, false).kind == LaneVerdict::kFree);
+  CHECK(w.count == 6);
+  v = w.admit(buf(0x30000, 64), buf(0x31000, 64), true, false);
+  CHECK(v.kind == LaneVerdict::kFullyOrdered && w.count == 1);
+  // a join: the next frame is fully ordered again
+  w.invalidate();
+  v = w.admit(buf(0x40000, 64), buf(0x41000, 64), true, false);
+  CHECK(v.kind == LaneVerdict::kFullyOrdered);
+  // a partial overlap supersedes nothing: the window keeps the older entry (something may conflict with the part the new frame does not cover)
+  v = w.admit(buf(0x50000, 128), buf(0x51000, 128), true, false);
+  CHECK(v.kind == LaneVerdict::kFree);
+  const int big_lane = v.lane;
+  const int before = w.count;
+  v = w.admit(buf(0x52000, 64), buf(0x51000, 64), true, false);  // overwrites HALF of the big frame's output
+  CHECK(v.kind == LaneVerdict::kLaneOrdered && v.lane == big_lane && w.count == before + 1);
+  // one lane (KMC_DIRECT_LANES=1): everything on lane 0, conflicts cost the barrier bit only
+  kmc_book::LaneWindow<4> one;
+  one.lanes = 1;
+  CHECK(one.admit(a_in, a_out, true, false).kind == LaneVerdict::kFullyOrdered);
+  v = one.admit(b_in, b_out, true, false);
+  CHECK(v.kind == LaneVerdict::kFree && v.lane == 0);
+  v = one.admit(c_in, c_out, true, false);
+  CHECK(v.kind == LaneVerdict::kFree && v.lane == 0);
+  v = one.admit(b_out, c_in, true, false);
+  CHECK(v.kind == LaneVerdict::kLaneOrdered && v.lane == 0);
+}
+
 int main() {
   test_overlap_rules();
   test_any_order_window();
+  test_lane_window();
   test_gather_list();
   if (failures) {
     std::fprintf(stderr, "%d check(s) failed\n", failures);

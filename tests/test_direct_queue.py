@@ -40,11 +40,12 @@ def test_direct_frames_write_the_hip_launch_bits_and_keep_the_call_order():
             if a.shape[0]:
                 direct.synth_points(a, a.shape[0], 900 + k)      # HIP-stream work of the SAME context right before the frames: a transition
         outs = {name: [torch.zeros_like(a) for a in ins] for name in ("direct", "hip")}
+        copy = torch.zeros_like(outs["direct"][6])
+        torch.cuda.synchronize()  # torch's fills run on ITS stream: nothing orders them against the contexts' own streams
         for k, a in enumerate(ins):
             st = direct.deskew_f32(a, outs["direct"][k], _params(k))
             assert st.n_points == a.shape[0] and st.n_launches == (1 if a.shape[0] else 0)
         # another entry point of the context right behind the frames: a batch over the biggest frame's OUTPUT (must see it)
-        copy = torch.zeros_like(outs["direct"][6])
         ident = capi.FrameParams.make([0, 0, 0, 0, 0, 0], 0.5)
         direct.deskew_batch_f32(outs["direct"][6], copy, np.array([0, sizes[6]], dtype=np.uint64), [ident], None)
         direct.synchronize()
@@ -61,6 +62,7 @@ def test_direct_frames_write_the_hip_launch_bits_and_keep_the_call_order():
         # a chain and an in-place repeat through the queue: the barrier bit keeps the order of the calls
         n = 150_001
         bufs = [torch.zeros((n, 4), dtype=torch.float32, device="cuda") for _ in range(5)]
+        torch.cuda.synchronize()
         hip.synth_points(bufs[0], n, 77)
         hip.synchronize()
         want = [bufs[0]]
@@ -133,6 +135,8 @@ def test_every_packet_carries_the_barrier_bit_with_kmc_any_order_0():
     n, nf = 30_000, 10
     ins = [torch.empty((n, 4), dtype=torch.float32, device="cuda") for _ in range(nf)]
     outs = [torch.zeros_like(x) for x in ins]
+    outs2 = [torch.zeros_like(x) for x in ins]
+    torch.cuda.synchronize()  # (torch's fills run on its stream)
     free, ordered = _ctx(), _ctx(KMC_ANY_ORDER="0")
     try:
         for k, x in enumerate(ins):
@@ -142,7 +146,6 @@ def test_every_packet_carries_the_barrier_bit_with_kmc_any_order_0():
             ordered.deskew_f32(ins[k], outs[k], _params(k))
         ordered.synchronize()
         assert ordered.any_order_launches() == 0
-        outs2 = [torch.zeros_like(x) for x in ins]
         for k in range(nf):
             free.deskew_f32(ins[k], outs2[k], _params(k))
         free.synchronize()
@@ -169,6 +172,7 @@ def test_the_argument_ring_wraps_without_a_stale_block():
         direct.synchronize()
         got = torch.zeros_like(src)
         want = torch.zeros_like(src)
+        torch.cuda.synchronize()
         params = [capi.FrameParams.make([1.0 + 1e-4 * k, 0.02, -0.01, 0.001, -0.002, 0.03 + 1e-5 * k], (k % 97) / 96.0) for k in range(nf)]
         for k in range(nf):
             direct.deskew_f32(src[k * n:(k + 1) * n], got[k * n:(k + 1) * n], params[k])
@@ -205,8 +209,11 @@ def test_a_frame_behind_an_ordered_frame_still_sees_what_was_written_before_it()
         def script(ctx, pad):
             """pad = number of independent small frames ahead of G: it decides which lane G and N land on"""
             made = []
+            # the outputs exist and are zeroed BEFORE the first call: torch fills on ITS stream, which nothing orders against the context's
+            pool = [torch.zeros((big, 4), dtype=torch.float32, device="cuda")] + [torch.zeros((small, 4), dtype=torch.float32, device="cuda") for _ in range(pad + 6)]
+            torch.cuda.synchronize()
             def frame(a, k):
-                o = torch.zeros_like(a)
+                o = pool.pop(0) if a.shape[0] == big else pool.pop()
                 ctx.deskew_f32(a, o, _params(k))
                 made.append(o)
                 return o
@@ -267,18 +274,27 @@ def test_n_knot_frames_with_their_records_in_the_argument_block_go_through_the_d
 
         def script(ctx):
             outs = []
+            # every output exists and is zeroed BEFORE the first call (torch fills on its own stream, which nothing orders against the context's)
+            fresh = {}
+            for a in ins:
+                fresh.setdefault(a.shape[0], [])
+                fresh[a.shape[0]] += [torch.zeros_like(a) for _ in range(2)]
+            fresh[sizes[0]] += [torch.zeros_like(ins[0]) for _ in range(5)]
+            idx = torch.zeros((sizes[0],), dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            zeros_like = lambda a: fresh[a.shape[0]].pop()
             for k, a in enumerate(ins):                        # independent frames, 3 and 4 knots alternating with two-pose frames
-                o = torch.zeros_like(a)
+                o = zeros_like(a)
                 tk, P, ts, te, tr = _knots(k, 3 + k % 2)
                 st = ctx.deskew_traj_f32(a, o, tk, P, ts, te, tr)
                 assert st.n_points == a.shape[0] and st.n_launches == 1
                 outs.append(o)
-                o2 = torch.zeros_like(a)
+                o2 = zeros_like(a)
                 ctx.deskew_f32(a, o2, _params(k))
                 outs.append(o2)
             chain = [ins[0]]                                     # a chain: N-knot -> two-pose -> N-knot, then in place twice
             for k in range(3):
-                o = torch.zeros_like(ins[0])
+                o = zeros_like(ins[0])
                 if k % 2 == 0:
                     tk, P, ts, te, tr = _knots(10 + k, 3)
                     ctx.deskew_traj_f32(chain[-1], o, tk, P, ts, te, tr)
@@ -290,12 +306,11 @@ def test_n_knot_frames_with_their_records_in_the_argument_block_go_through_the_d
                 tk, P, ts, te, tr = _knots(20 + k, 4)
                 ctx.deskew_traj_f32(y, y, tk, P, ts, te, tr)
             outs.append(y)
-            five = torch.zeros_like(ins[0])                      # five knots: four segments do not fit the block -> HIP launch behind the queue
+            five = zeros_like(ins[0])                            # five knots: four segments do not fit the block -> HIP launch behind the queue
             tk, P, ts, te, tr = _knots(30, 5)
             ctx.deskew_traj_f32(y, five, tk, P, ts, te, tr)
             outs.append(five)
-            idx = torch.zeros((sizes[0],), dtype=torch.int32, device="cuda")
-            with_idx = torch.zeros_like(ins[0])
+            with_idx = zeros_like(ins[0])
             tk, P, ts, te, tr = _knots(31, 3)
             ctx.deskew_traj_f32(five, with_idx, tk, P, ts, te, tr, bracket_idx_out=idx)
             outs += [with_idx, idx.view(torch.float32).reshape(-1, 1)]
