@@ -372,7 +372,7 @@ def inplace_round(ctx, rng, acc, torch):
     acc["inplace_failures"] += 0 if ok else 1
 
 
-def stream_round(ctx, plain_ctx, gather_ctx, rng, acc, torch):
+def stream_round(ctx, plain_ctx, gather_ctx, rng, acc, torch, hip_ctx=None):
     """A random PROGRAM of device-resident single-frame calls on the context's own stream, issued back to back: every call reads one
     buffer of a small pool and writes another (or the same one, or a sub-range of one), so that consecutive calls are independent,
     chained, write-after-read or write-after-write at random; two-pose and short N-knot frames, now and then another entry point in
@@ -429,6 +429,13 @@ def stream_round(ctx, plain_ctx, gather_ctx, rng, acc, torch):
     torch.cuda.synchronize()
     run(gather_ctx, got2, False)
     ok = ok and all(bool(torch.equal(g.view(torch.int32), w.view(torch.int32))) for g, w in zip(got2, want))
+    # ... and through a context whose frames are HIP launches (KMC_DIRECT_DISPATCH=0; `ctx` dispatches them through its direct queue, two lanes)
+    if hip_ctx is not None:
+        got3 = [x.clone() for x in base]
+        torch.cuda.synchronize()
+        run(hip_ctx, got3, False)
+        ok = ok and all(bool(torch.equal(g.view(torch.int32), w.view(torch.int32))) for g, w in zip(got3, want))
+    acc["stream_direct_queue_frames"] = ctx.direct_frames()
     # the first call of the program against the oracle (its input is still the pristine buffer in `base`)
     kind, src, dst, lo, m, arg = prog[0]
     if kind != "traj":
@@ -455,6 +462,9 @@ def main():
     os.environ["KMC_ANY_ORDER"] = "0"
     plain_ctx = capi.Context(0)  # every dispatch with its barrier bit: the reference of stream_round
     del os.environ["KMC_ANY_ORDER"]
+    os.environ["KMC_DIRECT_DISPATCH"] = "0"
+    hip_ctx = capi.Context(0)  # single-frame calls as HIP launches (the default context writes AQL packets into its own queues)
+    del os.environ["KMC_DIRECT_DISPATCH"]
     gather_ctx = capi.Context(0)
     gather_ctx.set_frame_queues(4)  # single-frame calls gathered into list launches
     calib = util.load_kitti_calibration(os.path.join(ROOT, "tests", "golden"))
@@ -487,7 +497,7 @@ def main():
         elif r == 6:
             inplace_round(ctx, rng, acc, torch)
         elif r == 8:
-            stream_round(ctx, plain_ctx, gather_ctx, rng, acc, torch)
+            stream_round(ctx, plain_ctx, gather_ctx, rng, acc, torch, hip_ctx)
         else:
             traj_round(ctx, rng, acc, torch)
         acc["rounds"] += 1
