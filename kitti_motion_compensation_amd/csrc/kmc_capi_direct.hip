@@ -71,6 +71,7 @@ static_assert(kSlotBytes % 64 == 0 && sizeof(DirectArgs) <= kSlotBytes, "ring sl
 
 namespace {
 constexpr uint32_t kQueuePackets = 4096;
+constexpr uint32_t kArgQuarter = kQueuePackets / 4;
 constexpr double kWaitSeconds = 10.0;
 
 struct AgentCode {  // per HSA agent, once per process
@@ -200,6 +201,11 @@ struct Lane {
   hsa_queue_t* q = nullptr;
   char* ring = nullptr;        // kQueuePackets slots of kSlotBytes: device-local memory, host-mapped
   hsa_signal_t done{};         // direct_join's completion signal
+  // the argument ring is re-used a quarter at a time: a marker (barrier packet with a completion signal) follows each quarter's dispatches,
+  // and a quarter is written again only when its marker of the lap before has completed -- no wave can still be reading a block
+  hsa_signal_t quarter_done[4] = {};
+  bool quarter_armed[4] = {false, false, false, false};
+  uint64_t aidx = 0;           // next argument slot (mod kQueuePackets)
   uint64_t widx = 0;           // next packet slot (single producer: the context's calling thread)
   bool first_after_transition = true;
 };
@@ -273,6 +279,8 @@ void direct_close(kmc_ctx* c) {
     if (l.q) (void)hsa_queue_destroy(l.q);
     if (l.ring) (void)hsa_amd_memory_pool_free(l.ring);
     if (l.done.handle) (void)hsa_signal_destroy(l.done);
+    for (hsa_signal_t& sg : l.quarter_done)
+      if (sg.handle) (void)hsa_signal_destroy(sg);
   }
   for (OrderRec& r : d->order)
     for (hsa_signal_t* sg : {&r.s, &r.x, &r.w})
@@ -345,7 +353,25 @@ int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_by
     if (!wait_for_room(l)) return queue_stuck(c, "direct queue: the packet processor stopped consuming packets");
     const uint32_t tiles = (uint32_t)std::min<uint64_t>(kMaxTilesPerLaunch, n_tiles - t0);
     const bool last_packet = t0 + kMaxTilesPerLaunch >= n_tiles;
-    char* a = l->ring + (size_t)(l->widx % kQueuePackets) * kSlotBytes;
+    const uint32_t slot = (uint32_t)(l->aidx % kQueuePackets);
+    if (slot % kArgQuarter == 0) {
+      const uint32_t q = slot / kArgQuarter, prev = (q + 3) % 4;
+      if (l->aidx != 0) {  // the quarter just filled: its marker, behind every dispatch so far on this lane
+        hsa_signal_store_relaxed(l->quarter_done[prev], 1);
+        const int rc = barrier_packet(c, l, hsa_signal_t{0}, l->quarter_done[prev], HSA_FENCE_SCOPE_AGENT);
+        if (rc != KMC_OK) return rc;
+        l->quarter_armed[prev] = true;
+      }
+      if (l->quarter_armed[q]) {  // this quarter's blocks of the lap before (3072 slots ago: over long since, one load)
+        const double t_wait = now_s();
+        while (hsa_signal_load_scacquire(l->quarter_done[q]) > 0)
+          if (now_s() - t_wait > kWaitSeconds) return queue_stuck(c, "direct queue: a quarter of the argument ring did not drain within the timeout");
+        l->quarter_armed[q] = false;
+      }
+      if (!wait_for_room(l)) return queue_stuck(c, "direct queue: the packet processor stopped consuming packets");
+    }
+    ++l->aidx;
+    char* a = l->ring + (size_t)slot * kSlotBytes;
     std::memcpy(static_cast<char*>(args) + tile_base_at, &t0, sizeof(t0));
     std::memcpy(a, args, arg_bytes);  // over the BAR, write-combined: one sequential pass over the block
     // the block must have landed in device memory before the packet processor can see the packet: fence, HDP flush, one read back over the
@@ -424,6 +450,7 @@ bool direct_open(kmc_ctx* c) {
     ok = ok && hsa_amd_memory_pool_allocate(code->device_pool, kSlotBytes * kQueuePackets, 0, (void**)&l.ring) == HSA_STATUS_SUCCESS;
     ok = ok && hsa_amd_agents_allow_access(1, &code->cpu, nullptr, l.ring) == HSA_STATUS_SUCCESS;  // fails without a large BAR
     ok = ok && hsa_signal_create(1, 0, nullptr, &l.done) == HSA_STATUS_SUCCESS;
+    for (hsa_signal_t& sg : l.quarter_done) ok = ok && hsa_amd_signal_create(0, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &sg) == HSA_STATUS_SUCCESS;
     if (ok) l.widx = hsa_queue_load_write_index_relaxed(l.q);
   }
   for (OrderRec& r : d->order)
