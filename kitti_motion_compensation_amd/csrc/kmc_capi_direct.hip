@@ -217,8 +217,6 @@ struct DirectQueue {
   OrderRec* lane1_must_wait_for = nullptr; // the last ordered frame's record, if lane 1 has not been told to wait for that frame yet
   bool lane1_dirty = false;                // lane 1 has taken packets since the last point at which lane 0 waited for it
   bool two_lanes = true;                   // KMC_DIRECT_LANES=1: everything on lane 0 (measurement knob)
-  bool readback = true;
-  bool light = false;  // KMC_DIRECT_LIGHT=1 (measurement knob): packets without the barrier bit acquire nothing
   uint64_t frames = 0;
 };
 
@@ -379,7 +377,7 @@ int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_by
     // of 2.1 and no stale block in 40 000 dispatches -- kept all the same: a stale argument block is a silently wrong frame)
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     if (d->code->hdp.HDP_MEM_FLUSH_CNTL) *(volatile uint32_t*)d->code->hdp.HDP_MEM_FLUSH_CNTL = 1u;
-    if (d->readback) (void)*(volatile uint32_t*)(a + arg_bytes - 4);  // (KMC_DIRECT_READBACK=0, a measurement knob: the posted writes alone)
+    (void)*(volatile uint32_t*)(a + arg_bytes - 4);
     auto* p = reinterpret_cast<hsa_kernel_dispatch_packet_t*>(l->q->base_address) + (l->widx % kQueuePackets);
     p->workgroup_size_x = kTile; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
     p->reserved0 = 0;
@@ -393,7 +391,7 @@ int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_by
     // ordered packets acquire at agent scope (the frame before them may have written what they read), a lane's first one behind HIP-stream
     // work at system scope (copies, host writes); every frame releases at agent scope, direct_join's barrier packets at system scope
     const bool ordered = ordered_frame || lane_ordered || l->first_after_transition || t0 != 0;
-    const uint16_t acquire = l->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : (!ordered && d->light) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
+    const uint16_t acquire = l->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((ordered ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                             (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     ring_doorbell(l, p, header, (uint16_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS));
@@ -437,8 +435,6 @@ bool direct_open(kmc_ctx* c) {
   DirectQueue* d = new (std::nothrow) DirectQueue();
   if (!d) return false;
   d->code = code;
-  if (const char* e = std::getenv("KMC_DIRECT_READBACK")) d->readback = std::atoi(e) != 0;
-  if (const char* e = std::getenv("KMC_DIRECT_LIGHT")) d->light = std::atoi(e) != 0;
   c->dd = d;
   if (const char* e = std::getenv("KMC_DIRECT_LANES")) d->two_lanes = std::atoi(e) != 1;
   if (!c->dd_free_order) d->two_lanes = false;  // every frame ordered (KMC_ANY_ORDER=0): nothing for a second lane to overlap
