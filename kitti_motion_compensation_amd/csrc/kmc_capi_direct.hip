@@ -308,9 +308,10 @@ int direct_join(kmc_ctx* c) {
   return KMC_OK;
 }
 
-// one frame = one packet (frames beyond 2^26 - 1 tiles: several, told their first tile).  `barrier`: the frame is ORDERED behind every
-// frame dispatched before it; false: it is independent of every frame in flight.  `args`: the kernel's argument block (arg_bytes of it,
-// <= kSlotBytes, 16-byte aligned), `tile_base_at`: where its first-tile field sits.
+// one frame = one packet (frames beyond 2^26 - 1 tiles: several, told their first tile).  `v`: the window's verdict -- independent of
+// every frame in flight (lane v.lane, no barrier bit), behind the frames of lane v.lane only (that lane, barrier bit), or behind
+// everything (lane 0, cross-lane wait).  `args`: the kernel's argument block (arg_bytes of it, <= kSlotBytes, 16-byte aligned),
+// `tile_base_at`: where its first-tile field sits.
 namespace {
 int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_bytes, size_t tile_base_at, uint64_t n_tiles, kmc_book::LaneVerdict v, uint32_t* launches_out) {
   DirectQueue* d = c->dd;
