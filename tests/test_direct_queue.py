@@ -330,3 +330,36 @@ def test_n_knot_frames_with_their_records_in_the_argument_block_go_through_the_d
     finally:
         direct.close()
         hip.close()
+
+
+def test_many_contexts_each_with_its_own_queues_or_a_graceful_fallback():
+    """Every context that dispatches directly owns two HSA queues; a process may hold many contexts (one per calling thread in the C++
+    drop-in).  Forty contexts at once: each either opens its queues or -- if the runtime has no more to give -- stays on HIP launches; every
+    one writes the same bits."""
+    import torch
+
+    n = 20_011
+    a = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    ctxs = []
+    try:
+        first = _ctx()
+        ctxs.append(first)
+        first.synth_points(a, n, 31337)
+        first.synchronize()
+        outs = [torch.zeros_like(a) for _ in range(40)]
+        torch.cuda.synchronize()
+        for k in range(1, 40):
+            ctxs.append(_ctx())
+        for k, c in enumerate(ctxs):
+            c.deskew_f32(a, outs[k], _params(3))
+            c.deskew_f32(outs[k], outs[k], _params(4))   # ordered behind the first, in place
+        for c in ctxs:
+            c.synchronize()
+        for k in range(1, 40):
+            assert torch.equal(outs[k].view(torch.int32), outs[0].view(torch.int32)), k
+        direct = sum(1 for c in ctxs if c.direct_frames() == 2)
+        assert all(c.direct_frames() in (0, 2) for c in ctxs)
+        print(f"{direct} of {len(ctxs)} contexts dispatched through their own queues")
+    finally:
+        for c in ctxs:
+            c.close()
