@@ -122,7 +122,8 @@ int main(int argc, char** argv) {
   HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv));
   if (karg != sizeof(Args)) { std::printf("{\"failed\": \"kernarg segment is %u bytes\"}\n", karg); return 3; }
   const uint32_t kQueue = 4096;
-  hsa_queue_t* qs[2] = {nullptr, nullptr};  // [1]: the second queue of the two-queue trains (independent frames alternate between them)
+  constexpr int kMaxQueues = 4;
+  hsa_queue_t* qs[kMaxQueues] = {nullptr, nullptr, nullptr, nullptr};  // [1..]: the further queues of the multi-queue trains (independent frames alternate between them)
   for (auto& qq : qs) HSA_OK(hsa_queue_create(g_gpu, kQueue, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &qq));
   int cur = 0;  // the queue dispatch() writes to
   hsa_queue_t* q = qs[0];
@@ -136,7 +137,7 @@ int main(int argc, char** argv) {
   if (device_kernargs) {
     HSA_OK(hsa_amd_agent_iterate_memory_pools(g_gpu, on_gpu_pool, nullptr));
     if (!g_have_dev_pool) { std::printf("{\"failed\": \"no device-local pool\"}\n"); return 3; }
-    HSA_OK(hsa_amd_memory_pool_allocate(g_dev_pool, sizeof(Args) * kQueue * 2, 0, (void**)&ring));
+    HSA_OK(hsa_amd_memory_pool_allocate(g_dev_pool, sizeof(Args) * kQueue * kMaxQueues, 0, (void**)&ring));
     const hsa_status_t acc = hsa_amd_agents_allow_access(1, &g_cpu, nullptr, ring);
     if (acc != HSA_STATUS_SUCCESS) { std::printf("{\"failed\": \"the host cannot map device memory (no large BAR?)\"}\n"); return 3; }
     HSA_OK(hsa_agent_get_info(g_gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp));
@@ -147,12 +148,16 @@ int main(int argc, char** argv) {
   hsa_signal_t done;
   HSA_OK(hsa_signal_create(1, 0, nullptr, &done));
 
-  const int kBufs = 8;
-  void *in[kBufs + 1], *out[kBufs + 1];  // (the extra pair belongs to the drain's own dispatch)
+  // argv[5]: buffer pairs the dispatches rotate through (default 8: with 1 M-point frames everything then sits in the 256 MiB Infinity Cache;
+  // 64 pairs = 2 GiB do not), argv[6] = "distinct_inputs": every pair has its own input buffer too
+  const int kBufs = argc > 5 ? std::max(1, std::min(256, std::atoi(argv[5]))) : 8;
+  const bool distinct_inputs = argc > 6 && std::strcmp(argv[6], "distinct_inputs") == 0;
+  std::vector<void*> in((size_t)kBufs + 1), out((size_t)kBufs + 1);  // (the extra pair belongs to the drain's own dispatch)
   for (int b = 0; b <= kBufs; ++b) { HIP_OK(hipMalloc(&in[b], n * 16)); HIP_OK(hipMalloc(&out[b], n * 16)); HIP_OK(hipMemset(in[b], 0, n * 16)); HIP_OK(hipMemset(out[b], 0xFF, n * 16)); }
   {  // in[0]: x = 1.0 everywhere, so that out.x = 1 * f.v[0] + f.v[1] + d.v[3] is checkable
     std::vector<float> h(4 * n, 1.0f);
     HIP_OK(hipMemcpy(in[0], h.data(), n * 16, hipMemcpyHostToDevice));
+    for (int b = 1; b <= kBufs; ++b) HIP_OK(hipMemcpy(in[b], in[0], n * 16, hipMemcpyDeviceToDevice));
   }
   HIP_OK(hipDeviceSynchronize());
   Args proto;
@@ -160,7 +165,8 @@ int main(int argc, char** argv) {
   proto.n = n;
   for (int i = 0; i < 16; ++i) { proto.f.v[i] = 1.0f + i; proto.d.v[i] = 0.5 * i; }
   const uint32_t grid = (uint32_t)((n + 63) / 64) * 64;
-  uint64_t widxs[2] = {hsa_queue_load_write_index_relaxed(qs[0]), hsa_queue_load_write_index_relaxed(qs[1])};
+  uint64_t widxs[kMaxQueues];
+  for (int k = 0; k < kMaxQueues; ++k) widxs[k] = hsa_queue_load_write_index_relaxed(qs[k]);
   Args* const ring0 = ring;
   auto wait_for_room = [&](uint64_t idx) {  // never more than kQueue - 64 packets ahead of the packet processor
     const auto t0 = clk::now();
@@ -176,7 +182,7 @@ int main(int argc, char** argv) {
     wait_for_room(widx);
     Args* a = ring + (widx % kQueue);
     Args mine = proto;
-    mine.in = in[0];               // x = 1 everywhere
+    mine.in = distinct_inputs && i >= 0 ? in[i % kBufs] : in[0];  // x = 1 everywhere
     mine.out = i < 0 ? out[kBufs] : out[i % kBufs];
     mine.f.v[1] = i < 0 ? 0.0f : (float)(i % 4096);  // this dispatch's own number: out.x = f.v[0] + f.v[1] + d.v[3]
     *a = mine;
@@ -201,7 +207,7 @@ int main(int argc, char** argv) {
     ++widx;
   };
   auto drain = [&] {  // per queue: a last packet with the barrier bit and a completion signal; waited for with a timeout
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < kMaxQueues; ++qi) {
       cur = qi;
       hsa_signal_store_relaxed(done, 1);
       dispatch(-1, true, done);
@@ -248,16 +254,18 @@ int main(int argc, char** argv) {
     }
     std::printf(", \"%s\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", barrier ? "aql_with_barrier_bit" : "aql_without_barrier_bit", host, train);
   }
-  {  // independent frames alternating between TWO queues (no barrier bit): does the packet processor overlap what it serialises in one queue?
-    for (int i = 0; i < 2000; ++i) { cur = i & 1; dispatch(i, false, none); }
+  // independent frames alternating between K queues (no barrier bit): does the packet processor overlap what it serialises in one queue?
+  for (int K = 2; K <= kMaxQueues; ++K) {
+    for (int i = 0; i < 2000; ++i) { cur = i % K; dispatch(i, false, none); }
     drain();
     const auto t0 = clk::now();
-    for (int i = 0; i < N; ++i) { cur = i & 1; dispatch(i, false, none); }
+    for (int i = 0; i < N; ++i) { cur = i % K; dispatch(i, false, none); }
     const double host = us_since(t0) / N;
     drain();
     const double train = us_since(t0) / N;
-    std::printf(", \"aql_two_queues_alternating_without_barrier_bit\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", host, train);
+    std::printf(", \"aql_%s_queues_alternating_without_barrier_bit\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", K == 2 ? "two" : K == 3 ? "three" : "four", host, train);
   }
+  std::printf(", \"buffer_pairs\": %d, \"distinct_inputs\": %s", kBufs, distinct_inputs ? "true" : "false");
   std::printf(", \"note\": \"host = packet + 232-byte kernarg block + doorbell per frame, including the back-pressure of a 4096-packet queue when the device is the slower side\"}\n");
   for (auto& qq : qs) hsa_queue_destroy(qq);
   return 0;
