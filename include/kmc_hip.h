@@ -287,7 +287,7 @@ uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
 uint64_t kmc_hip_direct_frames(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
  * (HOST arrays of device pointers / sizes / params), each frame in its own buffer (any 16-byte-aligned addresses).  ONE launch of the
- * frame-list kernel (one row of tiles, frame after frame: no workgroup without a tile, however ragged the frames) on the context's stream with the frames' records IN ITS KERNEL ARGUMENTS -- up to 256 frames
+ * frame-list kernel (2-D grid: frame x tile) on the context's stream with the frames' records IN ITS KERNEL ARGUMENTS -- up to 256 frames
  * per launch (a 56 KiB argument block; a KITTI drive of 108 frames is one launch of 24 KiB), longer lists in launches of 256: nothing is
  * uploaded, the host never waits, the call only enqueues.  Under stream capture the launches carry 16 frames each (the block every
  * runtime is known to take; so does everything after a runtime has refused a larger one).  KMC_LIST_ROUTE=table selects the round-4

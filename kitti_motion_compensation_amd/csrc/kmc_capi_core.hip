@@ -122,15 +122,7 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
     if (n_recs < (uint32_t)kCap) std::memset(&inl, 0, sizeof(inl));  // (no stale stack bytes in the kernel arguments)
     std::memcpy(inl.recs, recs + first, n_recs * sizeof(ListRec));
     std::memcpy(inl.recs64, recd + first, n_recs * sizeof(FrameRecD));
-    uint64_t total_tiles = 0;  // one row of tiles, frame after frame (the callers keep a list below 2^32 work-items)
-    for (uint32_t k = 0; k < (uint32_t)kCap; ++k) {
-      if (k < n_recs) total_tiles += (recs[first + k].n + kTile - 1) / kTile;
-      inl.tile_end[k] = (uint32_t)total_tiles;
-    }
-    if (total_tiles == 0) return;
-    inl.n_frames = n_recs;
-    inl.frames_per_tile = (float)((double)n_recs / (double)total_tiles);
-    const dim3 grid((uint32_t)total_tiles, 1, 1);
+    const dim3 grid(std::max(1u, tiles_of(first, n_recs)), n_recs, 1);
     with_tier(tier, [&](auto T) {
       if (any_order)
         hipExtLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kCap>), grid, dim3(kTile), 0, c->stream, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, (const ListRec*)nullptr,

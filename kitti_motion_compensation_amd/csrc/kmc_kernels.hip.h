@@ -425,12 +425,6 @@ template <int CAP>
 struct ListInlineT {
   ListRec recs[CAP];
   FrameRecD recs64[CAP];
-  // the launch's grid is ONE row of tiles, frame after frame (no workgroup without a tile, however ragged the frames): frame k owns
-  // workgroups [tile_end[k - 1], tile_end[k]); frames_per_tile = n_frames / total tiles is a workgroup's first guess at its frame
-  uint32_t tile_end[CAP];
-  uint32_t n_frames;
-  float frames_per_tile;
-  uint32_t pad[2];
 };
 static_assert(sizeof(ListInlineT<kInlineListFrames>) <= 3800, "the 16-frame block fits the 4 KiB every runtime takes");
 static_assert(sizeof(ListInlineT<kInlineListFramesMax>) <= 60 * 1024, "the largest block stays below the 64 KiB the probe verified");
@@ -450,50 +444,15 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   } else {
     recs = (rec_cp)(uintptr_t)recs_g;  // written by the host before the launch: constant for the kernel, uniform reads are scalar loads
   }
-  uint32_t fi, tile;
-  if constexpr (CAP > 0) {
-    // one row of tiles: find this workgroup's frame -- a guess from the mean frame size, corrected against the cumulative tile counts
-    // (scalar loads from the argument block; frames of similar size: the guess is right or one off)
-    using L = ListInlineT<(CAP > 0 ? CAP : 1)>;
-    struct ArgLayout { const ListRec* recs_g; const FrameRecD* recs64; L inl; };
-    using u32_cp = const uint32_t __attribute__((address_space(4)))*;
-    const auto blk = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ArgLayout, inl);
-    const u32_cp tile_end = (u32_cp)(blk + offsetof(L, tile_end));
-    const uint32_t nf = *(u32_cp)(blk + offsetof(L, n_frames));
-    const float fpt = *(const float __attribute__((address_space(4)))*)(blk + offsetof(L, frames_per_tile));
-    const uint32_t b = blockIdx.x;
-    uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)((float)b * fpt));
-    g = g < nf ? g : nf - 1;
-    // the frame is the smallest k with tile_end[k] > b: the guess and its two neighbours on the side it missed by, then a binary search
-    // (a list of one huge frame among tiny ones: the guess is dozens of frames off -- at most eight more loads)
-    uint32_t lo, hi;
-    if (tile_end[g] > b) {
-      lo = 0u; hi = g;
-      if (g == 0u || tile_end[g - 1] <= b) lo = g;
-      else { hi = g - 1; if (g == 1u || tile_end[g - 2] <= b) lo = g - 1; }
-    } else {
-      lo = g + 1; hi = nf - 1;
-      if (tile_end[lo] > b) hi = lo;
-      else if (lo < hi) { ++lo; if (tile_end[lo] > b) hi = lo; }
-    }
-    while (lo < hi) {
-      const uint32_t m = (lo + hi) >> 1;
-      if (tile_end[m] > b) hi = m; else lo = m + 1;
-    }
-    fi = lo;
-    tile = b - (fi ? tile_end[fi - 1] : 0u);
-  } else {
-    fi = blockIdx.y;  // the table route: a 2-D grid, frame x tile
-    tile = blockIdx.x;
-  }
+  const uint32_t fi = blockIdx.y;
   ListRec r;
   {
     const v4u __attribute__((address_space(4)))* w = (const v4u __attribute__((address_space(4)))*)(recs + fi);
     const v4u a[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
     __builtin_memcpy(&r, a, sizeof(r));
   }
-  if ((uint64_t)tile * kTile >= r.n) return;  // (2-D grid: beyond this frame's last tile)
-  frame_tile<TIER>(r.in, r.out, r.n, r.f, r.head, as_constant(recs64 + opaque_uniform(fi)), tile);
+  if ((uint64_t)blockIdx.x * kTile >= r.n) return;  // beyond this frame's last tile
+  frame_tile<TIER>(r.in, r.out, r.n, r.f, r.head, as_constant(recs64 + opaque_uniform(fi)), blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
