@@ -207,6 +207,7 @@ struct Lane {
   bool quarter_armed[4] = {false, false, false, false};
   uint64_t aidx = 0;           // next argument slot (mod kQueuePackets)
   uint64_t widx = 0;           // next packet slot (single producer: the context's calling thread)
+  uint64_t room_until = 0;     // packets below this index fit the queue for sure (wait_for_room)
   bool first_after_transition = true;
 };
 struct DirectQueue {
@@ -223,11 +224,15 @@ struct DirectQueue {
 namespace {
 // room for one more packet?  (never more than kQueuePackets - 64 ahead of the packet processor)  false: the queue stopped consuming
 bool wait_for_room(Lane* l) {
-  if (l->widx - hsa_queue_load_read_index_relaxed(l->q) < kQueuePackets - 64) return true;
+  // (the read index is a word the packet processor rewrites with every packet: reading it misses the host's caches each time -- so the
+  // bound it gave is used until it is exhausted)
+  if (l->widx < l->room_until) return true;
   const double t0 = now_s();
-  while (l->widx - hsa_queue_load_read_index_scacquire(l->q) >= kQueuePackets - 64)
+  for (;;) {
+    l->room_until = hsa_queue_load_read_index_scacquire(l->q) + (kQueuePackets - 64);
+    if (l->widx < l->room_until) return true;
     if (now_s() - t0 > kWaitSeconds) return false;
-  return true;
+  }
 }
 void ring_doorbell(Lane* l, void* packet, uint16_t header, uint16_t setup_or_rest) {
   // header and the following 16 bits are published together, last, with release semantics: the packet processor may look at the slot at any time
