@@ -268,7 +268,7 @@ uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
 /* THE DIRECT QUEUE (ABI 5).  On the context's OWN stream (the state after kmc_hip_create) a device-resident kmc_hip_deskew_f32 call -- and a
  * device-resident kmc_hip_deskew_traj_f32 call of up to four knots without an index output (north_star's three bracketing poses: the segment
  * records ride in the argument block, 2.7 us per KITTI frame instead of 5.5) -- does not go through a HIP launch: the library writes the frame's AQL dispatch packet into an HSA queue of the context's own, with the
- * argument block in device memory -- 1.7-2.0 us per KITTI frame per call instead of the 3.5-4.7 us of the HIP runtime's launch path
+ * argument block in device memory -- 1.7-2.4 us per KITTI frame per call instead of the 3.5-4.9 us of the HIP runtime's launch path
  * (which costs 2.2-3.5 us through every launch API).  Same kernel body, same bits (checked on the device when the queue is opened, at the
  * first such call).  The barrier bit of a packet is decided like before: a frame that shares no buffer with the frames in flight goes out
  * without it (KMC_ANY_ORDER=0: every packet carries it).  TWO LANES: the direct queue is two HSA queues; independent frames alternate
