@@ -215,8 +215,8 @@ struct DirectQueue {
   Lane lane[kLanes];
   OrderRec order[kOrderRecords];           // used round-robin, one per ordered frame
   uint32_t next_record = 0;
-  OrderRec* lane1_must_wait_for = nullptr; // the last ordered frame's record, if lane 1 has not been told to wait for that frame yet
-  bool lane1_dirty = false;                // lane 1 has taken packets since the last point at which lane 0 waited for it
+  kmc_book::LaneSync sync;                 // which cross-lane waits the next frame needs (kmc_dispatch_book.hpp: unit-tested against a model of two queues)
+  OrderRec* last_full = nullptr;           // the last fully ordered frame's record (what lane 1's next packet waits for, if sync says it must)
   bool two_lanes = true;                   // KMC_DIRECT_LANES=1: everything on lane 0 (measurement knob)
   uint64_t frames = 0;
 };
@@ -268,7 +268,10 @@ int take_order_record(kmc_ctx* c, DirectQueue* d, OrderRec** out) {
   while (hsa_signal_load_scacquire(r->s) > 0 || hsa_signal_load_scacquire(r->x) > 0 || (r->w_used && hsa_signal_load_scacquire(r->w) > 0))
     if (now_s() - t0 > kWaitSeconds) return queue_stuck(c, "direct queue: an ordered frame did not complete within the timeout");
   r->w_used = false;
-  if (d->lane1_must_wait_for == r) d->lane1_must_wait_for = nullptr;  // (it has completed: nothing to wait for)
+  if (d->last_full == r) {  // (it has completed: nothing to wait for)
+    d->last_full = nullptr;
+    d->sync.last_full_has_completed();
+  }
   *out = r;
   return KMC_OK;
 }
@@ -308,8 +311,8 @@ int direct_join(kmc_ctx* c) {
   }
   c->dd_pending = false;
   c->lw.invalidate();  // nothing in flight; the next frame re-acquires at system scope, fully ordered
-  d->lane1_dirty = false;
-  d->lane1_must_wait_for = nullptr;
+  d->sync.joined();
+  d->last_full = nullptr;
   return KMC_OK;
 }
 
@@ -321,35 +324,31 @@ namespace {
 int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_bytes, size_t tile_base_at, uint64_t n_tiles, kmc_book::LaneVerdict v, uint32_t* launches_out) {
   DirectQueue* d = c->dd;
   // (a frame of several packets must have been admitted as fully ordered: direct_frame_is_huge)
-  const bool ordered_frame = v.kind == kmc_book::LaneVerdict::kFullyOrdered || n_tiles > kMaxTilesPerLaunch;
-  const bool lane_ordered = v.kind == kmc_book::LaneVerdict::kLaneOrdered;
-  int li = 0;
+  if (n_tiles > kMaxTilesPerLaunch) v = {kmc_book::LaneVerdict::kFullyOrdered, 0};  // (admitted as such already: direct_frame_is_huge)
   hsa_signal_t completion{0};
   OrderRec* rec = nullptr;
-  if (ordered_frame && d->two_lanes) {
-    int rc = take_order_record(c, d, &rec);
+  if (d->two_lanes && v.kind == kmc_book::LaneVerdict::kFullyOrdered) {  // (before the plan: a record that has completed may clear a wait lane 1 still owes)
+    const int rc = take_order_record(c, d, &rec);
     if (rc != KMC_OK) return rc;
-    if (d->lane1_dirty) {  // lane 0 waits for what lane 1 has taken so far
-      hsa_signal_store_relaxed(rec->x, 1);
-      rc = barrier_packet(c, &d->lane[1], hsa_signal_t{0}, rec->x, HSA_FENCE_SCOPE_AGENT);
-      if (rc == KMC_OK) rc = barrier_packet(c, &d->lane[0], rec->x, hsa_signal_t{0}, HSA_FENCE_SCOPE_AGENT);
-      if (rc != KMC_OK) return rc;
-      d->lane1_dirty = false;
-    }
+  }
+  const kmc_book::LanePlan plan = d->sync.plan(v, d->two_lanes ? 2 : 1);
+  const int li = plan.lane;
+  if (plan.cross_lane_wait) {  // lane 0 waits for what lane 1 has taken so far
+    hsa_signal_store_relaxed(rec->x, 1);
+    int rc = barrier_packet(c, &d->lane[1], hsa_signal_t{0}, rec->x, HSA_FENCE_SCOPE_AGENT);
+    if (rc == KMC_OK) rc = barrier_packet(c, &d->lane[0], rec->x, hsa_signal_t{0}, HSA_FENCE_SCOPE_AGENT);
+    if (rc != KMC_OK) return rc;
+  }
+  if (plan.wait_for_last_full && d->last_full) {  // everything before the last fully ordered frame must be over before lane 1 goes on
+    OrderRec* r = d->last_full;
+    hsa_signal_store_relaxed(r->w, 1);
+    r->w_used = true;
+    const int rc = barrier_packet(c, &d->lane[1], r->s, r->w, HSA_FENCE_SCOPE_AGENT);
+    if (rc != KMC_OK) return rc;
+  }
+  if (plan.completion_signal) {
     hsa_signal_store_relaxed(rec->s, 1);
     completion = rec->s;
-  } else if (!ordered_frame && d->two_lanes) {
-    li = v.lane;  // the window's choice: the next lane in turn (independent of everything in flight) or the lane its conflicts sit in
-    if (li == 1) {
-      if (OrderRec* r = d->lane1_must_wait_for) {  // everything before the last fully ordered frame must be over before lane 1 goes on
-        hsa_signal_store_relaxed(r->w, 1);
-        r->w_used = true;
-        const int rc = barrier_packet(c, &d->lane[1], r->s, r->w, HSA_FENCE_SCOPE_AGENT);
-        if (rc != KMC_OK) return rc;
-        d->lane1_must_wait_for = nullptr;
-      }
-      d->lane1_dirty = true;
-    }
   }
   Lane* l = &d->lane[li];
   uint32_t launches = 0;
@@ -396,14 +395,14 @@ int dispatch_frame(kmc_ctx* c, uint64_t kernel_object, void* args, size_t arg_by
     p->completion_signal.handle = last_packet ? completion.handle : 0;
     // ordered packets acquire at agent scope (the frame before them may have written what they read), a lane's first one behind HIP-stream
     // work at system scope (copies, host writes); every frame releases at agent scope, direct_join's barrier packets at system scope
-    const bool ordered = ordered_frame || lane_ordered || l->first_after_transition || t0 != 0;
+    const bool ordered = plan.barrier_bit || l->first_after_transition || t0 != 0;
     const uint16_t acquire = l->first_after_transition ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
     const uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((ordered ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                             (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     ring_doorbell(l, p, header, (uint16_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS));
     l->first_after_transition = false;
   }
-  if (rec) d->lane1_must_wait_for = rec;  // (the latest ordered frame: its completion implies that of everything before it)
+  if (rec) d->last_full = rec;  // (the latest fully ordered frame: its completion implies that of everything before it)
   c->dd_pending = true;
   ++d->frames;
   if (launches_out) *launches_out = launches;

@@ -135,6 +135,45 @@ struct LaneWindow {
   }
 };
 
+// What the direct queue puts into its lanes for one frame, given the window's verdict (kmc_capi_direct.hip turns a plan into AQL packets;
+// tests/cpp/test_dispatch_book.cpp runs plans through a model of two in-order queues with random kernel durations and checks that no
+// frame ever starts before a frame it conflicts with has completed).  Lanes are AQL queues: packets of one lane LAUNCH in order; a packet
+// with the barrier bit waits for every earlier packet of its lane to COMPLETE; a barrier packet holds back every later packet of its lane
+// until the signal it waits for has been raised.
+struct LanePlan {
+  int lane;                  // where the frame's packet goes
+  bool barrier_bit;          // on the frame's packet
+  bool cross_lane_wait;      // first: a barrier packet on lane 1 raises X when lane 1 has drained so far, a barrier packet on lane 0 waits for X
+  bool wait_for_last_full;   // first: a barrier packet on this lane (1) waits for the completion signal of the last fully ordered frame
+  bool completion_signal;    // the frame raises a completion signal (it is fully ordered: lane 1's next packet will wait for it)
+};
+struct LaneSync {
+  bool lane1_dirty = false;      // lane 1 has taken packets since the last point at which lane 0 waited for it
+  bool lane1_owes_wait = false;  // lane 1 has not been told yet to wait for the last fully ordered frame
+
+  LanePlan plan(const LaneVerdict& v, int lanes) {
+    LanePlan p = {0, v.kind != LaneVerdict::kFree, false, false, false};
+    if (lanes < 2) return p;  // one lane: the barrier bit is all there is
+    if (v.kind == LaneVerdict::kFullyOrdered) {
+      p.cross_lane_wait = lane1_dirty;
+      lane1_dirty = false;
+      p.completion_signal = true;
+      lane1_owes_wait = true;  // everything before this frame has left the window: lane 1 may not overtake it
+      return p;
+    }
+    p.lane = v.lane;
+    if (p.lane == 1) {
+      p.wait_for_last_full = lane1_owes_wait;
+      lane1_owes_wait = false;
+      lane1_dirty = true;
+    }
+    return p;
+  }
+  // both lanes have drained (a join), or the last fully ordered frame is known to have completed
+  void joined() { lane1_dirty = false; lane1_owes_wait = false; }
+  void last_full_has_completed() { lane1_owes_wait = false; }
+};
+
 template <int CAPACITY>
 struct GatherList {
   Range reads[CAPACITY], writes[CAPACITY];

@@ -207,10 +207,118 @@ static void test_lane_window() {
   CHECK(v.kind == LaneVerdict::kLaneOrdered && v.lane == 0);
 }
 
+// ---- the two-lane protocol against a MODEL of two AQL queues --------------------------------------------------------------------
+// Random programs of frames over a small pool of buffers (independent, chained, in place, overlapping sub-ranges) go through
+// LaneWindow::admit and LaneSync::plan exactly like kmc_capi_direct.hip's dispatch_frame; the plans become packets of two modelled
+// queues.  The model's rules are AQL's: packets of a queue launch in order; a packet with the barrier bit starts when every earlier
+// packet of its queue has completed; a barrier packet completes when its queue's earlier packets have completed and its signal has
+// been raised, and nothing behind it in its queue launches before that.  Kernels take random times (now and then a very long one).
+// Property: a frame never starts before a frame it conflicts with -- called earlier -- has completed.
+#include <algorithm>
+#include <random>
+
+namespace model {
+struct Packet {
+  int lane;
+  bool is_barrier, barrier_bit;
+  int dep, completion;  // signal ids, -1: none
+  int frame;            // index into the program, -1 for barrier packets
+  double dur, start = 0, done = 0;
+};
+struct Queues {
+  std::vector<Packet> packets;      // in host order
+  std::vector<double> signal_time;  // when each signal is raised
+  double prev_start[2] = {0, 0}, all_done[2] = {0, 0}, barrier_done[2] = {0, 0};
+  int new_signal() { signal_time.push_back(-1.0); return (int)signal_time.size() - 1; }
+  void push(Packet p) {
+    double t = std::max(prev_start[p.lane], barrier_done[p.lane]);
+    if (p.barrier_bit) t = std::max(t, all_done[p.lane]);
+    if (p.is_barrier && p.dep >= 0) {
+      CHECK(signal_time[(size_t)p.dep] >= 0.0);  // the signal's packet was written before this one (no wait on something not yet queued)
+      t = std::max(t, signal_time[(size_t)p.dep]);
+    }
+    p.start = t;
+    p.done = t + (p.is_barrier ? 0.0 : p.dur);
+    prev_start[p.lane] = p.start;
+    all_done[p.lane] = std::max(all_done[p.lane], p.done);
+    if (p.is_barrier) barrier_done[p.lane] = std::max(barrier_done[p.lane], p.done);
+    if (p.completion >= 0) signal_time[(size_t)p.completion] = p.done;
+    packets.push_back(p);
+  }
+};
+}  // namespace model
+
+static void test_two_lane_protocol_against_a_model_of_the_queues() {
+  std::mt19937_64 rng(20260930);
+  auto uni = [&](int lo, int hi) { return lo + (int)(rng() % (uint64_t)(hi - lo + 1)); };
+  long frames_checked = 0, conflicts_checked = 0, kinds[3] = {0, 0, 0}, lanes_used[2] = {0, 0};
+  for (int program = 0; program < 20000; ++program) {
+    const int lanes = program % 7 == 6 ? 1 : 2;
+    kmc_book::LaneWindow<6> win;  // (a small window: "full" happens often)
+    win.lanes = lanes;
+    kmc_book::LaneSync sync;
+    model::Queues q;
+    int last_full_signal = -1;
+    const int n_buf = uni(2, 6), n_calls = uni(2, 40);
+    struct Frame { Range r, w; double start, done; };
+    std::vector<Frame> fr;
+    for (int k = 0; k < n_calls; ++k) {
+      const uintptr_t len = 0x1000;
+      auto pick = [&] {
+        const uintptr_t base = 0x100000 * (uintptr_t)(1 + uni(0, n_buf - 1));
+        if (uni(0, 3) == 0) { const uintptr_t lo = (uintptr_t)uni(0, 3) * 0x400; return Range{base + lo, base + lo + 0x400 * (uintptr_t)uni(1, 2)}; }  // a sub-range
+        return Range{base, base + len};
+      };
+      Range r = pick(), w = uni(0, 4) == 0 ? r : pick();  // now and then in place
+      const kmc_book::LaneVerdict v = win.admit(r, w, true, uni(0, 60) == 0);
+      const kmc_book::LanePlan plan = sync.plan(v, lanes);
+      ++kinds[v.kind];
+      ++lanes_used[plan.lane];
+      if (plan.cross_lane_wait) {
+        const int x = q.new_signal();
+        q.push({1, true, true, -1, x, -1, 0.0});
+        q.push({0, true, true, x, -1, -1, 0.0});
+      }
+      if (plan.wait_for_last_full) {
+        CHECK(last_full_signal >= 0 && plan.lane == 1);
+        q.push({1, true, true, last_full_signal, -1, -1, 0.0});
+      }
+      int comp = -1;
+      if (plan.completion_signal) { comp = q.new_signal(); last_full_signal = comp; }
+      const double dur = uni(0, 20) == 0 ? 500.0 + uni(0, 500) : 1.0 + uni(0, 30);
+      q.push({plan.lane, false, plan.barrier_bit, -1, comp, (int)fr.size(), dur});
+      fr.push_back({r, w, q.packets.back().start, q.packets.back().done});
+      if (uni(0, 25) == 0) {  // a join: both lanes drain, the window ends (what every other entry point of a context does)
+        const double t = std::max(q.all_done[0], q.all_done[1]);
+        for (int l = 0; l < 2; ++l) { q.prev_start[l] = t; q.barrier_done[l] = t; q.all_done[l] = t; }
+        win.invalidate();
+        sync.joined();
+      }
+    }
+    for (size_t j = 0; j < fr.size(); ++j)
+      for (size_t i = 0; i < j; ++i)
+        if (!kmc_book::independent(fr[j].r, fr[j].w, fr[i].r, fr[i].w)) {
+          ++conflicts_checked;
+          if (!(fr[j].start >= fr[i].done)) {
+            std::fprintf(stderr, "program %d: frame %zu starts at %g before frame %zu (a conflict) is done at %g\n", program, j, fr[j].start, i, fr[i].done);
+            ++failures;
+            return;
+          }
+        }
+    frames_checked += (long)fr.size();
+  }
+  // the programs really went every way: free frames on both lanes, lane-ordered ones, fully ordered ones, with real conflicts among them
+  CHECK(frames_checked > 100000 && conflicts_checked > 100000);
+  CHECK(kinds[0] > 10000 && kinds[1] > 10000 && kinds[2] > 10000 && lanes_used[0] > 10000 && lanes_used[1] > 10000);
+  std::printf("two-lane protocol: %ld frames, %ld conflicting pairs ordered; free / lane-ordered / fully ordered: %ld / %ld / %ld\n", frames_checked, conflicts_checked, kinds[0], kinds[1],
+              kinds[2]);
+}
+
 int main() {
   test_overlap_rules();
   test_any_order_window();
   test_lane_window();
+  test_two_lane_protocol_against_a_model_of_the_queues();
   test_gather_list();
   if (failures) {
     std::fprintf(stderr, "%d check(s) failed\n", failures);
