@@ -314,11 +314,50 @@ static void test_two_lane_protocol_against_a_model_of_the_queues() {
               kinds[2]);
 }
 
+// the same property for the HIP-launch path's window (ONE queue: a frame either carries the barrier bit or it does not)
+static void test_any_order_window_against_a_model_of_the_queue() {
+  std::mt19937_64 rng(77);
+  auto uni = [&](int lo, int hi) { return lo + (int)(rng() % (uint64_t)(hi - lo + 1)); };
+  long conflicts_checked = 0, free_frames = 0;
+  for (int program = 0; program < 10000; ++program) {
+    kmc_book::AnyOrderWindow<5> win;
+    model::Queues q;
+    struct Frame { Range r, w; double start, done; };
+    std::vector<Frame> fr;
+    const int n_buf = uni(2, 6), n_calls = uni(2, 30);
+    for (int k = 0; k < n_calls; ++k) {
+      auto pick = [&] {
+        const uintptr_t base = 0x100000 * (uintptr_t)(1 + uni(0, n_buf - 1));
+        if (uni(0, 3) == 0) { const uintptr_t lo = (uintptr_t)uni(0, 3) * 0x400; return Range{base + lo, base + lo + 0x400}; }
+        return Range{base, base + 0x1000};
+      };
+      const Range r = pick(), w = uni(0, 4) == 0 ? r : pick();
+      const bool any_order = win.admit(r, w, true, true);
+      free_frames += any_order ? 1 : 0;
+      q.push({0, false, !any_order, -1, -1, (int)fr.size(), uni(0, 15) == 0 ? 400.0 : 1.0 + uni(0, 20)});
+      fr.push_back({r, w, q.packets.back().start, q.packets.back().done});
+      if (uni(0, 20) == 0) win.invalidate();  // some other entry point put ordinary work on the stream (the next frame is ordered, whatever its buffers)
+    }
+    for (size_t j = 0; j < fr.size(); ++j)
+      for (size_t i = 0; i < j; ++i)
+        if (!kmc_book::independent(fr[j].r, fr[j].w, fr[i].r, fr[i].w)) {
+          ++conflicts_checked;
+          if (!(fr[j].start >= fr[i].done)) {
+            std::fprintf(stderr, "one queue, program %d: frame %zu starts at %g before frame %zu (a conflict) is done at %g\n", program, j, fr[j].start, i, fr[i].done);
+            ++failures;
+            return;
+          }
+        }
+  }
+  CHECK(conflicts_checked > 100000 && free_frames > 10000);
+}
+
 int main() {
   test_overlap_rules();
   test_any_order_window();
   test_lane_window();
   test_two_lane_protocol_against_a_model_of_the_queues();
+  test_any_order_window_against_a_model_of_the_queue();
   test_gather_list();
   if (failures) {
     std::fprintf(stderr, "%d check(s) failed\n", failures);

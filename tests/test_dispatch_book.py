@@ -1,6 +1,8 @@
 """The bookkeeping of barrier-free dispatch and of gathered calls (kmc_dispatch_book.hpp) is HIP-free on purpose: this test builds its
 C++ unit test with the system compiler and runs it on the CPU -- a fake stream answers "have you run dry?" from a script
-(VERDICT r04 #7).  The GPU suite checks the same promises end to end (test_gathered_calls_keep_in_order_results, test_frame_queues_...)."""
+(VERDICT r04 #7); the direct queue's two-lane protocol (LaneWindow + LaneSync) and the one-queue window are run, as random programs of
+frames, through a MODEL of AQL queues with random kernel durations: no frame may start before a frame it conflicts with has completed.
+The GPU suite checks the same promises end to end (test_gathered_calls_keep_in_order_results, test_frame_queues_...)."""
 import os
 import subprocess
 
