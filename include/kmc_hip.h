@@ -280,7 +280,8 @@ uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
  * them in the order of the calls -- a frame waits for what the context put on its stream before it, every other entry point waits for
  * the frames before it (host waits, at such transitions only).  What a caller must know: the frames are not in a HIP stream, so
  * hipDeviceSynchronize() or a synchronize of some stream of the caller's does not wait for them -- kmc_hip_synchronize(ctx) does, and so
- * does every other call on the context.  Not used on a caller's stream (kmc_hip_set_stream), with gathering on, with per-call timing
+ * does every other call on the context; nor does hipFree's implicit wait cover them: a frame's buffers must not be freed before
+ * kmc_hip_synchronize(ctx) (or another call on the context) has returned.  Not used on a caller's stream (kmc_hip_set_stream), with gathering on, with per-call timing
  * on, or with KMC_DIRECT_DISPATCH=0; not available (HIP launches instead) where the host cannot map device memory.  A wait on the queue
  * that exceeds ten seconds turns into KMC_ERR_HIP, and the context goes back to HIP launches.
  * kmc_hip_direct_frames: frames this context has dispatched through its direct queue so far (0: the queue is not in use). */
