@@ -1,6 +1,13 @@
 // trajectory_interpolation.hpp -- geodesic interpolation between two stamped poses: the reference's
 // include/kitti_motion_compensation/trajectory_interpolation.hpp:9-31.  Host code (f64); the hot path uses it once per frame,
 // the per-point half of GetPoseAtTime runs on the GPU.
+//
+// How the GPU path uses this class: MotionCompensateFrame builds nothing per point.  The twist xi = Log(pose_1^-1 * pose_2) is taken
+// ONCE per frame on the host (kmc_host_math.hpp, f64), and because GetPoseAtTime(a)^-1 * GetPoseAtTime(q) = Exp((x_q - x_a) * xi) for
+// poses on one geodesic, a lane evaluates a single exponential at the point's own fraction (closed form: Rodrigues + the left Jacobian,
+// kmc_device_math.hip.h).  The class below is the reference's host-side object with the same names, argument meaning and failure mode;
+// RelativePoseBetweenTimes(anchor, query) returns T(anchor)^-1 * T(query) exactly as the reference composes it (two GetPoseAtTime
+// calls), which is also what the oracle's FAITHFUL mode does for every point.
 #pragma once
 
 #include "kitti_motion_compensation/data_types.hpp"
