@@ -152,6 +152,7 @@ int main(int argc, char** argv) {
   // 64 pairs = 2 GiB do not), argv[6] = "distinct_inputs": every pair has its own input buffer too
   const int kBufs = argc > 5 ? std::max(1, std::min(256, std::atoi(argv[5]))) : 8;
   const bool distinct_inputs = argc > 6 && std::strcmp(argv[6], "distinct_inputs") == 0;
+  const bool no_fences = argc > 7 && std::strcmp(argv[7], "no_fences") == 0;
   std::vector<void*> in((size_t)kBufs + 1), out((size_t)kBufs + 1);  // (the extra pair belongs to the drain's own dispatch)
   for (int b = 0; b <= kBufs; ++b) { HIP_OK(hipMalloc(&in[b], n * 16)); HIP_OK(hipMalloc(&out[b], n * 16)); HIP_OK(hipMemset(in[b], 0, n * 16)); HIP_OK(hipMemset(out[b], 0xFF, n * 16)); }
   {  // in[0]: x = 1.0 everywhere, so that out.x = 1 * f.v[0] + f.v[1] + d.v[3] is checkable
@@ -199,8 +200,11 @@ int main(int argc, char** argv) {
     p->kernel_object = kobj;
     p->kernarg_address = a;
     p->completion_signal = completion;
+    // (argv[7] = "no_fences": packets without the barrier bit acquire and release nothing -- what the fences of a dispatch cost; the drain's
+    // own packets keep theirs, so the checked outputs are still visible)
+    const uint16_t fence = (!barrier && i >= 0 && no_fences) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
     uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
-                      (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+                      (fence << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (fence << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     __atomic_store_n((uint16_t*)&p->header, header, __ATOMIC_RELEASE);
     hsa_queue_store_write_index_relaxed(q, widx + 1);
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)widx);
@@ -265,7 +269,7 @@ int main(int argc, char** argv) {
     const double train = us_since(t0) / N;
     std::printf(", \"aql_%s_queues_alternating_without_barrier_bit\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", K == 2 ? "two" : K == 3 ? "three" : "four", host, train);
   }
-  std::printf(", \"buffer_pairs\": %d, \"distinct_inputs\": %s", kBufs, distinct_inputs ? "true" : "false");
+  std::printf(", \"buffer_pairs\": %d, \"distinct_inputs\": %s, \"unordered_packets_without_fences\": %s", kBufs, distinct_inputs ? "true" : "false", no_fences ? "true" : "false");
   std::printf(", \"note\": \"host = packet + 232-byte kernarg block + doorbell per frame, including the back-pressure of a 4096-packet queue when the device is the slower side\"}\n");
   for (auto& qq : qs) hsa_queue_destroy(qq);
   return 0;
