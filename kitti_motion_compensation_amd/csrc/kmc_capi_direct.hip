@@ -242,9 +242,14 @@ void ring_doorbell(Lane* l, void* packet, uint16_t header, uint16_t setup_or_res
   hsa_signal_store_screlease(l->q->doorbell_signal, (hsa_signal_value_t)l->widx);
   ++l->widx;
 }
+// The queue made no progress within the timeout: THIS call reports it (frames still in the queue are lost, which is what the error says);
+// the context declares the queue dead -- nothing waits for it again (a later join must not stall another ten seconds), frames go out as
+// HIP launches from here on.
 int queue_stuck(kmc_ctx* c, const char* what) {
   c->last_error = what;
   c->dd_broken = true;
+  c->dd_pending = false;
+  c->lw.invalidate();
   return KMC_ERR_HIP;
 }
 // a barrier packet on lane `l`: waits for every packet before it on that lane (barrier bit) and for `dep` (handle 0: none); signals `completion` (handle 0: none)
