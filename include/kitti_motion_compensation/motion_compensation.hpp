@@ -49,6 +49,11 @@ namespace hip {
 void SetDevice(int device_id);
 int GetDevice();
 
+// Runs the calling thread on the CPUs of its device's NUMA node (what numactl / taskset do for a deployment; never done implicitly):
+// on a two-socket box the host side of every call crosses the inter-socket link otherwise -- 104-125 instead of 92 us per in-place
+// KITTI frame.  (The page-locked containers themselves are placed on the device's node by the pool.)  false: the topology is unknown.
+bool BindThreadNearDevice();
+
 // Devices of kmc::MotionCompensateRun (handlers.hpp): one worker with its own device context per entry, each deskewing one
 // contiguous, point-balanced range of the run's frames.  An id may repeat (several contexts on one GPU).  Empty list =
 // back to the default: $KMC_DEVICES ("0,1,2,..."), else the calling thread's device.  Process-wide setting.

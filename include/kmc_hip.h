@@ -168,6 +168,13 @@ int kmc_host_pool_free(void* ptr);
 int kmc_host_pool_owns(const void* ptr, size_t bytes);
 int kmc_host_pool_trim(void);
 
+/* NUMA.  Blocks of the pool are placed on the device's NUMA node (a PREFERRED memory policy around the allocation; the caller's own
+ * policy is put back).  kmc_hip_bind_thread_near_device runs the CALLING thread on that node's CPUs (the PCI device's local_cpulist) --
+ * what numactl / taskset do for a deployment: on a two-socket box the host side of a call crosses the inter-socket link otherwise (1.9
+ * against 2.2 us per direct-queue call, 92 against 104-125 us per in-place KITTI frame).  Never done implicitly; KMC_OK also when there
+ * is nothing to do. */
+int kmc_hip_bind_thread_near_device(int device);
+
 /* ------------------------------------------------------------------------------------------------
  * host pre-step (f64, pure host code, usable without a GPU)
  * ---------------------------------------------------------------------------------------------- */

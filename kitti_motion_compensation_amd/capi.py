@@ -138,6 +138,7 @@ SIGNATURES = {
     "kmc_host_pool_free": (C.c_int, [_vp]),
     "kmc_host_pool_owns": (C.c_int, [_vp, C.c_size_t]),
     "kmc_host_pool_trim": (C.c_int, []),
+    "kmc_hip_bind_thread_near_device": (C.c_int, [C.c_int]),
     "kmc_frame_params_from_poses": (C.c_int, [_dp, _dp, C.c_double, C.c_double, C.c_double, C.POINTER(FrameParams)]),
     "kmc_oxts_to_pose": (C.c_int, [C.POINTER(Oxts), C.c_double, _dp]),
     "kmc_interpolate_trajectory": (C.c_int, [C.POINTER(Oxts), C.POINTER(Oxts), C.c_double, _dp]),
@@ -341,6 +342,13 @@ class PooledArray:
             self.close()
         except Exception:
             pass
+
+
+def bind_thread_near_device(device: int = 0) -> None:
+    """The calling thread onto the CPUs of the device's NUMA node (kmc_hip_bind_thread_near_device): what numactl does for a deployment."""
+    rc = lib().kmc_hip_bind_thread_near_device(device)
+    if rc != OK:
+        raise KmcError(rc, "kmc_hip_bind_thread_near_device")
 
 
 def host_pool_owns(a: np.ndarray) -> bool:

@@ -77,6 +77,8 @@ void SetDevice(int device_id) {
 
 int GetDevice() { return detail::t_device < 0 ? detail::default_device() : detail::t_device; }
 
+bool BindThreadNearDevice() { return kmc_hip_bind_thread_near_device(GetDevice()) == KMC_OK; }
+
 void EnableFrameTrace(bool enabled) {
   detail::t_trace = enabled;
   detail::t_last_trace = FrameTrace{};

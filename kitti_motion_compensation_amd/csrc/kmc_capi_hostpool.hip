@@ -13,7 +13,13 @@
 //   - thread-safe; blocks are never returned to the system at process exit (the HIP runtime may already be gone by then).
 #include "kmc_internal.hip.h"
 
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <atomic>
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -40,6 +46,52 @@ void mark_exiting() { g_exiting.store(true, std::memory_order_relaxed); }
 Pool& pool() {
   static Pool* p = new Pool();  // intentionally leaked: see the header comment
   return *p;
+}
+
+// ---- NUMA placement of the blocks (Linux system calls, no libnuma) ----
+constexpr int kMpolDefault = 0, kMpolPreferred = 1;
+int device_numa_node() {  // of the calling thread's current HIP device; -1: unknown, or a machine with one node  (pool mutex held)
+  static int cached[64];
+  static bool known[64];
+  int dev = 0;
+  char bdf[64] = {0};
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if (dev >= 0 && dev < 64 && known[dev]) return cached[dev];
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  for (char* q = bdf; *q; ++q) *q = (char)std::tolower((unsigned char)*q);
+  char path[160];
+  std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  int node = -1;
+  if (FILE* f = std::fopen(path, "r")) {
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+  }
+  if (dev >= 0 && dev < 64) { cached[dev] = node; known[dev] = true; }
+  return node;
+}
+struct SavedPolicy {
+  int mode = kMpolDefault;
+  unsigned long mask[16] = {0};
+  bool valid = false;
+};
+thread_local SavedPolicy t_saved;
+bool prefer_node(int node) {  // remembers the calling thread's own policy (a caller under numactl keeps it)
+  unsigned long mask[16] = {0};
+  if (node < 0 || node >= (int)(sizeof(mask) * 8)) return false;
+  t_saved.valid = syscall(SYS_get_mempolicy, &t_saved.mode, t_saved.mask, sizeof(t_saved.mask) * 8 + 1, nullptr, 0) == 0;
+  if (!t_saved.valid) return false;
+  mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+  return syscall(SYS_set_mempolicy, kMpolPreferred, mask, sizeof(mask) * 8 + 1) == 0;
+}
+void restore_policy() {
+  if (t_saved.mode == kMpolDefault) (void)syscall(SYS_set_mempolicy, kMpolDefault, nullptr, 0);
+  else (void)syscall(SYS_set_mempolicy, t_saved.mode, t_saved.mask, sizeof(t_saved.mask) * 8 + 1);
 }
 
 constexpr size_t kMinClassBytes = 64 * 1024;
@@ -131,8 +183,16 @@ int kmc_host_pool_alloc(size_t bytes, void** out) {
     *out = b;
     return KMC_OK;
   }
+  // On the GPU's side of the machine: an in-place kernel reads and writes the block over the link, and a block on the other socket adds
+  // the inter-socket hop to every access (MI355X boxes here: 2 x EPYC, 92 us per KITTI frame with thread and memory on the GPU's node,
+  // 104-125 us on the other one; profiles/NOTES.md).  The block is allocated under a PREFERRED memory policy for the device's NUMA node
+  // (hipHostMallocNumaUser: "follow the caller's policy"); the calling thread's policy is put back right after.
   void* b = nullptr;
-  if (hipHostMalloc(&b, class_bytes(cls), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess || !b) {
+  const int node = device_numa_node();
+  const bool placed = node >= 0 && prefer_node(node);
+  const hipError_t e = hipHostMalloc(&b, class_bytes(cls), hipHostMallocPortable | hipHostMallocMapped | (placed ? hipHostMallocNumaUser : 0u));
+  if (placed) restore_policy();
+  if (e != hipSuccess || !b) {
     (void)hipGetLastError();
     return KMC_ERR_ALLOC;
   }
@@ -181,6 +241,43 @@ int kmc_host_pool_trim(void) {
   (void)hipGetLastError();
   p.cached_bytes = 0;
   return released;
+}
+
+// Runs the CALLING thread on the CPUs of the device's NUMA node (the PCI device's local_cpulist).  What a deployment does with numactl /
+// taskset, for callers that cannot: a call's host side -- argument blocks over the BAR, the read-back, filling a column of a page-locked
+// container -- crosses the inter-socket link when the thread sits on the other socket (1.9 against 2.2 us per direct-queue call, 92
+// against 104-125 us per in-place KITTI frame on the 2-socket MI355X boxes).  Never done implicitly.  KMC_OK also when there is nothing
+// to do (one node, unknown topology); the thread's previous mask is not remembered.
+int kmc_hip_bind_thread_near_device(int device) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) {
+    (void)hipGetLastError();
+    return KMC_ERR_INVALID_ARG;
+  }
+  for (char* q = bdf; *q; ++q) *q = (char)std::tolower((unsigned char)*q);
+  char path[160];
+  std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE* f = std::fopen(path, "r");
+  if (!f) return KMC_OK;
+  char list[1024] = {0};
+  const bool got = std::fgets(list, sizeof(list), f) != nullptr;
+  std::fclose(f);
+  if (!got) return KMC_OK;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n_set = 0;
+  for (char* q = list; *q;) {  // "0-63,128-191"
+    char* end = nullptr;
+    const long a = std::strtol(q, &end, 10);
+    if (end == q) break;
+    long b = a;
+    q = end;
+    if (*q == '-') { b = std::strtol(q + 1, &end, 10); q = end; }
+    for (long k = a; k <= b && k < CPU_SETSIZE; ++k) { CPU_SET((int)k, &set); ++n_set; }
+    if (*q == ',') ++q; else break;
+  }
+  if (n_set == 0) return KMC_OK;
+  return sched_setaffinity(0, sizeof(set), &set) == 0 ? KMC_OK : KMC_ERR_INVALID_ARG;
 }
 
 }  // extern "C"

@@ -1845,3 +1845,53 @@ def test_contexts_on_concurrent_host_threads(torch_mod, kitti):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
+def test_pool_blocks_live_on_the_devices_numa_node_and_the_thread_can_be_bound_there(torch_mod):
+    """kmc_host_pool_alloc places its page-locked blocks on the GPU's NUMA node (an in-place kernel's every access crosses the
+    inter-socket link otherwise), whatever node the allocating thread runs on; kmc_hip_bind_thread_near_device puts the calling thread
+    on that node's CPUs.  Checked through the kernel's own view: move_pages(2) says where a page lives, sched_getaffinity where the
+    thread may run.  Skipped on a machine with one node / no topology information."""
+    import ctypes
+
+    torch = torch_mod
+    props = torch.cuda.get_device_properties(0)
+    if not all(hasattr(props, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        pytest.skip("this torch does not say where device 0 sits on the PCI bus")
+    sysdir = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    if not os.path.exists(os.path.join(sysdir, "numa_node")):
+        pytest.skip("no topology information for " + sysdir)
+    node = int(open(os.path.join(sysdir, "numa_node")).read())
+    cpus = open(os.path.join(sysdir, "local_cpulist")).read().strip()
+    if node < 0 or len(os.listdir("/sys/devices/system/node")) == 0 or not os.path.exists("/sys/devices/system/node/node1"):
+        pytest.skip("one NUMA node: nothing to place")
+    local = set()
+    for part in cpus.split(","):
+        a, _, b = part.partition("-")
+        local.update(range(int(a), int(b or a) + 1))
+    other = sorted(set(os.sched_getaffinity(0)) - local)
+    if not other:
+        pytest.skip("this process may only run on the GPU's node")
+    libc = ctypes.CDLL(None, use_errno=True)
+    before = os.sched_getaffinity(0)
+
+    def node_of(addr):
+        pages = (ctypes.c_void_p * 1)(addr & ~4095)
+        status = (ctypes.c_int * 1)(-1)
+        rc = libc.syscall(279, 0, 1, pages, None, status, 0)  # move_pages(pid 0, 1 page, nodes = NULL: query)
+        assert rc == 0, ctypes.get_errno()
+        return status[0]
+
+    try:
+        os.sched_setaffinity(0, other[:8])                     # the allocating thread on the OTHER socket
+        blk = capi.PooledArray((1 << 20,), dtype=np.float64)   # 8 MiB: a fresh block (no cached one of this class: the sizes of the suite are smaller or larger)
+        try:
+            blk.a[:] = 1.0
+            assert node_of(blk.a.ctypes.data) == node and node_of(blk.a.ctypes.data + blk.a.nbytes - 8) == node
+        finally:
+            blk.close()
+        capi.bind_thread_near_device(0)
+        assert set(os.sched_getaffinity(0)) <= local and len(os.sched_getaffinity(0)) > 0
+    finally:
+        os.sched_setaffinity(0, before)
