@@ -702,6 +702,7 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
       workers.emplace_back([&, r] {
         try {
           hip::SetDevice(devices[r]);  // this worker thread's context lives on its device
+          (void)hip::BindThreadNearDevice();  // ... and the worker (a thread of the library's own) runs on that device's side of the machine
           DeskewFrameRange(in, 1 + bounds[r], 1 + bounds[r + 1], static_cast<int>(r));
         } catch (...) {
           errors[r] = std::current_exception();
