@@ -277,7 +277,14 @@ int kmc_hip_bind_thread_near_device(int device) {
     if (*q == ',') ++q; else break;
   }
   if (n_set == 0) return KMC_OK;
-  return sched_setaffinity(0, sizeof(set), &set) == 0 ? KMC_OK : KMC_ERR_INVALID_ARG;
+  // only CPUs the thread may run on anyway (a container's cpuset, an outer taskset): an empty intersection means "nothing to do"
+  cpu_set_t allowed, both;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return KMC_OK;
+  CPU_AND(&both, &set, &allowed);
+  if (CPU_COUNT(&both) == 0) return KMC_OK;
+  (void)sched_setaffinity(0, sizeof(both), &both);  // (a refusal leaves the thread where it was: a placement hint, not a requirement)
+  return KMC_OK;
 }
 
 }  // extern "C"

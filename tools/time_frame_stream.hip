@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
   const uint64_t total = offsets[F];
 
   kmc_ctx *ctx = nullptr, *drained = nullptr, *tabled = nullptr;
-  KMC_OK_OR_DIE(kmc_hip_bind_thread_near_device(0));  // the calling thread on the GPU's NUMA node (what numactl does for a deployment)
+  (void)kmc_hip_bind_thread_near_device(0);  // a placement hint: the calling thread on the GPU's NUMA node (what numactl does for a deployment)
   KMC_OK_OR_DIE(kmc_hip_create(&ctx, 0));
   setenv("KMC_LIST_ROUTE", "table", 1);
   KMC_OK_OR_DIE(kmc_hip_create(&tabled, 0));
