@@ -111,6 +111,7 @@ int main(int argc, char** argv) {
       kmc_ctx* ctx = nullptr;
       float *d_in = nullptr, *d_out = nullptr;
       auto bail = [&](const char* what) { me.error = what; barrier.arrive(); barrier.arrive(); };
+      (void)kmc_hip_bind_thread_near_device(me.device);  // a placement hint: this rank's thread on its device's side of the machine
       if (hipSetDevice(me.device) != hipSuccess || kmc_hip_create(&ctx, me.device) != KMC_OK) return bail("no device context");
       const uint32_t mine = me.last - me.first;
       const uint32_t resident = std::min<uint32_t>(std::max<uint32_t>(mine, 1), 2 * per_launch);  // rotating groups of distinct frames
