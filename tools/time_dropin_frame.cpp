@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "usage: time_dropin_frame <golden_dir> [iterations] [dump_prefix]\n");
     return 2;
   }
-  (void)kmc_hip_bind_thread_near_device(0);  // the calling thread on the GPU's NUMA node (what numactl does for a deployment)
+  if (!std::getenv("KMC_TOOL_NO_BIND")) (void)kmc_hip_bind_thread_near_device(0);  // the calling thread on the GPU's NUMA node (what numactl does for a deployment)
   Path const run{std::string(argv[1]) + "/kitti_2011_09_26_drive_0005"};
   int const iters = argc > 2 ? std::atoi(argv[2]) : 200;
   std::string const prefix = argc > 3 ? argv[3] : "";
