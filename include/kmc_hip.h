@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define KMC_ABI_VERSION 5
+#define KMC_ABI_VERSION 6
 
 /* ---- status codes ---- */
 #define KMC_OK 0
@@ -272,6 +272,12 @@ int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* ctx);
 /* How many frames of this context have been dispatched without the barrier bit so far (a counter for tests and tuning). */
 uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
+/* The in-place routes (KMC_MEM_HOST_MAPPED) wait for a completion word the kernel's last wave stores into page-locked memory.  If the
+ * stream runs dry without the word, the call synchronises the stream instead (every store of a finished, synchronised kernel is in host
+ * memory: the ordinary HIP contract) and returns normally; this counter says how often that happened over the context's life, and
+ * last_state (may be NULL) receives the last event's {sequence number expected, word seen, completion ticket seen}.  0 is the normal
+ * state; the event costs ~0.1 ms, never a result.  (ABI 6) */
+uint64_t kmc_hip_completion_word_fallbacks(kmc_ctx* ctx, uint32_t last_state[3]);
 /* THE DIRECT QUEUE (ABI 5).  On the context's OWN stream (the state after kmc_hip_create) a device-resident kmc_hip_deskew_f32 call -- and a
  * device-resident kmc_hip_deskew_traj_f32 call of up to four knots without an index output (north_star's three bracketing poses: the segment
  * records ride in the argument block, 2.7 us per KITTI frame instead of 5.5) -- does not go through a HIP launch: the library writes the frame's AQL dispatch packet into an HSA queue of the context's own, with the

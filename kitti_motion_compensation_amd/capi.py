@@ -148,6 +148,7 @@ SIGNATURES = {
     "kmc_hip_set_frame_queues": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_frame_queue_join": (C.c_int, [_vp]),
     "kmc_hip_any_order_launches": (C.c_uint64, [_vp]),
+    "kmc_hip_completion_word_fallbacks": (C.c_uint64, [_vp, C.POINTER(C.c_uint32)]),
     "kmc_hip_frame_queue_dropped": (C.c_uint64, [_vp]),
     "kmc_hip_direct_frames": (C.c_uint64, [_vp]),
     "kmc_hip_set_frame_queue_order": (C.c_int, [_vp, C.c_int]),
@@ -475,6 +476,13 @@ class Context:
     def frame_queue_dropped(self) -> int:
         """Gathered frames lost to a failed join over the context's life (kmc_hip.h, "Gathered frames and errors")."""
         return int(lib().kmc_hip_frame_queue_dropped(self._h))
+
+    def completion_word_fallbacks(self):
+        """(count, [sequence number expected, word seen, ticket seen] of the last event): in-place calls that ended on a stream
+        synchronisation because the kernel's completion word had not come (kmc_hip.h); (0, [0, 0, 0]) is the normal state."""
+        st = (C.c_uint32 * 3)()
+        n = int(lib().kmc_hip_completion_word_fallbacks(self._h, st))
+        return n, [int(v) for v in st]
 
     def any_order_launches(self) -> int:
         """Frames dispatched without the barrier bit so far (see kmc_hip_set_frame_queues in kmc_hip.h)."""

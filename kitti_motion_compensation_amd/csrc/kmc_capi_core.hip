@@ -71,6 +71,11 @@ DoneWord done_word_arm(kmc_ctx* c) {
 
 // The last armed launch has stored its sequence number <=> every wave's stores are in host memory (DoneWord, kmc_kernels.hip.h).
 // The stream is looked at every 16 Ki polls (~100 us): a launch that died never raises the word.
+// A stream that has run dry WITHOUT the word (seen once in round 5's GPU suite runs: the C++ test binary, which also runs four contexts on four host threads): the
+// kernel has finished, so the ordinary HIP contract takes over -- hipStreamSynchronize, after which every store of the stream's
+// kernels is in host memory whether or not the word came.  The event is counted and its state kept for
+// kmc_hip_completion_word_fallbacks (expected sequence number, word, ticket), and the ticket is put back to 0 so that the next
+// armed launch counts from a clean slate.
 int wait_done_word(kmc_ctx* c) {
   if (!c->done_armed) return KMC_OK;
   c->done_armed = false;
@@ -81,9 +86,17 @@ int wait_done_word(kmc_ctx* c) {
     const hipError_t q = hipStreamQuery(c->stream);
     if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
     if (q != hipSuccess) return fail_hip(c, q, "in-place kernel (hipStreamQuery while waiting for its completion word)");
-    if (*word == seq) break;  // the stream is idle: the word must be there
-    c->last_error = "in-place kernel finished without raising its completion word";
-    return KMC_ERR_HIP;
+    if (*word == seq) break;  // the stream is idle and the word is there
+    KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t seen = *word;
+    uint32_t ticket = 0;
+    KMC_HIP_TRY(c, hipMemcpy(&ticket, c->d_ticket, sizeof(ticket), hipMemcpyDeviceToHost));
+    c->done_fallbacks += 1;
+    c->done_fallback_state[0] = seq;
+    c->done_fallback_state[1] = seen;
+    c->done_fallback_state[2] = ticket;
+    if (ticket != 0) KMC_HIP_TRY(c, hipMemset(c->d_ticket, 0, sizeof(ticket)));
+    break;
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   return KMC_OK;
@@ -629,6 +642,13 @@ int kmc_hip_frame_queue_join(kmc_ctx* c) {
 uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* c) { return c ? c->fq_dropped : 0; }
 
 uint64_t kmc_hip_any_order_launches(kmc_ctx* c) { return c ? c->ao.launches + c->lw.launches : 0; }
+
+uint64_t kmc_hip_completion_word_fallbacks(kmc_ctx* c, uint32_t last_state[3]) {
+  if (!c) return 0;
+  if (last_state)
+    for (int i = 0; i < 3; ++i) last_state[i] = c->done_fallback_state[i];
+  return c->done_fallbacks;
+}
 
 int kmc_hip_enable_timing(kmc_ctx* c, int enabled) {
   if (!c) return KMC_ERR_INVALID_ARG;

@@ -56,6 +56,8 @@ struct kmc_ctx {
   uint32_t* d_ticket = nullptr;  // device word next to d_counter, 0 between kernels
   uint32_t done_seq = 0;         // sequence number of the last launch that carries a completion word
   bool done_armed = false;       // such a launch is in flight and nobody has waited for it yet
+  uint64_t done_fallbacks = 0;   // waits that ended on an idle stream without the word (wait_done_word): stream-synchronised instead
+  uint32_t done_fallback_state[3] = {0, 0, 0};  // the last such event: sequence number expected, word seen, ticket seen
   bool trace = false;            // kmc_hip_enable_call_trace
   kmc_call_trace last_trace = {};
   // batch tables: a ring of slots, each one device buffer + one pinned staging buffer holding

@@ -1891,7 +1891,16 @@ def test_pool_blocks_live_on_the_devices_numa_node_and_the_thread_can_be_bound_t
             assert node_of(blk.a.ctypes.data) == node and node_of(blk.a.ctypes.data + blk.a.nbytes - 8) == node
         finally:
             blk.close()
+        # the binding is a hint within the mask the thread already has (a container's cpuset, an outer taskset): from a mask
+        # that holds none of the node's CPUs nothing changes ...
         capi.bind_thread_near_device(0)
-        assert set(os.sched_getaffinity(0)) <= local and len(os.sched_getaffinity(0)) > 0
+        assert set(os.sched_getaffinity(0)) == set(other[:8])
+        # ... and from the process's own mask the thread ends up on the node's CPUs, and only on ones it was allowed before
+        os.sched_setaffinity(0, before)
+        if not (set(before) & local):
+            pytest.skip("this process may not run on the GPU's node")
+        capi.bind_thread_near_device(0)
+        now = set(os.sched_getaffinity(0))
+        assert len(now) > 0 and now <= local and now <= set(before)
     finally:
         os.sched_setaffinity(0, before)
