@@ -4,7 +4,10 @@ kernel works over the link and its last wave raises the completion word the call
 binary's re-entrancy case, where a wait once found the stream idle without the word.  Every call's result is compared bit for bit with
 the thread's first one; at the end: calls, mismatching calls, completion-word fallbacks and the state of the last one per thread.
 
-    python tools/stress_inplace_threads.py [threads=4] [seconds=20] [points=123397]
+    python tools/stress_inplace_threads.py [threads=4] [seconds=20] [points=123397] [churn=0]
+
+churn = 1: one more thread creates and destroys contexts all the while (hipMalloc / hipFree / hipHostFree / stream creation next to the
+running kernels -- what the C++ binary's threads do when they start and end).
 """
 import json
 import os
@@ -47,20 +50,35 @@ def worker(k, seconds, n, out, start):
         c.close()
 
 
+def churner(stop, count):
+    while not stop.is_set():
+        capi.Context(0).close()
+        count[0] += 1
+
+
 def main():
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 123397
+    churn = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     out = [None] * threads
     start = threading.Event()
+    stop = threading.Event()
+    churned = [0]
+    ch = threading.Thread(target=churner, args=(stop, churned)) if churn else None
     ws = [threading.Thread(target=worker, args=(k, seconds, n, out, start)) for k in range(threads)]
     for w in ws:
         w.start()
     time.sleep(0.5)
     start.set()
+    if ch:
+        ch.start()
     for w in ws:
         w.join()
-    print(json.dumps({"threads": threads, "seconds": seconds, "points": n,
+    stop.set()
+    if ch:
+        ch.join()
+    print(json.dumps({"threads": threads, "seconds": seconds, "points": n, "contexts_created_and_destroyed_meanwhile": churned[0],
                       "calls": sum(o["calls"] for o in out if o), "mismatching_calls": sum(o["mismatching_calls"] for o in out if o),
                       "completion_word_fallbacks": sum(o["completion_word_fallbacks"] for o in out if o), "per_thread": out}))
 
