@@ -276,7 +276,8 @@ uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
  * stream runs dry without the word, the call synchronises the stream instead (every store of a finished, synchronised kernel is in host
  * memory: the ordinary HIP contract) and returns normally; this counter says how often that happened over the context's life, and
  * last_state (may be NULL) receives the last event's {sequence number expected, word seen, completion ticket seen}.  0 is the normal
- * state; the event costs ~0.1 ms, never a result.  (ABI 6) */
+ * state; the event costs ~0.1 ms, never a result.  ctx == NULL: the total over every context the process has had (a per-thread context of
+ * the C++ drop-in ends with its thread).  (ABI 6) */
 uint64_t kmc_hip_completion_word_fallbacks(kmc_ctx* ctx, uint32_t last_state[3]);
 /* THE DIRECT QUEUE (ABI 5).  On the context's OWN stream (the state after kmc_hip_create) a device-resident kmc_hip_deskew_f32 call -- and a
  * device-resident kmc_hip_deskew_traj_f32 call of up to four knots without an index output (north_star's three bracketing poses: the segment

@@ -85,6 +85,7 @@ void EnableFrameTrace(bool enabled) {
   if (kmc_ctx* c = detail::thread_context()) (void)kmc_hip_enable_call_trace(c, enabled ? 1 : 0);
 }
 FrameTrace LastFrameTrace() { return detail::t_last_trace; }
+unsigned long long CompletionWordFallbacks() { return kmc_hip_completion_word_fallbacks(nullptr, nullptr); }
 
 void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t n, Affine3d const& T_start, Affine3d const& T_end, Time stamp_start,
                                 Time stamp_end, Time requested_time, float* xyzi_out) {

@@ -76,6 +76,9 @@ DoneWord done_word_arm(kmc_ctx* c) {
 // kernels is in host memory whether or not the word came.  The event is counted and its state kept for
 // kmc_hip_completion_word_fallbacks (expected sequence number, word, ticket), and the ticket is put back to 0 so that the next
 // armed launch counts from a clean slate.
+static std::atomic<uint64_t> g_done_fallbacks{0};        // the same, over every context of the process (ctx == NULL asks for these)
+static std::atomic<uint32_t> g_done_fallback_state[3];
+
 int wait_done_word(kmc_ctx* c) {
   if (!c->done_armed) return KMC_OK;
   c->done_armed = false;
@@ -95,6 +98,8 @@ int wait_done_word(kmc_ctx* c) {
     c->done_fallback_state[0] = seq;
     c->done_fallback_state[1] = seen;
     c->done_fallback_state[2] = ticket;
+    g_done_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    for (int i = 0; i < 3; ++i) g_done_fallback_state[i].store(c->done_fallback_state[i], std::memory_order_relaxed);
     if (ticket != 0) KMC_HIP_TRY(c, hipMemset(c->d_ticket, 0, sizeof(ticket)));
     break;
   }
@@ -644,7 +649,11 @@ uint64_t kmc_hip_frame_queue_dropped(kmc_ctx* c) { return c ? c->fq_dropped : 0;
 uint64_t kmc_hip_any_order_launches(kmc_ctx* c) { return c ? c->ao.launches + c->lw.launches : 0; }
 
 uint64_t kmc_hip_completion_word_fallbacks(kmc_ctx* c, uint32_t last_state[3]) {
-  if (!c) return 0;
+  if (!c) {  // the process's total: contexts that have been destroyed meanwhile (a thread's own context ends with the thread) are in it
+    if (last_state)
+      for (int i = 0; i < 3; ++i) last_state[i] = g_done_fallback_state[i].load(std::memory_order_relaxed);
+    return g_done_fallbacks.load(std::memory_order_relaxed);
+  }
   if (last_state)
     for (int i = 0; i < 3; ++i) last_state[i] = c->done_fallback_state[i];
   return c->done_fallbacks;

@@ -80,7 +80,8 @@ def main():
         ch.join()
     print(json.dumps({"threads": threads, "seconds": seconds, "points": n, "contexts_created_and_destroyed_meanwhile": churned[0],
                       "calls": sum(o["calls"] for o in out if o), "mismatching_calls": sum(o["mismatching_calls"] for o in out if o),
-                      "completion_word_fallbacks": sum(o["completion_word_fallbacks"] for o in out if o), "per_thread": out}))
+                      "completion_word_fallbacks": sum(o["completion_word_fallbacks"] for o in out if o),
+                      "completion_word_fallbacks_of_the_process": int(capi.lib().kmc_hip_completion_word_fallbacks(None, None)), "per_thread": out}))
 
 
 if __name__ == "__main__":
