@@ -302,13 +302,13 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
 
     # ---- ceilings: the box's own memory ceilings for the kernels' access patterns, without their arithmetic (tools/copy_ceiling.hip) ----
     # (driver-observed, in the same line as the kernels they bound)
-    def run_ceilings():
+    def run_ceilings(cols_only=False):
         import subprocess
 
         exe = os.path.join(ROOT, "kitti_motion_compensation_amd", "lib", "copy_ceiling")
         if not os.path.exists(exe):
             raise ToolMissing("copy_ceiling is missing (tools/Makefile builds it)")
-        r = subprocess.run([exe, "67108864", "3", "10"], capture_output=True, text=True, timeout=600, env=unprofiled_env())
+        r = subprocess.run([exe, "67108864", "3", "10"] + (["0", "cols"] if cols_only else []), capture_output=True, text=True, timeout=600, env=unprofiled_env())
         rows = [l.split(",") for l in r.stdout.splitlines() if "," in l and not l.startswith("kernel,")]
         if r.returncode != 0 or not rows:
             raise SystemExit(f"copy_ceiling failed ({r.returncode}): {r.stdout[-500:]} {r.stderr[-1000:]}")
@@ -527,6 +527,14 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
             ctx.deskew_f64cols_begin(cols[0], cols[1], cols[2], w, stamps, 100.0, 100.1, turn, *outs)
         ctx.deskew_f64cols_end()
 
+    def adjacent_ceiling():  # the nine- and seven-stream copies in the minute (clock, temperature) the kernel is measured in
+        try:
+            return run_ceilings(cols_only=True)
+        except (ToolMissing, SystemExit):
+            return {}
+
+    torch.cuda.synchronize()
+    ceil_before = adjacent_ceiling()
     ms = timed(f64_burst, 3, 1) / K64
 
     def f64_burst_ones():  # the homogeneous column KNOWN to be ones (what the C++ drop-in passes for every cloud its loaders made): neither read nor written
@@ -535,6 +543,8 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         ctx.deskew_f64cols_end()
 
     ms_ones = timed(f64_burst_ones, 3, 1) / K64
+    torch.cuda.synchronize()
+    ceil_after = adjacent_ceiling()
     ctx.enable_timing(True)
     for _ in range(3):
         ctx.deskew_f64cols(cols[0], cols[1], cols[2], w, stamps, 100.0, 100.1, turn, *outs)
@@ -567,6 +577,15 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         leg["frac_of_9_stream_ceiling"] = round(leg["GBps"] / max(c9), 4)
         leg["l2_hit_rate_explained"] = ("profiles/r04_pmc_sq_tcc_f64cols.json: TCC hits 16.0 M = exactly half of the 32.0 M write requests -- a 128-byte line arrives as two 64-byte "
                                         "write requests, the second meets the first in the L2; every one of the 20.0 M read requests (128 B each = the 2.56 GB read) misses: nothing is re-read")
+    adj9 = [v["GBps_median"] for cc in (ceil_before, ceil_after) for k, v in cc.items() if k.startswith("copy_cols9")]
+    adj7 = [v["GBps_median"] for cc in (ceil_before, ceil_after) for k, v in cc.items() if k.startswith("copy_cols7")]
+    if adj9:  # the same copies run right before and right after the kernel's bursts: no half minute of clock / temperature drift in between
+        leg["ceiling_9_streams_adjacent_GBps"] = {"before": max(v["GBps_median"] for k, v in ceil_before.items() if k.startswith("copy_cols9")) if ceil_before else None,
+                                                  "after": max(v["GBps_median"] for k, v in ceil_after.items() if k.startswith("copy_cols9")) if ceil_after else None,
+                                                  "is": "best copy variant (copy_cols9 / _w4 / _sc1, median of 3 rounds x 10 launches) of tools/copy_ceiling ... cols, run directly before and directly after the bursts above"}
+        leg["frac_of_adjacent_9_stream_ceiling"] = round(leg["GBps"] / max(adj9), 4)
+    if adj7:
+        leg["homogeneous_column_known_to_be_ones"]["frac_of_adjacent_7_stream_ceiling"] = round(leg["homogeneous_column_known_to_be_ones"]["GBps"] / max(adj7), 4)
     if c7:
         leg["homogeneous_column_known_to_be_ones"]["ceiling_7_streams_GBps"] = max(c7)
         leg["homogeneous_column_known_to_be_ones"]["frac_of_7_stream_ceiling"] = round(leg["homogeneous_column_known_to_be_ones"]["GBps"] / max(c7), 4)

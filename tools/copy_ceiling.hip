@@ -1,6 +1,7 @@
 // copy_ceiling.hip -- the memory system's own ceilings next to the deskew kernels, and the calibration kernel of the PMC traffic figures.
-//   copy_ceiling [n_points=67108864] [rounds=5] [iters=10] [out_shift_bytes=0]   (CSV on stdout: kernel, best / median us per launch, GB/s;
-//                 out_shift_bytes moves every output buffer relative to its input: does the memory care how the two streams line up?)
+//   copy_ceiling [n_points=67108864] [rounds=5] [iters=10] [out_shift_bytes=0] [cols]   (CSV on stdout: kernel, best / median us per launch, GB/s;
+//                 out_shift_bytes moves every output buffer relative to its input: does the memory care how the two streams line up?
+//                 `cols`: only the column-stream rows -- bench.py runs this right before and right after the f64 kernel's bursts)
 //   copy_points   one v4f per lane in, one out, 256-thread workgroups, nt loads + nt stores: 16 B read + 16 B written per point.  Its
 //                 FETCH_SIZE / WRITE_SIZE counts against its KNOWN traffic give the correction factors tools/summarize_profiles.py applies
 //                 to the bench kernel's counters (gfx950: FETCH_SIZE counts half of a wide coalesced stream; MI355X_MICROARCH.md, HBM section)
@@ -18,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -94,6 +96,7 @@ int main(int argc, char** argv) {
   const uint64_t n = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 67108864ull;
   const int rounds = argc > 2 ? std::atoi(argv[2]) : 5, iters = argc > 3 ? std::atoi(argv[3]) : 10;
   const size_t shift = argc > 4 ? std::strtoull(argv[4], nullptr, 10) & ~(size_t)15 : 0;
+  const bool cols_only = argc > 5 && std::string(argv[5]) == "cols";
   CHECK(hipSetDevice(0));
   hipStream_t s;
   CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -111,7 +114,7 @@ int main(int argc, char** argv) {
   struct K { const char* name; void (*fn)(const v4f*, v4f*, uint64_t); int block; int points_per_block; double bytes_per_point; };
   const K ks[] = {{"copy_points", copy_points, 256, 256, 32.0}, {"copy_tiles", copy_tiles, 64, 64, 32.0}, {"read_points", read_points, 64, 256, 16.0}, {"write_points", write_points, 64, 256, 16.0}};
   std::vector<std::vector<double>> us(4);
-  for (int r = 0; r < rounds; ++r)
+  for (int r = 0; r < (cols_only ? 0 : rounds); ++r)
     for (int k = 0; k < 4; ++k) {  // interleaved: every kernel sees every clock state
       const dim3 grid((unsigned)((n + ks[k].points_per_block - 1) / ks[k].points_per_block)), block(ks[k].block);
       for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(ks[k].fn, grid, block, 0, s, in[w % kBufs], out[w % kBufs], n);
@@ -124,7 +127,7 @@ int main(int argc, char** argv) {
       us[k].push_back(ms * 1e3 / iters);
     }
   std::printf("kernel,points,best_us,median_us,GBps_best,GBps_median\n");
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < (cols_only ? 0 : 4); ++k) {
     std::sort(us[k].begin(), us[k].end());
     const double best = us[k].front(), med = us[k][us[k].size() / 2];
     std::printf("%s,%llu,%.2f,%.2f,%.1f,%.1f\n", ks[k].name, (unsigned long long)n, best, med, ks[k].bytes_per_point * n / best / 1e3, ks[k].bytes_per_point * n / med / 1e3);
