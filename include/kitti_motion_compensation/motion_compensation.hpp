@@ -79,7 +79,7 @@ void EnableFrameTrace(bool enabled);
 FrameTrace LastFrameTrace();
 // In-place calls of this PROCESS that ended on a stream synchronisation because the kernel's completion word had not come (kmc_hip.h,
 // kmc_hip_completion_word_fallbacks): 0 normally; such a call costs ~0.1 ms more and returns the same cloud.
-unsigned long long CompletionWordFallbacks();
+unsigned long long CompletionWordFallbacks(unsigned last_state[3] = nullptr);  // last_state: {sequence number expected, word seen, ticket seen} of the last event
 
 // One frame in the on-disk KITTI layout (f32 AoS x,y,z,intensity): fuses GetPseudoTimeStamps (data_io.cpp:163),
 // MotionCompensateFrame (handlers.cpp:60) and WritePointcloud's f64->f32 cast (data_io.cpp:300-310) in one kernel.

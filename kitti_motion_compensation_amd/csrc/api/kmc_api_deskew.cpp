@@ -85,7 +85,13 @@ void EnableFrameTrace(bool enabled) {
   if (kmc_ctx* c = detail::thread_context()) (void)kmc_hip_enable_call_trace(c, enabled ? 1 : 0);
 }
 FrameTrace LastFrameTrace() { return detail::t_last_trace; }
-unsigned long long CompletionWordFallbacks() { return kmc_hip_completion_word_fallbacks(nullptr, nullptr); }
+unsigned long long CompletionWordFallbacks(unsigned last_state[3]) {
+  std::uint32_t st[3] = {0, 0, 0};
+  unsigned long long const count = kmc_hip_completion_word_fallbacks(nullptr, st);
+  if (last_state)
+    for (int i = 0; i < 3; ++i) last_state[i] = st[i];
+  return count;
+}
 
 void MotionCompensateKittiCloud(float const* xyzi_in, std::size_t n, Affine3d const& T_start, Affine3d const& T_end, Time stamp_start,
                                 Time stamp_end, Time requested_time, float* xyzi_out) {

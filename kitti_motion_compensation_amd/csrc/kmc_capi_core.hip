@@ -100,7 +100,10 @@ int wait_done_word(kmc_ctx* c) {
     c->done_fallback_state[2] = ticket;
     g_done_fallbacks.fetch_add(1, std::memory_order_relaxed);
     for (int i = 0; i < 3; ++i) g_done_fallback_state[i].store(c->done_fallback_state[i], std::memory_order_relaxed);
-    if (ticket != 0) KMC_HIP_TRY(c, hipMemset(c->d_ticket, 0, sizeof(ticket)));
+    if (ticket != 0) {  // (on the stream the kernels run on, and waited for: hipMemset alone returns before the fill has run)
+      KMC_HIP_TRY(c, hipMemsetAsync(c->d_ticket, 0, sizeof(ticket), c->stream));
+      KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     break;
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -510,7 +513,12 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
   for (auto& ev : c->group_consumed)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_counter, 64);  // the out-of-range counter + (16 bytes on) the completion ticket
-  if (e == hipSuccess) e = hipMemset(c->d_counter, 0, 64);
+  // hipMemset returns before the fill has run (it is asynchronous for device memory) and the null stream it runs on is not ordered with
+  // this context's non-blocking streams: the first armed in-place kernel of a fresh context once counted its tickets from the 9 a
+  // previous owner had left in the word (profiles/NOTES.md, section 10 -- seen with a second process on the GPU).  So: the fill on the
+  // context's own stream, and waited for.
+  if (e == hipSuccess) e = hipMemsetAsync(c->d_counter, 0, 64, c->own_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->own_stream);
   if (e == hipSuccess) c->d_ticket = reinterpret_cast<uint32_t*>(c->d_counter + 2);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_flag, 256, hipHostMallocPortable | hipHostMallocMapped);
   if (e == hipSuccess) {

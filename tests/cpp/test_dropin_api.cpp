@@ -755,7 +755,9 @@ int main(int argc, char** argv) {
     host_cases(argv[2]);
   } else if (mode == "gpu" && argc > 3) {
     gpu_cases(argv[2], argv[3]);
-    std::printf("completion-word fallbacks of this process: %llu\n", hip::CompletionWordFallbacks());  // 0 normally (kmc_hip.h); reported, not a failure
+    unsigned st[3] = {0, 0, 0};
+    unsigned long long const fb = hip::CompletionWordFallbacks(st);  // 0 normally (kmc_hip.h); reported, not a failure
+    std::printf("completion-word fallbacks of this process: %llu (last: expected %u, word %u, ticket %u)\n", fb, st[0], st[1], st[2]);
   } else if (mode == "death_pose") {  // test_trajectory_interpolation.cpp:77-81  EXPECT_DEATH(GetPoseAtTime(0))
     auto const ti{trajectory_interpolation::TrajectoryInterpolator(47072.35, Affine3d::Identity(), 47072.56, ArtificialPose(0.1, 1.0))};
     (void)ti.GetPoseAtTime(0);
