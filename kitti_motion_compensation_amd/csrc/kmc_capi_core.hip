@@ -71,7 +71,7 @@ DoneWord done_word_arm(kmc_ctx* c) {
 
 // The last armed launch has stored its sequence number <=> every wave's stores are in host memory (DoneWord, kmc_kernels.hip.h).
 // The stream is looked at every 16 Ki polls (~100 us): a launch that died never raises the word.
-// A stream that has run dry WITHOUT the word (seen once in round 5's GPU suite runs: the C++ test binary, which also runs four contexts on four host threads): the
+// A stream that has run dry WITHOUT the word (round 5: a fresh context's first armed kernel counted from a stale ticket -- see kmc_hip_create): the
 // kernel has finished, so the ordinary HIP contract takes over -- hipStreamSynchronize, after which every store of the stream's
 // kernels is in host memory whether or not the word came.  The event is counted and its state kept for
 // kmc_hip_completion_word_fallbacks (expected sequence number, word, ticket), and the ticket is put back to 0 so that the next
