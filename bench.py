@@ -771,6 +771,149 @@ def _run_stage_numbers(lines):
     return out
 
 
+LINE_TARGET_BYTES = 4096  # the printed line stays below this ...
+LINE_LIMIT_BYTES = 8192   # ... and bench.py fails rather than print a line the driver cannot hold (BENCH_r05: a 21 KB line, parsed = null)
+DETAIL_NAME = "bench_detail.json"
+
+
+def _get(d, *path):
+    """d[path[0]][path[1]]... or None: a leg that did not run leaves no hole in the line."""
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _short(s, limit=160):
+    s = " ".join(str(s).split())
+    return s if len(s) <= limit else s[:limit - 3] + "..."
+
+
+def compact_line(full, detail_path=None):
+    """The ONE line bench.py prints, made from the full record `full` (which goes to bench_detail.json): the contract's keys, `roofline`,
+    `cpu_baseline`, and one scalar per leg -- numbers and short identifiers only, no prose.  Raises when the result would exceed
+    LINE_LIMIT_BYTES."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: full[k] for k in keep}
+    cfg = full["config"]
+    line["config"] = {
+        "workload": _short(cfg["workload"], 200),
+        "points_per_frame": cfg["points_per_frame"], "frames_per_step_per_gpu": cfg["frames_per_step_per_gpu"],
+        "points_per_step_per_gpu": cfg["points_per_step_per_gpu"], "parallelism": _short(cfg["parallelism"], 60),
+        "kernel": _short(cfg["kernel"], 60), "device": _short(cfg["device"], 40), "arch": _short(cfg["arch"], 40),
+    }
+    rf = full["roofline"]
+    line["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_point", "points_per_launch", "kernel_ms_avg")}
+    line["roofline"]["traffic_source"] = rf.get("traffic_kind")
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"], 120)}
+        ac = cb.get("all_cores")
+        if ac:
+            line["cpu_baseline"]["all_cores"] = {"cores": ac["cores"], "faithful_Mpts_s": ac["faithful_Mpts_s"], "hoisted_Mpts_s": ac["hoisted_closed_form_Mpts_s"]}
+    if "parity_spot_check" in full:
+        line["parity_spot_check"] = {"max_rel_err": float("%.3g" % full["parity_spot_check"]["max_rel_err"]), "bar": full["parity_spot_check"]["bar"]}
+    rk = full.get("ranks")
+    if rk:
+        line["ranks"] = {"backend": _short(rk["collective_backend"], 24), "rccl_world_size": rk["rccl_world_size"], "world_size": rk["world_size"],
+                         "distinct_devices": rk["distinct_devices"]}
+    pr = full.get("per_rank")
+    if pr:
+        line["per_rank"] = {"Mpts_s_min": pr["Mpts_s_min"], "Mpts_s_max": pr["Mpts_s_max"], "slowest_rank": pr["slowest_rank"]}
+        if "configs3_Mpts_s_min" in pr:
+            line["per_rank"]["configs3_Mpts_s_min"], line["per_rank"]["configs3_Mpts_s_max"] = pr["configs3_Mpts_s_min"], pr["configs3_Mpts_s_max"]
+    c3 = full.get("configs3")
+    if c3:
+        line["configs3"] = {"value": c3["value"], "unit": c3["unit"], "points_per_frame": c3["points_per_frame"], "frames_total": c3["frames_total"],
+                            "timed_frames_per_rank": c3["timed_frames_per_rank"], "ms_per_frame": c3["ms_per_frame"], "frac_rank0": c3["frac_of_peak_rank0"],
+                            "parity_max_rel_err": (float("%.3g" % c3["parity_first_last_frame_per_rank"]["max_rel_err"]) if c3.get("parity_first_last_frame_per_rank") else None)}
+    su = full.get("sustained")
+    if su:
+        line["sustained"] = {k: su[k] for k in ("seconds", "launches", "Mpts_s_mean", "Mpts_s_min", "Mpts_s_max", "frac_mean")}
+    # one scalar per leg: fractions of the 8 TB/s peak unless the name says otherwise
+    legs = {}
+    for name, path in LEG_SCALARS:
+        v = _get(full, *path)
+        if isinstance(v, bool) or isinstance(v, int):
+            legs[name] = v
+        elif isinstance(v, float):
+            legs[name] = float("%.4g" % v) if abs(v) < 1e-3 else v
+    if legs:
+        line["legs"] = legs
+    if "secondary_legs_error" in full:
+        line["legs_error"] = _short(full["secondary_legs_error"], 200)
+    line["peak_device_GiB_per_rank"] = full.get("peak_device_GiB_per_rank")
+    line["detail"] = detail_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_TARGET_BYTES:  # shed the optional parts, legs last
+        for k in ("sustained", "per_rank", "legs"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_TARGET_BYTES:
+                break
+    if len(text) > LINE_LIMIT_BYTES:
+        raise RuntimeError(f"bench line of {len(text)} bytes exceeds {LINE_LIMIT_BYTES}: the driver would not hold it")
+    return text
+
+
+# name in the line's "legs" object -> where the number lives in the full record (bench_detail.json)
+LEG_SCALARS = (
+    ("ceiling_f32_copy_frac", ("ceilings", "f32_one_stream_in_one_out", "frac_of_peak")),
+    ("ceiling_f64_9stream_frac", ("ceilings", "f64_nine_column_streams", "copy_cols9", "frac_of_peak")),
+    ("c1_per_call_frac", ("configs1_literal", "in_order", "frac")),
+    ("c1_per_call_direct_queue_frac", ("configs1_literal", "in_order_direct_queue", "frac")),
+    ("c1_gathered_frac", ("configs1_literal", "gathered_calls", "frac")),
+    ("c1_list_frac", ("configs1_literal", "list_one_launch", "frac")),
+    ("c1_batch_frac", ("configs1_literal", "batch_packed", "frac")),
+    ("c1_nknot3_per_call_frac", ("configs1_literal", "in_order_nknot3", "frac")),
+    ("c1_parity_max_rel_err", ("configs1_literal", "parity", "max_rel_err")),
+    ("c2_batched_frac", ("configs2_drive", "frac")),
+    ("c2_per_call_us", ("configs2_drive", "frame_by_frame_from_c", "per_call", "us_per_frame")),
+    ("c2_per_call_frac", ("configs2_drive", "frame_by_frame_from_c", "per_call", "frac")),
+    ("c2_per_call_direct_queue_us", ("configs2_drive", "frame_by_frame_from_c", "per_call_direct_queue", "us_per_frame")),
+    ("c2_per_call_direct_queue_frac", ("configs2_drive", "frame_by_frame_from_c", "per_call_direct_queue", "frac")),
+    ("c2_gathered_frac", ("configs2_drive", "frame_by_frame_from_c", "per_call_gathered", "frac")),
+    ("c2_list_frac", ("configs2_drive", "frame_by_frame_from_c", "list_one_launch", "frac")),
+    ("c2_list_equals_per_call_bitwise", ("configs2_drive", "frame_by_frame_from_c", "list_equals_per_call_bitwise")),
+    ("c2_parity_max_rel_err", ("configs2_drive", "parity", "max_rel_err")),
+    ("nknot3_frac", ("nknot3", "frac")),
+    ("nknot3_parity_max_rel_err", ("nknot3", "parity", "max_rel_err")),
+    ("f64cols_frac", ("f64cols", "frac")),
+    ("f64cols_frac_of_adjacent_9_stream_ceiling", ("f64cols", "frac_of_adjacent_9_stream_ceiling")),
+    ("f64cols_ones_frac", ("f64cols", "homogeneous_column_known_to_be_ones", "frac")),
+    ("f64cols_parity_max_rel_err", ("f64cols", "parity", "max_rel_err")),
+    ("dropin_frame_f64_us", ("dropin_cpp", "MotionCompensateFrame_f64", "page_locked_containers", "us_per_frame")),
+    ("dropin_frame_f64_pageable_us", ("dropin_cpp", "MotionCompensateFrame_f64", "pageable_containers", "us_per_frame")),
+    ("dropin_frame_3arg_f64_us", ("dropin_cpp", "MotionCompensateFrame_3arg_f64", "page_locked_containers", "us_per_frame")),
+    ("dropin_kitti_cloud_f32_us", ("dropin_cpp", "MotionCompensateKittiCloud_f32", "page_locked_containers", "us_per_frame")),
+    ("dropin_f64_parity_max_rel_err", ("dropin_cpp", "parity", "MotionCompensateFrame_f64_max_rel_err")),
+    ("dropin_oracle_1_thread_ms_per_frame", ("dropin_cpp", "oracle_faithful_1_thread_ms_per_frame")),
+    ("run_frames_per_s", ("dropin_cpp", "MotionCompensateRun", "frames_per_s")),
+    ("run_wall_s_best_of_3", ("dropin_cpp", "MotionCompensateRun", "process_wall_s_best_of_3")),
+    ("run_parity_max_rel_err", ("dropin_cpp", "MotionCompensateRun", "parity", "max_rel_err")),
+    ("sharded_cpp_world", ("sharded_cpp", "world")),
+    ("sharded_cpp_Mpts_s", ("sharded_cpp", "reduced", "Mpts_s")),
+)
+
+
+def write_detail(full):
+    """The full record (every leg's numbers, notes and workload descriptions) as a file: $KMC_BENCH_DETAIL, else gpurun_out/ under the
+    repo (what gpurun brings back), else the repo root.  Returns the path relative to the repo, or None when nothing was writable."""
+    cands = [os.environ["KMC_BENCH_DETAIL"]] if os.environ.get("KMC_BENCH_DETAIL") else []
+    cands += [os.path.join(ROOT, "gpurun_out", DETAIL_NAME), os.path.join(ROOT, DETAIL_NAME)]
+    for path in cands:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as fh:
+                json.dump(full, fh, indent=1)
+                fh.write("\n")
+            return os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+        except OSError:
+            continue
+    return None
+
+
 def relaunch_under_launcher(n, torch):
     """-> exit code.  The driver's N > 1 launch line, built here when bench.py was started bare with --gpus N: one process per GPU under
     torch.distributed.run, rendezvous on 127.0.0.1 at a free port.  KMC_BENCH_LAUNCH_DRY=1 prints the line as JSON instead of running it
@@ -984,20 +1127,23 @@ def main():
         # and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md's HBM section prescribes with the factors
         # profiles/pmc_traffic.json derived from the copy kernel); if the box does not allow counter collection, or N > 1, the
         # per-point figure of the committed passes is scaled to this launch size -- traffic_source says which.
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_kind = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fjson:
                 tj = json.load(fjson)
             traffic = round(tj["hbm_bytes_per_point"] * n)
             traffic_source = "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this command), per point x points per launch"
+            traffic_kind = "committed_pmc_per_point_scaled"
             if world == 1 and dist is None and not args.no_live_traffic:
                 live = live_traffic(F, POINTS_PER_FRAME, args.yaw_per_frame, tj)
                 if live:
                     traffic = round(live)
                     traffic_source = "measured in this run: rocprofv3 --pmc child runs of this invocation (FETCH_SIZE, WRITE_SIZE passes)"
+                    traffic_kind = "live_pmc_this_run"
                 else:
                     traffic_source += " -- counter collection was not possible on this box"
+                    traffic_kind += "_live_collection_not_possible"
         out = {
             "metric": "M points/sec deskewed",
             "value": round(pts_total / t_max / 1e6, 1),
@@ -1022,7 +1168,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_kind": traffic_kind,
                 "bytes_per_point": BYTES_PER_POINT, "points_per_launch": n, "kernel_ms_avg": round(step_ms, 4),
                 "kernel_ms_avg_is": "HIP-event time of the timed region on the launch stream / steps (one launch per step)",
             },
@@ -1075,7 +1221,9 @@ def main():
         if cpu_sample is not None:
             k_cpu, sample, gpu_frame0 = cpu_sample
             out["cpu_baseline"], out["parity_spot_check"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k_cpu, gpu_frame0)
-        print(json.dumps(out), flush=True)
+        # the full record goes to a file; the ONE stdout line is compact (numbers and identifiers, < 4 KB): a line the driver cannot hold is
+        # an unmeasured round (BENCH_r05)
+        print(compact_line(out, write_detail(out)), flush=True)
     ctx.close()
     if dist:
         dist.destroy_process_group()

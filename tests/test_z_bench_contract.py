@@ -8,19 +8,113 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# what the driver's record of round 4 held (BENCH_r04.json "parsed"): the line must keep carrying every one of them
+R04_PARSED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                   "dtype", "data", "config", "roofline", "cpu_baseline")
+LINE_TARGET_BYTES, LINE_LIMIT_BYTES = 4096, 8192
+
+
+def _no_prose(obj, limit=200):
+    """Every string of the line is an identifier or a short label, never a paragraph."""
+    if isinstance(obj, dict):
+        for v in obj.values():
+            _no_prose(v, limit)
+    elif isinstance(obj, list):
+        for v in obj:
+            _no_prose(v, limit)
+    elif isinstance(obj, str):
+        assert len(obj) <= limit, obj
+
+
+def check_line(stdout, n1=True):
+    """The contract of the ONE stdout line: a single JSON object, compact (BENCH_r05: a 21 KB line, the driver's parsed = null), round-trips,
+    carries the key set the driver parsed in round 4."""
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    assert stdout.rstrip("\n").splitlines()[-1] == lines[0]  # it is the LAST line of stdout
+    line = lines[0]
+    assert len(line) < LINE_TARGET_BYTES, len(line)
+    d = json.loads(line)
+    assert json.loads(json.dumps(d)) == d
+    for key in R04_PARSED_KEYS:
+        if key == "cpu_baseline" and not n1:
+            continue
+        assert key in d, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    _no_prose(d)
+    return d, line
+
+
+def run_bench(cmd, tmp_path, env=None, cwd=None, timeout=900):
+    """-> (the parsed line, the full record bench.py wrote beside it, the process)"""
+    detail = os.path.join(str(tmp_path), "bench_detail.json")
+    env = dict(os.environ if env is None else env, KMC_BENCH_DETAIL=detail)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=cwd)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d, _ = check_line(r.stdout, n1="cpu_baseline" in r.stdout)
+    assert d["detail"] == detail
+    with open(detail) as fh:
+        full = json.load(fh)
+    for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup"):
+        assert full[k] == d[k]  # the line is an extract of the record, not a second measurement
+    return d, full, r
+
+
+def test_compact_line_from_the_21_KB_record_of_round_5():
+    """CPU: bench.compact_line on the full record whose printed form the driver could not hold (profiles/r05_bench_default.json, 21 KB):
+    < 4 KB, every key of the round-4 parsed set, roofline + cpu_baseline intact, one scalar per leg.  And the size guard raises."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("kmc_bench_module_line", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert (bench.LINE_TARGET_BYTES, bench.LINE_LIMIT_BYTES) == (LINE_TARGET_BYTES, LINE_LIMIT_BYTES)
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as fh:
+        full = json.load(fh)
+    assert len(json.dumps(full)) > 20_000
+    full["roofline"]["traffic_kind"] = "live_pmc_this_run"
+    d, line = check_line(bench.compact_line(full, "gpurun_out/bench_detail.json") + "\n")
+    assert d["value"] == full["value"] and d["roofline"]["frac"] == full["roofline"]["frac"] and d["roofline"]["traffic"] == full["roofline"]["traffic"]
+    assert d["cpu_baseline"]["value"] == full["cpu_baseline"]["value"] and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
+    assert d["legs"]["f64cols_frac"] == full["f64cols"]["frac"] and d["legs"]["c2_per_call_us"] > 0 and d["configs3"]["value"] == full["configs3"]["value"]
+    assert all(isinstance(v, (int, float, bool)) for v in d["legs"].values())  # one scalar per leg, nothing else
+    # a record that grows (a leg nobody told compact_line about) cannot grow the line
+    full["a_new_leg"] = {"note": "x" * 50_000}
+    assert len(bench.compact_line(full, None)) == len(line) - len('"gpurun_out/bench_detail.json"') + len("null")
+    # and a line that would not fit is an error, not a silent 21 KB
+    full["config"]["workload"] = "w" * 100
+    bench_limit = bench.LINE_LIMIT_BYTES
+    try:
+        bench.LINE_TARGET_BYTES, bench.LINE_LIMIT_BYTES = 10, 20
+        with pytest.raises(RuntimeError):
+            bench.compact_line(full, None)
+    finally:
+        bench.LINE_TARGET_BYTES, bench.LINE_LIMIT_BYTES = LINE_TARGET_BYTES, bench_limit
+
 
 @pytest.mark.gpu
-def test_bench_prints_one_contract_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
-                        "--frames-per-step", "176", "--cpu-sample-frames", "1", "--configs3-frames", "24", "--configs3-frames-per-launch", "8", "--no-live-traffic",
-                        "--sustained-seconds", "1.5"],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline"):
+def test_bench_prints_one_contract_line(tmp_path):
+    line, d, r = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                            "--frames-per-step", "176", "--cpu-sample-frames", "1", "--configs3-frames", "24", "--configs3-frames-per-launch", "8", "--no-live-traffic",
+                            "--sustained-seconds", "1.5"], tmp_path)
+    # ---- the line itself (check_line: one object, < 4 KB, round-trips, the round-4 key set, no prose) ----
+    assert line["n_gpus"] == 1 and line["steps"] == 6 and line["warmup"] == 2 and line["dtype"] == "f32" and line["unit"] == "Mpts/s"
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"] and line["config"]["workload"].startswith("configs[1]")
+    lrf = line["roofline"]
+    assert lrf["bound"] == "hbm" and lrf["unit"] == "GB/s" and lrf["peak"] == 8000.0 and abs(lrf["frac"] - lrf["achieved"] / lrf["peak"]) < 1e-3
+    assert lrf["traffic_source"].startswith("committed_pmc") and lrf["traffic"] > 0
+    lcb = line["cpu_baseline"]
+    assert lcb["kind"] == "port" and lcb["cores"] == 1 and lcb["value"] > 0 and "sample" in lcb and lcb["all_cores"]["cores"] >= 1
+    assert line["parity_spot_check"]["max_rel_err"] <= 1e-5 and line["configs3"]["parity_max_rel_err"] <= 1e-5
+    lg = line["legs"]  # one scalar per leg, each equal to the record's number
+    assert lg["c1_list_frac"] == d["configs1_literal"]["list_one_launch"]["frac"] and lg["f64cols_frac"] == d["f64cols"]["frac"]
+    assert lg["c2_per_call_us"] == d["configs2_drive"]["frame_by_frame_from_c"]["per_call"]["us_per_frame"]
+    assert lg["dropin_frame_f64_us"] == d["dropin_cpp"]["MotionCompensateFrame_f64"]["page_locked_containers"]["us_per_frame"]
+    assert lg["sharded_cpp_world"] == 1 and lg["run_frames_per_s"] > 50
+    # ---- the full record (bench_detail.json): everything below is read from the file ----
+    for key in R04_PARSED_KEYS:
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -36,7 +130,7 @@ def test_bench_prints_one_contract_line():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert d["parity_spot_check"]["max_rel_err"] <= 1e-5 and d["parity_spot_check"]["intensity_bit_identical"]
     assert d["value"] > 50_000  # > 50 G points/s even on a short, cold run
-    assert "committed" in rf["traffic_source"]  # --no-live-traffic: the committed figure, and the line says so
+    assert "committed" in rf["traffic_source"]  # --no-live-traffic: the committed figure, and the record says so
     # the configs[3] leg of the same invocation: 10 M-point frames, the rank's contiguous frame range, oracle-checked
     c3 = d["configs3"]
     assert c3["frames_total"] == 8000 and c3["points_per_frame"] == 10_000_000
@@ -95,19 +189,18 @@ def test_bench_prints_one_contract_line():
 
 
 @pytest.mark.gpu
-def test_bench_rccl_path_initialises_and_reduces_on_one_gpu():
+def test_bench_rccl_path_initialises_and_reduces_on_one_gpu(tmp_path):
     """WORLD_SIZE = 1 with the RCCL process group forced on: the barriers and the one all_gather of the counters run through RCCL."""
     env = dict(os.environ, KMC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
-                        "--frames-per-step", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    line, d, r = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+                            "--frames-per-step", "8", "--no-cpu-baseline"], tmp_path, env=env)
     assert d["n_gpus"] == 1 and d["value"] > 10_000
     assert d["ranks"]["collective_backend"].startswith("nccl") and d["ranks"]["rccl_world_size"] == 1  # what the process group itself reports
+    assert line["ranks"]["backend"].startswith("nccl") and line["ranks"]["rccl_world_size"] == 1
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_end_to_end_on_one_gpu():
+def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
     """The driver's N > 1 launch line (torch.distributed.run, one process per rank) with both ranks placed on the only GPU of
     the test box and the counters reduced over gloo (KMC_BENCH_DEVICE / KMC_BENCH_BACKEND are test knobs): rank-specific
     workloads, barrier + max-over-ranks timing, ONE JSON line from rank 0 with the whole-job aggregate."""
@@ -115,11 +208,8 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
            "--frames-per-step", "176", "--configs3-frames", "16", "--configs3-frames-per-launch", "8"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    line, d, r = run_bench(cmd, tmp_path, env=env, cwd=ROOT)
+    assert line["n_gpus"] == 2 and line["ranks"]["world_size"] == 2 and line["per_rank"]["Mpts_s_min"] <= line["per_rank"]["Mpts_s_max"] and "legs" not in line
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert d["config"]["frames_per_step_per_gpu"] == 176 and "x2" in d["config"]["parallelism"]
     # two ranks share one GPU here: the aggregate is about one GPU's rate (each rank gets half), never two GPUs' worth
@@ -145,17 +235,15 @@ def test_bench_two_ranks_end_to_end_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_bench_gpus_2_without_a_launcher_reexecutes_itself_under_the_launcher():
+def test_bench_gpus_2_without_a_launcher_reexecutes_itself_under_the_launcher(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE: not a one-GPU number under a two-GPU label -- the script
     re-executes itself as the contract's launch line (both ranks on the one GPU of this box through the test knobs)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(KMC_BENCH_BACKEND="gloo", KMC_BENCH_DEVICE="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--frames-per-step", "32",
-                        "--configs3-frames", "8", "--configs3-frames-per-launch", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
+    line, d, r = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--frames-per-step", "32",
+                            "--configs3-frames", "8", "--configs3-frames-per-launch", "4", "--no-cpu-baseline"], tmp_path, env=env, cwd=ROOT)
     assert "re-executing as" in r.stderr and "torch.distributed.run" in r.stderr
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and line["n_gpus"] == 2
 
 
 def test_bench_gpus_n_without_a_launcher_never_runs_as_one_process():
@@ -182,7 +270,7 @@ def test_bench_gpus_n_without_a_launcher_never_runs_as_one_process():
 
 
 @pytest.mark.gpu
-def test_bench_eight_ranks_dry_run_on_one_gpu():
+def test_bench_eight_ranks_dry_run_on_one_gpu(tmp_path):
     """The driver's 8-GPU launch line, dry: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8`
     with all eight ranks placed on the only GPU of the test box and the counters reduced over gloo (KMC_BENCH_DEVICE /
     KMC_BENCH_BACKEND are test knobs; unset = RCCL, one rank per GPU), with reduced frame counts.  What the first real SCALE run
@@ -193,11 +281,8 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", "29587", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1",
            "--frames-per-step", "16", "--configs3-frames", "24", "--configs3-frames-per-launch", "12"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    line, d, r = run_bench(cmd, tmp_path, env=env, cwd=ROOT, timeout=1500)
+    assert line["n_gpus"] == 8 and line["ranks"]["world_size"] == 8 and line["ranks"]["distinct_devices"] == 1 and "x8" in line["config"]["parallelism"]
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "x8" in d["config"]["parallelism"]
     c3 = d["configs3"]
     assert c3["rank_frame_ranges"] == [[1000 * r, 1000 * (r + 1)] for r in range(8)] and c3["timed_frames_per_rank"] == 24
@@ -228,7 +313,7 @@ def test_bench_child_tools_do_not_inherit_a_profiler():
 
 
 @pytest.mark.gpu
-def test_bench_live_traffic_matches_the_algorithmic_bytes():
+def test_bench_live_traffic_matches_the_algorithmic_bytes(tmp_path):
     """The default at N = 1: HBM bytes per launch from rocprofv3 --pmc child runs of the same invocation (FETCH_SIZE and WRITE_SIZE
     in separate passes) -- within 1 % of 32 B x points per launch, i.e. nothing is re-read."""
     import shutil
@@ -236,12 +321,11 @@ def test_bench_live_traffic_matches_the_algorithmic_bytes():
     if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
         pytest.skip("rocprofv3 not installed")
     env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames-per-step", "64",
-                        "--no-cpu-baseline", "--no-legs", "--sustained-seconds", "0"], capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    line, d, r = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--frames-per-step", "64",
+                            "--no-cpu-baseline", "--no-legs", "--sustained-seconds", "0"], tmp_path, env=env, cwd="/tmp")
     rf = d["roofline"]
+    assert line["roofline"]["traffic"] == rf["traffic"] and line["roofline"]["traffic_source"] == rf["traffic_kind"]
     if "measured in this run" not in rf["traffic_source"]:
-        assert "not possible" in rf["traffic_source"]  # the fallback is announced in the line itself
+        assert "not possible" in rf["traffic_source"] and line["roofline"]["traffic_source"].endswith("not_possible")  # the fallback is announced in the line itself
         pytest.skip("PMC counters could not be collected on this box (bench.py fell back to the committed passes)")
     assert abs(rf["traffic"] / (32.0 * rf["points_per_launch"]) - 1.0) < 0.01
