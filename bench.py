@@ -354,12 +354,13 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
             "workload": "configs[1] literally: synthetic 1 M-point frames, each in its own allocation (256 distinct frames, 8.2 GB), per-frame twists; driven from C++ through the C-ABI (tools/time_frame_stream.hip), HIP events on the context's stream, 8 timed sweeps",
             "kernel": "kmc_dev::deskew_frame_f32<series3, ppt=1, nt loads + nt|sc1 stores, block=64> per call; kmc_dev::deskew_list_f32 for the list",
             "any_order_dispatch_verdict": fs["any_order_dispatch"],
-            "in_order": stream_leg(fs, "per_call", n, "ONE kmc_hip_deskew_f32 call per frame, in order on the context's own stream: since round 5 an AQL packet in the context's direct queue "
-                                   "(through_the_direct_queue = share of the frames; below the HIP runtime's launch path); frames that share no buffer with one in flight go out without the barrier bit"),
-            "in_order_hip_launches": stream_leg(fs, "per_call_hip_launches", n, "the same calls with KMC_DIRECT_DISPATCH=0: one HIP launch per frame (round 4's route), barrier-free where the run-time probe verified it") if "per_call_hip_launches" in fs else None,
+            "in_order": stream_leg(fs, "per_call", n, "ONE kmc_hip_deskew_f32 call per frame, in order on a default context's own stream: one HIP launch per frame; frames that share "
+                                   "no buffer with one in flight go out without the barrier bit where the run-time probe verified it"),
+            "in_order_direct_queue": stream_leg(fs, "per_call_direct_queue", n, "the same calls on a context that opted in with kmc_hip_set_direct_dispatch(ctx, 1): an AQL packet per frame in the context's "
+                                                "direct queue, below the HIP runtime's launch path (through_the_direct_queue = share of the frames)") if "per_call_direct_queue" in fs else None,
             "in_order_nknot3": stream_leg(fs, "per_call_nknot3", n, "ONE kmc_hip_deskew_traj_f32 call per frame (north_star's three bracketing poses, every frame its own knots): the segment records ride in the "
-                                          "direct queue's argument block") if "per_call_nknot3" in fs else None,
-            "in_order_nknot3_hip_launches": stream_leg(fs, "per_call_nknot3_hip_launches", n, "the same calls with KMC_DIRECT_DISPATCH=0") if "per_call_nknot3_hip_launches" in fs else None,
+                                          "launch's argument block") if "per_call_nknot3" in fs else None,
+            "in_order_nknot3_direct_queue": stream_leg(fs, "per_call_nknot3_direct_queue", n, "the same calls on the opted-in context") if "per_call_nknot3_direct_queue" in fs else None,
             "in_order_drained": stream_leg(fs, "per_call_drained", n, "the same calls on a context created with KMC_ANY_ORDER=0: every dispatch waits for the last wave of the one before it"),
             "gathered_calls": stream_leg(fs, "per_call_gathered", n, "the same calls, one per frame, with kmc_hip_set_frame_queues(ctx, 4): the library gathers them on the host and issues "
                                          "ONE launch of the frame-list kernel per up to 16 frames (deferred issue, in-order results)"),
@@ -371,8 +372,6 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         }
         assert fs["list_equals_per_call_bitwise"] is True, fs
         leg["list_launches"] = fs["list_launches"]
-        if "list_table_route" in fs:
-            leg["list_table_route"] = stream_leg(fs, "list_table_route", n, "the same list call with KMC_LIST_ROUTE=table: ONE launch over an uploaded device table (the round-4 route)")
         if check:  # oracle spot check of the per-call entry point on this workload's first frame shape (outside any timing)
             work = make_workload(capi, 1, 0, yaw_per_frame=0.03)[0]
             prm, (t0, tm, t1), oxs = work
@@ -438,18 +437,18 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
         leg["frame_by_frame_from_c"] = {
             "workload": "108 separate frames ~N(121 k, 3 k) points, each in its own allocation, 3 rotating sets, per-frame twists; tools/time_frame_stream.hip, 50 timed sweeps",
             "mean_points_per_frame": npts, "any_order_dispatch_verdict": fd["any_order_dispatch"],
-            "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call per frame, in order on the context's own stream: an AQL packet in the context's direct queue (round 5)"),
-            "per_call_hip_launches": stream_leg(fd, "per_call_hip_launches", npts, "KMC_DIRECT_DISPATCH=0: one HIP launch per frame (the runtime's launch path, 2.2-3.5 us through every launch API)") if "per_call_hip_launches" in fd else None,
-            "per_call_nknot3": stream_leg(fd, "per_call_nknot3", npts, "one kmc_hip_deskew_traj_f32 call per frame (three knots, the records in the direct queue's argument block)") if "per_call_nknot3" in fd else None,
-            "per_call_nknot3_hip_launches": stream_leg(fd, "per_call_nknot3_hip_launches", npts, "the same calls with KMC_DIRECT_DISPATCH=0") if "per_call_nknot3_hip_launches" in fd else None,
+            "per_call": stream_leg(fd, "per_call", npts, "one kmc_hip_deskew_f32 call per frame, in order on a default context's own stream: one HIP launch per frame (the runtime's launch path)"),
+            "per_call_direct_queue": stream_leg(fd, "per_call_direct_queue", npts, "the same calls after kmc_hip_set_direct_dispatch(ctx, 1): an AQL packet per frame in the context's direct queue") if "per_call_direct_queue" in fd else None,
+            "per_call_nknot3": stream_leg(fd, "per_call_nknot3", npts, "one kmc_hip_deskew_traj_f32 call per frame (three knots, the records in the launch's argument block)") if "per_call_nknot3" in fd else None,
+            "per_call_nknot3_direct_queue": stream_leg(fd, "per_call_nknot3_direct_queue", npts, "the same calls on the opted-in context") if "per_call_nknot3_direct_queue" in fd else None,
             "per_call_drained": stream_leg(fd, "per_call_drained", npts, "KMC_ANY_ORDER=0: the barrier bit on every dispatch"),
             "per_call_gathered": stream_leg(fd, "per_call_gathered", npts, "the same calls with kmc_hip_set_frame_queues(ctx, 4): gathered on the host, one list launch per up to 16 frames"),
             "list_one_launch": stream_leg(fd, "list_one_launch", npts, "kmc_hip_deskew_frames_f32: the 108 separate frames as one list -> 7 chained kernel-argument launches of <= 16 frames, "
                                           "barrier-free behind the first where verified (round 5: no table upload, no host wait; key name kept)"),
-            "list_table_route": stream_leg(fd, "list_table_route", npts, "the same call with KMC_LIST_ROUTE=table: ONE launch over an uploaded device table (the round-4 route)") if "list_table_route" in fd else None,
             "list_launches": fd.get("list_launches"),
             "batch_packed": stream_leg(fd, "batch_packed", npts, "the same frames packed into one buffer, one batched launch"),
             "per_call_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call"]["us_per_frame"], 3),
+            "direct_queue_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call_direct_queue"]["us_per_frame"], 3) if "per_call_direct_queue" in fd else None,
             "gathered_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["per_call_gathered"]["us_per_frame"], 3),
             "list_rate_vs_batched": round(fd["batch_packed"]["us_per_frame"] / fd["list_one_launch"]["us_per_frame"], 3),
             "list_equals_per_call_bitwise": fd["list_equals_per_call_bitwise"],
@@ -867,6 +866,7 @@ LEG_SCALARS = (
     ("c1_list_frac", ("configs1_literal", "list_one_launch", "frac")),
     ("c1_batch_frac", ("configs1_literal", "batch_packed", "frac")),
     ("c1_nknot3_per_call_frac", ("configs1_literal", "in_order_nknot3", "frac")),
+    ("c1_nknot3_direct_queue_frac", ("configs1_literal", "in_order_nknot3_direct_queue", "frac")),
     ("c1_parity_max_rel_err", ("configs1_literal", "parity", "max_rel_err")),
     ("c2_batched_frac", ("configs2_drive", "frac")),
     ("c2_per_call_us", ("configs2_drive", "frame_by_frame_from_c", "per_call", "us_per_frame")),
@@ -1223,10 +1223,21 @@ def main():
             out["cpu_baseline"], out["parity_spot_check"] = cpu_baseline(sample, [(w[1], w[2]) for w in work], k_cpu, gpu_frame0)
         # the full record goes to a file; the ONE stdout line is compact (numbers and identifiers, < 4 KB): a line the driver cannot hold is
         # an unmeasured round (BENCH_r05)
-        print(compact_line(out, write_detail(out)), flush=True)
+        line = compact_line(out, write_detail(out))
     ctx.close()
     if dist:
         dist.destroy_process_group()
+    # The line is the LAST thing on stdout: native libraries write there too (RCCL's "Librccl path ..." sits in the C library's buffer until
+    # the process ends and would land behind a line printed earlier), so everything is torn down and the C buffers are flushed first, and
+    # nothing runs after the line.
+    import ctypes
+
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        os.write(1, (line + "\n").encode())
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

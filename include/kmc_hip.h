@@ -23,6 +23,20 @@
  *   - there is NO CPU fallback: without a usable HIP device kmc_hip_create() fails with
  *     KMC_ERR_NO_DEVICE and nothing else can be called.
  *
+ * Environment (read at kmc_hip_create / first use; each has a default, and an API equivalent where one makes sense)
+ *   knob                        default  meaning                                                         non-default covered by
+ *   KMC_ANY_ORDER               on*      0: every dispatch carries the AQL barrier bit (* on only where   tests/test_dispatch_modes.py; the GPU suite run
+ *                                        the run-time probe verified barrier-free dispatch)               under it (tests/test_suite_modes.py)
+ *   KMC_DIRECT_DISPATCH         unset    1: contexts start opted in to the direct queue; 0: never,        tests/test_direct_queue.py, test_suite_modes.py
+ *                                        even when kmc_hip_set_direct_dispatch asks
+ *   KMC_HOST_POOL               1        0: no pool of page-locked host memory (staged copies)            tests/test_host_pool.py, bench.py dropin leg
+ *   KMC_HOST_POOL_MAX_MB        2048     MiB of free blocks the pool keeps page-locked                    tests/test_host_pool.py
+ *   KMC_HOST_DETECT_PINNED      1        0: only pool memory and KMC_MEM_HOST_MAPPED run in place         tests/test_host_pool.py
+ *   KMC_TEST_HOST_POOL_FAIL_AT  unset    k: the process's k-th pool allocation fails (fault injection)    tests/test_run_driver.py
+ * The C++ drop-in adds KMC_DEVICE, KMC_DEVICES, KMC_RUN_BATCH_FRAMES, KMC_RUN_TIMING, KMC_RUN_KNOTS, KMC_FIX_LAST_FRAME_COPY
+ * (include/kitti_motion_compensation/motion_compensation.hpp).  Retired in ABI 7: KMC_LIST_ROUTE, KMC_DIRECT_LANES, KMC_MAPPED_WAVES,
+ * KMC_DIRECT_DEBUG (measurement switches whose questions are answered: profiles/NOTES.md).
+ *
  * Data conventions
  *   - pose      : double[12], row-major 3x4 [R | t]  (Eigen::Affine3d::matrix().topRows<3>(), row-major)
  *   - twist     : double[6] = [rho(3); phi(3)]  -- same order as the reference, lie_algebra.cpp:84-85
@@ -39,7 +53,7 @@
 extern "C" {
 #endif
 
-#define KMC_ABI_VERSION 6
+#define KMC_ABI_VERSION 7
 
 /* ---- status codes ---- */
 #define KMC_OK 0
@@ -164,6 +178,9 @@ int kmc_hip_host_free(kmc_ctx* ctx, void* ptr);
  * recycled), 0 if it is not the pool's.  kmc_host_pool_owns: 1 if [ptr, ptr + bytes) lies inside ONE live block.
  * kmc_host_pool_trim: unpins every cached free block, returns how many. */
 int kmc_host_pool_alloc(size_t bytes, void** out);
+/* The same with the block placed on `device`'s side of the machine whatever the calling thread's current HIP device is (and without making
+ * any device current): for helper threads that allocate on behalf of a worker bound to another GPU.  device < 0: the current device. (ABI 7) */
+int kmc_host_pool_alloc_near(size_t bytes, int device, void** out);
 int kmc_host_pool_free(void* ptr);
 int kmc_host_pool_owns(const void* ptr, size_t bytes);
 int kmc_host_pool_trim(void);
@@ -265,7 +282,7 @@ int kmc_hip_set_frame_queues(kmc_ctx* ctx, int queues);
 int kmc_hip_set_frame_queue_order(kmc_ctx* ctx, int after_producers);
 int kmc_hip_frame_queue_join(kmc_ctx* ctx);
 /* Gathered frames and errors: a gathered call returns KMC_OK when its frame has been QUEUED.  If the launch that later issues the queue
- * fails (first the table route, then a fallback of kernel-argument launches that needs no table), the frames of that queue were never
+ * fails (also as launches of 16 frames, the argument block every runtime takes), the frames of that queue were never
  * computed; the error is returned by whichever entry point triggered the join AND stays sticky -- kmc_hip_frame_queue_join and
  * kmc_hip_synchronize return it (once) even when the join happened inside an unrelated call -- and kmc_hip_frame_queue_dropped counts
  * the frames lost that way over the context's life (0 in every run so far: a launch only fails when the runtime itself is failing). */
@@ -279,34 +296,46 @@ uint64_t kmc_hip_any_order_launches(kmc_ctx* ctx);
  * state; the event costs ~0.1 ms, never a result.  ctx == NULL: the total over every context the process has had (a per-thread context of
  * the C++ drop-in ends with its thread).  (ABI 6) */
 uint64_t kmc_hip_completion_word_fallbacks(kmc_ctx* ctx, uint32_t last_state[3]);
-/* THE DIRECT QUEUE (ABI 5).  On the context's OWN stream (the state after kmc_hip_create) a device-resident kmc_hip_deskew_f32 call -- and a
- * device-resident kmc_hip_deskew_traj_f32 call of up to four knots without an index output (north_star's three bracketing poses: the segment
- * records ride in the argument block, 2.7 us per KITTI frame instead of 5.5) -- does not go through a HIP launch: the library writes the frame's AQL dispatch packet into an HSA queue of the context's own, with the
- * argument block in device memory -- 1.7-2.4 us per KITTI frame per call instead of the 3.5-4.9 us of the HIP runtime's launch path
- * (which costs 2.2-3.5 us through every launch API).  Same kernel body, same bits (checked on the device when the queue is opened, at the
- * first such call).  The barrier bit of a packet is decided like before: a frame that shares no buffer with the frames in flight goes out
+/* THE DIRECT QUEUE (ABI 5; OPT-IN since ABI 7).  After kmc_hip_set_direct_dispatch(ctx, 1), on the context's OWN stream (the state after
+ * kmc_hip_create), a device-resident kmc_hip_deskew_f32 call -- and a device-resident kmc_hip_deskew_traj_f32 call of up to four knots without
+ * an index output (north_star's three bracketing poses: the segment records ride in the argument block) -- does not go through a HIP launch:
+ * the library writes the frame's AQL dispatch packet into an HSA queue of the context's own, with the argument block in device memory --
+ * 1.7-2.4 us per KITTI frame per call instead of the 3.5-4.9 us of the HIP runtime's launch path.  Same kernel body, same bits (checked on
+ * the device when the queue is opened, at the first such call).
+ * WHY IT IS NOT THE DEFAULT.  Frames in the direct queue are in NO HIP stream: hipDeviceSynchronize(), hipStreamSynchronize of a stream of the
+ * caller's, hipFree's implicit wait and a caching allocator that recycles a buffer "after the stream has passed it" (torch's) do not
+ * wait for them.  Code that is correct under the ordinary HIP rules -- free or reuse a frame's buffers after hipDeviceSynchronize() -- would
+ * free memory under a running kernel.  A context therefore issues HIP launches until its owner says it plays by the queue's rules:
+ *     kmc_hip_set_direct_dispatch(ctx, 1)   "I wait with kmc_hip_synchronize(ctx) (or any other call on the context -- every one of them
+ *                                            waits for the frames before it) before I free, reuse or read a frame's buffers outside the
+ *                                            library"; 0 switches back (waits for the frames still in the queue first).
+ * The C++ drop-in (which owns its buffers and synchronises through the context) and the frame-stream clients under tools/ opt in.
+ * KMC_DIRECT_DISPATCH=1 makes every context of the process start opted in (test runs of the whole suite on the queue);
+ * KMC_DIRECT_DISPATCH=0 keeps the HIP launches even for a caller that opts in (A/B measurements).
+ * The barrier bit of a packet is decided like for HIP launches: a frame that shares no buffer with the frames in flight goes out
  * without it (KMC_ANY_ORDER=0: every packet carries it).  TWO LANES: the direct queue is two HSA queues; independent frames alternate
  * between them (two packet processors fetch argument blocks and launch waves side by side); a frame that shares a buffer with frames in
  * flight in ONE lane follows them in that lane (barrier bit, nothing crosses lanes: a chain stays in its lane, buffer pairs used in
  * rotation keep both lanes busy); a frame with conflicts in both lanes goes to lane 0 behind a barrier packet that waits for lane 1, and
- * lane 1's next frame waits for that frame -- so a frame always sees what every frame called before it wrote, on whichever lane either ran (KMC_DIRECT_LANES=1: one lane; with KMC_ANY_ORDER=0 one lane as
- * well, every packet ordered).  ORDER: the direct queue and the context's HIP stream are separate queues; the library keeps
- * them in the order of the calls -- a frame waits for what the context put on its stream before it, every other entry point waits for
- * the frames before it (host waits, at such transitions only).  What a caller must know: the frames are not in a HIP stream, so
- * hipDeviceSynchronize() or a synchronize of some stream of the caller's does not wait for them -- kmc_hip_synchronize(ctx) does, and so
- * does every other call on the context; nor does hipFree's implicit wait cover them: a frame's buffers must not be freed before
- * kmc_hip_synchronize(ctx) (or another call on the context) has returned.  Not used on a caller's stream (kmc_hip_set_stream), with gathering on, with per-call timing
- * on, or with KMC_DIRECT_DISPATCH=0; not available (HIP launches instead) where the host cannot map device memory.  A wait on the queue
- * that exceeds ten seconds turns into KMC_ERR_HIP, and the context goes back to HIP launches.
- * kmc_hip_direct_frames: frames this context has dispatched through its direct queue so far (0: the queue is not in use). */
+ * lane 1's next frame waits for that frame -- so a frame always sees what every frame called before it wrote, on whichever lane either
+ * ran (with KMC_ANY_ORDER=0 one lane, every packet ordered).  ORDER: the direct queue and the context's HIP stream are separate queues; the
+ * library keeps them in the order of the calls -- a frame waits for what the context put on its stream before it, every other entry point
+ * waits for the frames before it (host waits, at such transitions only).  Not used on a caller's stream (kmc_hip_set_stream), with
+ * gathering on or with per-call timing on; not available (HIP launches instead, kmc_hip_direct_dispatch_active == 0) where the host cannot
+ * map device memory or the device is one partition of several at one PCI address.  A wait on the queue that exceeds ten seconds turns
+ * into KMC_ERR_HIP, and the context goes back to HIP launches.
+ * kmc_hip_direct_dispatch_active: 1 if the context's eligible frames really go through the queue now (opens it if asked for and not yet
+ * open), else 0.  kmc_hip_direct_frames: frames this context has dispatched through its direct queue so far. */
+int kmc_hip_set_direct_dispatch(kmc_ctx* ctx, int enabled);
+int kmc_hip_direct_dispatch_active(kmc_ctx* ctx);
 uint64_t kmc_hip_direct_frames(kmc_ctx* ctx);
 /* n_frames separate device-resident frames in ONE call: frame f = n_points[f] points at xyzi_in[f] -> xyzi_out[f] with params[f]
  * (HOST arrays of device pointers / sizes / params), each frame in its own buffer (any 16-byte-aligned addresses).  ONE launch of the
  * frame-list kernel (2-D grid: frame x tile) on the context's stream with the frames' records IN ITS KERNEL ARGUMENTS -- up to 256 frames
  * per launch (a 56 KiB argument block; a KITTI drive of 108 frames is one launch of 24 KiB), longer lists in launches of 256: nothing is
  * uploaded, the host never waits, the call only enqueues.  Under stream capture the launches carry 16 frames each (the block every
- * runtime is known to take; so does everything after a runtime has refused a larger one).  KMC_LIST_ROUTE=table selects the round-4
- * route for lists beyond 16 frames: one launch over an uploaded table, the host waits for the copy.  Per-point results
+ * runtime is known to take; so does everything after a runtime has refused a larger one -- the refused launch's frames and the
+ * rest of the list, nothing twice).  Per-point results
  * are bit-identical to kmc_hip_deskew_f32 on the same frame: every frame runs at its own coefficient tier (a list that mixes tiers goes
  * out as one launch per tier present -- at most four; out_stats->variant reports the widest).  The frames must
  * be independent of each other (in == out of ONE frame is fine): a list in which one frame's output overlaps another frame's input or

@@ -135,6 +135,7 @@ SIGNATURES = {
     "kmc_hip_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "kmc_hip_host_free": (C.c_int, [_vp, _vp]),
     "kmc_host_pool_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "kmc_host_pool_alloc_near": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(_vp)]),
     "kmc_host_pool_free": (C.c_int, [_vp]),
     "kmc_host_pool_owns": (C.c_int, [_vp, C.c_size_t]),
     "kmc_host_pool_trim": (C.c_int, []),
@@ -151,6 +152,8 @@ SIGNATURES = {
     "kmc_hip_completion_word_fallbacks": (C.c_uint64, [_vp, C.POINTER(C.c_uint32)]),
     "kmc_hip_frame_queue_dropped": (C.c_uint64, [_vp]),
     "kmc_hip_direct_frames": (C.c_uint64, [_vp]),
+    "kmc_hip_set_direct_dispatch": (C.c_int, [_vp, C.c_int]),
+    "kmc_hip_direct_dispatch_active": (C.c_int, [_vp]),
     "kmc_hip_set_frame_queue_order": (C.c_int, [_vp, C.c_int]),
     "kmc_hip_deskew_frames_f32": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(FrameParams), C.c_uint32, C.POINTER(Stats)]),
     "kmc_hip_deskew_batch_f32": (
@@ -472,6 +475,16 @@ class Context:
     def direct_frames(self) -> int:
         """Frames dispatched through the context's direct queue (kmc_hip.h, "THE DIRECT QUEUE"); 0: HIP launches."""
         return int(lib().kmc_hip_direct_frames(self._h))
+
+    def set_direct_dispatch(self, on: bool = True):
+        """Opt in to (or out of) the direct queue (kmc_hip.h, "THE DIRECT QUEUE"): with it on, device-resident single-frame calls on the context's
+        own stream are in NO HIP stream -- torch.cuda.synchronize() does not wait for them, only self.synchronize() (or any other call on the
+        context) does, and a frame's tensors must stay alive and untouched until then."""
+        self._check(lib().kmc_hip_set_direct_dispatch(self._h, 1 if on else 0), "kmc_hip_set_direct_dispatch")
+
+    def direct_dispatch_active(self) -> bool:
+        """True if eligible frames of this context really go through the direct queue now (asked for, and the device / runtime can)."""
+        return bool(lib().kmc_hip_direct_dispatch_active(self._h))
 
     def frame_queue_dropped(self) -> int:
         """Gathered frames lost to a failed join over the context's life (kmc_hip.h, "Gathered frames and errors")."""

@@ -261,11 +261,13 @@ namespace {
 // (KMC_HOST_POOL=0) -- the caller then allocates through its device context as before.
 class PinnedSets {
  public:
-  PinnedSets(std::size_t floats_per_buffer, int n_buffers) : floats_(floats_per_buffer), n_(std::min(n_buffers, 4)) {
-    worker_ = std::thread([this] {
+  // `device`: whose side of the machine the blocks are placed on -- the helper thread's own current device is the default one, which
+  // is neither the worker's (KMC_DEVICE=N, the multi-device run) nor one this thread should initialise
+  PinnedSets(std::size_t floats_per_buffer, int n_buffers, int device) : floats_(floats_per_buffer), n_(std::min(n_buffers, 4)) {
+    worker_ = std::thread([this, device] {
       for (int k = 0; k < n_; ++k) {
         void* q = nullptr;
-        int const rc = kmc_host_pool_alloc(floats_ * sizeof(float), &q);
+        int const rc = kmc_host_pool_alloc_near(floats_ * sizeof(float), device, &q);
         std::lock_guard<std::mutex> lock(mu_);
         if (rc != KMC_OK || !q) {
           failed_rc_ = rc != KMC_OK ? rc : KMC_ERR_ALLOC;
@@ -295,6 +297,11 @@ class PinnedSets {
   int failed_rc() {
     std::lock_guard<std::mutex> lock(mu_);
     return failed_rc_;
+  }
+  // buffers the helper has made so far (final once failed_rc() != KMC_OK)
+  int ready() {
+    std::lock_guard<std::mutex> lock(mu_);
+    return ready_;
   }
   // milliseconds from the construction of this object to its first page-locked buffer: the HIP runtime's start-up (+ ~5 ms of page-locking)
   double first_ready_ms() {
@@ -393,7 +400,7 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
   auto const t_ctx0 = clk::now();
   std::unique_ptr<PinnedSets> own_sets;
   if (!prepared) {
-    own_sets = std::make_unique<PinnedSets>(4 * max_points + 16, plans.size() > 1 ? 4 : 2);
+    own_sets = std::make_unique<PinnedSets>(4 * max_points + 16, plans.size() > 1 ? 4 : 2, hip::GetDevice());
     prepared = own_sets.get();
   }
   // The device context is only needed by the first GPU round trip: it is taken (adopted from the caller's helper thread, or created)
@@ -415,8 +422,22 @@ void DeskewFrameRange(RunInputs const& in, std::size_t const first, std::size_t 
     }
     float* const q = prepared->wait(2 * k + which);
     std::unique_lock<std::mutex> lock(mu);
-    if (q) slot.p = q;  // borrowed: PinnedSets frees it
-    else cv.wait(lock, [&] { return fallback_buffers || failure; });
+    if (q) {
+      slot.p = q;  // borrowed: PinnedSets frees it
+      return q;
+    }
+    if (prepared->ready() > 0) {
+      // The helper page-locked some buffers and then failed (a memlock limit, a large batch): nobody is going to make the missing one --
+      // the GPU thread's fallback below only covers a pool that declined from the start.  Waiting would wait forever; the
+      // run ends with the error instead.
+      if (!failure)
+        failure = std::make_exception_ptr(std::runtime_error(std::string("MotionCompensateRun: page-locking buffer ") + std::to_string(2 * k + which) +
+                                                             " of the run failed: " + kmc_status_string(prepared->failed_rc())));
+      lock.unlock();
+      cv.notify_all();
+      return nullptr;
+    }
+    cv.wait(lock, [&] { return fallback_buffers || failure; });
     return slot.p;  // (nullptr only with `failure` set: the caller's next wait_for ends the thread)
   };
   sets[0].state = State::kFree;
@@ -597,6 +618,33 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
     return static_cast<std::size_t>(v > 0 ? std::min(v, 4096L) : 8L);
   }();
 
+  std::vector<int> const devices = hip::GetRunDevices();
+  bool const one_device_here = n_frames >= 3 && std::min<std::size_t>(devices.size(), n_frames - 2) == 1 && devices[0] == hip::GetDevice();
+  // One device, the caller's thread: the device context (12 ms for a process's second context, ~40 ms for its first: the HIP runtime's
+  // start-up, streams, the code objects' load) is made on a helper thread from HERE on, while this thread copies the two uncompensated
+  // frames, sizes the run and parses the text files; this thread adopts it once they are parsed
+  struct EarlyContext {
+    std::thread worker;
+    kmc_ctx* ctx = nullptr;
+    int rc = KMC_OK;
+    ~EarlyContext() {  // (an exception on the way: the helper is joined, a context nobody adopted is destroyed)
+      if (worker.joinable()) worker.join();
+      if (ctx) kmc_hip_destroy(ctx);
+    }
+  } early;
+  if (one_device_here && !detail::thread_has_context()) {
+    int const device = hip::GetDevice();
+    try {
+      early.worker = std::thread([&early, device] { early.rc = kmc_hip_create(&early.ctx, device); });
+    } catch (std::system_error const&) {  // no helper to be had: the context is created where it always was
+    }
+  }
+  // handlers.cpp:46 does this first, before it looks at any other frame: a run with a missing middle frame still gets its two
+  // uncompensated frames copied, like the reference's
+  CopyOverUncompensatedFirstAndLastFrame(run_folder);
+  if (n_frames < 3) return;
+  double const copied_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+
   // points per frame, from the file sizes: they decide the batch boundaries, the buffer sizes and the split across devices
   std::vector<std::uint64_t> frame_points(n_frames, 0);
   for (std::size_t i = 1; i + 1 < n_frames; ++i) {
@@ -608,36 +656,13 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
     frame_points[i] = bytes / 16;
   }
   double const sizes_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
-  std::vector<int> const devices = hip::GetRunDevices();
-  bool const one_device_here = n_frames >= 3 && std::min<std::size_t>(devices.size(), n_frames - 2) == 1 && devices[0] == hip::GetDevice();
-  // One device, the caller's thread: the HIP runtime starts up and the buffers are page-locked on a helper thread from HERE on, while
-  // this thread copies the two uncompensated frames and parses the text files (handlers.cpp:41-54 does those first, too).
+  // ... and the buffers are page-locked on a second helper (~0.3 ms per MiB) while this thread parses the text files and the reader
+  // already fills the first buffer
   std::unique_ptr<PinnedSets> prepared;
-  // ... and so is the device context (12 ms for a process's second context, ~40 ms for its first: streams, the code objects' load, the
-  // dispatch probe), on a helper of its own; this thread adopts it once the text files are parsed
-  struct EarlyContext {
-    std::thread worker;
-    kmc_ctx* ctx = nullptr;
-    int rc = KMC_OK;
-    ~EarlyContext() {  // (an exception on the way: the helper is joined, a context nobody adopted is destroyed)
-      if (worker.joinable()) worker.join();
-      if (ctx) kmc_hip_destroy(ctx);
-    }
-  } early;
   if (one_device_here) {
     std::size_t const most = MaxBatchPoints(frame_points, 1, n_frames - 1, max_batch_frames);
-    prepared = std::make_unique<PinnedSets>(4 * most + 16, n_frames - 2 > max_batch_frames ? 4 : 2);
-    if (!detail::thread_has_context()) {
-      int const device = hip::GetDevice();
-      try {
-        early.worker = std::thread([&early, device] { early.rc = kmc_hip_create(&early.ctx, device); });
-      } catch (std::system_error const&) {  // no helper to be had: the context is created where it always was
-      }
-    }
+    prepared = std::make_unique<PinnedSets>(4 * most + 16, n_frames - 2 > max_batch_frames ? 4 : 2, hip::GetDevice());
   }
-  CopyOverUncompensatedFirstAndLastFrame(run_folder);
-  if (n_frames < 3) return;
-  double const copied_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
 
   // every text file is parsed once per run
   auto const t_start = LoadAllTimeStamps(velodyne / Path("timestamps_start.txt"));
@@ -676,7 +701,7 @@ void MotionCompensateRun(Path const run_folder) {  // :41-65
     if (rc != KMC_OK) detail::throw_status(rc, "kmc_frame_ranges_balanced");
   }
   if (in.timing)
-    std::cerr << "kmc run timing: file sizes " << sizes_ms << " ms, first / last frame copied " << copied_ms << " ms, time stamp files " << stamps_ms
+    std::cerr << "kmc run timing: first / last frame copied " << copied_ms << " ms, file sizes " << sizes_ms << " ms, time stamp files " << stamps_ms
               << " ms, text files parsed " << parsed_ms << " ms after entry\n";
   if (n_parts == 1 && devices[0] == hip::GetDevice()) {  // the common case: no extra worker, the caller's own context
     auto const adopt = [&early] {

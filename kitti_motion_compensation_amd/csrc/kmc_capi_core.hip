@@ -146,10 +146,9 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
     const dim3 grid(std::max(1u, tiles_of(first, n_recs)), n_recs, 1);
     with_tier(tier, [&](auto T) {
       if (any_order)
-        hipExtLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kCap>), grid, dim3(kTile), 0, c->stream, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, (const ListRec*)nullptr,
-                              (const FrameRecD*)nullptr, inl);
+        hipExtLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kCap>), grid, dim3(kTile), 0, c->stream, nullptr, nullptr, (uint32_t)hipExtAnyOrderLaunch, inl);
       else
-        hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kCap>), grid, dim3(kTile), 0, c->stream, (const ListRec*)nullptr, (const FrameRecD*)nullptr, inl);
+        hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, kCap>), grid, dim3(kTile), 0, c->stream, inl);
     });
   };
   auto launch_inline = [&](uint32_t first, uint32_t n_recs, bool any_order) {
@@ -159,60 +158,40 @@ int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t
   };
   uint32_t launches = 0;
   bool capturing = false;
-  if (count > (uint32_t)kInlineListFrames) {  // (a table upload cannot be part of a stream capture: the slot is reused by later calls, and the host waits for the copy)
+  if (count > (uint32_t)kInlineListFrames) {  // (a captured launch carries the 16-frame block every runtime is known to take)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     capturing = hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     (void)hipGetLastError();
   }
-  // Every list goes out in kernel-argument launches (round 5): ONE launch for up to 256 frames; longer lists in launches of 256 (the
+  // Every list goes out in kernel-argument launches: ONE launch for up to 256 frames; longer lists in launches of 256 (the
   // frames of a list are independent of each other -- the callers have checked -- so where barrier-free dispatch is verified and the
   // stream is the context's own, every launch after the first goes out without the barrier bit: the ordinary first launch orders
   // the chain behind everything before it, the next ordinary packet on the stream waits for all of it).  Launches of at most 16 frames
   // -- the block every runtime is known to take -- under stream capture, for fq_join's fallback (inline_only) and once a large block
-  // has been refused (kmc_ctx::big_kernargs).  KMC_LIST_ROUTE=table: one launch over an uploaded device table, the round-4 route.
-  const bool table = count > (uint32_t)kInlineListFrames && c->list_route == 1 && !capturing && !inline_only;
-  if (!table) {
-    const bool small_blocks = capturing || inline_only || !c->big_kernargs;
-    const uint32_t per_launch = small_blocks ? (uint32_t)kInlineListFrames : (uint32_t)kInlineListFramesMax;
-    if (count > per_launch && !capturing && c->stream == c->own_stream) ao_ensure(c);
-    const bool free_order = count > per_launch && !capturing && c->ao_enabled && c->stream == c->own_stream && c->stream != nullptr;
-    for (uint32_t first = 0; first < count; first += per_launch, ++launches)
-      launch_inline(first, std::min<uint32_t>(per_launch, count - first), free_order && first != 0);
+  // has been refused (kmc_ctx::big_kernargs).  (The round-4 route -- one launch over an uploaded device table -- lost every measurement
+  // against these blocks and is gone: profiles/r05_frame_stream.json.)
+  const bool small_blocks = capturing || inline_only || !c->big_kernargs;
+  const uint32_t per_launch = small_blocks ? (uint32_t)kInlineListFrames : (uint32_t)kInlineListFramesMax;
+  if (count > per_launch && !capturing && c->stream == c->own_stream) ao_ensure(c);
+  const bool free_order = count > per_launch && !capturing && c->ao_enabled && c->stream == c->own_stream && c->stream != nullptr;
+  for (uint32_t first = 0; first < count; first += per_launch) {
+    const uint32_t n_recs = std::min<uint32_t>(per_launch, count - first);
+    launch_inline(first, n_recs, free_order && first != 0);
     hipError_t le = hipGetLastError();
-    if (le != hipSuccess && !small_blocks && count > (uint32_t)kInlineListFrames) {
-      // this runtime refused a block beyond 4 KiB: remember it, and issue the list again in 16-frame launches (a refused launch ran nothing;
-      // launches of the loop that did go through ran frames that are now simply written twice with the same bits)
-      c->big_kernargs = false;
-      launches = 0;
-      for (uint32_t first = 0; first < count; first += kInlineListFrames, ++launches)
-        launch_inline(first, std::min<uint32_t>(kInlineListFrames, count - first), false);
-      le = hipGetLastError();
+    if (le == hipSuccess) {
+      ++launches;
+      continue;
     }
-    KMC_HIP_TRY(c, le);
-  } else {
-    // slot layout: [ListRec x F | FrameRecD x F], one upload on the side stream, awaited on the host (like a batch's tables)
-    const size_t recs_bytes = ((size_t)count * sizeof(ListRec) + 255) & ~(size_t)255;
-    const size_t need = recs_bytes + (size_t)count * sizeof(FrameRecD);
-    int slot_id = 0;
-    int rc = slot_begin(c, need, &slot_id);
-    if (rc != KMC_OK) return rc;
-    kmc_ctx::TableSlot& sl = c->slots[slot_id];
-    std::memcpy(sl.h_buf, recs, (size_t)count * sizeof(ListRec));
-    std::memcpy(sl.h_buf + recs_bytes, recd, (size_t)count * sizeof(FrameRecD));
-    // (the kernel reading the records straight from the page-locked staging block -- no upload at all -- was measured and dropped: 0.83 us
-    // per KITTI frame against 0.79 with the upload and 0.72 chained; profiles/NOTES_r05.md)
-    rc = slot_upload(c, slot_id, need);
-    if (rc != KMC_OK) return rc;
-    const dim3 grid(std::max(1u, tiles_of(0, count)), count, 1);
-    const ListRec* d_recs = reinterpret_cast<const ListRec*>(sl.d_buf);
-    const FrameRecD* d_recd = reinterpret_cast<const FrameRecD*>(sl.d_buf + recs_bytes);
-    with_tier(tier, [&](auto T) {
-      hipLaunchKernelGGL((deskew_list_f32<decltype(T)::value, 0>), grid, dim3(kTile), 0, c->stream, d_recs, d_recd, ListNoInline{});
-    });
-    KMC_HIP_TRY(c, hipGetLastError());
-    rc = slot_end(c, slot_id);
-    if (rc != KMC_OK) return rc;
-    launches = 1;
+    if (small_blocks || n_recs <= (uint32_t)kInlineListFrames) KMC_HIP_TRY(c, le);
+    // This runtime refused a block beyond 4 KiB: remember it, and issue THIS launch's frames and the rest of the list in 16-frame
+    // launches.  A refused launch ran nothing and the launches before it are not repeated -- a frame with in == out must not be
+    // deskewed twice.
+    c->big_kernargs = false;
+    for (uint32_t f2 = first; f2 < count; f2 += kInlineListFrames, ++launches) {
+      launch_inline(f2, std::min<uint32_t>(kInlineListFrames, count - f2), false);
+      KMC_HIP_TRY(c, hipGetLastError());
+    }
+    break;
   }
   if (launches_out) *launches_out = launches;
   return KMC_OK;
@@ -227,14 +206,14 @@ int fq_join(kmc_ctx* c) {
   if (c->gl.count == 0) return KMC_OK;
   KMC_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t count = c->gl.count;
-  c->gl.flushed();  // (first: launch_list's table route may re-enter fq_join through slot_begin)
+  c->gl.flushed();
   c->stream_dirty = true;  // the list launch goes to the HIP stream
   int rc = launch_list(c, c->gather, c->gather64, count, c->gl.tier, nullptr);
   if (rc != KMC_OK) {
-    // The table route failed (a slot could not grow, the upload did not go through).  The calls that queued these frames have already
-    // returned KMC_OK, so the frames must not be dropped on the floor: the records are still in c->gather -- issue them
-    // as kernel-argument launches of at most 16 frames, which need no table.  If even that fails the error is STICKY: it is what this
-    // join returns, and what kmc_hip_frame_queue_join / kmc_hip_synchronize keep returning until the caller has seen it once.
+    // The launch failed.  The calls that queued these frames have already returned KMC_OK, so the frames must not be dropped on the floor
+    // (ADVICE r04): the records are still in c->gather -- issue them once more as launches of at most 16 frames, the block every runtime
+    // takes.  If even that fails the error is STICKY: it is what this join returns, and what kmc_hip_frame_queue_join /
+    // kmc_hip_synchronize keep returning until the caller has seen it once.
     (void)hipGetLastError();
     rc = launch_list(c, c->gather, c->gather64, count, c->gl.tier, nullptr, /*inline_only*/ true);
     if (rc != KMC_OK) {
@@ -532,15 +511,12 @@ int kmc_hip_create(kmc_ctx** out, int device_id) {
     return KMC_ERR_NO_DEVICE;
   }
   c->stream = c->own_stream;
-  if (const char* e = std::getenv("KMC_LIST_ROUTE")) c->list_route = std::strcmp(e, "table") == 0 ? 1 : 0;  // lists of more than 16 frames: "table" = one launch + one table upload
-  if (const char* e = std::getenv("KMC_MAPPED_WAVES")) {  // tuning knob: persistent waves of the in-place kernels (default 128; tools/link_probe)
-    const int w = std::atoi(e);
-    if (w >= 1 && w <= 65535) c->mapped_waves = w;
-  }
   if (const char* e = std::getenv("KMC_ANY_ORDER"))  // the switch is read HERE, like every other knob of a context; the probe itself runs at first need (ao_ensure)
     if (std::atoi(e) == 0) { c->ao_probed = true; c->ao_verdict = 0; c->ao_enabled = false; c->dd_free_order = false; }
-  if (const char* e = std::getenv("KMC_DIRECT_DISPATCH"))
-    if (std::atoi(e) == 0) c->dd_tried = true;  // (never opened: every frame is a HIP launch)
+  if (const char* e = std::getenv("KMC_DIRECT_DISPATCH")) {  // unset: off until kmc_hip_set_direct_dispatch(ctx, 1); 1: every context starts with it on; 0: never, even when asked
+    if (std::atoi(e) == 0) c->dd_never = true;
+    else c->dd_wanted = true;
+  }
   *out = c;
   return KMC_OK;
 }

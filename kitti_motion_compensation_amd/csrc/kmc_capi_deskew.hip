@@ -193,7 +193,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
   // launch of the frame-list kernel (gather_push) -- host work only unless the list goes out
   if (mem_kind == KMC_MEM_DEVICE && c->fq_count > 1 && !c->timing && n && n <= kmc_ctx::kGatherMaxPoints) return gather_push(c, xyzi_in, xyzi_out, n, params, st);
   // (a frame for an OPEN direct queue needs no HIP call at all unless it follows HIP-stream work: no hipSetDevice on that path)
-  const bool direct_fast = mem_kind == KMC_MEM_DEVICE && c->dd && !c->dd_broken && !c->stream_dirty && n && !c->timing && c->stream == c->own_stream && c->gl.count == 0;
+  const bool direct_fast = mem_kind == KMC_MEM_DEVICE && c->dd && c->dd_wanted && !c->dd_broken && !c->stream_dirty && n && !c->timing && c->stream == c->own_stream && c->gl.count == 0;
   if (!direct_fast) KMC_HIP_TRY(c, hipSetDevice(c->device));
   CallTimer tm(c);
   if (mem_kind == KMC_MEM_DEVICE) {
@@ -207,7 +207,7 @@ int kmc_hip_deskew_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, uint64
     // runtime's launch path (kmc_capi_direct.hip: 2.1 us per call instead of 3.6-4.7 on KITTI-sized frames).  Order: behind whatever the
     // context put on its HIP stream before (a host wait, at such a transition only); among frames the barrier bit, unless the window
     // says the frame shares no buffer with the frames in flight.
-    if (n && !c->timing && c->stream == c->own_stream && !c->dd_broken && direct_open(c)) {
+    if (n && !c->timing && c->stream == c->own_stream && c->dd_wanted && !c->dd_broken && direct_open(c)) {
       if (c->stream_dirty) {
         KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->stream_dirty = false;

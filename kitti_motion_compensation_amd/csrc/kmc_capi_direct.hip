@@ -91,7 +91,8 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 struct FindAgents {
   uint32_t want_bdf = 0, want_domain = 0;
-  bool have_gpu = false, have_cpu = false;
+  int gpus_matched = 0;  // GPU agents at the wanted PCI address: more than one = a partitioned device (the partitions share the address)
+  bool have_cpu = false;
   hsa_agent_t gpu{}, cpu{};
 };
 hsa_status_t on_agent(hsa_agent_t a, void* data) {
@@ -99,11 +100,15 @@ hsa_status_t on_agent(hsa_agent_t a, void* data) {
   hsa_device_type_t t;
   if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
   if (t == HSA_DEVICE_TYPE_CPU && !f->have_cpu) { f->cpu = a; f->have_cpu = true; }
-  if (t == HSA_DEVICE_TYPE_GPU && !f->have_gpu) {
+  if (t == HSA_DEVICE_TYPE_GPU) {
     uint32_t bdf = 0, domain = 0;
     (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
     (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
-    if (bdf == f->want_bdf && domain == f->want_domain) { f->gpu = a; f->have_gpu = true; }
+    // bus and device; the function bits may carry a partition id on partitioned parts, so they are not compared -- and counted instead
+    if ((bdf & ~7u) == f->want_bdf && domain == f->want_domain) {
+      if (f->gpus_matched == 0) f->gpu = a;
+      ++f->gpus_matched;
+    }
   }
   return HSA_STATUS_SUCCESS;
 }
@@ -120,7 +125,9 @@ hsa_status_t on_gpu_pool(hsa_amd_memory_pool_t p, void* data) {
   return HSA_STATUS_SUCCESS;
 }
 
-// the code object on HIP device `device`'s agent (matched by PCI address), loaded once per process
+// the code object on HIP device `device`'s agent, loaded once per process.  The agent is matched by PCI address and must be the ONLY GPU
+// agent there: on a partitioned device (CPX / DPX modes) several agents share one address, the match would be a guess, and a packet on
+// the wrong partition's queue reads memory that is mapped to its owner only -- such devices keep the HIP launches.
 AgentCode* agent_code(int device) {
   if (device < 0 || device >= 64) return nullptr;
   std::lock_guard<std::mutex> lock(g_code_mu);
@@ -137,7 +144,7 @@ AgentCode* agent_code(int device) {
   FindAgents fa;
   fa.want_bdf = ((uint32_t)bus << 8) | ((uint32_t)dev << 3);  // function 0
   fa.want_domain = (uint32_t)domain;
-  if (hsa_iterate_agents(on_agent, &fa) != HSA_STATUS_SUCCESS || !fa.have_gpu || !fa.have_cpu) return nullptr;
+  if (hsa_iterate_agents(on_agent, &fa) != HSA_STATUS_SUCCESS || fa.gpus_matched != 1 || !fa.have_cpu) return nullptr;
   ac.gpu = fa.gpu;
   ac.cpu = fa.cpu;
   FindPool fp;
@@ -217,7 +224,7 @@ struct DirectQueue {
   uint32_t next_record = 0;
   kmc_book::LaneSync sync;                 // which cross-lane waits the next frame needs (kmc_dispatch_book.hpp: unit-tested against a model of two queues)
   OrderRec* last_full = nullptr;           // the last fully ordered frame's record (what lane 1's next packet waits for, if sync says it must)
-  bool two_lanes = true;                   // KMC_DIRECT_LANES=1: everything on lane 0 (measurement knob)
+  bool two_lanes = true;                   // false with KMC_ANY_ORDER=0: every frame ordered, nothing for a second lane to overlap
   uint64_t frames = 0;
 };
 
@@ -436,17 +443,20 @@ int direct_traj_frame(kmc_ctx* c, int tier, const v4f* in, v4f* out, uint64_t n,
 // self-test differs).  The self-test runs one 1000-point frame through the direct queue and through a HIP launch and compares the bits.
 bool direct_open(kmc_ctx* c) {
   if (c->dd) return true;
-  if (c->dd_tried) return false;
+  if (!c->dd_wanted || c->dd_never || c->dd_tried) return false;
   c->dd_tried = true;
-  if (const char* e = std::getenv("KMC_DIRECT_DISPATCH"))
-    if (std::atoi(e) == 0) return false;
+  // everything below -- the self-test's buffers, copies and its HIP launch above all -- belongs on the context's device, whatever device the
+  // calling thread had current (a thread that holds contexts for several GPUs)
+  if (hipSetDevice(c->device) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
   AgentCode* code = agent_code(c->device);
   if (!code) return false;
   DirectQueue* d = new (std::nothrow) DirectQueue();
   if (!d) return false;
   d->code = code;
   c->dd = d;
-  if (const char* e = std::getenv("KMC_DIRECT_LANES")) d->two_lanes = std::atoi(e) != 1;
   if (!c->dd_free_order) d->two_lanes = false;  // every frame ordered (KMC_ANY_ORDER=0): nothing for a second lane to overlap
   c->lw.lanes = d->two_lanes ? 2 : 1;
   c->lw.invalidate();
@@ -462,8 +472,6 @@ bool direct_open(kmc_ctx* c) {
   for (OrderRec& r : d->order)
     for (hsa_signal_t* sg : {&r.s, &r.x, &r.w})  // waited for by barrier packets only (the host polls their values, it never sleeps on them): no interrupt per completion
       ok = ok && hsa_amd_signal_create(0, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, sg) == HSA_STATUS_SUCCESS;
-  const bool debug = std::getenv("KMC_DIRECT_DEBUG") != nullptr;
-  if (debug) std::fprintf(stderr, "kmc direct queue: lanes, rings and signals %s\n", ok ? "ok" : "FAILED");
   // ---- self-test: the direct queue's frame against the HIP launch's, bit for bit ----
   float *t_in = nullptr, *t_a = nullptr, *t_b = nullptr;
   constexpr uint64_t kN = 1000;
@@ -498,7 +506,6 @@ bool direct_open(kmc_ctx* c) {
   if (t_a) (void)hipFree(t_a);
   if (t_b) (void)hipFree(t_b);
   (void)hipGetLastError();
-  if (debug) std::fprintf(stderr, "kmc direct queue: self-test %s (%s)\n", ok ? "ok" : "FAILED", c->last_error.c_str());
   if (!ok) {
     direct_close(c);
     c->dd_broken = false;  // (not broken: absent -- HIP launches from the start)
@@ -512,3 +519,22 @@ bool direct_open(kmc_ctx* c) {
 }  // namespace kmc_impl
 
 extern "C" uint64_t kmc_hip_direct_frames(kmc_ctx* c) { return (c && c->dd) ? c->dd->frames : 0; }
+
+// Opt in / out (include/kmc_hip.h).  Switching off first waits for the frames still in the queue: from the return on, everything the context
+// issues is in its HIP stream again.  The queue itself stays open (switching on again costs nothing).
+extern "C" int kmc_hip_set_direct_dispatch(kmc_ctx* c, int enabled) {
+  if (!c) return KMC_ERR_INVALID_ARG;
+  if (!enabled && c->dd_pending) {
+    const int rc = kmc_impl::direct_join(c);
+    if (rc != KMC_OK) return rc;
+  }
+  c->dd_wanted = enabled != 0;
+  return KMC_OK;
+}
+
+// 1: this context's eligible frames go through the direct queue (asked for, opened, self-test passed); 0: HIP launches (not asked for, the
+// device / runtime cannot, KMC_DIRECT_DISPATCH=0, or the queue broke).  Asked for but not opened yet: opens it (once).
+extern "C" int kmc_hip_direct_dispatch_active(kmc_ctx* c) {
+  if (!c || !c->dd_wanted || c->dd_never || c->dd_broken) return 0;
+  return (c->dd || kmc_impl::direct_open(c)) ? 1 : 0;
+}

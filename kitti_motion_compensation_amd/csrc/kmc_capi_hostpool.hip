@@ -34,6 +34,7 @@ struct Pool {
   std::vector<std::vector<void*>> free_lists;  // by size class
   size_t cached_bytes = 0, max_cached = (size_t)2048 << 20;
   int state = 0;  // 0 = untested, 1 = usable, -1 = no device / disabled
+  int fail_at = 0, new_blocks_asked = 0;  // KMC_TEST_HOST_POOL_FAIL_AT=k: the k-th allocation request fails with KMC_ERR_ALLOC (tests only)
 };
 
 // Set by an atexit handler registered the first time the pool is found usable -- i.e. AFTER the HIP runtime registered its own
@@ -50,12 +51,11 @@ Pool& pool() {
 
 // ---- NUMA placement of the blocks (Linux system calls, no libnuma) ----
 constexpr int kMpolDefault = 0, kMpolPreferred = 1;
-int device_numa_node() {  // of the calling thread's current HIP device; -1: unknown, or a machine with one node  (pool mutex held)
+int device_numa_node(int dev) {  // of HIP device `dev` (< 0: the calling thread's current device); -1: unknown, or a machine with one node  (pool mutex held)
   static int cached[64];
   static bool known[64];
-  int dev = 0;
   char bdf[64] = {0};
-  if (hipGetDevice(&dev) != hipSuccess) {
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
     return -1;
   }
@@ -115,6 +115,7 @@ bool usable(Pool& p) {  // p.m held
       p.state = 1;
       std::atexit(mark_exiting);
       if (const char* mb = std::getenv("KMC_HOST_POOL_MAX_MB")) p.max_cached = (size_t)std::max(0, std::atoi(mb)) << 20;
+      if (const char* k = std::getenv("KMC_TEST_HOST_POOL_FAIL_AT")) p.fail_at = std::atoi(k);  // test hook: the k-th allocation request of the process fails
     }
   }
   return p.state == 1;
@@ -167,13 +168,16 @@ bool host_in_place_ok(const void* ptr, size_t bytes) {
 
 extern "C" {
 
-int kmc_host_pool_alloc(size_t bytes, void** out) {
+int kmc_host_pool_alloc(size_t bytes, void** out) { return kmc_host_pool_alloc_near(bytes, -1, out); }
+
+int kmc_host_pool_alloc_near(size_t bytes, int device, void** out) {
   if (!out) return KMC_ERR_INVALID_ARG;
   *out = nullptr;
   if (bytes == 0) return KMC_OK;
   Pool& p = pool();
   std::lock_guard<std::mutex> lock(p.m);
   if (!usable(p)) return KMC_ERR_NO_DEVICE;
+  if (p.fail_at > 0 && ++p.new_blocks_asked == p.fail_at) return KMC_ERR_ALLOC;  // KMC_TEST_HOST_POOL_FAIL_AT: fault injection for the tests
   const int cls = class_of(std::max(bytes, kMinClassBytes));
   if ((size_t)cls < p.free_lists.size() && !p.free_lists[cls].empty()) {
     void* b = p.free_lists[cls].back();
@@ -188,7 +192,7 @@ int kmc_host_pool_alloc(size_t bytes, void** out) {
   // 104-125 us on the other one; profiles/NOTES.md).  The block is allocated under a PREFERRED memory policy for the device's NUMA node
   // (hipHostMallocNumaUser: "follow the caller's policy"); the calling thread's policy is put back right after.
   void* b = nullptr;
-  const int node = device_numa_node();
+  const int node = device_numa_node(device);
   const bool placed = node >= 0 && prefer_node(node);
   const hipError_t e = hipHostMalloc(&b, class_bytes(cls), hipHostMallocPortable | hipHostMallocMapped | (placed ? hipHostMallocNumaUser : 0u));
   if (placed) restore_policy();

@@ -171,8 +171,8 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   const bool window = inline_records && !c->timing && c->gl.count == 0 && !bracket_idx_out && n;
   // The context's OWN stream: such a frame goes out through the direct queue like a two-pose frame (kmc_capi_direct.hip) -- its records
   // ride in the packet's argument block, no HIP call on the way.  Same tile body as the HIP launch below, same bits.
-  const bool direct = window && c->stream == c->own_stream && c->fq_count <= 1 && !c->dd_broken && (c->dd || direct_open(c));  // (not with gathering on: kmc_hip.h)
-  if (!(direct && !c->stream_dirty)) KMC_HIP_TRY(c, hipSetDevice(c->device));
+  if (!(c->dd && c->dd_wanted && !c->stream_dirty)) KMC_HIP_TRY(c, hipSetDevice(c->device));  // (before direct_open: its self-test allocates and launches on the CURRENT device)
+  const bool direct = window && c->stream == c->own_stream && c->fq_count <= 1 && c->dd_wanted && !c->dd_broken && (c->dd || direct_open(c));  // (not with gathering on: kmc_hip.h)
   if (direct) {
     if (c->stream_dirty) {
       KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -47,7 +47,7 @@ struct kmc_ctx {
   int f64_result = 0;
   kmc_stats f64_stats = {};
   bool counter_dirty = true;   // d_counter may be non-zero: the f64 entry points clear it only then (a memset per call costs ~5 us)
-  int mapped_waves = 128;      // persistent one-wave workgroups of the f64 kernel when it works on page-locked host memory (64 ... 1024 measured: profiles/r03_inplace_f64.txt)
+  static constexpr int mapped_waves = 128;      // persistent one-wave workgroups of the f64 kernel when it works on page-locked host memory (64 ... 1024 measured: profiles/r03_inplace_f64.txt)
   uint32_t* h_flag = nullptr;  // page-locked word the f64 kernels raise when a stamp is out of range (read by the host after the sync: no D2H copy on the good path)
   // completion word of the in-place kernels (kmc_kernels.hip.h, DoneWord): the last wave stores the call's sequence number into h_done,
   // the host spins on it instead of waiting for the stream (~8.5 us per call).  All in h_flag's page-locked block, one cache line each.
@@ -115,13 +115,15 @@ struct kmc_ctx {
   // the direct queue (kmc_capi_direct.hip): device-resident single-frame calls on the context's OWN stream are dispatched as AQL packets in an
   // HSA queue of the context's, below the HIP runtime's launch path
   kmc_impl::DirectQueue* dd = nullptr;
+  bool dd_wanted = false;            // the caller asked for it (kmc_hip_set_direct_dispatch, or KMC_DIRECT_DISPATCH=1 at kmc_hip_create): OFF by default --
+                                     // frames in the direct queue are outside every HIP stream, which a caller has to know about (include/kmc_hip.h)
+  bool dd_never = false;             // KMC_DIRECT_DISPATCH=0: not even when asked (A/B runs of a client that asks)
   bool dd_tried = false;             // direct_open() has been attempted
   bool dd_pending = false;           // frames are in the direct queue that nobody has waited for (direct_join)
   bool dd_broken = false;            // a wait on the queue timed out: HIP launches from here on
   bool dd_free_order = true;         // independent frames go out without the AQL barrier bit (KMC_ANY_ORDER=0: every packet carries it)
   bool stream_dirty = true;          // the context has put work on its HIP stream since the last host wait for it: a direct frame waits first
   bool big_kernargs = true;          // kernel-argument blocks beyond 4 KiB are taken by this runtime (cleared by the first refused launch: launch_list)
-  int list_route = 0;                // lists of more than 16 frames: 0 = kernel-argument launches of up to 256 frames (launch_list), 1 = one launch over an uploaded device table (KMC_LIST_ROUTE=table)
   int fq_error = 0;                  // sticky: a join failed to issue gathered frames whose calls had already returned KMC_OK (fq_join)
   uint64_t fq_dropped = 0;           // how many frames that has cost so far (kmc_hip_frame_queue_dropped)
   // independent frames on ONE stream without the drain between them: a device-resident single-frame launch whose buffers overlap
@@ -178,7 +180,7 @@ int pick_tier(const kmc_ctx* c, const kmc_frame_params* p, uint32_t n);
 // point that puts other work on the stream starts with; gather_push() adds a frame (kmc_capi_deskew.hip)
 int fq_join(kmc_ctx* c);
 // ONE launch of the frame-list kernel for `count` filled records on the context's stream: kernel-argument records for at most
-// up to kInlineListFramesMax (256) frames per launch (16 under stream capture and for `inline_only`; KMC_LIST_ROUTE=table: one table upload).  -> launches_out
+// up to kInlineListFramesMax (256) frames per launch (16 under stream capture and for `inline_only`).  -> launches_out
 int launch_list(kmc_ctx* c, const ListRec* recs, const FrameRecD* recd, uint32_t count, int tier, uint32_t* launches_out, bool inline_only = false);
 int fq_take_error(kmc_ctx* c);  // the sticky error of a join that could not issue its frames (reported once)
 
@@ -276,7 +278,7 @@ inline void launch_on(void (*kernel)(KArgs...), int grid, int block, hipStream_t
 }
 
 // the direct queue (kmc_capi_direct.hip)
-bool direct_open(kmc_ctx* c);   // the context's queue exists (opened at first need; false: not on this device / runtime, or KMC_DIRECT_DISPATCH=0)
+bool direct_open(kmc_ctx* c);   // the context's queue exists (opened at first need; false: not asked for (kmc_ctx::dd_wanted), not on this device / runtime, or KMC_DIRECT_DISPATCH=0)
 void direct_close(kmc_ctx* c);
 int direct_join(kmc_ctx* c);    // every frame dispatched through the queue has completed (bounded wait)
 bool direct_frame_is_huge(uint64_t n);

@@ -418,7 +418,7 @@ static_assert(sizeof(ListRec) == 96, "ListRec must stay one 96-byte record");
 // waits, the call only enqueues a launch.  Round 4 assumed a 4 KiB limit on the argument block (16 frames); the runtime takes 64 KiB and
 // more (tools/launch_probe, profiles/r05_launch_probe.json: 8 KiB 3.1 us, 16 KiB 4.1 us, 64 KiB 10 us of host time per launch against
 // 2.2-3.4 us for a small block), so a whole KITTI drive -- 108 frames, 24 KiB -- is ONE launch without a table.  Three capacities, so
-// that a short list does not copy a long list's block: 16 (3.5 KiB), 64 (14 KiB), 256 (56 KiB).  CAP == 0: a device table.
+// that a short list does not copy a long list's block: 16 (3.5 KiB), 64 (14 KiB), 256 (56 KiB).  (The device-table form of round 4 is gone.)
 constexpr int kInlineListFrames = 16;     // what a launch under stream capture and the fallback chain carry (the block round 4 proved everywhere)
 constexpr int kInlineListFramesMax = 256;
 template <int CAP>
@@ -428,22 +428,13 @@ struct ListInlineT {
 };
 static_assert(sizeof(ListInlineT<kInlineListFrames>) <= 3800, "the 16-frame block fits the 4 KiB every runtime takes");
 static_assert(sizeof(ListInlineT<kInlineListFramesMax>) <= 60 * 1024, "the largest block stays below the 64 KiB the probe verified");
-struct ListNoInline { uint32_t unused; };
-template <int CAP> using ListInlineArg = typename std::conditional<(CAP > 0), ListInlineT<(CAP > 0 ? CAP : 1)>, ListNoInline>::type;
-
-template <int TIER, int CAP = 0>
-__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_list_f32(const ListRec* __restrict__ recs_g, const FrameRecD* __restrict__ recs64,
-                                                                                              ListInlineArg<CAP> inl) {
+template <int TIER, int CAP>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void deskew_list_f32(ListInlineT<CAP> inl) {
+  static_assert(CAP > 0, "the records travel in the kernel arguments");
   using rec_cp = const ListRec __attribute__((address_space(4)))*;
-  rec_cp recs;
-  if constexpr (CAP > 0) {
-    struct ArgLayout { const ListRec* recs_g; const FrameRecD* recs64; ListInlineT<(CAP > 0 ? CAP : 1)> inl; };
-    const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    recs = (rec_cp)(kernarg + offsetof(ArgLayout, inl) + offsetof(ListInlineT<(CAP > 0 ? CAP : 1)>, recs));
-    recs64 = (const FrameRecD*)(const char*)(kernarg + offsetof(ArgLayout, inl) + offsetof(ListInlineT<(CAP > 0 ? CAP : 1)>, recs64));
-  } else {
-    recs = (rec_cp)(uintptr_t)recs_g;  // written by the host before the launch: constant for the kernel, uniform reads are scalar loads
-  }
+  const auto kernarg = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  const rec_cp recs = (rec_cp)(kernarg + offsetof(ListInlineT<CAP>, recs));
+  const FrameRecD* recs64 = (const FrameRecD*)(const char*)(kernarg + offsetof(ListInlineT<CAP>, recs64));
   const uint32_t fi = blockIdx.y;
   ListRec r;
   {

@@ -429,7 +429,7 @@ def stream_round(ctx, plain_ctx, gather_ctx, rng, acc, torch, hip_ctx=None):
     torch.cuda.synchronize()
     run(gather_ctx, got2, False)
     ok = ok and all(bool(torch.equal(g.view(torch.int32), w.view(torch.int32))) for g, w in zip(got2, want))
-    # ... and through a context whose frames are HIP launches (KMC_DIRECT_DISPATCH=0; `ctx` dispatches them through its direct queue, two lanes)
+    # ... and through a default context, whose frames are HIP launches (`ctx` opted in: it dispatches them through its direct queue, two lanes)
     if hip_ctx is not None:
         got3 = [x.clone() for x in base]
         torch.cuda.synchronize()
@@ -459,12 +459,11 @@ def main():
     last_checkpoint = time.time()
     rng = np.random.default_rng(seed)
     ctx = capi.Context(0)
+    ctx.set_direct_dispatch(True)  # the soak waits through the context only (ctx.synchronize): the direct queue's rule
     os.environ["KMC_ANY_ORDER"] = "0"
     plain_ctx = capi.Context(0)  # every dispatch with its barrier bit: the reference of stream_round
     del os.environ["KMC_ANY_ORDER"]
-    os.environ["KMC_DIRECT_DISPATCH"] = "0"
-    hip_ctx = capi.Context(0)  # single-frame calls as HIP launches (the default context writes AQL packets into its own queues)
-    del os.environ["KMC_DIRECT_DISPATCH"]
+    hip_ctx = capi.Context(0)  # the default: single-frame calls as HIP launches (`ctx` writes AQL packets into its own queues)
     gather_ctx = capi.Context(0)
     gather_ctx.set_frame_queues(4)  # single-frame calls gathered into list launches
     calib = util.load_kitti_calibration(os.path.join(ROOT, "tests", "golden"))

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r"\sT\s+(kmc_[a-z0-9_]+)", out))
     assert set(_declared_symbols()) <= exported
-    assert L.kmc_abi_version() == 6  # 6: kmc_hip_completion_word_fallbacks (an in-place wait that finds the stream idle without the word synchronises the stream and carries on); 5: kmc_hip_frame_queue_dropped + the sticky join error, a list call launches once per tier present; 4: kmc_device_info.any_order_dispatch (run-time probe), queued kmc_hip_deskew_f64cols_begin calls, kmc_hip_deskew_frames_f32 as one launch
+    assert L.kmc_abi_version() == 7  # 7: the direct queue is opt-in (kmc_hip_set_direct_dispatch, kmc_hip_direct_dispatch_active), kmc_host_pool_alloc_near, KMC_LIST_ROUTE / KMC_DIRECT_LANES / KMC_MAPPED_WAVES / KMC_DIRECT_DEBUG retired; 6: kmc_hip_completion_word_fallbacks (an in-place wait that finds the stream idle without the word synchronises the stream and carries on); 5: kmc_hip_frame_queue_dropped + the sticky join error, a list call launches once per tier present; 4: kmc_device_info.any_order_dispatch (run-time probe), queued kmc_hip_deskew_f64cols_begin calls, kmc_hip_deskew_frames_f32 as one launch
 
 
 def test_library_contains_gfx950_code_object():

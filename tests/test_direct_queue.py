@@ -1,7 +1,7 @@
-"""THE DIRECT QUEUE (include/kmc_hip.h, kmc_capi_direct.hip): on a context's own stream a device-resident kmc_hip_deskew_f32 call is an
-AQL packet the library writes into an HSA queue of its own, not a HIP launch.  Same bits as the HIP launch; ordered against everything
-else the context does (HIP-stream work before it, other entry points after it); never used on a caller's stream, with per-call timing,
-or with KMC_DIRECT_DISPATCH=0.  tests/test_dispatch_modes.py replays a whole script of calls under both dispatch paths."""
+"""THE DIRECT QUEUE (include/kmc_hip.h, kmc_capi_direct.hip): after kmc_hip_set_direct_dispatch(ctx, 1), on a context's own stream a
+device-resident kmc_hip_deskew_f32 call is an AQL packet the library writes into an HSA queue of its own, not a HIP launch.  Same bits as
+the HIP launch; ordered against everything else the context does (HIP-stream work before it, other entry points after it); never used
+without the opt-in (round 6), on a caller's stream, with per-call timing, or with KMC_DIRECT_DISPATCH=0.  tests/test_dispatch_modes.py replays a whole script of calls under both dispatch paths."""
 import os
 
 import numpy as np
@@ -13,10 +13,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _ctx(**env):
+    """A context that opted in to the direct queue; _ctx(KMC_DIRECT_DISPATCH="0"): one whose opt-in the environment refuses (HIP launches)."""
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        return capi.Context(0)
+        c = capi.Context(0)
+        c.set_direct_dispatch(True)
+        return c
     finally:
         for k, v in saved.items():
             if v is None:

@@ -2,15 +2,16 @@
 repeats, an overwritten input, shared inputs, mixed coefficient tiers, empty and ragged frames, other entry points (a list, a batch, an
 N-knot frame, a host in-place call) in between -- replayed under every dispatch configuration a context can be in:
 
-    default                          the context's own stream: frames go out through the DIRECT QUEUE (AQL packets the library writes itself),
-                                     without the barrier bit when they share no buffer with a frame in flight
-    direct_queue_on_one_lane         KMC_DIRECT_LANES=1: the direct queue on ONE HSA queue (by default independent frames alternate between two)
-    hip_launches_only                KMC_DIRECT_DISPATCH=0: every frame a HIP launch, barrier-free (hipExtAnyOrderLaunch) where probed
-    barrier_bit_on_every_dispatch    KMC_ANY_ORDER=0 (direct queue, every packet ordered)
-    hip_launches_with_the_barrier_bit  KMC_DIRECT_DISPATCH=0 and KMC_ANY_ORDER=0
+    default                          the context's own stream: every frame a HIP launch, barrier-free (hipExtAnyOrderLaunch) where probed when it
+                                     shares no buffer with a frame in flight
+    direct_queue                     kmc_hip_set_direct_dispatch(ctx, 1): frames go out through the DIRECT QUEUE (AQL packets the library writes
+                                     itself, two lanes), without the barrier bit when they share no buffer with a frame in flight
+    direct_queue_by_environment      KMC_DIRECT_DISPATCH=1: the same, switched on for every context of the process
+    direct_queue_refused             KMC_DIRECT_DISPATCH=0 and a caller that opts in all the same: HIP launches (the A/B switch)
+    barrier_bit_on_every_dispatch    KMC_ANY_ORDER=0 (HIP launches, every one ordered)
+    direct_queue_with_the_barrier_bit  opted in and KMC_ANY_ORDER=0 (one lane, every packet ordered)
     gathered_calls                   kmc_hip_set_frame_queues(ctx, 4): calls gathered into list launches
     gathered_on_a_callers_stream     the same on torch's stream, with the caller's word that nothing is produced between calls
-    list_table_route                 KMC_LIST_ROUTE=table: lists beyond 16 frames over an uploaded table
     serial                           KMC_ANY_ORDER=0 and a synchronize after every call: the definition of "in-order results"
 
 Every buffer the script touches must hold the SAME BITS in every configuration, and those of `serial`; the f32 results are within the bar
@@ -27,15 +28,21 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-MODES = ["serial", "default", "direct_queue_on_one_lane", "hip_launches_only", "barrier_bit_on_every_dispatch", "hip_launches_with_the_barrier_bit", "gathered_calls", "gathered_on_a_callers_stream",
-         "list_table_route"]
+MODES = ["serial", "default", "direct_queue", "direct_queue_by_environment", "direct_queue_refused", "barrier_bit_on_every_dispatch", "direct_queue_with_the_barrier_bit", "gathered_calls",
+         "gathered_on_a_callers_stream"]
 
 
 def _make_ctx(mode, torch):
-    env = {"serial": {"KMC_ANY_ORDER": "0"}, "barrier_bit_on_every_dispatch": {"KMC_ANY_ORDER": "0"}, "list_table_route": {"KMC_LIST_ROUTE": "table"},
-           "direct_queue_on_one_lane": {"KMC_DIRECT_LANES": "1"}, "hip_launches_only": {"KMC_DIRECT_DISPATCH": "0"}, "hip_launches_with_the_barrier_bit": {"KMC_DIRECT_DISPATCH": "0", "KMC_ANY_ORDER": "0"}}.get(mode, {})
+    env = {"serial": {"KMC_ANY_ORDER": "0"}, "barrier_bit_on_every_dispatch": {"KMC_ANY_ORDER": "0"}, "direct_queue_by_environment": {"KMC_DIRECT_DISPATCH": "1"},
+           "direct_queue_refused": {"KMC_DIRECT_DISPATCH": "0"}, "direct_queue_with_the_barrier_bit": {"KMC_ANY_ORDER": "0"}}.get(mode, {})
+    if mode not in ("direct_queue_by_environment", "direct_queue_refused"):
+        env = dict({"KMC_DIRECT_DISPATCH": None}, **env)  # (the suite itself may be running under KMC_DIRECT_DISPATCH=1: tests/test_suite_modes.py)
     saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    for k, v in env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     try:
         c = capi.Context(0)
     finally:
@@ -44,6 +51,8 @@ def _make_ctx(mode, torch):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+    if mode in ("direct_queue", "direct_queue_refused", "direct_queue_with_the_barrier_bit"):
+        c.set_direct_dispatch(True)
     if mode.startswith("gathered"):
         c.set_frame_queues(4)
     if mode == "gathered_on_a_callers_stream":
@@ -153,15 +162,16 @@ def test_the_configurations_really_differ(replay):
     assert results["serial"]["_any_order_launches"] == 0 and results["barrier_bit_on_every_dispatch"]["_any_order_launches"] == 0
     assert results["barrier_bit_on_every_dispatch"]["_verdict"] == 0
     assert results["gathered_calls"]["_any_order_launches"] == 0  # gathered frames go out as list launches
-    # the direct queue carries the frames of the own-stream configurations (where this device offers it), never those of the others
-    assert results["hip_launches_only"]["_direct_frames"] == 0 and results["hip_launches_with_the_barrier_bit"]["_direct_frames"] == 0
-    assert results["gathered_calls"]["_direct_frames"] == 0 and results["gathered_on_a_callers_stream"]["_direct_frames"] == 0
-    if results["default"]["_direct_frames"]:
-        assert results["default"]["_direct_frames"] >= 20 and results["serial"]["_direct_frames"] >= 20
-        assert results["direct_queue_on_one_lane"]["_direct_frames"] == results["default"]["_direct_frames"]
-        assert results["default"]["_any_order_launches"] >= 8  # plain AQL semantics: no probe needed for packets without the barrier bit
-    if results["hip_launches_only"]["_verdict"] == 1:
-        assert results["hip_launches_only"]["_any_order_launches"] >= 8
+    # the direct queue carries the frames of the configurations that opted in (where this device offers it), never those of the others
+    for plain in ("serial", "default", "direct_queue_refused", "barrier_bit_on_every_dispatch", "gathered_calls", "gathered_on_a_callers_stream"):
+        assert results[plain]["_direct_frames"] == 0, plain  # the default is HIP launches: frames of a default context are in its HIP stream
+    if results["direct_queue"]["_direct_frames"]:
+        assert results["direct_queue"]["_direct_frames"] >= 20 and results["direct_queue_with_the_barrier_bit"]["_direct_frames"] >= 20
+        assert results["direct_queue_by_environment"]["_direct_frames"] == results["direct_queue"]["_direct_frames"]
+        assert results["direct_queue"]["_any_order_launches"] >= 8  # plain AQL semantics: no probe needed for packets without the barrier bit
+        assert results["direct_queue_with_the_barrier_bit"]["_any_order_launches"] == 0
+    if results["default"]["_verdict"] == 1:
+        assert results["default"]["_any_order_launches"] >= 8
 
 
 def test_the_serial_bits_are_within_the_bar_of_the_oracle(replay):

@@ -4,7 +4,9 @@ this process keeps the same GPU busy with resident deskew launches of its own --
 where the binary's one completion-word event of round 5 happened (profiles/NOTES.md, section 10).  Prints the binary's exit codes and the
 completion-word fallbacks it reported.
 
-    python tools/stress_two_processes.py [runs=40] [busy=1]
+    python tools/stress_two_processes.py [runs=40] [busy=1] [max_seconds=0]
+
+max_seconds > 0: no new run of the binary is started after that many seconds (the short form tests/test_race_hunters.py runs under -m gpu).
 """
 import json
 import os
@@ -13,6 +15,7 @@ import subprocess
 import sys
 import tempfile
 import threading
+import time
 
 import numpy as np
 
@@ -24,6 +27,7 @@ from kitti_motion_compensation_amd import capi  # noqa: E402
 def main():
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     busy = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    max_seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     import torch
 
     dev = torch.device("cuda", 0)
@@ -49,7 +53,10 @@ def main():
     golden = os.path.join(ROOT, "tests", "golden")
     codes, fallbacks, fails, states = [], [], [], []
     with tempfile.TemporaryDirectory() as tmp:
+        t_start = time.time()
         for _ in range(runs):
+            if max_seconds > 0 and time.time() - t_start > max_seconds:
+                break
             r = subprocess.run([exe, "gpu", golden, tmp], capture_output=True, text=True, timeout=120)
             codes.append(r.returncode)
             m = re.search(r"completion-word fallbacks of this process: (\d+)", r.stdout)
@@ -61,7 +68,7 @@ def main():
     stop.set()
     if busy:
         th.join()
-    print(json.dumps({"runs": runs, "other_process_keeps_the_gpu_busy": bool(busy), "its_launches_meanwhile": launches[0], "nonzero_exit_codes": sum(1 for c in codes if c != 0),
+    print(json.dumps({"runs": len(codes), "other_process_keeps_the_gpu_busy": bool(busy), "its_launches_meanwhile": launches[0], "nonzero_exit_codes": sum(1 for c in codes if c != 0),
                       "completion_word_fallbacks_reported": [f for f in fallbacks if f], "their_lines": states, "runs_without_a_report": sum(1 for f in fallbacks if f is None), "failures": fails[:3]}))
 
 

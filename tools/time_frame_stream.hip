@@ -7,15 +7,16 @@
 // N(121 000, 3 000) clipped to [90 000, 140 000] like bench.py's configs2_drive leg; `sets` rotating sets of such frames (so that a
 // sweep's working set exceeds the 256 MiB Infinity Cache when the frames are small).  Timed with HIP events on the context's stream
 // (kmc_hip_timer_begin / _end, which also join the frame queues), `iters` sweeps over all sets' frames after two warm-up sweeps:
-//   per_call            one kmc_hip_deskew_f32 call per frame, in order on the context's own stream: since round 5 through the context's DIRECT
-//                       QUEUE (AQL packets the library writes itself; frames that share no buffer with one in flight without the barrier bit)
-//   per_call_hip_launches   the same calls on a context created with KMC_DIRECT_DISPATCH=0: one HIP launch per frame (round 4's route)
-//   per_call_nknot3     one kmc_hip_deskew_traj_f32 call per frame (three knots, the records in the argument block): direct queue; _hip_launches: its twin
+//   per_call            one kmc_hip_deskew_f32 call per frame, in order on a DEFAULT context's own stream: one HIP launch per frame (frames that
+//                       share no buffer with one in flight without the barrier bit, where the run-time probe verified that)
+//   per_call_direct_queue   the same calls on a context that opted in with kmc_hip_set_direct_dispatch(ctx, 1): AQL packets the library writes
+//                       itself, below the HIP runtime's launch path (this client waits with kmc_hip_synchronize / kmc_hip_timer_end only)
+//   per_call_nknot3     one kmc_hip_deskew_traj_f32 call per frame (three knots, the records in the argument block), default context;
+//                       _direct_queue: its twin on the opted-in context, compared bit for bit
 //   per_call_drained    the same calls on a context created with KMC_ANY_ORDER=0 (every dispatch carries the barrier bit)
 //   per_call_gathered   the same calls with kmc_hip_set_frame_queues(ctx, 4): the library gathers them into list launches of up to 16 frames
 //   list_one_launch     kmc_hip_deskew_frames_f32: the set's frames handed over as ONE list (the key keeps its round-4 name; since round 5 a
 //                       list of more than 16 frames goes out as chained kernel-argument launches of 16 frames, barrier-free where verified)
-//   list_table_route    the same call on a context created with KMC_LIST_ROUTE=table: one launch of the frame-list kernel over an uploaded table
 //   batch_packed        kmc_hip_deskew_batch_f32 on the same frames packed into one buffer (the ceiling for this frame mix)
 // plus the host's own time per call (steady_clock around the issuing loop) and a bit-for-bit comparison of what the list kernel and
 // the per-frame kernel wrote for every frame.  Prints one JSON object.
@@ -78,12 +79,11 @@ int main(int argc, char** argv) {
   }
   const uint64_t total = offsets[F];
 
-  kmc_ctx *ctx = nullptr, *drained = nullptr, *tabled = nullptr;
+  kmc_ctx *ctx = nullptr, *drained = nullptr, *direct = nullptr;
   (void)kmc_hip_bind_thread_near_device(0);  // a placement hint: the calling thread on the GPU's NUMA node (what numactl does for a deployment)
   KMC_OK_OR_DIE(kmc_hip_create(&ctx, 0));
-  setenv("KMC_LIST_ROUTE", "table", 1);
-  KMC_OK_OR_DIE(kmc_hip_create(&tabled, 0));
-  unsetenv("KMC_LIST_ROUTE");
+  KMC_OK_OR_DIE(kmc_hip_create(&direct, 0));
+  KMC_OK_OR_DIE(kmc_hip_set_direct_dispatch(direct, 1));  // this client plays by the queue's rules: it waits through the context only
   setenv("KMC_ANY_ORDER", "0", 1);
   KMC_OK_OR_DIE(kmc_hip_create(&drained, 0));
   unsetenv("KMC_ANY_ORDER");
@@ -164,7 +164,7 @@ int main(int argc, char** argv) {
   };
 
   // north_star's three bracketing poses, one kmc_hip_deskew_traj_f32 call per frame (every frame its own knots): the records ride in the
-  // dispatch's argument block -- through the direct queue on `ctx`, as HIP launches on `hip_only`
+  // dispatch's argument block -- as HIP launches on `ctx`, through the direct queue on `direct`
   std::vector<double> knot_times((size_t)F * 3), knot_poses((size_t)F * 36);
   const double T0 = 47072.0;
   for (uint32_t f = 0; f < F; ++f)
@@ -179,27 +179,24 @@ int main(int argc, char** argv) {
       KMC_OK_OR_DIE(kmc_hip_deskew_traj_f32(c, S.in[f], S.out[f], sizes[f], &knot_times[(size_t)f * 3], &knot_poses[(size_t)f * 36], 3, T0 + 0.10, T0 + 0.20, T0 + 0.13 + 0.0005 * (f % 40), nullptr,
                                             KMC_MEM_DEVICE, nullptr));
   };
-  const double us_nknot = timed(ctx, per_call_nknot);
-  const double host_nknot = host_us, dd_share_nknot = dd_share_last;
+  const double us_nknot_dq = timed(direct, per_call_nknot);
+  const double host_nknot_dq = host_us, dd_share_nknot = dd_share_last;
   std::vector<std::vector<float>> want_nknot(F);
-  KMC_OK_OR_DIE(kmc_hip_synchronize(ctx));
+  KMC_OK_OR_DIE(kmc_hip_synchronize(direct));
   for (uint32_t f = 0; f < F; ++f) {
     want_nknot[f].resize(4 * sizes[f]);
     HIP_OK(hipMemcpy(want_nknot[f].data(), sets[n_sets - 1].out[f], sizes[f] * 16, hipMemcpyDeviceToHost));
   }
+  const double us_call_dq = timed(direct, per_call);
+  const double host_call_dq = host_us, dd_share = dd_share_last;
+  KMC_OK_OR_DIE(kmc_hip_synchronize(direct));
+  // the same calls on the default context: one HIP launch per frame -- what the runtime's launch path costs
   const double us_call = timed(ctx, per_call);
-  const double host_call = host_us, ao_share = ao_share_last, dd_share = dd_share_last;
-  // the same calls as HIP launches (KMC_DIRECT_DISPATCH=0): what the runtime's launch path costs per frame
-  setenv("KMC_DIRECT_DISPATCH", "0", 1);
-  kmc_ctx* hip_only = nullptr;
-  KMC_OK_OR_DIE(kmc_hip_create(&hip_only, 0));
-  unsetenv("KMC_DIRECT_DISPATCH");
-  const double us_call_hip = timed(hip_only, per_call);
-  const double host_call_hip = host_us;
-  const double us_nknot_hip = timed(hip_only, per_call_nknot);
-  const double host_nknot_hip = host_us;
+  const double host_call = host_us, ao_share = ao_share_last;
+  const double us_nknot = timed(ctx, per_call_nknot);
+  const double host_nknot = host_us;
   bool same_nknot = true;  // the direct queue's N-knot frames against the HIP launches', bit for bit
-  KMC_OK_OR_DIE(kmc_hip_synchronize(hip_only));
+  KMC_OK_OR_DIE(kmc_hip_synchronize(ctx));
   {
     std::vector<float> got;
     for (uint32_t f = 0; f < F; ++f) {
@@ -208,7 +205,6 @@ int main(int argc, char** argv) {
       same_nknot = same_nknot && std::memcmp(got.data(), want_nknot[f].data(), sizes[f] * 16) == 0;
     }
   }
-  kmc_hip_destroy(hip_only);
   const double us_drained = timed(drained, per_call);
   KMC_OK_OR_DIE(kmc_hip_set_frame_queues(ctx, 4));
   const double us_q4 = timed(ctx, per_call);
@@ -236,8 +232,6 @@ int main(int argc, char** argv) {
   }
   const double us_list = timed(ctx, list);
   const double host_list = host_us;
-  const double us_list_table = timed(tabled, list);
-  const double host_list_table = host_us;
   const double us_batch = timed(ctx, batch);
 
   const double mean_pts = (double)total / F;
@@ -245,19 +239,19 @@ int main(int argc, char** argv) {
   std::printf(
       "{\"frames_per_set\": %u, \"frames_are\": \"%s\", \"sets\": %d, \"iters\": %d, \"mean_points_per_frame\": %.1f, \"points_per_set\": %llu, \"device\": \"%s\", "
       "\"any_order_dispatch\": %d, \"list_launches\": %u, \"list_equals_per_call_bitwise\": %s, "
-      "\"per_call\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"dispatched_without_barrier_bit\": %.3f, \"through_the_direct_queue\": %.3f}, "
-      "\"per_call_hip_launches\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
-      "\"per_call_nknot3\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"through_the_direct_queue\": %.3f, \"same_bits_as_hip_launches\": %s}, "
-      "\"per_call_nknot3_hip_launches\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
+      "\"per_call\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"dispatched_without_barrier_bit\": %.3f}, "
+      "\"per_call_direct_queue\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"through_the_direct_queue\": %.3f}, "
+      "\"per_call_nknot3\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
+      "\"per_call_nknot3_direct_queue\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f, \"through_the_direct_queue\": %.3f, \"same_bits_as_hip_launches\": %s}, "
       "\"per_call_drained\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}, "
       "\"per_call_gathered\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_call\": %.3f}, "
       "\"list_one_launch\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
-      "\"list_table_route\": {\"us_per_frame\": %.3f, \"GBps\": %.1f, \"host_us_per_frame\": %.3f}, "
       "\"batch_packed\": {\"us_per_frame\": %.3f, \"GBps\": %.1f}}\n",
       F, carve ? "carved out of one allocation per set (1 KiB-aligned starts)" : "separate hipMalloc allocations", n_sets, iters, mean_pts, (unsigned long long)total, info.name, info.any_order_dispatch, st.n_launches, same ? "true" : "false", us_call,
-      gbps(us_call), host_call, ao_share, dd_share, us_call_hip, gbps(us_call_hip), host_call_hip, us_nknot, gbps(us_nknot), host_nknot, dd_share_nknot, same_nknot ? "true" : "false", us_nknot_hip, gbps(us_nknot_hip), host_nknot_hip, us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_list_table, gbps(us_list_table), host_list_table, us_batch, gbps(us_batch));
+      gbps(us_call), host_call, ao_share, us_call_dq, gbps(us_call_dq), host_call_dq, dd_share, us_nknot, gbps(us_nknot), host_nknot, us_nknot_dq, gbps(us_nknot_dq), host_nknot_dq, dd_share_nknot, same_nknot ? "true" : "false",
+      us_drained, gbps(us_drained), us_q4, gbps(us_q4), host_q4, us_list, gbps(us_list), host_list, us_batch, gbps(us_batch));
   kmc_hip_destroy(drained);
-  kmc_hip_destroy(tabled);
+  kmc_hip_destroy(direct);
   kmc_hip_destroy(ctx);
   return same && same_nknot ? 0 : 1;
 }
