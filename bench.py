@@ -599,7 +599,7 @@ def run_secondary_legs(capi, torch, ctx, dev, check):
     # RCCL reduction of the counters (ncclCommInitAll + ncclAllReduce sum / max).  At N = 1 a world of one; the driver's 8-GPU box can run
     # `run_sharded 0,1,2,3,4,5,6,7` -- unmeasured on hardware so far (SCALE was skipped in every round).
     try:
-        sh = run_tool([os.path.join(ROOT, "kitti_motion_compensation_amd", "lib", "run_sharded"), "0", "64", "1000000", "8"])
+        sh = run_tool([os.path.join(ROOT, "kitti_motion_compensation_amd", "lib", "run_sharded"), "all", "64", "1000000", "8"])  # one rank per VISIBLE device: 1 here, a real RCCL group on a multi-GPU node
         out["sharded_cpp"] = {"what": "tools/run_sharded.hip: 64 synthetic 1 M-point frames in contiguous frame ranges per rank (kmc_frame_ranges_balanced), one device context per rank, "
                                       "8 frames per batched launch; counters reduced by ONE RCCL group (librccl dlopen'ed by the tool only)", **sh}
         assert sh["reduction_agrees_with_host_arithmetic"] is True, sh
@@ -816,7 +816,7 @@ def compact_line(full, detail_path=None):
     rk = full.get("ranks")
     if rk:
         line["ranks"] = {"backend": _short(rk["collective_backend"], 24), "rccl_world_size": rk["rccl_world_size"], "world_size": rk["world_size"],
-                         "distinct_devices": rk["distinct_devices"]}
+                         "distinct_devices": rk["distinct_devices"], "host_cpus_allowed_min": rk.get("host_cpus_allowed_min")}
     pr = full.get("per_rank")
     if pr:
         line["per_rank"] = {"Mpts_s_min": pr["Mpts_s_min"], "Mpts_s_max": pr["Mpts_s_max"], "slowest_rank": pr["slowest_rank"]}
@@ -995,7 +995,14 @@ def main():
             local_rank = int(os.environ["KMC_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # eager initialisation (device_id) + one collective: a group RCCL cannot form -- two ranks on one GPU, a rank without a device -- is
+            # reported HERE, as what it is, not minutes later as a hang or a wrong number (exit code 3, the reason on stderr)
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()
+            except Exception as e:
+                print(f"bench: RCCL could not form a group of {world} rank(s) (this is rank {rank} on device {local_rank}): {type(e).__name__}: {str(e)[:1500]}", file=sys.stderr, flush=True)
+                os._exit(3)
         else:
             dist.init_process_group(backend=backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the deskew path has no CPU fallback"
@@ -1113,10 +1120,11 @@ def main():
     # backend -- and are what the timing contract asks for.)
     props = torch.cuda.get_device_properties(dev)
     pci_code = (int(getattr(props, "pci_domain_id", 0)) << 16) | ((int(getattr(props, "pci_bus_id", 0)) & 0xFF) << 8) | (int(getattr(props, "pci_device_id", 0)) & 0xFF)
+    cpus_now = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []  # after bind_thread_near_device: this rank's host side
     sums, maxes, rows = sharding.reduce_counters(
         dist, reduce_dev, [float(n * args.steps), c3["points"] if c3 else 0.0],
         [wall, ev_ms * 1e-3, c3["wall"] if c3 else 0.0, c3["ev_s"] if c3 else 0.0, c3["parity_err"] if c3 else 0.0,
-         torch.cuda.max_memory_allocated(dev) / 2**30, float(dev.index or 0), float(pci_code)], with_rows=True)
+         torch.cuda.max_memory_allocated(dev) / 2**30, float(dev.index or 0), float(pci_code), float(len(cpus_now)), float(min(cpus_now) if cpus_now else -1)], with_rows=True)
     pts_total, t_max = sums[0], maxes[0]
 
     if rank == 0:
@@ -1176,7 +1184,8 @@ def main():
         # who measured: the collective backend and its world size as the process group reports them, and every rank's device (ordinal +
         # PCI address) out of the same all_gather -- the record itself shows that N ranks sat on N distinct GPUs
         nsum = 2  # width of the SUM block in a gathered row
-        devs = [{"rank": r, "device_ordinal": int(row[nsum + 6]), "pci": "%04x:%02x:%02x" % (int(row[nsum + 7]) >> 16, (int(row[nsum + 7]) >> 8) & 0xFF, int(row[nsum + 7]) & 0xFF)}
+        devs = [{"rank": r, "device_ordinal": int(row[nsum + 6]), "pci": "%04x:%02x:%02x" % (int(row[nsum + 7]) >> 16, (int(row[nsum + 7]) >> 8) & 0xFF, int(row[nsum + 7]) & 0xFF),
+                 "host_cpus_allowed": int(row[nsum + 8]), "first_host_cpu": int(row[nsum + 9])}  # the rank's CPU set after it was bound to its GPU's NUMA node
                 for r, row in enumerate(rows)]
         backend_name = dist.get_backend() if dist else None
         out["ranks"] = {
@@ -1184,6 +1193,7 @@ def main():
             "rccl_world_size": dist.get_world_size() if (dist and backend_name == "nccl") else None,
             "world_size": dist.get_world_size() if dist else 1,
             "devices": devs, "distinct_devices": len({d["pci"] for d in devs}),
+            "host_cpus_allowed_min": min(d["host_cpus_allowed"] for d in devs),
         }
         out["peak_device_GiB_per_rank"] = round(maxes[5], 2)  # torch's allocator high-water mark, MAX over the ranks (8 ranks of the default run: ~8 x 15.4 GiB of the 288)
         if world > 1:  # a straggler is invisible in SUM / MAX: every rank's own rate (its points / its own wall time of the timed region)
@@ -1228,16 +1238,15 @@ def main():
     if dist:
         dist.destroy_process_group()
     # The line is the LAST thing on stdout: native libraries write there too (RCCL's "Librccl path ..." sits in the C library's buffer until
-    # the process ends and would land behind a line printed earlier), so everything is torn down and the C buffers are flushed first, and
-    # nothing runs after the line.
+    # the process ends and would land behind a line printed earlier), so everything is torn down and the C buffers are flushed first.
+    # (The process then ends the ordinary way -- a profiler attached to it, rocprofv3's counter passes of live_traffic() among them, writes its
+    # results from an exit handler.)
     import ctypes
 
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     if rank == 0:
         os.write(1, (line + "\n").encode())
-    sys.stderr.flush()
-    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -90,7 +90,7 @@ int deskew_f64cols_host_pipelined(kmc_ctx* c, const double* x, const double* y, 
     if (e == hipSuccess) e = hipEventRecord(c->ev_pool[2 * k], s_up);
     if (e == hipSuccess) e = hipStreamWaitEvent(s_run, c->ev_pool[2 * k], 0);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(deskew_f64cols<false>, dim3((uint32_t)((m + 127) / 128)), dim3(64), 0, s_run, cols[0] + off, cols[1] + off, cols[2] + off, w ? cols[3] + off : nullptr,
+      hipLaunchKernelGGL(deskew_f64cols<false>, dim3((uint32_t)(((m + 127) / 128 + kF64TilesPerWave - 1) / kF64TilesPerWave)), dim3(64), 0, s_run, cols[0] + off, cols[1] + off, cols[2] + off, w ? cols[3] + off : nullptr,
                          cols[4] + off, m, f, cols[5] + off, cols[6] + off, cols[7] + off, down_w ? cols[8] + off : nullptr, c->d_counter, (uint32_t*)nullptr, (uint64_t)0, DoneWord{});
       e = hipGetLastError();
     }
@@ -170,8 +170,9 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
   f.t_start = stamp_start;
   f.t_end = stamp_end;
   f.dur = stamp_end - stamp_start;
+  f.inv_dur = 1.0 / f.dur;
   f.halvings = halvings_for(f.phi2);  // |s| <= 1 inside the scan
-  f.pad = 0;
+  f.terms = series_terms_for(f.phi2);
 
   const double *dx = x, *dy = y, *dz = z, *dw = w, *ds = stamps;
   double *dox = ox, *doy = oy, *doz = oz, *dow = ow;
@@ -232,7 +233,7 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
     hipLaunchKernelGGL(deskew_f64cols<true>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, (uint64_t)0, done);
     if (c->trace) { c->last_trace.waves = (uint32_t)grid; c->last_trace.route = 2; }
   } else {  // one wave per workgroup, two points per lane
-    launch_tiles((n + 127) / 128, [&](uint64_t t0, int grid) {
+    launch_tiles(((n + 127) / 128 + kF64TilesPerWave - 1) / kF64TilesPerWave, [&](uint64_t t0, int grid) {  // (t0 and grid count WORKGROUPS)
       launch_on(deskew_f64cols<false>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, t0, DoneWord{});
     });
     c->done_armed = false;  // resident or staged columns: this queue is waited for on the stream

@@ -58,7 +58,7 @@ void fill_rec64(const kmc_host::Twist& f, FrameRec64* r) {
   r->c2[0] = c2.x; r->c2[1] = c2.y; r->c2[2] = c2.z;
   r->phi2 = kmc_host::dot(f.phi, f.phi);
   r->halvings = halvings_for(r->phi2);  // |s| <= 1 inside a segment
-  r->pad = 0;
+  r->terms = series_terms_for(r->phi2);
 }
 
 // direction (cos, sin) of the knot azimuth alpha = pi - 2 pi c; exact on the quarter turns
@@ -417,6 +417,7 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
     segs[k].f.t_start = th.t0[k];
     segs[k].f.t_end = th.t0[k] + th.dur[k];
     segs[k].f.dur = th.dur[k];
+    segs[k].f.inv_dur = 1.0 / th.dur[k];
     th.M[k].to_rt12(segs[k].M);
     segs[k].identity = (k == th.r) ? 1 : 0;
   }

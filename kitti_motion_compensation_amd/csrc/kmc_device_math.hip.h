@@ -338,8 +338,9 @@ struct FrameRec64 {
   double phi2;
   double x_req;
   double t_start, t_end, dur;
-  int halvings;  // the series is evaluated at t / 2^halvings and doubled back: 0 for |phi| <= 0.5 rad (every vehicle), else 3
-  int pad;
+  double inv_dur;  // 1 / dur, rounded once on the host (scan_offset_f64)
+  int halvings;  // the series is evaluated at t / 2^halvings and doubled back: 0 for |phi| <= 0.5 rad (every vehicle), else whatever it takes
+  int terms;     // series length: kShortSeriesTerms (5) up to kShortSeriesTheta rad per scan, else 8
 };
 
 // f64 trajectory segment (global-memory table, read by the f64 Eigen-layout trajectory kernel)
@@ -351,30 +352,47 @@ struct TrajSeg64 {
 };
 
 // alpha = A s, beta = B s^2, gamma = C s^3 with A = sin t / t, B = (1 - cos t) / t^2, C = (t - sin t) / t^3, t = |s phi|:
-// 8-term series at t / 2^h (truncation < 1e-19 for t / 2^h <= 0.5), then h angle doublings
+// Taylor series at t / 2^h, then h angle doublings
 //     A(2x) = A(x) cos x,  cos x = 1 - x^2 B(x);   B(2x) = A(x)^2 / 2;   C(2x) = (C(x) + A(x) B(x)) / 4
-// -- no cancellation anywhere, no trig, no divide; h is a per-frame constant chosen on the host (0 up to 0.5 rad of rotation
-// per scan, 3 beyond: wave-uniform loop).  (Round 1 switched per point between a 7-term series and a half-angle sincos at
-// t^2 = 0.04; ocml's f64 sincos carries its large-argument reduction along: 122 VGPRs and 4 waves per SIMD for the
-// Eigen-layout kernel, 54 now.)
-__device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, int halvings, double& alpha, double& beta, double& gamma) {
+// -- no cancellation anywhere, no trig, no divide; h and the series length are per-frame constants chosen on the host (wave-uniform):
+//   5 terms  for |phi| <= 0.11 rad per scan (every vehicle: 1.1 rad/s of rotation; truncation < 1e-17 relative in all three series),
+//   8 terms  up to t / 2^h <= 0.5 (truncation < 1e-19), h = 0 up to 0.5 rad per scan, whatever it takes beyond.
+// Round 6: the series are summed in POWER form, smallest term first -- acc = fma(c_k, u^k, acc) with the powers of u shared by the three
+// series -- instead of three Horner chains.  Horner's p = fma(p, u, c_k) has the CONSTANT as its addend, and the compiler's two-address
+// v_fmac_f64 wants the addend in the destination VGPR pair: two v_mov_b32 per step, ~50 of the ~140 VALU instructions of a point were
+// copies of constants.  In power form the constant is a multiplicand (an SGPR source of the same v_fmac), the accumulator stays where
+// it is: 18 instructions for the 5-term tier, 30 for the 8-term one, against 63.  (Round 1 switched per point between a 7-term series
+// and a half-angle sincos; ocml's f64 sincos carries its large-argument reduction along: 122 VGPRs.)
+constexpr double kSerA[8] = {1.0, -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0, -1.0 / 1307674368000.0};       // (-1)^k / (2k+1)!
+constexpr double kSerB[8] = {0.5, -1.0 / 24, 1.0 / 720, -1.0 / 40320, 1.0 / 3628800, -1.0 / 479001600, 1.0 / 87178291200.0, -1.0 / 20922789888000.0};  // (-1)^k / (2k+2)!
+constexpr double kSerC[8] = {1.0 / 6, -1.0 / 120, 1.0 / 5040, -1.0 / 362880, 1.0 / 39916800, -1.0 / 6227020800.0, 1.0 / 1307674368000.0, -1.0 / 355687428096000.0};  // (-1)^k / (2k+3)!
+constexpr int kShortSeriesTerms = 5;
+constexpr double kShortSeriesTheta = 0.11;  // rad per scan up to which 5 terms are exact to f64 (0.11^10 / 11! = 6.5e-18)
+template <int TERMS>
+__device__ __forceinline__ void se3_series_f64(double u, double& A, double& B, double& C) {
+  double pw[TERMS];  // u^k
+  pw[1] = u;
+#pragma unroll
+  for (int k = 2; k < TERMS; ++k) pw[k] = pw[k - 1] * u;
+  A = kSerA[TERMS - 1] * pw[TERMS - 1];
+  B = kSerB[TERMS - 1] * pw[TERMS - 1];
+  C = kSerC[TERMS - 1] * pw[TERMS - 1];
+#pragma unroll
+  for (int k = TERMS - 2; k >= 1; --k) {
+    A = __builtin_fma(kSerA[k], pw[k], A);
+    B = __builtin_fma(kSerB[k], pw[k], B);
+    C = __builtin_fma(kSerC[k], pw[k], C);
+  }
+  A += kSerA[0];
+  B += kSerB[0];
+  C += kSerC[0];
+}
+__device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, int halvings, int terms, double& alpha, double& beta, double& gamma) {
   const double s2 = s * s;
   double u = __builtin_ldexp(s2 * phi2, -2 * halvings);  // (t / 2^h)^2
-  // [12..19] A, [20..27] B, [28..35] C, highest degree first; one series after the other, each behind the previous one's
-  // result: 16 SGPRs of coefficients at a time instead of 48 (with all 24 resident the Eigen-layout kernel spilled SGPRs
-  // through VGPR lanes: 52 v_writelane + 123 v_readlane)
-  cdouble_p t = after((cdouble_p)kRedoTable, u);
-  double A = t[12];
-#pragma unroll
-  for (int k = 1; k < 8; ++k) A = __builtin_fma(A, u, t[12 + k]);
-  t = after(t, A);
-  double B = t[20];
-#pragma unroll
-  for (int k = 1; k < 8; ++k) B = __builtin_fma(B, u, t[20 + k]);
-  t = after(t, B);
-  double C = t[28];
-#pragma unroll
-  for (int k = 1; k < 8; ++k) C = __builtin_fma(C, u, t[28 + k]);
+  double A, B, C;
+  if (terms == kShortSeriesTerms) se3_series_f64<kShortSeriesTerms>(u, A, B, C);  // (wave-uniform: a per-frame constant)
+  else se3_series_f64<8>(u, A, B, C);
   for (int k = 0; k < halvings; ++k) {
     const double cosx = __builtin_fma(-u, B, 1.0);
     C = __builtin_ldexp(__builtin_fma(A, B, C), -2);
@@ -387,10 +405,18 @@ __device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, int 
   gamma = C * (s2 * s);
 }
 
+// s = FractionOfTrajectory(t) - x_req (trajectory_interpolation.cpp:49-51) as ONE fma with the frame's 1 / (t2 - t1) -- round 6; until then a
+// true divide like the reference's, ~14 VALU instructions with a quarter-rate v_rcp_f64 among them.  The fraction differs from the quotient
+// by at most 1.5 ulp (2e-16 of a scan, 2e-17 s), five orders below the f64 parity bar (1e-11); which stamps are IN RANGE is decided on the
+// stamps themselves, exactly (TimeIsInRange, :47).
+__device__ __forceinline__ double scan_offset_f64(double t, double t_start, double inv_dur, double x_req) {
+  return __builtin_fma(t - t_start, inv_dur, -x_req);
+}
+
 __device__ __forceinline__ void deskew_point_f64(double x, double y, double z, double w, double s, const FrameRec64& f,
                                                  double& ox, double& oy, double& oz) {
   double al, be, ga;
-  se3_coefficients_f64(s, f.phi2, f.halvings, al, be, ga);
+  se3_coefficients_f64(s, f.phi2, f.halvings, f.terms, al, be, ga);
   const double q1x = f.phi[1] * z - f.phi[2] * y;
   const double q1y = f.phi[2] * x - f.phi[0] * z;
   const double q1z = f.phi[0] * y - f.phi[1] * x;

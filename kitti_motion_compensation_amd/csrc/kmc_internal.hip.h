@@ -167,6 +167,9 @@ inline int halvings_for(double phi2) {
   return h < 0 ? 0 : (h > 60 ? 60 : h);
 }
 
+// ... and how many terms of it: 5 up to kShortSeriesTheta rad per scan (every vehicle), else 8 (NaN -> 8)
+inline int series_terms_for(double phi2) { return std::sqrt(phi2) <= kShortSeriesTheta ? kShortSeriesTerms : 8; }
+
 // the cheapest tier valid up to theta_max = max over the frames of |phi| * max|s| (NaN -> the any-angle tier)
 inline int tier_of_theta(double theta_max) {
   if (theta_max <= kThetaSeries3) return kSeries3;

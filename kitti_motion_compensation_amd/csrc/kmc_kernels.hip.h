@@ -460,8 +460,7 @@ __device__ __forceinline__ void deskew_one_f64(double px, double py, double pz, 
 #pragma clang fp contract(off)  // the fraction of the trajectory is the reference's (t - t1) / (t2 - t1), each operation rounded
   in_range = (t >= f.t_start) && (t <= f.t_end);  // TimeIsInRange, trajectory_interpolation.cpp:47
   if (in_range) {
-    const double xi = (t - f.t_start) / f.dur;  // FractionOfTrajectory, :49-51 (a true divide, like the reference)
-    deskew_point_f64(px, py, pz, pw, xi - f.x_req, f, rx, ry, rz);
+    deskew_point_f64(px, py, pz, pw, scan_offset_f64(t, f.t_start, f.inv_dur, f.x_req), f, rx, ry, rz);  // FractionOfTrajectory - x_req, :49-51
   } else {
     rx = ry = rz = __builtin_nan("");
   }
@@ -534,6 +533,10 @@ __device__ __forceinline__ void f64_report_bad(uint32_t bad_count, uint32_t tid,
 #ifndef KMC_F64_WAVES
 #define KMC_F64_WAVES 4  // waves per SIMD of the f64 column kernels (2 / 6 / 8 measured: profiles/NOTES_r04.md)
 #endif
+#ifndef KMC_F64_TPW
+#define KMC_F64_TPW 1  // tiles per workgroup of the device-resident kernel: > 1 = all of them loaded before the first is computed (A/B: tools/ab_f64_waves.py)
+#endif
+constexpr int kF64TilesPerWave = KMC_F64_TPW;
 template <bool STREAMED = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, KMC_F64_WAVES))) void deskew_f64cols(const double* __restrict__ x, const double* __restrict__ y,
                                                      const double* __restrict__ z, const double* __restrict__ w,
@@ -561,7 +564,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, KMC_F64_W
       t = next;
     }
     t = n_full + blockIdx.x;  // only the ragged last tile is left, for the first workgroup
+  } else if constexpr (kF64TilesPerWave > 1) {  // several tiles per workgroup: every load of the workgroup in flight before its first fma
+    t = (tile_base + blockIdx.x) * kF64TilesPerWave;
+    if (t + kF64TilesPerWave <= n_full) {  // (wave-uniform)
+      F64Tile tl[kF64TilesPerWave];
+#pragma unroll
+      for (int j = 0; j < kF64TilesPerWave; ++j) tl[j] = f64_tile_load(x, y, z, w, stamps, (t + j) * kTile64 + 2 * (uint64_t)tid);
+      uint32_t bad = 0;
+#pragma unroll
+      for (int j = 0; j < kF64TilesPerWave; ++j) bad += f64_tile_finish<false>(tl[j], f, ox, oy, oz, ow, (t + j) * kTile64, tid);
+      f64_report_bad(bad, tid, n_bad, bad_flag);
+      return;
+    }
   }
+  for (int j = 0; j < (STREAMED ? 1 : kF64TilesPerWave); ++j, ++t)  // (one turn unless this is the last workgroup of a several-tiles-per-workgroup launch)
   if (t < n_tiles) {
     const uint64_t i = t * kTile64 + 2 * (uint64_t)tid;
     uint32_t bad_count;
@@ -928,9 +944,8 @@ __device__ __forceinline__ void traj_one_f64(double px, double py, double pz, do
   if (in_range) {
     while (k + 1 < n_seg && t >= segs[k + 1].f.t_start) ++k;  // t_k <= t < t_{k+1}; the last knot belongs to the last segment
     const TrajSeg64& sg = segs[k];
-    const double xi = (t - sg.f.t_start) / sg.f.dur;
     double qx, qy, qz;
-    deskew_point_f64(px, py, pz, pw, xi - sg.f.x_req, sg.f, qx, qy, qz);
+    deskew_point_f64(px, py, pz, pw, scan_offset_f64(t, sg.f.t_start, sg.f.inv_dur, sg.f.x_req), sg.f, qx, qy, qz);
     if (sg.identity) {
       rx = qx; ry = qy; rz = qz;
     } else {  // M_k * (q, w): rotation on the point, translation scaled by the homogeneous coordinate

@@ -117,3 +117,29 @@ def test_multi_device_run_writes_the_same_files(run_dir):
         lines = [l for l in stdout.splitlines() if l.startswith("Motion compensated pointcloud number:")]
         assert sorted(int(l.split(":")[1]) for l in lines) == list(range(1, N_FRAMES - 1)), devices
     _check_against_oracle(run_dir[2], multi)
+
+
+def test_a_page_locking_failure_ends_the_run_with_an_error_or_a_fallback_never_a_hang(run_dir):
+    """the run's page-locked buffers come from a helper thread; when it failed after its FIRST buffer (a memlock limit, a large
+    batch) the reader and the GPU thread waited for each other for ever.  KMC_TEST_HOST_POOL_FAIL_AT=k makes the process's k-th pool
+    allocation fail: whichever allocation that hits, the run must END -- with the very same files (the failure hit a buffer the run can
+    make another way: the pool declining from the start falls back to buffers of the device context) or with the error on stderr and
+    exit code 1.  At least one k must hit the part-way case."""
+    data_dir, name, run = run_dir
+    baseline, _ = _run_cli(run_dir, KMC_RUN_BATCH_FRAMES=4)
+    out_dir = os.path.join(run, "velodyne_points", "data_motion_compensated")
+    part_way = 0
+    for k in range(1, 9):
+        for f in os.listdir(out_dir):
+            os.remove(os.path.join(out_dir, f))
+        e = dict(os.environ, KMC_RUN_BATCH_FRAMES="4", KMC_TEST_HOST_POOL_FAIL_AT=str(k))
+        r = subprocess.run([CLI, data_dir + "/", name], capture_output=True, text=True, env=e, timeout=120)  # (a hang ends here, as a TimeoutExpired)
+        if r.returncode == 0:
+            for i in range(N_FRAMES):
+                got = np.fromfile(os.path.join(out_dir, "%010d.bin" % i), dtype=np.float32).reshape(-1, 4)
+                assert np.array_equal(got.view(np.uint32), baseline[i].view(np.uint32)), (k, i)
+        else:
+            assert r.returncode == 1 and "error:" in r.stderr, (k, r.stderr[-500:])
+            if "page-locking buffer" in r.stderr:
+                part_way += 1
+    assert part_way >= 1

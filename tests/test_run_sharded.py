@@ -42,3 +42,17 @@ def test_world_2_on_one_device_shards_contiguously_and_says_who_reduced():
     assert d["reduction_agrees_with_host_arithmetic"] is True
     # one GPU twice: RCCL either builds the communicator or refuses the duplicate -- the line must say which path reduced
     assert d["reduced_by"].startswith("rccl") or ("host" in d["reduced_by"] and "ncclCommInitAll refused" in d["rccl_note"]), d
+
+
+@pytest.mark.gpu
+def test_all_means_one_rank_per_visible_device():
+    """`run_sharded all` (what bench.py's leg runs): a rank per device the process can see.  One device on the test box; on a multi-GPU node
+    the same command forms a real RCCL group -- world == visible devices, every device once, reduced by RCCL (which no box this repository
+    has run on could show: ncclAllReduce across more than one rank has never executed, README.md says so)."""
+    import torch
+
+    visible = torch.cuda.device_count()
+    d = _run("all", max(24, 8 * visible), 200_000, 8)
+    assert d["world"] == visible and d["devices"] == list(range(visible))
+    assert d["reduced_by"].startswith("rccl: ncclCommInitAll + ncclAllReduce"), d
+    assert d["reduction_agrees_with_host_arithmetic"] is True

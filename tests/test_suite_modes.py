@@ -17,7 +17,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MODULES = ["tests/test_gpu_parity.py", "tests/test_trajectory.py", "tests/test_near_origin.py", "tests/test_special_values.py", "tests/test_projection.py",
-           "tests/test_alias_contract.py", "tests/test_configs_at_size.py", "tests/test_inplace_threads.py", "tests/test_cpp_dropin.py", "tests/test_c_boundary.py",
+           "tests/test_alias_contract.py", "tests/test_inplace_threads.py", "tests/test_cpp_dropin.py", "tests/test_c_boundary.py",
            "tests/test_run_driver.py"]
 # asserts what a context created WITHOUT the knob reports (the probe's verdict 1, barrier-free launches > 0): true by construction only there
 DESELECT = {

@@ -236,6 +236,30 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_over_rccl_on_one_gpu_forms_a_group_or_says_exactly_why_not(tmp_path):
+    """VERDICT r05 #4, first-contact readiness: the driver's N = 2 launch line over **nccl** (= RCCL), both ranks on the one GPU of this box
+    (KMC_BENCH_DEVICE=0).  RCCL either forms the two-rank group -- then the line says rccl_world_size == 2 -- or refuses a GPU that appears
+    twice; bench.py must then stop at the rendezvous with exit code 3 and RCCL's own reason on stderr, not hang, not print a number.  Either
+    way everything up to the first collective of a real two-GPU run (launcher, rendezvous on 127.0.0.1, eager communicator creation) has
+    run here.  What a one-GPU box cannot show -- ncclAllReduce across two devices -- stays unmeasured (README.md)."""
+    env = dict(os.environ, KMC_BENCH_DEVICE="0", KMC_BENCH_DETAIL=os.path.join(str(tmp_path), "bench_detail.json"))
+    env.pop("KMC_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--frames-per-step", "16", "--configs3-frames", "8", "--configs3-frames-per-launch", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    if r.returncode == 0:
+        d, _ = check_line(r.stdout, n1=False)
+        assert d["n_gpus"] == 2 and d["ranks"]["backend"].startswith("nccl") and d["ranks"]["rccl_world_size"] == 2 and d["ranks"]["distinct_devices"] == 1
+        print("RCCL formed a two-rank group on one device")
+    else:
+        refusal = [l for l in r.stderr.splitlines() if "RCCL could not form a group of 2 rank(s)" in l]
+        assert refusal, r.stderr[-3000:]
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]  # no number under a label it does not deserve
+        print(refusal[0][:600])
+
+
+@pytest.mark.gpu
 def test_bench_gpus_2_without_a_launcher_reexecutes_itself_under_the_launcher(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE: not a one-GPU number under a two-GPU label -- the script
     re-executes itself as the contract's launch line (both ranks on the one GPU of this box through the test knobs)."""
@@ -292,6 +316,9 @@ def test_bench_eight_ranks_dry_run_on_one_gpu(tmp_path):
     assert len(pr["Mpts_s"]) == 8 and len(pr["configs3_Mpts_s"]) == 8 and all(v > 0 for v in pr["Mpts_s"] + pr["configs3_Mpts_s"])
     rk = d["ranks"]  # (with RCCL, the contract: collective_backend "nccl (= RCCL on ROCm)", rccl_world_size == 8, distinct_devices == 8)
     assert rk["world_size"] == 8 and [x["rank"] for x in rk["devices"]] == list(range(8)) and "pci" in rk["devices"][0]
+    # every rank bound its host side to its GPU's NUMA node (kmc_hip_bind_thread_near_device) and still has CPUs to run on: eight ranks under
+    # the box's CPU quota, each with a non-empty set (a binding that emptied a rank's mask would have left it where it was)
+    assert all(x["host_cpus_allowed"] >= 1 and x["first_host_cpu"] >= 0 for x in rk["devices"]) and line["ranks"]["host_cpus_allowed_min"] >= 1
     assert abs(d["value"] - 8 * 16 * 1_000_000 * 4 / (d["ms_per_step"] * 4 * 1e-3) / 1e6) / d["value"] < 0.02
     # eight ranks' buffers lived on ONE device here; the default run's 15.4 GB per rank is one rank per 288 GB device
     assert 8 * d["peak_device_GiB_per_rank"] < 250

@@ -7,7 +7,9 @@
 //   run_sharded [devices=0] [frames=64] [points_per_frame=1000000] [frames_per_launch=8]
 //     devices: comma-separated HIP device ids, one rank each ("0,1,2,3,4,5,6,7" on an 8-GPU node).  An id may repeat ("0,0"): the
 //     ranks then share a GPU -- RCCL refuses a communicator with a duplicate device, the tool says so and reduces on the host instead
-//     (the JSON names which path reduced: "reduced_by").
+//     (the JSON names which path reduced: "reduced_by").  "all": one rank per device this process can see (hipGetDeviceCount under
+//     whatever HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES the caller set) -- what bench.py's leg passes, so that the first run on a
+//     multi-GPU node forms a real RCCL group without anybody editing a command line.
 // librccl.so (570 MB) is opened with dlopen only here: the product libraries do not link it.  Prints ONE JSON object.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
@@ -79,10 +81,19 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 int main(int argc, char** argv) {
   std::vector<int> devices;
   {
-    std::istringstream is(argc > 1 ? argv[1] : "0");
-    std::string tok;
-    while (std::getline(is, tok, ','))
-      if (!tok.empty()) devices.push_back(std::atoi(tok.c_str()));
+    if (argc > 1 && std::strcmp(argv[1], "all") == 0) {
+      int count = 0;
+      if (hipGetDeviceCount(&count) != hipSuccess || count < 1) {
+        std::fprintf(stderr, "run_sharded all: no HIP device visible\n");
+        return 2;
+      }
+      for (int d = 0; d < count; ++d) devices.push_back(d);
+    } else {
+      std::istringstream is(argc > 1 ? argv[1] : "0");
+      std::string tok;
+      while (std::getline(is, tok, ','))
+        if (!tok.empty()) devices.push_back(std::atoi(tok.c_str()));
+    }
   }
   const uint32_t n_frames = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 64u;
   const uint64_t per = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 1000000ull;
