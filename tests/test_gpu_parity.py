@@ -504,6 +504,49 @@ def test_f64cols_vs_faithful_oracle(ctx, kitti, kats):
     util.assert_float_eq(np.stack(outs, axis=1), np.array(k["expected"]))
 
 
+@pytest.mark.parametrize("theta", [0.0, 1e-9, 0.02, 0.1099, 0.1101, 0.3, 0.4999, 0.5001, 1.3, 3.0, 7.5])
+def test_f64_series_tiers_and_doublings_keep_the_f64_bar(ctx, theta):
+    """The f64 kernels' coefficient series (kmc_device_math.hip.h, round 6: power form, 5 terms up to 0.11 rad per scan, 8 beyond, angle
+    doublings beyond 0.5 rad) on both sides of every switch-over, against the closed form of lie_algebra.cpp:83-92 evaluated in extended
+    precision HERE (numpy longdouble: neither the library nor the oracle): p' = R(s phi) p + J(s phi) s rho."""
+    n = 40_001
+    rng = np.random.default_rng(int(theta * 1e4) + 3)
+    pts = rng.uniform(-60, 60, size=(n, 3))
+    pts[:, 2] = rng.uniform(-3, 3, size=n)
+    t0, t1 = 100.0, 100.1
+    stamps = np.sort(rng.uniform(t0, t1, size=n))
+    stamps[0], stamps[-1] = t0, t1  # both ends of the range included
+    axis = np.array([0.3, -0.2, 0.93])
+    axis /= np.linalg.norm(axis)
+    twist = np.concatenate([[1.2, -0.4, 0.05], theta * axis])
+    x_req = 0.37
+    params = capi.FrameParams.make(twist, x_req)
+    cols = [np.ascontiguousarray(pts[:, j]) for j in range(3)]
+    outs = [np.empty(n) for _ in range(3)]
+    rc, st = ctx.deskew_f64cols(cols[0], cols[1], cols[2], None, stamps, t0, t1, params, outs[0], outs[1], outs[2], None)
+    assert rc == capi.OK and st.n_out_of_range == 0
+    got = np.stack(outs, axis=1)
+    L = np.longdouble
+    s = (stamps.astype(L) - L(t0)) / (L(t1) - L(t0)) - L(x_req)
+    phi, rho = twist[3:].astype(L), twist[:3].astype(L)
+    th = np.abs(s) * L(theta)
+    small = th < L(1e-4)
+    th_safe = np.where(small, L(1), th)
+    A = np.where(small, 1 - th**2 / 6, np.sin(th_safe) / th_safe)
+    B = np.where(small, L(0.5) - th**2 / 24, (1 - np.cos(th_safe)) / th_safe**2)
+    C = np.where(small, L(1) / 6 - th**2 / 120, (th_safe - np.sin(th_safe)) / th_safe**3)
+    P = pts.astype(L)
+    w = s[:, None] * phi[None, :]                  # s phi
+    v = s[:, None] * rho[None, :]                  # s rho
+    wxp = np.cross(w, P)
+    wxwxp = np.cross(w, wxp)
+    wxv = np.cross(w, v)
+    wxwxv = np.cross(w, wxv)
+    want = P + A[:, None] * wxp + B[:, None] * wxwxp + v + B[:, None] * wxv + C[:, None] * wxwxv
+    err = np.linalg.norm((got.astype(L) - want).astype(np.float64), axis=1) / np.maximum(np.linalg.norm(want.astype(np.float64), axis=1), 1e-3)
+    assert err.max() <= 2e-14, (theta, float(err.max()))  # rounding of ~40 f64 operations on |p| <= 85 m; the parity bar itself is REL_TOL_F64 = 1e-11
+
+
 def test_f64cols_out_of_range_stamps_are_reported(ctx, kitti):
     """trajectory_interpolation.cpp:32 aborts; the ABI returns KMC_ERR_TIME_OUT_OF_RANGE and counts the offenders."""
     xyzi, P1 = kitti

@@ -8,6 +8,8 @@ points, 4 bursts of 20 launches between one event pair.  Variant libraries are b
       hipcc --offload-arch=gfx950 -fPIC -shared -o lib/ab/libkmc_hip_w$W.so lib/obj/kmc_capi_{core,deskew,traj,project,synth,hostpool,direct}.o \
             lib/ab/kmc_capi_f64_w$W.o -lhsa-runtime64; done
     python tools/ab_f64_waves.py 4|6|8          (4 = the product's library)
+Round 6: tools/build_f64_variants.sh builds the variants (old = a git revision's kernel, w6, w8, tpw2, tpw2w6); any of those names is
+accepted here ("base" / "4" = the product's library), and tools/ab_f64_variants.py runs them interleaved on one box.
 
 Round 5, one box whose nine-stream copy ran at 6.20 TB/s: 4 waves 744-760 us (6.08-6.20 TB/s), 6 waves 768-801, 8 waves 783-788."""
 import os, sys, subprocess, json
@@ -16,8 +18,10 @@ sys.path.insert(0, "/root/repo")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 which = sys.argv[1]
 from kitti_motion_compensation_amd import capi
-if which != "4":
-    capi.LIB_PATH = os.path.join(ROOT, "kitti_motion_compensation_amd", "lib", "ab", f"libkmc_hip_w{which}.so")
+if which not in ("4", "base"):
+    name = f"w{which}" if which.isdigit() else which
+    capi.LIB_PATH = os.path.join(ROOT, "kitti_motion_compensation_amd", "lib", "ab", f"libkmc_hip_{name}.so")
+    assert os.path.exists(capi.LIB_PATH), capi.LIB_PATH
 import torch
 ctx = capi.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)

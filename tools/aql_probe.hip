@@ -4,11 +4,15 @@
 // the HSA loader; kernel arguments in a ring of kernarg memory; one doorbell per packet), with and without the barrier bit, and reports
 // the host's time per dispatch and the train's time per dispatch (the device's side).  Device buffers come from hipMalloc (one process,
 // one HSA runtime: the addresses are valid on both sides).  Every wait has a timeout: a queue that hangs ends the probe, not the box.
-//   aql_probe [dispatches=20000] [points=123397] [code_object=<next to the binary>] [kernargs=device|host]   -> one JSON object
+//   aql_probe [dispatches=20000] [points=123397] [code_object=<next to the binary>] [kernargs=device|device_noreadback|host|host_coarse]   -> one JSON object
+// host_coarse (round 6): the argument blocks in COARSE-GRAINED host memory -- which the GPU may keep in its L2 between a kernel's acquire and
+// release, so that only the first wave per L2 crosses the link for a block instead of every wave -- with a SYSTEM-scope acquire on every
+// packet (a block of the lap before must not be served from the L2).  The host then pays no BAR write, no HDP flush and no read-back.
 #include <hip/hip_runtime_api.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -56,8 +60,8 @@ static hsa_status_t on_agent(hsa_agent_t a, void*) {
   if (t == HSA_DEVICE_TYPE_CPU && !g_have_cpu) { g_cpu = a; g_have_cpu = true; }
   return HSA_STATUS_SUCCESS;
 }
-static hsa_amd_memory_pool_t g_kernarg_pool;
-static bool g_have_pool = false;
+static hsa_amd_memory_pool_t g_kernarg_pool, g_coarse_host_pool;
+static bool g_have_pool = false, g_have_coarse_host_pool = false;
 static hsa_status_t on_pool(hsa_amd_memory_pool_t p, void*) {
   hsa_amd_segment_t seg;
   hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
@@ -65,6 +69,9 @@ static hsa_status_t on_pool(hsa_amd_memory_pool_t p, void*) {
   uint32_t flags = 0;
   hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
   if ((flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_KERNARG_INIT) && !g_have_pool) { g_kernarg_pool = p; g_have_pool = true; }
+  bool alloc_ok = false;
+  hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc_ok);
+  if (alloc_ok && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && !g_have_coarse_host_pool) { g_coarse_host_pool = p; g_have_coarse_host_pool = true; }
   return HSA_STATUS_SUCCESS;
 }
 // device-local memory the host can write (large BAR): where the HIP runtime itself keeps kernel arguments on this class of device --
@@ -113,7 +120,9 @@ int main(int argc, char** argv) {
   HSA_OK(hsa_executable_load_agent_code_object(exe, g_gpu, reader, nullptr, nullptr));
   HSA_OK(hsa_executable_freeze(exe, nullptr));
   hsa_executable_symbol_t sym;
-  HSA_OK(hsa_executable_get_symbol_by_name(exe, "k_frame.kd", &g_gpu, &sym));
+  // argv[8] = "walk=<waves>": the walking twin of the kernel, <waves> one-wave workgroups per frame whatever its size (aql_kernel.hip)
+  const int walk_waves = (argc > 8 && std::strncmp(argv[8], "walk=", 5) == 0) ? std::atoi(argv[8] + 5) : 0;
+  HSA_OK(hsa_executable_get_symbol_by_name(exe, walk_waves > 0 ? "k_frame_walk.kd" : "k_frame.kd", &g_gpu, &sym));
   uint64_t kobj = 0;
   uint32_t karg = 0, group = 0, priv = 0;
   HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &kobj));
@@ -127,7 +136,8 @@ int main(int argc, char** argv) {
   for (auto& qq : qs) HSA_OK(hsa_queue_create(g_gpu, kQueue, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &qq));
   int cur = 0;  // the queue dispatch() writes to
   hsa_queue_t* q = qs[0];
-  const bool device_kernargs = argc > 4 ? std::strcmp(argv[4], "host") != 0 : true;
+  const bool host_coarse = argc > 4 && std::strcmp(argv[4], "host_coarse") == 0;
+  const bool device_kernargs = argc > 4 ? (std::strcmp(argv[4], "host") != 0 && !host_coarse) : true;
   // "device_noreadback": the block is only fenced (sfence) in front of the HDP flush and the doorbell -- three posted writes to one device --
   // without the read over the link that proves they landed.  Every dispatch of the timed trains then carries its own number, and the
   // last frames' outputs are checked: a stale argument block would show.
@@ -141,8 +151,12 @@ int main(int argc, char** argv) {
     const hsa_status_t acc = hsa_amd_agents_allow_access(1, &g_cpu, nullptr, ring);
     if (acc != HSA_STATUS_SUCCESS) { std::printf("{\"failed\": \"the host cannot map device memory (no large BAR?)\"}\n"); return 3; }
     HSA_OK(hsa_agent_get_info(g_gpu, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &hdp));
+  } else if (host_coarse) {
+    if (!g_have_coarse_host_pool) { std::printf("{\"failed\": \"the CPU agent has no coarse-grained pool\"}\n"); return 3; }
+    HSA_OK(hsa_amd_memory_pool_allocate(g_coarse_host_pool, sizeof(Args) * kQueue * kMaxQueues, 0, (void**)&ring));
+    HSA_OK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, ring));
   } else {
-    HSA_OK(hsa_amd_memory_pool_allocate(g_kernarg_pool, sizeof(Args) * kQueue * 2, 0, (void**)&ring));
+    HSA_OK(hsa_amd_memory_pool_allocate(g_kernarg_pool, sizeof(Args) * kQueue * kMaxQueues, 0, (void**)&ring));
     HSA_OK(hsa_amd_agents_allow_access(1, &g_gpu, nullptr, ring));
   }
   hsa_signal_t done;
@@ -165,7 +179,7 @@ int main(int argc, char** argv) {
   std::memset(&proto, 0, sizeof(proto));
   proto.n = n;
   for (int i = 0; i < 16; ++i) { proto.f.v[i] = 1.0f + i; proto.d.v[i] = 0.5 * i; }
-  const uint32_t grid = (uint32_t)((n + 63) / 64) * 64;
+  const uint32_t grid = (walk_waves > 0 ? (uint32_t)std::min<uint64_t>((n + 63) / 64, (uint64_t)walk_waves) : (uint32_t)((n + 63) / 64)) * 64;
   uint64_t widxs[kMaxQueues];
   for (int k = 0; k < kMaxQueues; ++k) widxs[k] = hsa_queue_load_write_index_relaxed(qs[k]);
   Args* const ring0 = ring;
@@ -185,6 +199,7 @@ int main(int argc, char** argv) {
     Args mine = proto;
     mine.in = distinct_inputs && i >= 0 ? in[i % kBufs] : in[0];  // x = 1 everywhere
     mine.out = i < 0 ? out[kBufs] : out[i % kBufs];
+    if (walk_waves > 0) mine.tile_base = grid / 64;  // the walking kernel's stride (aql_kernel.hip)
     mine.f.v[1] = i < 0 ? 0.0f : (float)(i % 4096);  // this dispatch's own number: out.x = f.v[0] + f.v[1] + d.v[3]
     *a = mine;
     if (device_kernargs) {  // the block went over the BAR: make it land before the packet can be seen (what the HIP runtime does for device kernargs)
@@ -203,8 +218,10 @@ int main(int argc, char** argv) {
     // (argv[7] = "no_fences": packets without the barrier bit acquire and release nothing -- what the fences of a dispatch cost; the drain's
     // own packets keep theirs, so the checked outputs are still visible)
     const uint16_t fence = (!barrier && i >= 0 && no_fences) ? HSA_FENCE_SCOPE_NONE : HSA_FENCE_SCOPE_AGENT;
+    const uint16_t acquire = host_coarse ? (uint16_t)HSA_FENCE_SCOPE_SYSTEM : fence;  // (the block may sit in the L2 from the lap before)
+    if (host_coarse) __atomic_thread_fence(__ATOMIC_RELEASE);
     uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((barrier ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
-                      (fence << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (fence << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+                      (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (fence << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     __atomic_store_n((uint16_t*)&p->header, header, __ATOMIC_RELEASE);
     hsa_queue_store_write_index_relaxed(q, widx + 1);
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)widx);
@@ -236,7 +253,8 @@ int main(int argc, char** argv) {
     if (!ok) { std::printf("{\"failed\": \"the AQL-dispatched kernel wrote %g, expected %g\"}\n", (double)h[0], (double)want); return 1; }
   }
   std::printf("{\"dispatches\": %d, \"points\": %llu, \"kernarg_bytes\": %u, \"kernargs_in\": \"%s\", \"first_frame_checked\": true", N, (unsigned long long)n, karg,
-              !device_kernargs ? "host memory (the kernarg pool): every wave's scalar loads cross the link"
+              host_coarse ? "COARSE-GRAINED host memory, system-scope acquire per packet"
+              : !device_kernargs ? "host memory (the kernarg pool): every wave's scalar loads cross the link"
                                : readback ? "device memory written by the host over the BAR (+ HDP flush, read-back)" : "device memory written by the host over the BAR (+ HDP flush, NO read-back)");
   for (int barrier = 1; barrier >= 0; --barrier) {
     for (int i = 0; i < 2000; ++i) dispatch(i, barrier != 0, none);
@@ -269,7 +287,7 @@ int main(int argc, char** argv) {
     const double train = us_since(t0) / N;
     std::printf(", \"aql_%s_queues_alternating_without_barrier_bit\": {\"host_us_per_dispatch\": %.3f, \"train_us_per_dispatch\": %.3f}", K == 2 ? "two" : K == 3 ? "three" : "four", host, train);
   }
-  std::printf(", \"buffer_pairs\": %d, \"distinct_inputs\": %s, \"unordered_packets_without_fences\": %s", kBufs, distinct_inputs ? "true" : "false", no_fences ? "true" : "false");
+  std::printf(", \"waves_per_frame\": %u, \"buffer_pairs\": %d, \"distinct_inputs\": %s, \"unordered_packets_without_fences\": %s", grid / 64, kBufs, distinct_inputs ? "true" : "false", no_fences ? "true" : "false");
   std::printf(", \"note\": \"host = packet + 232-byte kernarg block + doorbell per frame, including the back-pressure of a 4096-packet queue when the device is the slower side\"}\n");
   for (auto& qq : qs) hsa_queue_destroy(qq);
   return 0;

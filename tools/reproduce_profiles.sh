@@ -25,6 +25,7 @@ KMC_ANY_ORDER=0 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt_stream" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 4 > "$O/stream_kt.json" 2> "$O/stream_kt.err"
 run rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_stream_fetch" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 2 > /dev/null 2>&1
 run rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_stream_write" -o stream -- kitti_motion_compensation_amd/lib/time_frame_stream 256 1000000 1 2 > /dev/null 2>&1
-timeout 600 python bench.py > "$O/bench_plain.json" 2> "$O/bench_plain.err"
+# the default invocation, un-profiled: the ONE compact line (stdout) and the full record it was extracted from (bench_detail.json)
+KMC_BENCH_DETAIL="$O/bench_detail.json" timeout 600 python bench.py > "$O/bench_plain.json" 2> "$O/bench_plain.err"
 tail -1 "$O/bench_plain.json" | cut -c1-200
 grep -h "deskew_batch_f32" "$O"/kt/bench_kernel_stats.csv | cut -c1-60,200-320

@@ -38,7 +38,7 @@ def main():
     shutil.copy(os.path.join(src, "kt", "bench_kernel_stats.csv"), os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
     for extra_src, extra_dst in (("kt_legs/legs_kernel_stats.csv", f"{tag}_legs_kernel_stats.csv"), ("ceilings.csv", f"{tag}_ceilings.csv"),
                                  ("kt_legs_serial/legs_kernel_stats.csv", f"{tag}_legs_serialized_kernel_stats.csv"), ("kt_stream/stream_kernel_stats.csv", f"{tag}_frame_stream_kernel_stats.csv"),
-                                 ("legs_kt.log", f"{tag}_legs_profiled_run.json")):
+                                 ("legs_kt.log", f"{tag}_legs_profiled_run.json"), ("bench_plain.json", f"{tag}_bench_default.json"), ("bench_detail.json", f"{tag}_bench_detail.json")):
         if os.path.exists(os.path.join(src, extra_src)):
             if extra_src.endswith(".log"):  # the legs' own JSON line of the profiled run (HIP-event figures next to the profiler's)
                 with open(os.path.join(src, extra_src)) as fh:
