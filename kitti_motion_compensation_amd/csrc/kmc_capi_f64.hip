@@ -169,8 +169,7 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
   f.x_req = params->x_req;
   f.t_start = stamp_start;
   f.t_end = stamp_end;
-  f.dur = stamp_end - stamp_start;
-  f.inv_dur = 1.0 / f.dur;
+  f.inv_dur = 1.0 / (stamp_end - stamp_start);
   f.halvings = halvings_for(f.phi2);  // |s| <= 1 inside the scan
   f.terms = series_terms_for(f.phi2);
 

@@ -171,8 +171,11 @@ int kmc_hip_deskew_traj_f32(kmc_ctx* c, const float* xyzi_in, float* xyzi_out, u
   const bool window = inline_records && !c->timing && c->gl.count == 0 && !bracket_idx_out && n;
   // The context's OWN stream: such a frame goes out through the direct queue like a two-pose frame (kmc_capi_direct.hip) -- its records
   // ride in the packet's argument block, no HIP call on the way.  Same tile body as the HIP launch below, same bits.
-  if (!(c->dd && c->dd_wanted && !c->stream_dirty)) KMC_HIP_TRY(c, hipSetDevice(c->device));  // (before direct_open: its self-test allocates and launches on the CURRENT device)
-  const bool direct = window && c->stream == c->own_stream && c->fq_count <= 1 && c->dd_wanted && !c->dd_broken && (c->dd || direct_open(c));  // (not with gathering on: kmc_hip.h)
+  const bool direct_eligible = window && c->stream == c->own_stream && c->fq_count <= 1 && c->dd_wanted && !c->dd_broken;  // (not with gathering on: kmc_hip.h)
+  // (a frame for an OPEN direct queue needs no HIP call at all unless it follows HIP-stream work; everything else -- opening the queue
+  // included: its self-test allocates and launches -- happens on the context's device)
+  if (!(direct_eligible && c->dd && !c->stream_dirty)) KMC_HIP_TRY(c, hipSetDevice(c->device));
+  const bool direct = direct_eligible && (c->dd || direct_open(c));
   if (direct) {
     if (c->stream_dirty) {
       KMC_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -416,7 +419,6 @@ int kmc_hip_deskew_traj_f64cols(kmc_ctx* c, const double* x, const double* y, co
     segs[k].f.x_req = (k == th.r) ? th.x_r : 0.0;
     segs[k].f.t_start = th.t0[k];
     segs[k].f.t_end = th.t0[k] + th.dur[k];
-    segs[k].f.dur = th.dur[k];
     segs[k].f.inv_dur = 1.0 / th.dur[k];
     th.M[k].to_rt12(segs[k].M);
     segs[k].identity = (k == th.r) ? 1 : 0;

@@ -337,15 +337,15 @@ struct FrameRec64 {
   double phi[3], rho[3], c1[3], c2[3];
   double phi2;
   double x_req;
-  double t_start, t_end, dur;
-  double inv_dur;  // 1 / dur, rounded once on the host (scan_offset_f64)
+  double t_start, t_end;
+  double inv_dur;  // 1 / (t_end - t_start), rounded once on the host (scan_offset_f64)
   int halvings;  // the series is evaluated at t / 2^halvings and doubled back: 0 for |phi| <= 0.5 rad (every vehicle), else whatever it takes
   int terms;     // series length: kShortSeriesTerms (5) up to kShortSeriesTheta rad per scan, else 8
 };
 
 // f64 trajectory segment (global-memory table, read by the f64 Eigen-layout trajectory kernel)
 struct TrajSeg64 {
-  FrameRec64 f;      // twist of the segment; f.x_req holds the anchor a_k, f.t_start/f.dur the segment's time span
+  FrameRec64 f;      // twist of the segment; f.x_req holds the anchor a_k, f.t_start / f.t_end / f.inv_dur the segment's time span
   double M[12];      // row-major 3x4 [R | t] applied after the exponential (identity for the anchor segment)
   int identity;
   int pad;
@@ -361,38 +361,35 @@ struct TrajSeg64 {
 // series -- instead of three Horner chains.  Horner's p = fma(p, u, c_k) has the CONSTANT as its addend, and the compiler's two-address
 // v_fmac_f64 wants the addend in the destination VGPR pair: two v_mov_b32 per step, ~50 of the ~140 VALU instructions of a point were
 // copies of constants.  In power form the constant is a multiplicand (an SGPR source of the same v_fmac), the accumulator stays where
-// it is: 18 instructions for the 5-term tier, 30 for the 8-term one, against 63.  (Round 1 switched per point between a 7-term series
+// it is: 18 instructions for the 5-term tier, 32 for the 8-term one, against 63.  (Round 1 switched per point between a 7-term series
 // and a half-angle sincos; ocml's f64 sincos carries its large-argument reduction along: 122 VGPRs.)
-constexpr double kSerA[8] = {1.0, -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0, -1.0 / 1307674368000.0};       // (-1)^k / (2k+1)!
-constexpr double kSerB[8] = {0.5, -1.0 / 24, 1.0 / 720, -1.0 / 40320, 1.0 / 3628800, -1.0 / 479001600, 1.0 / 87178291200.0, -1.0 / 20922789888000.0};  // (-1)^k / (2k+2)!
-constexpr double kSerC[8] = {1.0 / 6, -1.0 / 120, 1.0 / 5040, -1.0 / 362880, 1.0 / 39916800, -1.0 / 6227020800.0, 1.0 / 1307674368000.0, -1.0 / 355687428096000.0};  // (-1)^k / (2k+3)!
+// The coefficients come out of kRedoTable ([12..19] A, [20..27] B, [28..35] C, highest degree first) through scalar loads pinned behind
+// the powers they multiply (`after`): 24 SGPRs of table at a time.  As literals they were materialised with s_mov pairs and -- in the
+// STREAMED kernels, whose tile loop invites hoisting -- kept alive across the loop: 29 SGPR spills in deskew_f64cols<true>.
 constexpr int kShortSeriesTerms = 5;
 constexpr double kShortSeriesTheta = 0.11;  // rad per scan up to which 5 terms are exact to f64 (0.11^10 / 11! = 6.5e-18)
-template <int TERMS>
-__device__ __forceinline__ void se3_series_f64(double u, double& A, double& B, double& C) {
-  double pw[TERMS];  // u^k
-  pw[1] = u;
-#pragma unroll
-  for (int k = 2; k < TERMS; ++k) pw[k] = pw[k - 1] * u;
-  A = kSerA[TERMS - 1] * pw[TERMS - 1];
-  B = kSerB[TERMS - 1] * pw[TERMS - 1];
-  C = kSerC[TERMS - 1] * pw[TERMS - 1];
-#pragma unroll
-  for (int k = TERMS - 2; k >= 1; --k) {
-    A = __builtin_fma(kSerA[k], pw[k], A);
-    B = __builtin_fma(kSerB[k], pw[k], B);
-    C = __builtin_fma(kSerC[k], pw[k], C);
+__device__ __forceinline__ void se3_series_f64(double u, int terms, double& A, double& B, double& C) {
+  const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+  A = 0.0; B = 0.0; C = 0.0;
+  if (terms != kShortSeriesTerms) {  // (wave-uniform: a per-frame constant) degrees 7, 6, 5
+    const double u5 = u4 * u, u6 = u3 * u3, u7 = u4 * u3;
+    cdouble_p t = after((cdouble_p)kRedoTable, u7);
+    A = t[12] * u7; B = t[20] * u7; C = t[28] * u7;
+    A = __builtin_fma(t[13], u6, A); B = __builtin_fma(t[21], u6, B); C = __builtin_fma(t[29], u6, C);
+    A = __builtin_fma(t[14], u5, A); B = __builtin_fma(t[22], u5, B); C = __builtin_fma(t[30], u5, C);
   }
-  A += kSerA[0];
-  B += kSerB[0];
-  C += kSerC[0];
+  cdouble_p t = after((cdouble_p)kRedoTable, u4 + A);  // degrees 4 .. 0, smallest term first
+  A = __builtin_fma(t[15], u4, A); B = __builtin_fma(t[23], u4, B); C = __builtin_fma(t[31], u4, C);
+  A = __builtin_fma(t[16], u3, A); B = __builtin_fma(t[24], u3, B); C = __builtin_fma(t[32], u3, C);
+  A = __builtin_fma(t[17], u2, A); B = __builtin_fma(t[25], u2, B); C = __builtin_fma(t[33], u2, C);
+  A = __builtin_fma(t[18], u, A);  B = __builtin_fma(t[26], u, B);  C = __builtin_fma(t[34], u, C);
+  A += 1.0; B += 0.5; C += t[35];
 }
 __device__ __forceinline__ void se3_coefficients_f64(double s, double phi2, int halvings, int terms, double& alpha, double& beta, double& gamma) {
   const double s2 = s * s;
   double u = __builtin_ldexp(s2 * phi2, -2 * halvings);  // (t / 2^h)^2
   double A, B, C;
-  if (terms == kShortSeriesTerms) se3_series_f64<kShortSeriesTerms>(u, A, B, C);  // (wave-uniform: a per-frame constant)
-  else se3_series_f64<8>(u, A, B, C);
+  se3_series_f64(u, terms, A, B, C);
   for (int k = 0; k < halvings; ++k) {
     const double cosx = __builtin_fma(-u, B, 1.0);
     C = __builtin_ldexp(__builtin_fma(A, B, C), -2);
