@@ -1234,19 +1234,32 @@ def main():
         # the full record goes to a file; the ONE stdout line is compact (numbers and identifiers, < 4 KB): a line the driver cannot hold is
         # an unmeasured round (BENCH_r05)
         line = compact_line(out, write_detail(out))
-    ctx.close()
-    if dist:
-        dist.destroy_process_group()
-    # The line is the LAST thing on stdout: native libraries write there too (RCCL's "Librccl path ..." sits in the C library's buffer until
-    # the process ends and would land behind a line printed earlier), so everything is torn down and the C buffers are flushed first.
-    # (The process then ends the ordinary way -- a profiler attached to it, rocprofv3's counter passes of live_traffic() among them, writes its
-    # results from an exit handler.)
+    # The line is the LAST thing on stdout -- of the whole job: native libraries write there too (RCCL's "Librccl path ..." sits in the C
+    # library's buffer of EVERY rank until that process flushes or ends, and the launcher merges the ranks' streams).  So: every rank flushes
+    # what it has buffered, every rank but 0 then closes its stdout for good, a barrier, rank 0 writes the line and closes its own.  Whatever
+    # a teardown prints afterwards goes nowhere.  (The process ends the ordinary way: a profiler attached to it -- rocprofv3's counter passes
+    # of live_traffic() among them -- writes its results from an exit handler.)
     import ctypes
+
+    def seal_stdout():
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        null_fd = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null_fd, 1)
+        os.close(null_fd)
 
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
+    if rank != 0:
+        seal_stdout()
+    if dist:
+        dist.barrier()
     if rank == 0:
         os.write(1, (line + "\n").encode())
+        seal_stdout()
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
