@@ -19,7 +19,7 @@ void CopyOverUncompensatedFirstAndLastFrame(Path const run_folder);
 // Several GPUs: KMC_DEVICES=0,1,... or kmc::hip::SetRunDevices() -- the frames are cut into one contiguous, point-balanced
 // range per device (the frames of a run are independent), every range on its own device context; the files written are
 // the same whatever the device list.
-// Environment: KMC_RUN_BATCH_FRAMES (frames per GPU batch, default 16), KMC_RUN_KNOTS=3 (use the three OXTS poses around each
+// Environment: KMC_RUN_BATCH_FRAMES (frames per GPU batch, default 8), KMC_RUN_KNOTS=3 (use the three OXTS poses around each
 // frame as they are), KMC_RUN_TIMING=1 (busy time per stage on stderr), KMC_DEVICES (device list).
 void MotionCompensateRun(Path const run_folder);
 

@@ -33,8 +33,9 @@
  *   KMC_HOST_POOL_MAX_MB        2048     MiB of free blocks the pool keeps page-locked                    tests/test_host_pool.py
  *   KMC_HOST_DETECT_PINNED      1        0: only pool memory and KMC_MEM_HOST_MAPPED run in place         tests/test_host_pool.py
  *   KMC_TEST_HOST_POOL_FAIL_AT  unset    k: the process's k-th pool allocation fails (fault injection)    tests/test_run_driver.py
- * The C++ drop-in adds KMC_DEVICE, KMC_DEVICES, KMC_RUN_BATCH_FRAMES, KMC_RUN_TIMING, KMC_RUN_KNOTS, KMC_FIX_LAST_FRAME_COPY
- * (include/kitti_motion_compensation/motion_compensation.hpp).  Retired in ABI 7: KMC_LIST_ROUTE, KMC_DIRECT_LANES, KMC_MAPPED_WAVES,
+ * The C++ drop-in adds KMC_DEVICE, KMC_DEVICES (include/kitti_motion_compensation/motion_compensation.hpp), KMC_RUN_BATCH_FRAMES,
+ * KMC_RUN_TIMING, KMC_RUN_KNOTS, KMC_FIX_LAST_FRAME_COPY (.../handlers.hpp; tests/test_run_driver.py) and its CLI KMC_CLI_FULL_TEARDOWN
+ * (tools/motion_compensate_runs.cpp): 13 in all, and tests/test_abi_exports.py fails on a getenv that is not listed here.  Retired in ABI 7: KMC_LIST_ROUTE, KMC_DIRECT_LANES, KMC_MAPPED_WAVES,
  * KMC_DIRECT_DEBUG (measurement switches whose questions are answered: profiles/NOTES.md).
  *
  * Data conventions

@@ -115,3 +115,28 @@ def test_host_pool_declines_without_a_device_and_never_claims_foreign_memory():
     else:
         assert rc == capi.ERR_NO_DEVICE and not p.value and L.kmc_host_pool_trim() == 0
     assert L.kmc_host_pool_alloc(0, C.byref(p)) in (capi.OK, capi.ERR_NO_DEVICE)
+
+
+def test_every_environment_knob_the_product_reads_is_in_the_headers_table():
+    """the knobs had grown to 15, several of them measurement switches that kept dead routes alive.  Every getenv("KMC_*")
+    in the product sources must be listed in include/kmc_hip.h's table (with its default and the test that covers the non-default value),
+    the retired ones must be gone from the code, and the count stays below round 5's."""
+    import re
+
+    srcs = []
+    for d in (os.path.join(ROOT, "kitti_motion_compensation_amd", "csrc"), os.path.join(ROOT, "kitti_motion_compensation_amd", "csrc", "api"), os.path.join(ROOT, "include"),
+              os.path.join(ROOT, "include", "kitti_motion_compensation")):
+        srcs += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".h", ".hpp", ".cpp"))]
+    srcs.append(os.path.join(ROOT, "tools", "motion_compensate_runs.cpp"))
+    read = set()
+    for path in srcs:
+        with open(path) as fh:
+            read |= set(re.findall(r'getenv\("(KMC_[A-Z0-9_]+)"\)', fh.read()))
+    with open(os.path.join(ROOT, "include", "kmc_hip.h")) as fh:
+        header = fh.read()
+    table = header[header.index("Environment (read at kmc_hip_create"):header.index("Data conventions")]
+    missing = sorted(k for k in read if k not in table)
+    assert not missing, f"read by the product but not in kmc_hip.h's table: {missing}"
+    retired = {"KMC_LIST_ROUTE", "KMC_DIRECT_LANES", "KMC_MAPPED_WAVES", "KMC_DIRECT_DEBUG"}
+    assert not (read & retired), read & retired
+    assert len(read) < 15, sorted(read)
