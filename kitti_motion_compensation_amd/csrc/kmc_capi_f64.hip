@@ -232,9 +232,14 @@ static int f64cols_issue(kmc_ctx* c, const double* x, const double* y, const dou
     hipLaunchKernelGGL(deskew_f64cols<true>, dim3(grid), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, (uint64_t)0, done);
     if (c->trace) { c->last_trace.waves = (uint32_t)grid; c->last_trace.route = 2; }
   } else {  // one wave per workgroup, two points per lane
+#ifdef KMC_F64_PERSISTENT  // A/B only (tools/build_f64_variants.sh): the walking kernel of the in-place route on RESIDENT columns -- that many persistent waves, the next tile's loads in flight while the current one is computed
+    hipLaunchKernelGGL(deskew_f64cols<true>, dim3((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 127) / 128, (uint64_t)(KMC_F64_PERSISTENT)))), dim3(64), 0, c->stream, dx, dy, dz, dw, ds, n, f, dox, doy,
+                       doz, dow, c->d_counter, c->h_flag, (uint64_t)0, DoneWord{});
+#else
     launch_tiles(((n + 127) / 128 + kF64TilesPerWave - 1) / kF64TilesPerWave, [&](uint64_t t0, int grid) {  // (t0 and grid count WORKGROUPS)
       launch_on(deskew_f64cols<false>, grid, 64, c->stream, false, dx, dy, dz, dw, ds, n, f, dox, doy, doz, dow, c->d_counter, c->h_flag, t0, DoneWord{});
     });
+#endif
     c->done_armed = false;  // resident or staged columns: this queue is waited for on the stream
   }
   KMC_HIP_TRY(c, hipGetLastError());
