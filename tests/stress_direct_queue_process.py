@@ -5,7 +5,7 @@ opted in to the direct queue (kmc_hip_set_direct_dispatch) issues the reference'
 only.  The first sweep's results are held to the FAITHFUL oracle; every later sweep must reproduce the first bit for bit
 (motion_compensation.cpp:16-28 is pure).  Prints one JSON object.
 
-    python tools/stress_direct_queue_process.py [seconds=6] [seed=1]
+    python tests/stress_direct_queue_process.py [seconds=6] [seed=1]
 """
 import json
 import os

@@ -68,6 +68,14 @@ def test_product_never_references_the_oracle():
                 if re.search(r"kmc_oracle|kmo_|from oracle|import oracle|libkmc_oracle", txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+    # ... nor do the measurement tools: a tool that needs the checker lives under tests/ (soak_*.py, stress_direct_queue_process.py)
+    tools = os.path.join(ROOT, "tools")
+    for fn in os.listdir(tools):
+        if fn.endswith((".py", ".hip", ".cpp", ".sh")):
+            with open(os.path.join(tools, fn), errors="ignore") as f:
+                if re.search(r"kmc_oracle|kmo_|from oracle|import oracle|libkmc_oracle", f.read()):
+                    bad.append(os.path.join(tools, fn))
+    assert not bad, bad
     out = subprocess.run(["nm", "-D", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "kmo_" not in out
     ldd = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout

@@ -47,7 +47,7 @@ def test_in_place_calls_from_four_threads_with_context_churn():
 
 
 def test_direct_queue_from_two_processes_on_one_gpu_against_the_oracle():
-    tool = os.path.join(ROOT, "tools", "stress_direct_queue_process.py")
+    tool = os.path.join(ROOT, "tests", "stress_direct_queue_process.py")
     procs = [subprocess.Popen([sys.executable, tool, "6", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for seed in (1, 2)]
     outs = []
     for p in procs:
