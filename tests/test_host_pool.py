@@ -13,10 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 CHILD = r'''
-import ctypes as C, json, sys
+import ctypes as C, faulthandler, json, sys
+faulthandler.dump_traceback_later(60, exit=True)  # a hang names its line on stderr instead of running into the parent's timeout
 import numpy as np
 sys.path.insert(0, %r)
 from kitti_motion_compensation_amd import capi
+def mark(what):  # progress on stderr (unbuffered): a child that hangs says where
+    sys.stderr.write("step: " + what + "\n"); sys.stderr.flush()
 L = capi.lib()
 n = 60_000
 rng = np.random.default_rng(11)
@@ -24,6 +27,7 @@ out = {}
 p = C.c_void_p()
 rc = L.kmc_host_pool_alloc(1 << 20, C.byref(p))
 out["alloc_rc"] = rc
+mark("pool alloc done")
 if rc == capi.OK:
     out["owns"] = L.kmc_host_pool_owns(p, 1 << 20)
     out["freed"] = L.kmc_host_pool_free(p)
@@ -36,19 +40,25 @@ if rc == capi.OK:
     out["alloc_near_rc"] = L.kmc_host_pool_alloc_near(1 << 20, 0, C.byref(r))
     out["alloc_near_owned"] = L.kmc_host_pool_owns(r, 1 << 20)
     L.kmc_host_pool_free(r)
+mark("pool calls done")
 import torch
+mark("torch imported")
 pts = capi.synth_points_host(n, 77)
 prm = capi.FrameParams.make(np.array([1.1, 0.02, -0.01, 0.002, -0.001, 0.03]), 0.4)
 with capi.Context(0) as ctx:
     ctx.enable_call_trace(True)
+    mark("context created")
     # (a) ordinary pageable memory: staged copies
     a = pts.copy(); b = np.zeros_like(a)
     ctx.deskew_f32(a, b, prm)
     out["pageable_route"] = ctx.last_call_trace().route
+    mark("pageable call done")
     # (b) page-locked memory the CALLER made (torch's pin_memory): in place unless KMC_HOST_DETECT_PINNED=0
     ta = torch.from_numpy(pts.copy()).pin_memory(); tb = torch.zeros_like(ta).pin_memory()
+    mark("torch pinned tensors made")
     ctx.deskew_f32(ta.numpy(), tb.numpy(), prm)
     out["pinned_route"] = ctx.last_call_trace().route
+    mark("pinned call done")
     out["pinned_equals_pageable"] = bool(np.array_equal(tb.numpy().view(np.uint32), b.view(np.uint32)))
     # (c) pool memory, when there is a pool
     if rc == capi.OK:
@@ -58,14 +68,23 @@ with capi.Context(0) as ctx:
         out["pool_route"] = ctx.last_call_trace().route
         out["pool_equals_pageable"] = bool(np.array_equal(pb.a.view(np.uint32), b.view(np.uint32)))
         pa.close(); pb.close()
+        mark("pool call done")
+mark("context closed")
 print(json.dumps(out))
+sys.stdout.flush()
+mark("result printed")
+import os
+os._exit(0)  # the subject is the pool and the routes, not the teardown of torch's and HIP's pinned-memory caches in one process
 '''
 
 
 def _child(**env):
     e = {k: v for k, v in os.environ.items() if k not in ("KMC_HOST_POOL", "KMC_HOST_POOL_MAX_MB", "KMC_HOST_DETECT_PINNED")}
     e.update(env)
-    r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=e, timeout=300)
+    try:
+        r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, env=e, timeout=180)
+    except subprocess.TimeoutExpired as t:
+        raise AssertionError("the child hung; its last steps: " + str((t.stderr or b"")[-600:])) from None
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
