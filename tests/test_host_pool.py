@@ -18,8 +18,10 @@ faulthandler.dump_traceback_later(60, exit=True)  # a hang names its line on std
 import numpy as np
 sys.path.insert(0, %r)
 from kitti_motion_compensation_amd import capi
-def mark(what):  # progress on stderr (unbuffered): a child that hangs says where
-    sys.stderr.write("step: " + what + "\n"); sys.stderr.flush()
+import time
+T0 = time.time()
+def mark(what):  # progress on stderr (unbuffered), with the seconds since the start: a child that hangs says where
+    sys.stderr.write("step: %%.2f s " %% (time.time() - T0) + what + "\n"); sys.stderr.flush()
 L = capi.lib()
 n = 60_000
 rng = np.random.default_rng(11)
