@@ -840,6 +840,8 @@ def compact_line(full, detail_path=None):
             legs[name] = float("%.4g" % v) if abs(v) < 1e-3 else v
     if legs:
         line["legs"] = legs
+        if legs.get("ceiling_f32_copy_frac"):  # the headline against the same access pattern without arithmetic, measured on this box in this run
+            line["roofline"]["frac_of_same_run_copy_ceiling"] = round(rf["frac"] / legs["ceiling_f32_copy_frac"], 4)
     if "secondary_legs_error" in full:
         line["legs_error"] = _short(full["secondary_legs_error"], 200)
     line["peak_device_GiB_per_rank"] = full.get("peak_device_GiB_per_rank")
