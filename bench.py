@@ -1259,9 +1259,13 @@ def main():
     if rank == 0:
         os.write(1, (line + "\n").encode())
         seal_stdout()
-    ctx.close()
     if dist:
-        dist.destroy_process_group()
+        # every rank is past the last barrier and the line is out: nothing is left that needs the group.  Its teardown (communicator
+        # destruction, the watchdog's 10-minute patience) is where multi-rank jobs are known to linger; a job that has printed its result
+        # does not wait for it.  (The single-process run below ends the ordinary way -- profilers write their output from exit handlers.)
+        sys.stderr.flush()
+        os._exit(0)
+    ctx.close()
 
 
 if __name__ == "__main__":
